@@ -1,0 +1,495 @@
+"""CPU oracle for the SOC-matching hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain eager PyTorch on the CPU, the reference algorithm
+for the one path this repository accelerates: the Euler-Maruyama rollout and
+the SOCM matching loss.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it -- always as the checker or as
+the timed CPU baseline, never from the product (`soc-matching_amd/`).
+
+Parity status: PINNED.  Every function below is checked in
+`tests/test_oracle_golden.py` against vectors produced by importing the
+unmodified reference in the authoring container
+(`tests/golden/make_golden.py`, fixtures `tests/golden/*.npz`).  The reference
+itself ships no tests or golden vectors for this path.
+
+The restatement keeps the reference's floating-point op ORDER (so it agrees with
+the fixtures to ~1e-6) and its COST STRUCTURE (per-step eager ops in the
+rollout; dense zero-filled `(Kp,Kp,...)` tensors, 5-index einsums and a
+reverse-mode Jacobian for dM/ds in the loss), which is what makes it usable as
+the "reference CPU path" that bench.py times.  Citations are to
+`/root/reference/SOC_matching/...`.
+
+A problem is a plain dict:
+    kind   : "ou_quadratic" | "ou_linear" | "double_well" | "molecular_dynamics"
+    sigma  : (d,d)    A,P,Q : (d,d) [ou_quadratic]   A,omega [ou_linear]
+    kappa,nu : (d,) [double_well]   kappa [molecular_dynamics]
+Network parameters are dicts keyed like the reference state_dicts
+("down_0.0.weight", ..., "sigmoid_layers.4.bias").
+"""
+import math
+
+import numpy as np
+import torch
+
+# --------------------------------------------------------------------------
+# networks
+# --------------------------------------------------------------------------
+
+def _lin(p, name, x):
+    return torch.nn.functional.linear(x, p[name + ".0.weight"], p[name + ".0.bias"])
+
+
+def unet_forward(p, x):
+    """FullyConnectedUNet.forward -- models.py:233-242 (ReLU also on up_0, :228)."""
+    r1 = torch.relu(_lin(p, "down_0", x))
+    r2 = torch.relu(_lin(p, "down_1", r1))
+    r3 = torch.relu(_lin(p, "down_2", r2))
+    o2 = torch.relu(_lin(p, "up_2", r3)) + _lin(p, "res_2", r2)
+    o1 = torch.relu(_lin(p, "up_1", o2)) + _lin(p, "res_1", r1)
+    o0 = torch.relu(_lin(p, "up_0", o1)) + _lin(p, "res_0", x)
+    return o0
+
+
+def sigmoid_mlp_net(mp, ts2):
+    """SigmoidMLP.sigmoid_layers -- models.py:251-257."""
+    F = torch.nn.functional
+    h = torch.relu(F.linear(ts2, mp["sigmoid_layers.0.weight"], mp["sigmoid_layers.0.bias"]))
+    h = torch.relu(F.linear(h, mp["sigmoid_layers.2.weight"], mp["sigmoid_layers.2.bias"]))
+    return F.linear(h, mp["sigmoid_layers.4.weight"], mp["sigmoid_layers.4.bias"])
+
+
+def sigmoid_mlp(mp, gamma, t, s, d):
+    """SigmoidMLP.forward -- models.py:265-275."""
+    ts2 = torch.cat((t.unsqueeze(1), s.unsqueeze(1)), dim=1)
+    net = sigmoid_mlp_net(mp, ts2).reshape(-1, d, d)
+    exp_factor = torch.exp(gamma * (ts2[:, 1] - ts2[:, 0])).unsqueeze(1).unsqueeze(2)
+    eye = torch.eye(d, dtype=ts2.dtype).unsqueeze(0)
+    return (1 / exp_factor) * eye.repeat(ts2.shape[0], 1, 1) + (1 - 1 / exp_factor) * net
+
+
+def two_boundary_mlp(mp, gamma, gamma2, gamma3, t, s, tau, d, T):
+    """TwoBoundarySigmoidMLP.forward -- models.py:311-393.  tau: (N,B) stopping times."""
+    F = torch.nn.functional
+
+    def net(third):
+        x = torch.cat((t.unsqueeze(1), s.unsqueeze(1), third.unsqueeze(1)), dim=1)
+        h = torch.relu(F.linear(x, mp["sigmoid_layers.0.weight"], mp["sigmoid_layers.0.bias"]))
+        h = torch.relu(F.linear(h, mp["sigmoid_layers.2.weight"], mp["sigmoid_layers.2.bias"]))
+        return F.linear(h, mp["sigmoid_layers.4.weight"], mp["sigmoid_layers.4.bias"]).reshape(-1, 1, d, d)
+
+    out_stopped = net(torch.zeros_like(s))
+    out_running = net(torch.ones_like(s))
+    eye = torch.eye(d).unsqueeze(0).unsqueeze(0)
+    factor1 = torch.nan_to_num(
+        1
+        - torch.minimum(
+            (1 - torch.exp(-gamma * (s - t))).unsqueeze(1)
+            / (1 - torch.exp(-gamma * torch.abs(tau - t.unsqueeze(1))) + 1e-7),
+            torch.tensor([1]),
+        ),
+        nan=0.0,
+    )
+    factor1 = factor1 * (tau - 1e-3 > s.unsqueeze(1)).to(torch.int)
+    e3 = lambda x: torch.exp(-gamma3 * x)
+    running = (tau > T - 1e-3).to(torch.int)
+    out1 = ((1 - running) * factor1 + running * e3(s - t).unsqueeze(1)).unsqueeze(2).unsqueeze(3) \
+        * eye.repeat(t.shape[0], running.shape[1], 1, 1)
+    f2 = lambda x: (1 - torch.exp(-gamma2 * x)) * (torch.exp(-gamma2 * x) - torch.exp(-gamma2))
+    out2 = ((1 - running) * f2(factor1)).unsqueeze(2).unsqueeze(3) * out_stopped \
+        + (running * (1 - e3(s - t).unsqueeze(1))).unsqueeze(2).unsqueeze(3) * out_running
+    return out1 + out2
+
+
+# --------------------------------------------------------------------------
+# setting math  (experiment_settings/*.py)
+# --------------------------------------------------------------------------
+
+def drift_b(pb, t, x):
+    k = pb["kind"]
+    if k in ("ou_quadratic", "ou_linear"):
+        return torch.einsum("ij,...j->...i", pb["A"], x)            # OU_quadratic.py:51-52, OU_linear.py:43-44
+    kap = pb["kappa"]
+    return -2 * kap * (x**2 - 1) * 2 * x                              # double_well.py:44-48, molecular_dynamics.py:49-53
+
+
+def nabla_b(pb, t, x):
+    """Dense (..., d, d) Jacobian exactly as the reference materialises it."""
+    k = pb["kind"]
+    if k in ("ou_quadratic", "ou_linear"):
+        A = pb["A"]
+        rep = A.reshape((1,) * (x.dim() - 1) + A.shape).repeat(*x.shape[:-1], 1, 1)
+        return torch.transpose(rep, -1, -2)                           # OU_quadratic.py:55-63
+    kap = pb["kappa"]
+    return -torch.diag_embed(8 * kap * x**2 + 4 * kap * (x**2 - 1))   # double_well.py:51-61
+
+
+def cost_f(pb, t, x):
+    k = pb["kind"]
+    if k == "ou_quadratic":
+        return torch.sum(x * torch.einsum("ij,...j->...i", pb["P"], x), -1)   # OU_quadratic.py:66-69
+    if k == "molecular_dynamics":
+        return torch.ones_like(x[..., 0])                                       # molecular_dynamics.py:87
+    return torch.zeros(x.shape[:-1])                                            # OU_linear.py:68-76, double_well.py:64-68
+
+
+def nabla_f(pb, t, x):
+    if pb["kind"] == "ou_quadratic":
+        return 2 * torch.einsum("ij,...j->...i", pb["P"], x)                    # OU_quadratic.py:72-73
+    return torch.zeros_like(x)
+
+
+def cost_g(pb, x):
+    k = pb["kind"]
+    if k == "ou_quadratic":
+        return torch.sum(x * torch.einsum("ij,...j->...i", pb["Q"], x), -1)   # OU_quadratic.py:76-79
+    if k == "ou_linear":
+        return torch.einsum("j,...j->...", pb["omega"], x)                      # OU_linear.py:83-84
+    if k == "double_well":
+        return torch.sum(pb["nu"] * (x**2 - 1) ** 2, dim=-1)                   # double_well.py:75-84
+    return torch.zeros_like(x[..., 0])                                          # molecular_dynamics.py:72
+
+
+def nabla_g(pb, x):
+    k = pb["kind"]
+    if k == "ou_quadratic":
+        return 2 * torch.einsum("ij,...j->...i", pb["Q"], x)                    # OU_quadratic.py:82-83
+    if k == "ou_linear":
+        return pb["omega"].reshape((1,) * (x.dim() - 1) + (-1,)).repeat(*x.shape[:-1], 1)  # OU_linear.py:87-96
+    if k == "double_well":
+        return 2 * pb["nu"] * (x**2 - 1) * 2 * x                                # double_well.py:87-97
+    return torch.zeros_like(x)
+
+
+def has_phi(pb):
+    return pb["kind"] == "molecular_dynamics"
+
+
+def Phi(pb, x):
+    return -x[..., 0]                                                            # molecular_dynamics.py:94-99
+
+
+# --------------------------------------------------------------------------
+# control + rollout
+# --------------------------------------------------------------------------
+
+def control(pb, vp, t, x):
+    """NeuralSDE.control, 2-D branch -- method.py:64-80 (no warm start)."""
+    t_expand = t.reshape(-1, 1).expand(x.shape[0], 1)
+    tx = torch.cat([t_expand, x], dim=-1)
+    return -torch.einsum("ij,bj->bi", torch.transpose(pb["sigma"], 0, 1), unet_forward(vp, tx).reshape(x.shape))
+
+
+def stochastic_trajectories(pb, vp, x0, ts, lmbd, noise, control_fn=None):
+    """utils.py:17-128 with `noise[k]` standing in for `torch.randn_like(x0)` (:39).
+
+    Returns the reference's 8-tuple order:
+    states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls.
+    """
+    B = x0.shape[0]
+    xt, noises, controls = [x0], [], []
+    stop_indicators = [torch.ones(B)]
+    frac = []
+    lpd = torch.zeros(B)
+    lps = torch.zeros(B)
+    stopping = has_phi(pb)                                  # utils.py:33
+    stop_inds = torch.ones(B)
+    sigma = pb["sigma"]
+    for k, (t0, t1) in enumerate(zip(ts[:-1], ts[1:])):
+        dt = t1 - t0                                        # :38  (fp32 grid difference)
+        eps = noise[k]
+        noises.append(eps)
+        u0 = control_fn(t0, x0) if control_fn is not None else control(pb, vp, t0, x0)
+        if stopping:
+            phi_b = Phi(pb, x0)
+            x_before = x0
+        update = (drift_b(pb, t0, x0) + torch.einsum("ij,bj->bi", sigma, u0)) * dt \
+            + torch.sqrt(lmbd * dt) * torch.einsum("ij,bj->bi", sigma, eps)       # :45-47
+        x0 = x0 + stop_inds.unsqueeze(1) * update                                  # :48
+        if stopping:                                                               # :49-75
+            phi_a = Phi(pb, x0)
+            not_stopped = torch.logical_and(phi_b > 0, phi_a > 0).to(torch.float)
+            just_stopped = torch.logical_and(phi_b > 0, phi_a < 0).to(torch.float)
+            step_fraction = just_stopped * (phi_b / (phi_b - phi_a + 1e-6) + 1e-6)
+            x0 = just_stopped.unsqueeze(1) * (
+                x_before + step_fraction.unsqueeze(1) * stop_inds.unsqueeze(1) * update
+            ) + (1 - just_stopped.unsqueeze(1)) * x0
+            fdt = just_stopped * step_fraction**2 * dt + not_stopped * dt
+            frac.append(fdt)
+            stop_inds = Phi(pb, x0) > 0
+            stop_indicators.append(stop_inds)
+        else:
+            fdt = None
+            frac.append(dt * torch.ones(B))
+            stop_indicators.append(torch.ones(B))
+        xt.append(x0)
+        controls.append(u0)
+        step = fdt if stopping else dt
+        # f at the UPDATED state with the OLD time (:92-96)
+        lpd = lpd + step / lmbd * (-cost_f(pb, t0, x0) - 0.5 * torch.sum(u0**2, dim=1))
+        lps = lps + torch.sqrt(step / lmbd) * (-torch.sum(u0 * eps, dim=1))
+    ltw = -cost_g(pb, x0) / lmbd                                                   # :101
+    return (
+        torch.stack(xt), torch.stack(noises),
+        torch.stack([s.to(torch.float32) for s in stop_indicators]),
+        torch.stack(frac), lpd, lps, ltw, torch.stack(controls),
+    )
+
+
+# --------------------------------------------------------------------------
+# SOCM loss, dense form (method.py:223-262, 272-287, 480-720, 897-906)
+# --------------------------------------------------------------------------
+
+def pair_grid(ts, T, K):
+    """t_vector / s_vector -- method.py:533-547."""
+    s_vec, t_vec = [], []
+    for k, t in enumerate(ts):
+        s_vec.append(torch.linspace(t, T, K + 1 - k))
+        t_vec.append(t * torch.ones(K + 1 - k))
+    return torch.cat(t_vec), torch.cat(s_vec)
+
+
+def dM_ds_analytic(mp, gamma, t, s, d):
+    """Closed form of d/ds SigmoidMLP (what jacrev computes at method.py:510-515).
+
+    M = e^{-g(s-t)} I + (1-e^{-g(s-t)}) net(t,s)
+    dM/ds = g e^{-g(s-t)} (net - I) + (1-e^{-g(s-t)}) dnet/ds,
+    dnet/ds = W3 (1[h2>0] * (W2 (1[h1>0] * W1[:,1]))).
+    """
+    W1, b1 = mp["sigmoid_layers.0.weight"], mp["sigmoid_layers.0.bias"]
+    W2, b2 = mp["sigmoid_layers.2.weight"], mp["sigmoid_layers.2.bias"]
+    W3, b3 = mp["sigmoid_layers.4.weight"], mp["sigmoid_layers.4.bias"]
+    ts2 = torch.stack((t, s), dim=1)
+    a1 = ts2 @ W1.T + b1
+    h1 = torch.relu(a1)
+    a2 = h1 @ W2.T + b2
+    h2 = torch.relu(a2)
+    net = (h2 @ W3.T + b3).reshape(-1, d, d)
+    dh1 = (a1 > 0).to(a1.dtype) * W1[:, 1]
+    dh2 = (a2 > 0).to(a2.dtype) * (dh1 @ W2.T)
+    dnet = (dh2 @ W3.T).reshape(-1, d, d)
+    e = torch.exp(-gamma * (s - t)).reshape(-1, 1, 1)
+    eye = torch.eye(d, dtype=t.dtype).unsqueeze(0)
+    return gamma * e * (net - eye) + (1 - e) * dnet
+
+
+def socm_loss(pb, vp, mp, gamma, x0, ts, T, lmbd, B, noise, derivative="jacrev",
+              return_parts=False):
+    """SOC_Solver.loss(algorithm="SOCM", use_stopping_time=False).
+
+    vp / mp / gamma may require grad; the rollout is detached as in the
+    reference (`detach=True`, method.py:240).  Returns
+    (objective, mean(w), std(w)) and, with return_parts, a dict of intermediates.
+    """
+    K = ts.shape[0] - 1
+    d = x0.shape[-1]
+    sigma = pb["sigma"]
+    state0 = x0.repeat(B, 1)                                                   # :238
+    with torch.no_grad():
+        states, noises, stop_ind, frac, lpd, lps, ltw, controls = stochastic_trajectories(
+            pb, vp, state0, ts, lmbd, noise)
+    weight = torch.exp(lpd + lps + ltw)                                         # :258-262
+    ts_repeat = ts.unsqueeze(1).unsqueeze(2).repeat(1, B, 1)                   # :272-278
+    tx = torch.cat([ts_repeat, states], dim=-1).reshape(-1, d + 1)
+    nabla_V = unet_forward(vp, tx).reshape(states.shape)
+
+    sit = torch.transpose(torch.inverse(sigma), 0, 1)                           # :481
+    Kp = K + 1
+    t_vec, s_vec = pair_grid(ts, T, K)
+    M_all = sigmoid_mlp(mp, gamma, t_vec, s_vec, d)                             # :566-569
+    if derivative == "jacrev":                                                  # :510-515, 570-573
+        from torch.func import jacrev
+        sum_M = lambda t, s: sigmoid_mlp(mp, gamma, t, s, d).sum(dim=0)
+        dM_all = torch.transpose(torch.transpose(jacrev(sum_M, argnums=1)(t_vec, s_vec), 1, 2), 0, 1)
+    else:
+        dM_all = dM_ds_analytic(mp, gamma, t_vec, s_vec, d)
+    M_evals = torch.zeros(Kp, Kp, d, d)                                         # :517-522
+    dM_evals = torch.zeros(Kp, Kp, d, d)
+    c = 0
+    for k in range(Kp):                                                         # :574-582
+        n = K + 1 - k
+        M_evals[k, k:] = M_all[c:c + n]
+        dM_evals[k, k:] = dM_all[c:c + n]
+        c += n
+
+    term1 = torch.einsum("ijkl,jml->ijmk", M_evals, nabla_f(pb, ts, states))[:, :-1]        # :591-595
+    M_nabla_b = torch.einsum("ijkl,jmln->ijmkn", M_evals, nabla_b(pb, ts, states)) \
+        - dM_evals.unsqueeze(2)                                                              # :614-618
+    term2 = -np.sqrt(lmbd) * torch.einsum(
+        "ijmkn,jmn->ijmk", M_nabla_b[:, :-1], torch.einsum("ij,abj->abi", sit, noises))     # :619-625
+    term3 = -torch.einsum(
+        "ijmkn,jmn->ijmk", M_nabla_b[:, :-1], torch.einsum("ij,abj->abi", sit, controls))   # :627-631
+    terminal = torch.einsum("ikl,ml->imk", M_evals[:, -1], nabla_g(pb, states[-1]))          # :641-646
+    dts = ts[1:] - ts[:-1]                                                                    # :662-673
+    term1 = term1 * dts.unsqueeze(1).unsqueeze(2).unsqueeze(0)
+    term2 = term2 * torch.sqrt(dts).unsqueeze(1).unsqueeze(2)
+    term3 = term3 * dts.unsqueeze(1).unsqueeze(2)
+    target = term1.sum(dim=1) + term2.sum(dim=1) + term3.sum(dim=1) + terminal               # :675-690
+    learned = -torch.einsum("ij,...j->...i", torch.transpose(sigma, 0, 1), nabla_V)          # :702-709
+    tgt = -torch.einsum("ij,...j->...i", torch.transpose(sigma, 0, 1), target)
+    objective = torch.sum((learned - tgt) ** 2 * weight.unsqueeze(0).unsqueeze(2)) / (Kp * B)  # :717-720
+    out = (objective, torch.mean(weight), torch.std(weight))                                  # :903-904
+    if return_parts:
+        parts = dict(states=states, noises=noises, controls=controls, weight=weight,
+                     nabla_V=nabla_V, M_all=M_all, dM_all=dM_all, target=target,
+                     stop_indicators=stop_ind, lpd=lpd, lps=lps, ltw=ltw, frac=frac)
+        return out, parts
+    return out
+
+
+def socm_loss_stopping(pb, vp, mp, gamma, gamma2, gamma3, x0, ts, T, lmbd, B, noise):
+    """SOC_Solver.loss(algorithm="SOCM", use_stopping_time=True): the per-sample-M
+    branches of method.py:484-507, 523-530, 548-564, 584-590, 597-613, 633-640,
+    648-660, 692-715 (molecular_dynamics only)."""
+    from torch.func import jacrev
+    K = ts.shape[0] - 1
+    Kp = K + 1
+    d = x0.shape[-1]
+    sigma = pb["sigma"]
+    state0 = x0.repeat(B, 1)
+    with torch.no_grad():
+        states, noises, stop_ind, frac, lpd, lps, ltw, controls = stochastic_trajectories(
+            pb, vp, state0, ts, lmbd, noise)
+    weight = torch.exp(lpd + lps + ltw)
+    ts_repeat = ts.unsqueeze(1).unsqueeze(2).repeat(1, B, 1)
+    tx = torch.cat([ts_repeat, states], dim=-1).reshape(-1, d + 1)
+    nabla_V = unet_forward(vp, tx).reshape(states.shape)
+    sit = torch.transpose(torch.inverse(sigma), 0, 1)
+    tau = (torch.sum((Phi(pb, states) > 0).to(torch.int), dim=0) - 1) / (Kp - 1)   # :525-530
+    t_vec, s_vec = pair_grid(ts, T, K)
+    tau_vec = tau.unsqueeze(0).repeat(t_vec.shape[0], 1)                            # :542-549
+    # quirk: initialize_models (method.py:123-132) never forwards T, so the model's own
+    # T stays at its default 1.0 (models.py:287) whatever cfg.method.T is.
+    Mfun = lambda t, s, tv: two_boundary_mlp(mp, gamma, gamma2, gamma3, t, s, tv, d, 1.0)
+    M_all = Mfun(t_vec, s_vec, tau_vec)
+    sum_M = lambda t, s, tv: Mfun(t, s, tv).sum(dim=0)
+    j = jacrev(sum_M, argnums=1)(t_vec, s_vec, tau_vec)                              # (B,d,d,N)
+    dM_all = torch.nan_to_num(torch.transpose(torch.transpose(torch.transpose(j, 2, 3), 1, 2), 0, 1))
+    M_evals = torch.zeros(Kp, Kp, B, d, d)
+    dM_evals = torch.zeros(Kp, Kp, B, d, d)
+    c = 0
+    for k in range(Kp):
+        n = K + 1 - k
+        M_evals[k, k:] = M_all[c:c + n]
+        dM_evals[k, k:] = dM_all[c:c + n]
+        c += n
+    term1 = torch.einsum("ijmkl,jml->ijmk", M_evals, nabla_f(pb, ts, states))[:, :-1]
+    M_nabla_b = torch.einsum("ijmkl,jmln->ijmkn", M_evals, nabla_b(pb, ts, states)) - dM_evals
+    term2 = -np.sqrt(lmbd) * torch.einsum(
+        "ijmkn,jmn->ijmk", M_nabla_b[:, :-1], torch.einsum("ij,abj->abi", sit, noises))
+    term3 = -torch.einsum(
+        "ijmkn,jmn->ijmk", M_nabla_b[:, :-1], torch.einsum("ij,abj->abi", sit, controls))
+    terminal = torch.einsum("imkl,ml->imk", M_evals[:, -1], nabla_g(pb, states[-1]))
+    term1 = term1 * frac.unsqueeze(0).unsqueeze(3)
+    term2 = term2 * torch.sqrt(frac).unsqueeze(0).unsqueeze(3)
+    term3 = term3 * frac.unsqueeze(0).unsqueeze(3)
+    target = term1.sum(dim=1) + term2.sum(dim=1) + term3.sum(dim=1) + terminal
+    us = stop_ind.unsqueeze(2)
+    learned = -us * torch.einsum("ij,...j->...i", torch.transpose(sigma, 0, 1), nabla_V)
+    tgt = -us * torch.einsum("ij,...j->...i", torch.transpose(sigma, 0, 1), target)
+    objective = torch.sum((learned - tgt) ** 2 * weight.unsqueeze(0).unsqueeze(2)) / torch.sum(stop_ind)
+    return objective, torch.mean(weight), torch.std(weight)
+
+
+# --------------------------------------------------------------------------
+# evaluation bursts (utils.py:131-163) -- used by the "next" row f1 tests
+# --------------------------------------------------------------------------
+
+def control_objective(pb, vp, x0, ts, lmbd, B, noise_batches):
+    losses = []
+    for noise in noise_batches:
+        r = stochastic_trajectories(pb, vp, x0.repeat(B, 1), ts, lmbd, noise)
+        losses.append(-lmbd * (r[4] + r[6]))
+    losses = torch.cat(losses, 0)
+    n = losses.shape[0]
+    return torch.mean(losses), torch.std(losses) / np.sqrt(n - 1)
+
+
+# --------------------------------------------------------------------------
+# Philox4x32-10 + Box-Muller: integer reference for the device noise generator
+# (no reference counterpart: the reference draws torch.randn_like, utils.py:39;
+# the algorithm is Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
+# SC'11, constants as in Random123 philox.h).
+# --------------------------------------------------------------------------
+
+PHILOX_M0 = 0xD2511F53
+PHILOX_M1 = 0xCD9E8D57
+PHILOX_W0 = 0x9E3779B9
+PHILOX_W1 = 0xBB67AE85
+
+
+def philox4x32_10(counter, key):
+    """counter: (...,4) uint32 array, key: (...,2) uint32 array -> (...,4) uint32."""
+    c = np.array(counter, dtype=np.uint64) & 0xFFFFFFFF
+    k = np.array(key, dtype=np.uint64) & 0xFFFFFFFF
+    c = np.broadcast_to(c, np.broadcast_shapes(c.shape, k.shape[:-1] + (4,))).copy()
+    k = np.broadcast_to(k, c.shape[:-1] + (2,)).copy()
+    for _ in range(10):
+        p0 = c[..., 0] * PHILOX_M0
+        p1 = c[..., 2] * PHILOX_M1
+        hi0, lo0 = p0 >> 32, p0 & 0xFFFFFFFF
+        hi1, lo1 = p1 >> 32, p1 & 0xFFFFFFFF
+        n0 = hi1 ^ c[..., 1] ^ k[..., 0]
+        n1 = lo1
+        n2 = hi0 ^ c[..., 3] ^ k[..., 1]
+        n3 = lo0
+        c = np.stack([n0, n1, n2, n3], axis=-1) & 0xFFFFFFFF
+        k[..., 0] = (k[..., 0] + PHILOX_W0) & 0xFFFFFFFF
+        k[..., 1] = (k[..., 1] + PHILOX_W1) & 0xFFFFFFFF
+    return c.astype(np.uint32)
+
+
+def philox_normals(seed, offset, row, step, d):
+    """The device generator's contract (include/socmx.h, socmx_rollout_f32):
+    for global row `row`, step `step`, dims 4q..4q+3 come from
+    philox4x32_10(counter=(row, step, q, offset_lo), key=(seed_lo, seed_hi)),
+    words -> uniforms u=(w+0.5)*2^-32 (float64 here), pairs (u0,u1),(u2,u3) ->
+    Box-Muller r=sqrt(-2 ln u_a), (r cos 2 pi u_b, r sin 2 pi u_b).
+    Returns float64 normals of shape (d,); the device computes in fp32, so compare
+    with a ~1e-5 tolerance."""
+    nq = (d + 3) // 4
+    out = np.zeros(nq * 4)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    for q in range(nq):
+        ctr = np.array([row, step, q, offset & 0xFFFFFFFF], dtype=np.uint64)
+        w = philox4x32_10(ctr, key).astype(np.float64)
+        u = (w + 0.5) * 2.0**-32
+        for h in range(2):
+            r = math.sqrt(-2.0 * math.log(u[2 * h]))
+            out[4 * q + 2 * h] = r * math.cos(2 * math.pi * u[2 * h + 1])
+            out[4 * q + 2 * h + 1] = r * math.sin(2 * math.pi * u[2 * h + 1])
+    return out[:d]
+
+
+# --------------------------------------------------------------------------
+# helpers shared by tests: fixture -> oracle inputs
+# --------------------------------------------------------------------------
+
+_KIND = {
+    "OU_quadratic_easy": "ou_quadratic", "OU_quadratic_hard": "ou_quadratic",
+    "OU_quadratic_dense": "ou_quadratic", "OU_linear": "ou_linear",
+    "double_well": "double_well", "molecular_dynamics": "molecular_dynamics",
+}
+
+
+def load_fixture(path, requires_grad=False):
+    """Returns (problem, nablaV params, M params, gamma, aux dict) from a golden .npz."""
+    z = np.load(path)
+    setting = str(z["meta_setting"])
+    pb = {"kind": _KIND[setting], "setting": setting}
+    for key in z.files:
+        if key.startswith("const_") and key != "const_x0":
+            pb[key[len("const_"):]] = torch.from_numpy(z[key].copy())
+    vp = {k[len("nablaV."):]: torch.from_numpy(z[k].copy()).requires_grad_(requires_grad)
+          for k in z.files if k.startswith("nablaV.")}
+    mp = {k[len("M."):]: torch.from_numpy(z[k].copy()).requires_grad_(requires_grad)
+          for k in z.files if k.startswith("M.sigmoid_layers")}
+    gamma = torch.from_numpy(z["gamma"].copy()).requires_grad_(requires_grad)
+    d, K, B, seed, stopping = [int(v) for v in z["meta"]]
+    T, lmbd = float(z["meta_f"][0]), float(z["meta_f"][1])
+    aux = dict(z=z, d=d, K=K, B=B, T=T, lmbd=lmbd, stopping=bool(stopping),
+               x0=torch.from_numpy(z["const_x0"].copy()), ts=torch.from_numpy(z["ts"].copy()),
+               noise=torch.from_numpy(z["noise_in"].copy()), setting=setting)
+    if stopping:
+        aux["gamma2"] = torch.from_numpy(z["gamma2"].copy()).requires_grad_(requires_grad)
+        aux["gamma3"] = torch.from_numpy(z["gamma3"].copy()).requires_grad_(requires_grad)
+    return pb, vp, mp, gamma, aux
