@@ -1,0 +1,179 @@
+/*
+ * socmx.h -- C ABI of the MI355X-native SOC-matching hot path (libsocmx.so).
+ *
+ * The reference (facebookresearch/SOC-matching) is pure Python/PyTorch and has
+ * no FFI of its own; the "operator API" of its hot path is a set of Python call
+ * sites.  Each entry point below replaces one of them and says which
+ * (file:line are into the reference checkout):
+ *
+ *   socmx_rollout_f32            SOC_matching/utils.py:17-128  stochastic_trajectories()
+ *                                 + SOC_matching/method.py:58-80 NeuralSDE.control() (2-D branch)
+ *                                 + SOC_matching/models.py:233-242 FullyConnectedUNet.forward()
+ *                                 + experiment_settings/{OU_quadratic,OU_linear,double_well,
+ *                                   molecular_dynamics}.py  b(), f(), g(), Phi()
+ *   socmx_unet_pack_f32          (no counterpart: re-lays nn.Linear weights, models.py:212-228,
+ *                                 into MFMA fragment order once per optimizer step)
+ *   socmx_unet_forward_f32       SOC_matching/method.py:272-278 (nabla_V on the trajectory rows)
+ *   socmx_weights_stats_f32      SOC_matching/method.py:258-262, 903-904 (w, mean(w), std(w))
+ *   socmx_socm_prep_f32          SOC_matching/method.py:591-646 operand preparation
+ *                                 (nabla_f, nabla_b . v, nabla_g, sigma^-T noise / control)
+ *   socmx_socm_target_fwd_f32    SOC_matching/method.py:591-720 (least-squares target, residual,
+ *                                 weighted reduction to the scalar objective)
+ *   socmx_socm_target_bwd_f32    autograd of the above w.r.t. M, dM/ds (nabla_V grad comes out of fwd)
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, < 0 = invalid argument (SOCMX_E_*), > 0 = hipError_t;
+ *   - never throws, never allocates, never synchronises; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*); safe to capture in a hipGraph;
+ *   - every pointer marked "device" is caller-owned device memory (e.g. torch tensor storage),
+ *     fp32, contiguous, row-major in the shape given; structs themselves live on the host;
+ *   - re-entrant: no global mutable state.
+ *
+ * Reference-side binding: see INTEGRATION.md (ctypes stub).
+ */
+#ifndef SOCMX_H
+#define SOCMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOCMX_VERSION 100 /* 0.1.0 */
+
+#define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
+#define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
+#define SOCMX_E_KIND (-3)      /* unknown problem kind                 */
+#define SOCMX_E_WORKSPACE (-4) /* workspace too small                  */
+#define SOCMX_E_LDS (-5)       /* configuration does not fit in 160 KiB of LDS */
+
+typedef void* socmx_stream_t; /* hipStream_t */
+
+/* method.setting -> kind (experiment_settings/settings.py:143-207) */
+enum {
+  SOCMX_OU_QUADRATIC = 0,       /* OU_quadratic_easy / OU_quadratic_hard : b=Ax, f=x'Px, g=x'Qx */
+  SOCMX_OU_LINEAR = 1,          /* OU_linear                             : b=Ax, f=0,    g=omega.x */
+  SOCMX_DOUBLE_WELL = 2,        /* double_well   : b=-4k x(x^2-1), f=0, g=sum nu (x^2-1)^2 */
+  SOCMX_MOLECULAR_DYNAMICS = 3  /* molecular_dynamics : DW drift, f=1, g=0, Phi(x)=-x_0 (stopping) */
+};
+
+/* Closed-form problem constants; unused members may be NULL. All device, fp32. */
+typedef struct socmx_problem {
+  int32_t kind;
+  int32_t d;
+  const float* sigma;       /* (d,d) */
+  const float* sigma_inv_t; /* (d,d) transpose(inverse(sigma)); only the loss entry points read it */
+  const float* A;           /* (d,d)  OU_*            */
+  const float* P;           /* (d,d)  OU_QUADRATIC    */
+  const float* Q;           /* (d,d)  OU_QUADRATIC    */
+  const float* omega;       /* (d,)   OU_LINEAR       */
+  const float* kappa;       /* (d,)   DOUBLE_WELL, MD */
+  const float* nu;          /* (d,)   DOUBLE_WELL     */
+} socmx_problem;
+
+/* FullyConnectedUNet parameters in torch layout: weight (out,in) row-major, bias (out,).
+ * Index order is the module construction order of models.py:212-228. */
+enum {
+  SOCMX_L_DOWN0 = 0, SOCMX_L_DOWN1 = 1, SOCMX_L_DOWN2 = 2,
+  SOCMX_L_RES0 = 3, SOCMX_L_RES1 = 4, SOCMX_L_RES2 = 5,
+  SOCMX_L_UP2 = 6, SOCMX_L_UP1 = 7, SOCMX_L_UP0 = 8
+};
+typedef struct socmx_unet {
+  int32_t d;        /* state dimension: input is d+1 = [t, x], output is d */
+  int32_t hdims[3]; /* arch.hdims */
+  const float* weight[9];
+  const float* bias[9];
+} socmx_unet;
+
+int socmx_version(void);
+
+/* Writes up to `cap` bytes of a NUL-terminated description ("gfx950 wave64 mfma_f32_16x16x4 ...")
+ * and returns the number of bytes needed. */
+int socmx_capabilities(char* buf, int cap);
+
+/* ---- control network --------------------------------------------------- */
+
+/* Number of floats of the MFMA-fragment-ordered image of a U-Net. */
+size_t socmx_unet_packed_floats(int32_t d, const int32_t hdims[3]);
+
+/* packed (device, socmx_unet_packed_floats floats) <- net. Re-run after every optimizer step. */
+int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_stream_t stream);
+
+/* out (N,d) = UNet(tx (N,d+1)).  Same kernel body as the rollout's per-step evaluation. */
+int socmx_unet_forward_f32(const float* packed, int32_t d, const int32_t hdims[3],
+                           const float* tx, int64_t N, float* out, socmx_stream_t stream);
+
+/* ---- rollout ------------------------------------------------------------ */
+
+/*
+ * K Euler-Maruyama steps of B trajectories (utils.py:17-128), one launch.
+ *   x0        (B,d)  device   initial states (the reference passes x0.repeat(B,1))
+ *   ts        (K+1,) device   time grid; dt_k = ts[k+1]-ts[k] in fp32 (utils.py:38)
+ *   noise_in  (K,B,d) device or NULL.  NULL => Philox4x32-10 keyed by (seed, offset,
+ *             row0 + row, step): counter = (row0+row, step, dim/4, offset), key = seed;
+ *             Box-Muller in fp32.  Independent of how rows are split over launches / GPUs.
+ *   outputs (all device, step-major exactly as torch.stack in utils.py:103-128):
+ *     states (K+1,B,d)  noises (K,B,d)  controls (K,B,d)
+ *     stop_indicators (K+1,B)  fractional_timesteps (K,B)  lpd, lps, ltw (B,)
+ *   The stopping-time branch (utils.py:42-44, 49-75) is taken iff kind == MOLECULAR_DYNAMICS,
+ *   mirroring `hasattr(sde, "Phi")` (utils.py:33).
+ */
+int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
+                      const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
+                      uint64_t seed, uint64_t offset, int64_t row0, const float* noise_in,
+                      float* states, float* noises, float* controls, float* stop_indicators,
+                      float* fractional_timesteps, float* lpd, float* lps, float* ltw,
+                      socmx_stream_t stream);
+
+/* ---- importance weights --------------------------------------------------- */
+
+/* w[m] = exp(lpd+lps+ltw) (method.py:258-262); stats[0..2] = (sum w, sum (w - mean)^2, B): mean and
+ * unbiased std (method.py:903-904) follow on the host; shards combine with Chan's parallel-variance rule. */
+int socmx_weights_stats_f32(const float* lpd, const float* lps, const float* ltw, int32_t B,
+                            float* w, float* stats, socmx_stream_t stream);
+
+/* Number of (t_i <= s_j) pairs: (K+1)(K+2)/2, ordered i-major, j ascending (method.py:533-547).
+ * M_all / dM_all below are (Np,d,d) in that order. */
+int64_t socmx_num_pairs(int32_t K);
+
+/* ---- SOCM least-squares target + weighted residual -------------------------------- */
+
+/*
+ * Operands of the restated contraction, one thread per (j,m):
+ *   v[j,m,:] = -( sqrt(lmbd) sqrt(dt_j) S^-T noise[j,m] + dt_j S^-T control[j,m] )
+ *   q[j,m,:] = dt_j nabla_f(X[j,m]) + nabla_b(X[j,m])^T v[j,m]      ((nabla_b^T v)_l = sum_n d b_n/d x_l v_n)
+ *   gT[m,:]  = nabla_g(X[K,m])
+ * written twice: batch-major  v,q (K,B,d), gT (B,d)   -- read by socmx_socm_target_bwd_f32
+ *                batch-fastest vT,qT (K,d,B), gTT (d,B) -- read by socmx_socm_target_fwd_f32 (lanes run along m)
+ * frac (K,B) may be NULL (=> dt_j = ts[j+1]-ts[j]), else per-sample fractional time steps.
+ */
+int socmx_socm_prep_f32(const socmx_problem* problem, const float* ts, int32_t K, int32_t B, float lmbd,
+                        const float* states, const float* noises, const float* controls,
+                        const float* frac, float* v, float* q, float* gT, float* vT, float* qT, float* gTT,
+                        socmx_stream_t stream);
+
+/*
+ * target[i,m,:] = sum_{j=i}^{K-1} ( M_ij q[j,m] - dM_ij v[j,m] ) + M_iK gT[m]
+ * r[i,m,:]      = sigma^T ( nablaV[i,m] - target[i,m] )
+ * objective    += inv_norm * sum_{i,m} w[m] |r[i,m]|^2             (inv_norm = 1/((K+1) B_global))
+ * G[i,m,:]      = d objective / d nablaV[i,m,:] = 2 w[m] inv_norm sigma r[i,m]   ( = - d objective/d target )
+ * objective (1,) is ACCUMULATED with one atomic per workgroup: zero it first.  target (K+1,B,d) may be NULL.
+ * nablaV, G: (K+1,B,d).  1 <= d <= 128.
+ */
+int socmx_socm_target_fwd_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* M_all,
+                              const float* dM_all, const float* qT, const float* vT, const float* gTT,
+                              const float* nablaV, const float* w, float inv_norm, float* target,
+                              float* G, float* objective, socmx_stream_t stream);
+
+/* gM[p] = -sum_m G[i,m] (x) qx[j,m],  gdM[p] = +sum_m G[i,m] (x) v[j,m]   (p = pair (i,j); qx = q for j<K,
+ * gT for j=K; gdM at j=K is 0).  Overwrites gM, gdM (Np,d,d). */
+int socmx_socm_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* G, const float* q,
+                              const float* v, const float* gT, float* gM, float* gdM,
+                              socmx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOCMX_H */

@@ -1,0 +1,430 @@
+// socmx_rollout.hip -- fused Euler-Maruyama rollout for gfx950 (MI355X).
+//
+// Replaces reference SOC_matching/utils.py:17-128 (stochastic_trajectories) together with the
+// per-step control evaluation (method.py:58-80, models.py:233-242) and the per-setting closed
+// forms (experiment_settings/*.py).  One workgroup owns one 16-row tile of the batch for ALL
+// K steps: the state, the seven activation tiles of the control network and the per-row cost
+// accumulators never leave the CU; per step the only HBM traffic is the coalesced write of the
+// tile's slab of states / noises / controls (the algorithmic bytes).  Weights stream from L2
+// in MFMA fragment order (socmx_unet.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/socmx.h"
+#include "socmx_unet.h"
+
+namespace socmx {
+
+// ---- Philox4x32-10 (Salmon et al. SC'11) ---------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// one N(0,1) draw for (global row, step, dim) -- contract documented in include/socmx.h
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint32_t grow, uint32_t step,
+                                               int dim) {
+  uint32_t w[4];
+  philox4x32_10(grow, step, (uint32_t)(dim >> 2), (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const int h = (dim >> 1) & 1;
+  const float ua = ((float)w[2 * h] + 0.5f) * 2.3283064365386963e-10f;      // 2^-32
+  const float ub = ((float)w[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+  const float r = sqrtf(-2.0f * logf(ua));
+  float s, c;
+  sincospif(2.0f * ub, &s, &c);
+  return (dim & 1) ? r * s : r * c;
+}
+
+struct RolloutArgs {
+  UnetDesc u;
+  TileLayout t;
+  int kind, d, B, K;
+  float lmbd;
+  uint64_t seed, offset;
+  int64_t row0;
+  const float* packed;
+  const float *sigma, *A, *P, *Q, *omega, *kappa, *nu;
+  const float *x0, *ts, *noise_in;
+  float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
+  int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
+};
+
+// drift b_i(x) -- OU_quadratic.py:51-52, OU_linear.py:43-44, double_well.py:44-48, molecular_dynamics.py:49-53
+__device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x, const float* A_l,
+                                         const float* __restrict__ kappa) {
+  if (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR) {
+    float s = 0.f;
+    for (int j = 0; j < d; ++j) s += A_l[i * d + j] * x[j];
+    return s;
+  }
+  const float xi = x[i];
+  return -2.f * kappa[i] * (xi * xi - 1.f) * 2.f * xi;
+}
+
+template <int NW, bool STOPPING>
+__global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int nthr = NW * 64;
+  const int d = a.d, B = a.B, K = a.K, kind = a.kind;
+  const int tile_row0 = blockIdx.x * 16;
+  float* X0 = lds + a.t.x0;
+  float* GV = lds + a.t.gv;
+  // small per-tile state (behind the network tiles)
+  float* sig = lds + a.lds_mats;          // (d,d)
+  float* A_l = sig + d * d;               // (d,d)  OU only
+  float* P_l = A_l + d * d;               // (d,d)  OU_quadratic only
+  float* XS = P_l + d * d;                // (16,d) current state
+  float* XN = XS + 16 * d;                // (16,d) proposed state
+  float* XF = XN + 16 * d;                // (16,d) state after the stopping re-interpolation
+  float* U = XF + 16 * d;                 // (16,d) control
+  float* E = U + 16 * d;                  // (16,d) noise
+  float* UP = E + 16 * d;                 // (16,d) update
+  float* ST = UP + 16 * d;                // (16,)  stop_inds (1 = still running)
+  float* SN = ST + 16;                    // (16,)  next stop_inds
+  float* FD = SN + 16;                    // (16,)  fractional time step
+
+  const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
+  for (int e = tid; e < d * d; e += nthr) {
+    sig[e] = a.sigma[e];
+    A_l[e] = is_ou ? a.A[e] : 0.f;
+    P_l[e] = (kind == SOCMX_OU_QUADRATIC) ? a.P[e] : 0.f;
+  }
+  for (int e = tid; e < 16 * d; e += nthr) {
+    const int r = e / d, i = e - r * d;
+    const int grow = min(tile_row0 + r, B - 1);  // ragged tail: replicate the last row, never stored
+    const float x = a.x0[(size_t)grow * d + i];
+    XS[e] = x;
+    if (tile_row0 + r < B) a.states[(size_t)(tile_row0 + r) * d + i] = x;  // states[0]
+  }
+  if (tid < 16) {
+    ST[tid] = 1.f;
+    if (tile_row0 + tid < B) a.stop_ind[tile_row0 + tid] = 1.f;  // stop_indicators[0] = ones (utils.py:28)
+  }
+  float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in threads 0..15
+  __syncthreads();
+
+  for (int k = 0; k < K; ++k) {
+    const float t0 = a.ts[k];
+    const float dt = a.ts[k + 1] - t0;        // utils.py:38
+    const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
+
+    // ---- network input [t, x, 0...]  (method.py:65-67) --------------------------------
+    for (int e = tid; e < 16 * a.u.in0p; e += nthr) {
+      const int r = e / a.u.in0p, c = e - r * a.u.in0p;
+      X0[r * a.t.s0 + c] = (c == 0) ? t0 : (c <= d ? XS[r * d + c - 1] : 0.f);
+    }
+    __syncthreads();
+    unet_tile_forward<NW>(a.packed, a.u, a.t, lds);  // GV = nabla_V(t, x)
+
+    // ---- control u = -sigma^T nabla_V (method.py:68-72) and the step's noise (utils.py:39) ---
+    for (int e = tid; e < 16 * d; e += nthr) {
+      const int r = e / d, i = e - r * d;
+      float s = 0.f;
+      for (int j = 0; j < d; ++j) s += sig[j * d + i] * GV[r * a.t.sg + j];
+      const float u = -s;
+      const int grow = tile_row0 + r;
+      float eps;
+      if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
+      else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
+      U[e] = u;
+      E[e] = eps;
+      if (grow < B) {
+        a.controls[((size_t)k * B + grow) * d + i] = u;
+        a.noises[((size_t)k * B + grow) * d + i] = eps;
+      }
+    }
+    __syncthreads();
+
+    // ---- Euler-Maruyama update (utils.py:45-48) ------------------------------------------
+    for (int e = tid; e < 16 * d; e += nthr) {
+      const int r = e / d, i = e - r * d;
+      const float bi = drift_i(kind, d, i, XS + r * d, A_l, a.kappa);
+      float su = 0.f, se = 0.f;
+      for (int j = 0; j < d; ++j) {
+        su += sig[i * d + j] * U[r * d + j];
+        se += sig[i * d + j] * E[r * d + j];
+      }
+      const float upd = (bi + su) * dt + sq_ldt * se;
+      UP[e] = upd;
+      XN[e] = XS[e] + ST[r] * upd;
+    }
+    __syncthreads();
+
+    const float* XE = XN;  // state at the end of the step
+    if (STOPPING) {
+      // utils.py:42-44, 49-75 with Phi(x) = -x_0 (molecular_dynamics.py:94-99)
+      for (int e = tid; e < 16 * d; e += nthr) {
+        const int r = e / d, i = e - r * d;
+        const float phi_b = -XS[r * d], phi_a = -XN[r * d];
+        const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
+        const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
+        const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
+        const float xi = js * (XS[e] + fr * ST[r] * UP[e]) + (1.f - js) * XN[e];
+        XF[e] = xi;
+        if (i == 0) {
+          FD[r] = js * (fr * fr) * dt + ns * dt;   // utils.py:70-72 (step_fraction squared)
+          SN[r] = (-xi > 0.f) ? 1.f : 0.f;         // utils.py:74
+        }
+      }
+      XE = XF;
+      __syncthreads();
+    }
+
+    // ---- running cost / log path weights (utils.py:82-99), f at the NEW state, OLD time ----
+    if (tid < 16) {
+      const int r = tid;
+      const float* x = XE + r * d;
+      float f = 0.f;
+      if (kind == SOCMX_OU_QUADRATIC) {  // OU_quadratic.py:66-69
+        for (int i = 0; i < d; ++i) {
+          float px = 0.f;
+          for (int j = 0; j < d; ++j) px += P_l[i * d + j] * x[j];
+          f += x[i] * px;
+        }
+      } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
+        f = 1.f;                         // molecular_dynamics.py:87
+      }
+      float uu = 0.f, ue = 0.f;
+      for (int i = 0; i < d; ++i) {
+        uu += U[r * d + i] * U[r * d + i];
+        ue += U[r * d + i] * E[r * d + i];
+      }
+      const float step = STOPPING ? FD[r] : dt;
+      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
+      lps = lps + sqrtf(step / a.lmbd) * (-ue);
+      const int grow = tile_row0 + r;
+      if (grow < B) {
+        a.frac[(size_t)k * B + grow] = step;
+        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
+      }
+      if (STOPPING) ST[r] = SN[r];
+    }
+    for (int e = tid; e < 16 * d; e += nthr) {
+      const int r = e / d, i = e - r * d;
+      const float x = XE[e];
+      XS[e] = x;
+      if (tile_row0 + r < B) a.states[((size_t)(k + 1) * B + tile_row0 + r) * d + i] = x;
+    }
+    __syncthreads();
+  }
+
+  // ---- terminal cost (utils.py:101) --------------------------------------------------------
+  if (tid < 16 && tile_row0 + tid < B) {
+    const float* x = XS + tid * d;
+    float gval = 0.f;
+    if (kind == SOCMX_OU_QUADRATIC) {          // OU_quadratic.py:76-79
+      for (int i = 0; i < d; ++i) {
+        float qx = 0.f;
+        for (int j = 0; j < d; ++j) qx += a.Q[i * d + j] * x[j];
+        gval += x[i] * qx;
+      }
+    } else if (kind == SOCMX_OU_LINEAR) {      // OU_linear.py:83-84
+      for (int i = 0; i < d; ++i) gval += a.omega[i] * x[i];
+    } else if (kind == SOCMX_DOUBLE_WELL) {    // double_well.py:75-84
+      for (int i = 0; i < d; ++i) {
+        const float q = x[i] * x[i] - 1.f;
+        gval += a.nu[i] * (q * q);
+      }
+    }
+    a.lpd[tile_row0 + tid] = lpd;
+    a.lps[tile_row0 + tid] = lps;
+    a.ltw[tile_row0 + tid] = -gval / a.lmbd;
+  }
+}
+
+// ---- nabla_V on arbitrary rows (method.py:272-278): same tile code, rows from HBM ----------
+struct ForwardArgs {
+  UnetDesc u;
+  TileLayout t;
+  const float* packed;
+  const float* tx;  // (N, d+1)
+  float* out;       // (N, d)
+  int64_t N;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void unet_forward_kernel(const ForwardArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, nthr = NW * 64;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  float* X0 = lds + a.t.x0;
+  float* GV = lds + a.t.gv;
+  const int in0 = a.u.in0, in0p = a.u.in0p, d = a.u.d;
+  for (int e = tid; e < 16 * in0p; e += nthr) {
+    const int r = e / in0p, c = e - r * in0p;
+    const int64_t grow = min(row0 + r, a.N - 1);
+    X0[r * a.t.s0 + c] = (c < in0) ? a.tx[grow * in0 + c] : 0.f;
+  }
+  __syncthreads();
+  unet_tile_forward<NW>(a.packed, a.u, a.t, lds);
+  for (int e = tid; e < 16 * d; e += nthr) {
+    const int r = e / d, i = e - r * d;
+    if (row0 + r < a.N) a.out[(row0 + r) * d + i] = GV[r * a.t.sg + i];
+  }
+}
+
+// ---- weight re-layout ---------------------------------------------------------------------------
+struct PackArgs {
+  UnetDesc u;
+  int fin[9], fout[9];
+  const float* w[9];
+  const float* b[9];
+  float* packed;
+};
+
+__global__ void unet_pack_kernel(const PackArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.u.total_floats) return;
+  int l = 8;
+  while (l > 0 && idx < a.u.L[l].w_off) --l;
+  const LayerDesc L = a.u.L[l];
+  float v = 0.f;
+  if (idx >= L.b_off) {
+    const int n = idx - L.b_off;
+    if (n < a.fout[l]) v = a.b[l][n];
+  } else {
+    const int rel = idx - L.w_off;
+    const int i = rel & 3, lane = (rel >> 2) & 63, chunk = rel >> 8;  // chunk = nb*KC + kc
+    const int KC = L.in_pad >> 4;
+    const int nb = chunk / KC, kc = chunk - nb * KC;
+    const int n = nb * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + i;
+    if (n < a.fout[l] && kk < a.fin[l]) v = a.w[l][(size_t)n * a.fin[l] + kk];
+  }
+  a.packed[idx] = v;
+}
+
+}  // namespace socmx
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace socmx;
+
+static const int kMaxLdsBytes = 160 * 1024;
+
+static bool dims_ok(int d, const int32_t h[3]) {
+  if (d < 1 || d > 1024) return false;
+  for (int i = 0; i < 3; ++i)
+    if (h[i] < 1 || h[i] > 4096) return false;
+  return true;
+}
+
+extern "C" int socmx_version(void) { return SOCMX_VERSION; }
+
+extern "C" int socmx_capabilities(char* buf, int cap) {
+  static const char msg[] =
+      "socmx 0.1.0; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network; "
+      "Philox4x32-10 noise; kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target";
+  const int need = (int)sizeof(msg);
+  if (buf && cap > 0) {
+    const int n = need < cap ? need : cap;
+    memcpy(buf, msg, n);
+    buf[n - 1] = 0;
+  }
+  return need;
+}
+
+extern "C" size_t socmx_unet_packed_floats(int32_t d, const int32_t hdims[3]) {
+  if (!hdims || !dims_ok(d, hdims)) return 0;
+  const int h[3] = {hdims[0], hdims[1], hdims[2]};
+  return (size_t)make_unet_desc(d, h).total_floats;
+}
+
+extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_stream_t stream) {
+  if (!net || !packed) return SOCMX_E_NULL;
+  if (!dims_ok(net->d, net->hdims)) return SOCMX_E_DIM;
+  PackArgs a;
+  const int h[3] = {net->hdims[0], net->hdims[1], net->hdims[2]};
+  a.u = make_unet_desc(net->d, h);
+  unet_layer_dims(net->d, h, a.fin, a.fout);
+  for (int l = 0; l < 9; ++l) {
+    if (!net->weight[l] || !net->bias[l]) return SOCMX_E_NULL;
+    a.w[l] = net->weight[l];
+    a.b[l] = net->bias[l];
+  }
+  a.packed = packed;
+  const int threads = 256, blocks = (a.u.total_floats + threads - 1) / threads;
+  hipLaunchKernelGGL(unet_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)
+
+extern "C" int socmx_unet_forward_f32(const float* packed, int32_t d, const int32_t hdims[3], const float* tx,
+                                      int64_t N, float* out, socmx_stream_t stream) {
+  if (!packed || !hdims || !tx || !out) return SOCMX_E_NULL;
+  if (!dims_ok(d, hdims) || N < 0) return SOCMX_E_DIM;
+  if (N == 0) return 0;
+  ForwardArgs a;
+  const int h[3] = {hdims[0], hdims[1], hdims[2]};
+  a.u = make_unet_desc(d, h);
+  a.t = make_tile_layout(a.u, kWaves);
+  a.packed = packed; a.tx = tx; a.out = out; a.N = N;
+  const size_t lds_bytes = (size_t)a.t.floats * sizeof(float);
+  if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
+  auto kern = unet_forward_kernel<kWaves>;
+  hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err != hipSuccess) return (int)err;
+  const int64_t blocks = (N + 15) / 16;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3],
+                                 const float* x0, const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed,
+                                 uint64_t offset, int64_t row0, const float* noise_in, float* states, float* noises,
+                                 float* controls, float* stop_indicators, float* fractional_timesteps, float* lpd,
+                                 float* lps, float* ltw, socmx_stream_t stream) {
+  if (!pb || !packed_unet || !hdims || !x0 || !ts || !states || !noises || !controls || !stop_indicators ||
+      !fractional_timesteps || !lpd || !lps || !ltw || !pb->sigma)
+    return SOCMX_E_NULL;
+  const int d = pb->d;
+  if (!dims_ok(d, hdims) || B < 1 || K < 1) return SOCMX_E_DIM;
+  switch (pb->kind) {
+    case SOCMX_OU_QUADRATIC: if (!pb->A || !pb->P || !pb->Q) return SOCMX_E_NULL; break;
+    case SOCMX_OU_LINEAR: if (!pb->A || !pb->omega) return SOCMX_E_NULL; break;
+    case SOCMX_DOUBLE_WELL: if (!pb->kappa || !pb->nu) return SOCMX_E_NULL; break;
+    case SOCMX_MOLECULAR_DYNAMICS: if (!pb->kappa) return SOCMX_E_NULL; break;
+    default: return SOCMX_E_KIND;
+  }
+  RolloutArgs a;
+  const int h[3] = {hdims[0], hdims[1], hdims[2]};
+  a.u = make_unet_desc(d, h);
+  a.t = make_tile_layout(a.u, kWaves);
+  a.kind = pb->kind; a.d = d; a.B = B; a.K = K; a.lmbd = lmbd;
+  a.seed = seed; a.offset = offset; a.row0 = row0;
+  a.packed = packed_unet;
+  a.sigma = pb->sigma; a.A = pb->A; a.P = pb->P; a.Q = pb->Q; a.omega = pb->omega; a.kappa = pb->kappa; a.nu = pb->nu;
+  a.x0 = x0; a.ts = ts; a.noise_in = noise_in;
+  a.states = states; a.noises = noises; a.controls = controls; a.stop_ind = stop_indicators;
+  a.frac = fractional_timesteps; a.lpd = lpd; a.lps = lps; a.ltw = ltw;
+  a.lds_mats = (a.t.floats + 3) & ~3;
+  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * d + 6 * 16 * (size_t)d + 48;
+  const size_t lds_bytes = lds_floats * sizeof(float);
+  if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
+  const int blocks = (B + 15) / 16;
+  hipError_t err;
+  if (pb->kind == SOCMX_MOLECULAR_DYNAMICS) {
+    auto kern = rollout_kernel<kWaves, true>;
+    err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+  } else {
+    auto kern = rollout_kernel<kWaves, false>;
+    err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+  }
+  return (int)hipGetLastError();
+}

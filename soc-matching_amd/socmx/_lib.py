@@ -1,0 +1,114 @@
+"""ctypes binding of libsocmx.so (C ABI: include/socmx.h).
+
+The library is built in-tree by `make -C soc-matching_amd/csrc` (or
+`__graft_entry__.build()`) and sits next to this file.  There is no fallback:
+`lib()` raises if the shared object is missing or does not export the ABI, so a
+GPU run can never silently take another path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsocmx.so")
+
+OU_QUADRATIC, OU_LINEAR, DOUBLE_WELL, MOLECULAR_DYNAMICS = 0, 1, 2, 3
+
+# order of socmx_unet.weight[] / bias[] (include/socmx.h, SOCMX_L_*)
+UNET_LAYERS = ("down_0", "down_1", "down_2", "res_0", "res_1", "res_2", "up_2", "up_1", "up_0")
+
+_fp = C.c_void_p  # device pointers travel as plain addresses
+
+
+class Problem(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("sigma", _fp), ("sigma_inv_t", _fp),
+                ("A", _fp), ("P", _fp), ("Q", _fp), ("omega", _fp), ("kappa", _fp), ("nu", _fp)]
+
+
+class Unet(C.Structure):
+    _fields_ = [("d", C.c_int32), ("hdims", C.c_int32 * 3), ("weight", _fp * 9), ("bias", _fp * 9)]
+
+
+_I3 = C.c_int32 * 3
+_I2 = C.c_int32 * 2
+_P3 = _fp * 3
+
+# name -> (restype, argtypes); one entry per declaration in include/socmx.h
+PROTOTYPES = {
+    "socmx_version": (C.c_int, []),
+    "socmx_capabilities": (C.c_int, [C.c_char_p, C.c_int]),
+    "socmx_unet_packed_floats": (C.c_size_t, [C.c_int32, C.POINTER(C.c_int32)]),
+    "socmx_unet_pack_f32": (C.c_int, [C.POINTER(Unet), _fp, _fp]),
+    "socmx_unet_forward_f32": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_int32), _fp, C.c_int64, _fp, _fp]),
+    "socmx_rollout_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
+                                    C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
+                                    _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_weights_stats_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp]),
+    "socmx_num_pairs": (C.c_int64, [C.c_int32]),
+    "socmx_socm_prep_f32": (C.c_int, [C.POINTER(Problem), _fp, C.c_int32, C.c_int32, C.c_float,
+                                      _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_socm_target_fwd_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, _fp,
+                                            _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp]),
+    "socmx_socm_target_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
+                                            _fp]),
+}
+
+_lib = None
+
+
+class SocmxError(RuntimeError):
+    pass
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """The loaded library.  Raises SocmxError when it is missing -- by design no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SocmxError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(`make -C soc-matching_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "socmx has no CPU/torch fallback for the GPU hot path.")
+        # torch is imported above so that its bundled libamdhip64.so.7 is the HIP runtime in this
+        # process; libsocmx.so's DT_NEEDED of the same soname then binds to it.
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise SocmxError(f"{LIB_PATH} does not export {name}: stale build?") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        kind = "invalid argument" if status < 0 else "hipError_t"
+        raise SocmxError(f"{what} failed with status {status} ({kind})")
+
+
+def ptr(t):
+    """Device address of a contiguous fp32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def i3(v):
+    return _I3(*[int(x) for x in v])
+
+
+def i2(v):
+    return _I2(*[int(x) for x in v])

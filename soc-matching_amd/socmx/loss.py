@@ -1,0 +1,201 @@
+"""SOCM matching loss (reference SOC_matching/method.py:480-720), restated.
+
+With  v_jm = -( sqrt(lmbd) sqrt(dt_j) S^-T eps_jm + dt_j S^-T u_jm ),
+      q_jm = dt_j nabla_f(X_jm) + nabla_b(X_jm)^T v_jm,
+the reference's least-squares target (method.py:591-690) is
+
+  target[i,m] = sum_{j=i}^{K-1} ( M_ij q_jm - dM_ij v_jm ) + M_iK nabla_g(X_Km)
+
+and  objective = sum_{i,m} w_m | sigma^T (nabla_V(t_i,X_im) - target[i,m]) |^2 / ((K+1) B)
+(method.py:702-720).  This needs O(Np d^2 + Kp B d) memory instead of the
+reference's (Kp,Kp,B,d,d) intermediates (method.py:614-618) and is algebraically
+identical (checked against the reference-generated fixtures in tests/).
+
+Two executions of the same math:
+  * CUDA tensors -> HIP kernels through `libsocmx.so` (csrc/socmx_loss.hip) wrapped in
+    `torch.autograd.Function`s; missing library raises.
+  * CPU tensors  -> plain torch (BASELINE config 0 plumbing; gloo tests).
+The network GEMMs (nabla_V on the Kp*B trajectory rows, the M network on the Np
+pairs) are library GEMMs via torch autograd in both cases.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+# --------------------------------------------------------------------------------------
+# pair grid
+# --------------------------------------------------------------------------------------
+
+def pair_index(K, device):
+    """(i, j) index vectors of the Np=(K+1)(K+2)/2 pairs t_i <= s_j, i-major (method.py:533-547)."""
+    ii, jj = torch.triu_indices(K + 1, K + 1, device=device)
+    return ii, jj
+
+
+def pair_times(ts, T, K):
+    """The reference builds s by `linspace(t_k, T, K+1-k)` per row (method.py:535-537); those values
+    differ from ts[j] by <= 1 ulp.  We reproduce the linspace values exactly in closed form:
+    s = t_k + step*(j-k) for the lower half, T - step*(n-1-(j-k)) for the upper half (torch.linspace
+    semantics), which keeps CPU parity with the fixtures bit-tight."""
+    dev = ts.device
+    ii, jj = pair_index(K, dev)
+    t = ts[ii]
+    n = (K + 1 - ii).to(ts.dtype)                      # points in row i
+    r = (jj - ii).to(ts.dtype)                          # position inside the row
+    step = (T - t) / torch.clamp(n - 1, min=1)
+    lower = t + step * r
+    upper = T - step * (n - 1 - r)
+    s = torch.where(r < torch.floor(n / 2), lower, upper)
+    s = torch.where(n == 1, t, s)
+    return t, s, ii, jj
+
+
+# --------------------------------------------------------------------------------------
+# operands
+# --------------------------------------------------------------------------------------
+
+def socm_operands(pb, ts, lmbd, states, noises, controls, frac=None):
+    """v, q (K,B,d) and gT (B,d) in torch (any device)."""
+    sit = pb.sigma_inv_t()
+    dts = (ts[1:] - ts[:-1]).reshape(-1, 1, 1) if frac is None else frac.unsqueeze(-1)
+    vt = noises @ sit.T
+    ut = controls @ sit.T
+    v = -(math.sqrt(lmbd) * torch.sqrt(dts) * vt + dts * ut)
+    xs = states[:-1]
+    q = dts * pb.nabla_f(ts[:-1], xs) + pb.nabla_b_T_apply(xs, v)
+    gT = pb.nabla_g(states[-1])
+    return v, q, gT
+
+
+# --------------------------------------------------------------------------------------
+# target + residual
+# --------------------------------------------------------------------------------------
+
+def target_residual_torch(pb, K, M_all, dM_all, q, v, gT, nablaV, w, inv_norm):
+    """Dense-scatter formulation in plain torch: one (Kp d x K d) GEMM per operand."""
+    d = pb.d
+    dev = M_all.device
+    Kp = K + 1
+    ii, jj = pair_index(K, dev)
+    Md = torch.zeros(Kp, Kp, d, d, device=dev, dtype=M_all.dtype).index_put((ii, jj), M_all)
+    dMd = torch.zeros(Kp, Kp, d, d, device=dev, dtype=M_all.dtype).index_put((ii, jj), dM_all)
+    B = q.shape[1]
+    A1 = Md[:, :K].permute(0, 2, 1, 3).reshape(Kp * d, K * d)
+    A2 = dMd[:, :K].permute(0, 2, 1, 3).reshape(Kp * d, K * d)
+    qm = q.permute(0, 2, 1).reshape(K * d, B)
+    vm = v.permute(0, 2, 1).reshape(K * d, B)
+    tgt = (A1 @ qm - A2 @ vm).reshape(Kp, d, B).permute(0, 2, 1)
+    tgt = tgt + torch.einsum("ikl,ml->imk", Md[:, K], gT)
+    r = (nablaV - tgt) @ pb.sigma
+    objective = (r * r * w.reshape(1, -1, 1)).sum() * inv_norm
+    return objective, tgt
+
+
+def socm_operands_hip(pb, ts, lmbd, states, noises, controls, frac=None):
+    """socmx_socm_prep_f32: operands in both layouts (batch-major for bwd, batch-fastest for fwd)."""
+    L = _lib.lib()
+    K, B, d = noises.shape
+    dev = states.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    v, q = torch.empty(K, B, d, **f32), torch.empty(K, B, d, **f32)
+    vT, qT = torch.empty(K, d, B, **f32), torch.empty(K, d, B, **f32)
+    gT, gTT = torch.empty(B, d, **f32), torch.empty(d, B, **f32)
+    tsc = ts.detach().to(**f32).contiguous()
+    _lib.check(L.socmx_socm_prep_f32(
+        pb.c_struct(), _lib.ptr(tsc), K, B, float(lmbd), _lib.ptr(states.contiguous()),
+        _lib.ptr(noises.contiguous()), _lib.ptr(controls.contiguous()),
+        _lib.ptr(frac.contiguous()) if frac is not None else None,
+        _lib.ptr(v), _lib.ptr(q), _lib.ptr(gT), _lib.ptr(vT), _lib.ptr(qT), _lib.ptr(gTT),
+        _lib.stream_ptr(dev)), "socmx_socm_prep_f32")
+    return dict(v=v, q=q, gT=gT, vT=vT, qT=qT, gTT=gTT)
+
+
+class _TargetResidualHip(torch.autograd.Function):
+    """objective = socmx_socm_target_fwd_f32(...); grads by socmx_socm_target_bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, M_all, dM_all, nablaV, w, ops, pb, K, inv_norm, want_target):
+        L = _lib.lib()
+        dev = M_all.device
+        B, d = ops["gT"].shape
+        c = lambda t: t.detach().to(torch.float32).contiguous()
+        M_all, dM_all, nablaV, w = map(c, (M_all, dM_all, nablaV, w))
+        G = torch.empty_like(nablaV)
+        target = torch.empty_like(nablaV) if want_target else None
+        obj = torch.zeros(1, dtype=torch.float32, device=dev)
+        _lib.check(L.socmx_socm_target_fwd_f32(
+            pb.c_struct(), K, B, _lib.ptr(M_all), _lib.ptr(dM_all), _lib.ptr(ops["qT"]), _lib.ptr(ops["vT"]),
+            _lib.ptr(ops["gTT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm), _lib.ptr(target),
+            _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_f32")
+        ctx.save_for_backward(G, ops["q"], ops["v"], ops["gT"])
+        ctx.dims = (d, K, B, M_all.shape[0])
+        if want_target:
+            ctx.mark_non_differentiable(target)
+            return obj[0], target
+        return obj[0]
+
+    @staticmethod
+    def backward(ctx, gout, *unused):
+        L = _lib.lib()
+        G, q, v, gT = ctx.saved_tensors
+        d, K, B, Np = ctx.dims
+        gM = gdM = gV = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gM = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
+            gdM = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
+            _lib.check(L.socmx_socm_target_bwd_f32(
+                d, K, B, _lib.ptr(G), _lib.ptr(q), _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gM), _lib.ptr(gdM),
+                _lib.stream_ptr(G.device)), "socmx_socm_target_bwd_f32")
+            gM = gM * gout
+            gdM = gdM * gout
+        if ctx.needs_input_grad[2]:
+            gV = G * gout
+        return gM, gdM, gV, None, None, None, None, None, None
+
+
+def socm_objective(pb, ts, lmbd, K, states, noises, controls, M_all, dM_all, nablaV, w, inv_norm,
+                   want_target=False):
+    """The SOCM objective from the rollout buffers and the network outputs.
+    CUDA tensors: HIP kernels (raises if libsocmx.so is missing).  CPU tensors: plain torch."""
+    if M_all.is_cuda:
+        ops = socm_operands_hip(pb, ts, lmbd, states, noises, controls)
+        return _TargetResidualHip.apply(M_all, dM_all, nablaV, w, ops, pb, K, inv_norm, want_target)
+    v, q, gT = socm_operands(pb, ts, lmbd, states, noises, controls)
+    obj, tgt = target_residual_torch(pb, K, M_all, dM_all, q, v, gT, nablaV, w, inv_norm)
+    return (obj, tgt.detach()) if want_target else obj
+
+
+# --------------------------------------------------------------------------------------
+# importance weights
+# --------------------------------------------------------------------------------------
+
+def weights_and_stats(lpd, lps, ltw):
+    """w = exp(lpd+lps+ltw) (method.py:258-262) and stats = (sum w, sum (w-mean_local)^2, n): mean and
+    unbiased std (method.py:903-904) follow from it, and shards combine with Chan's formula."""
+    if lpd.is_cuda:
+        L = _lib.lib()
+        B = lpd.shape[0]
+        w = torch.empty_like(lpd)
+        stats = torch.empty(3, dtype=torch.float32, device=lpd.device)
+        _lib.check(L.socmx_weights_stats_f32(_lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), B, _lib.ptr(w),
+                                             _lib.ptr(stats), _lib.stream_ptr(lpd.device)),
+                   "socmx_weights_stats_f32")
+        return w, stats
+    w = torch.exp(lpd + lps + ltw)
+    return w, torch.stack([w.sum(), ((w - w.mean()) ** 2).sum(), torch.tensor(float(w.shape[0]))])
+
+
+def combine_stats(all_stats):
+    """(G,3) per-shard stats -> (3,) global stats (Chan et al. parallel variance)."""
+    s1, m2, n = all_stats[:, 0], all_stats[:, 1], all_stats[:, 2]
+    N = n.sum()
+    mean = s1.sum() / N
+    M2 = m2.sum() + (n * (s1 / n - mean) ** 2).sum()
+    return torch.stack([s1.sum(), M2, N])
+
+
+def mean_std_from_stats(stats):
+    return stats[0] / stats[2], torch.sqrt(stats[1] / (stats[2] - 1))

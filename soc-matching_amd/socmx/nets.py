@@ -1,0 +1,187 @@
+"""Networks of the hot path, parameter-compatible with the reference.
+
+* `FullyConnectedUNet`  -- nabla_V(t,x): reference models.py:202-242.
+* `SigmoidMLP`          -- M(t,s) with M(t,t)=I: reference models.py:245-275.
+* `TwoBoundarySigmoidMLP` -- per-sample M for stopping times: models.py:278-393.
+
+State-dict keys (`down_0.0.weight`, `sigmoid_layers.4.bias`, ...) and the order in
+which `nn.Linear` layers are constructed (hence the RNG stream consumed from a
+given `torch.manual_seed`) match the reference, so checkpoints and seeds carry
+over.  The modules are ordinary torch modules (autograd through hipBLASLt GEMMs);
+`FullyConnectedUNet.packed()` additionally exposes the MFMA-fragment image that
+the fused rollout kernel streams.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+# (name, fan_in, fan_out, relu) in reference construction order (models.py:212-228);
+# sizes as functions of (d, h0, h1, h2)
+_UNET_SPEC = (
+    ("down_0", lambda d, h: (d + 1, h[0]), True),
+    ("down_1", lambda d, h: (h[0], h[1]), True),
+    ("down_2", lambda d, h: (h[1], h[2]), True),
+    ("res_0", lambda d, h: (d + 1, d), False),
+    ("res_1", lambda d, h: (h[0], h[0]), False),
+    ("res_2", lambda d, h: (h[1], h[1]), False),
+    ("up_2", lambda d, h: (h[2], h[1]), True),
+    ("up_1", lambda d, h: (h[1], h[0]), True),
+    ("up_0", lambda d, h: (h[0], d), True),
+)
+
+
+def _scale_(seq, factor):
+    for m in seq:
+        if isinstance(m, nn.Linear):
+            m.weight.data *= factor
+            m.bias.data *= factor
+
+
+class FullyConnectedUNet(nn.Module):
+    def __init__(self, dim=2, hdims=(256, 128, 64), scaling_factor=1.0):
+        super().__init__()
+        self.dim = int(dim)
+        self.hdims = [int(h) for h in hdims]
+        for name, dims, relu in _UNET_SPEC:
+            fin, fout = dims(self.dim, self.hdims)
+            seq = nn.Sequential(nn.Linear(fin, fout), nn.ReLU()) if relu else nn.Sequential(nn.Linear(fin, fout))
+            setattr(self, name, seq)
+        # the reference scales in the order down_*, res_*, up_0, up_1, up_2 -- order is irrelevant
+        for name, _, _ in _UNET_SPEC:
+            _scale_(getattr(self, name), scaling_factor)
+        self._packed = None
+        self._packed_version = None
+
+    def forward(self, x):
+        r1 = self.down_0(x)
+        r2 = self.down_1(r1)
+        r3 = self.down_2(r2)
+        o2 = self.up_2(r3) + self.res_2(r2)
+        o1 = self.up_1(o2) + self.res_1(r1)
+        return self.up_0(o1) + self.res_0(x)
+
+    # ---- HIP side ---------------------------------------------------------------
+    def _version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def c_struct(self):
+        s = _lib.Unet(d=self.dim, hdims=_lib.i3(self.hdims))
+        keep = []
+        for i, name in enumerate(_lib.UNET_LAYERS):
+            lin = getattr(self, name)[0]
+            w = lin.weight.detach().contiguous()
+            b = lin.bias.detach().contiguous()
+            keep += [w, b]
+            s.weight[i] = _lib.ptr(w)
+            s.bias[i] = _lib.ptr(b)
+        return s, keep
+
+    def packed(self):
+        """Fragment-ordered image of the current weights (re-packed when any parameter changed)."""
+        L = _lib.lib()
+        ver = self._version()
+        if self._packed is None or self._packed_version != ver:
+            dev = next(self.parameters()).device
+            n = L.socmx_unet_packed_floats(self.dim, _lib.i3(self.hdims))
+            if self._packed is None or self._packed.numel() != n or self._packed.device != dev:
+                self._packed = torch.empty(n, dtype=torch.float32, device=dev)
+            s, keep = self.c_struct()
+            _lib.check(L.socmx_unet_pack_f32(s, _lib.ptr(self._packed), _lib.stream_ptr(dev)), "socmx_unet_pack_f32")
+            self._packed_version = ver
+        return self._packed
+
+    def __getstate__(self):  # keep the solver picklable (reference main.py:466 pickles the module)
+        st = self.__dict__.copy()
+        st["_packed"] = None
+        st["_packed_version"] = None
+        return st
+
+
+def unet_forward_hip(net, tx):
+    """nabla_V rows through the fused MFMA kernel (no autograd): socmx_unet_forward_f32."""
+    L = _lib.lib()
+    tx = tx.detach().to(torch.float32).contiguous()
+    out = torch.empty(tx.shape[0], net.dim, dtype=torch.float32, device=tx.device)
+    _lib.check(L.socmx_unet_forward_f32(_lib.ptr(net.packed()), net.dim, _lib.i3(net.hdims), _lib.ptr(tx),
+                                        tx.shape[0], _lib.ptr(out), _lib.stream_ptr(tx.device)),
+               "socmx_unet_forward_f32")
+    return out
+
+
+class SigmoidMLP(nn.Module):
+    def __init__(self, dim=10, hdims=(128, 128), gamma=3.0, scaling_factor=1.0):
+        super().__init__()
+        self.dim = int(dim)
+        self.hdims = [int(h) for h in hdims]
+        self.gamma = gamma  # shared nn.Parameter owned by the NeuralSDE (method.py:134)
+        self.sigmoid_layers = nn.Sequential(
+            nn.Linear(2, self.hdims[0]), nn.ReLU(),
+            nn.Linear(self.hdims[0], self.hdims[1]), nn.ReLU(),
+            nn.Linear(self.hdims[1], self.dim * self.dim),
+        )
+        self.scaling_factor = scaling_factor
+        _scale_(self.sigmoid_layers, scaling_factor)
+
+    def net(self, t, s):
+        return self.sigmoid_layers(torch.stack((t, s), dim=1)).reshape(-1, self.dim, self.dim)
+
+    def forward(self, t, s):
+        decay = torch.exp(-self.gamma * (s - t)).reshape(-1, 1, 1)
+        eye = torch.eye(self.dim, device=t.device, dtype=t.dtype)
+        return decay * eye + (1.0 - decay) * self.net(t, s)
+
+    def forward_with_ds(self, t, s):
+        """(M, dM/ds) with the s-derivative as an analytic forward tangent
+        (the reference differentiates with functorch.jacrev: method.py:510-515)."""
+        l0, l2, l4 = self.sigmoid_layers[0], self.sigmoid_layers[2], self.sigmoid_layers[4]
+        a1 = torch.addmm(l0.bias, torch.stack((t, s), dim=1), l0.weight.T)
+        h1 = torch.relu(a1)
+        a2 = torch.addmm(l2.bias, h1, l2.weight.T)
+        h2 = torch.relu(a2)
+        net = torch.addmm(l4.bias, h2, l4.weight.T).reshape(-1, self.dim, self.dim)
+        t1 = (a1 > 0).to(a1.dtype) * l0.weight[:, 1]
+        t2 = (a2 > 0).to(a2.dtype) * (t1 @ l2.weight.T)
+        dnet = (t2 @ l4.weight.T).reshape(-1, self.dim, self.dim)
+        decay = torch.exp(-self.gamma * (s - t)).reshape(-1, 1, 1)
+        eye = torch.eye(self.dim, device=t.device, dtype=t.dtype)
+        M = decay * eye + (1.0 - decay) * net
+        dM = self.gamma * decay * (net - eye) + (1.0 - decay) * dnet
+        return M, dM
+
+
+class TwoBoundarySigmoidMLP(nn.Module):
+    """Per-sample M(t, s; tau) for the stopping-time SOCM loss (molecular_dynamics)."""
+
+    def __init__(self, dim=10, hdims=(128, 128), gamma=3.0, gamma2=3.0, gamma3=3.0, scaling_factor=1.0, T=1.0):
+        super().__init__()
+        self.dim = int(dim)
+        self.gamma, self.gamma2, self.gamma3 = gamma, gamma2, gamma3
+        self.T = T
+        self.sigmoid_layers = nn.Sequential(
+            nn.Linear(3, hdims[0]), nn.ReLU(),
+            nn.Linear(hdims[0], hdims[1]), nn.ReLU(),
+            nn.Linear(hdims[1], self.dim * self.dim),
+        )
+        self.scaling_factor = scaling_factor
+        _scale_(self.sigmoid_layers, scaling_factor)
+
+    def forward(self, t, s, stopping_timestep_values):
+        tau = stopping_timestep_values                       # (N, B)
+        d = self.dim
+        flag = lambda v: torch.full_like(s, v)
+        net0 = self.sigmoid_layers(torch.stack((t, s, flag(0.0)), 1)).reshape(-1, 1, d, d)  # stopped
+        net1 = self.sigmoid_layers(torch.stack((t, s, flag(1.0)), 1)).reshape(-1, 1, d, d)  # running
+        eye = torch.eye(d, device=t.device).reshape(1, 1, d, d)
+        st = (s - t).unsqueeze(1)
+        ratio = (1 - torch.exp(-self.gamma * st)) / (1 - torch.exp(-self.gamma * torch.abs(tau - t.unsqueeze(1))) + 1e-7)
+        factor1 = torch.nan_to_num(1 - torch.minimum(ratio, torch.ones(1, device=t.device)), nan=0.0)
+        factor1 = factor1 * (tau - 1e-3 > s.unsqueeze(1)).to(torch.int)
+        running = (tau > self.T - 1e-3).to(torch.int)
+        e3 = torch.exp(-self.gamma3 * st)
+        g2 = lambda x: (1 - torch.exp(-self.gamma2 * x)) * (torch.exp(-self.gamma2 * x) - torch.exp(-self.gamma2))
+        w_eye = (1 - running) * factor1 + running * e3
+        out = w_eye.unsqueeze(2).unsqueeze(3) * eye
+        out = out + ((1 - running) * g2(factor1)).unsqueeze(2).unsqueeze(3) * net0
+        out = out + (running * (1 - e3)).unsqueeze(2).unsqueeze(3) * net1
+        return out

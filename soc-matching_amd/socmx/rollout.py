@@ -1,0 +1,136 @@
+"""Batched Euler-Maruyama rollout: `stochastic_trajectories`.
+
+Drop-in for reference SOC_matching/utils.py:17-128 -- same arguments, same
+8-tuple `(states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw,
+controls)` in the same step-major layouts.
+
+Routing (explicit, never silent):
+  * tensors on a CUDA (ROCm) device AND the sde is a known problem descriptor
+    with the learned control, no warm start, `detach=True`
+        -> ONE launch of the fused HIP kernel (csrc/socmx_rollout.hip).  If
+           libsocmx.so is missing this RAISES.
+  * anything else (CPU tensors = BASELINE config 0 "plumbing"; a user-supplied
+    `sde.u` control such as the ground-truth controls; `detach=False` for the
+    rel_entropy loss; warm start; a foreign NeuralSDE subclass)
+        -> `eager_trajectories`, a device-agnostic torch implementation of the
+           same recurrence.
+Extra keyword-only arguments (not in the reference): `noise_in` injects the
+(K,B,d) noise (exact parity runs), `seed`/`offset`/`row0` key the device Philox
+stream (row0 = global index of this shard's first trajectory, so multi-GPU runs
+are independent of the sharding).
+"""
+import torch
+
+from . import _lib
+
+_philox_calls = 0  # advances the Philox offset so successive rollouts draw fresh noise
+
+
+def _eligible_for_hip(sde, x0, detach):
+    return (
+        x0.is_cuda
+        and detach
+        and getattr(sde, "problem", None) is not None
+        and getattr(sde, "use_learned_control", False)
+        and not (getattr(sde, "use_warm_start", False) and getattr(sde, "u_warm_start", None))
+        and hasattr(sde, "nabla_V")
+        and hasattr(sde.nabla_V, "packed")
+    )
+
+
+def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noise_in=None, seed=None,
+                            offset=None, row0=0):
+    if _eligible_for_hip(sde, x0, detach):
+        return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0)
+    return eager_trajectories(sde, x0, t, lmbd, detach=detach, verbose=verbose, noise_in=noise_in)
+
+
+# --------------------------------------------------------------------------------------
+# fused HIP path
+# --------------------------------------------------------------------------------------
+
+def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0):
+    global _philox_calls
+    L = _lib.lib()
+    pb = sde.problem
+    dev = x0.device
+    B, d = x0.shape
+    K = t.shape[0] - 1
+    x0c = x0.detach().to(torch.float32).contiguous()
+    tc = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    states = torch.empty(K + 1, B, d, **f32)
+    noises = torch.empty(K, B, d, **f32)
+    controls = torch.empty(K, B, d, **f32)
+    stop = torch.empty(K + 1, B, **f32)
+    frac = torch.empty(K, B, **f32)
+    lpd = torch.empty(B, **f32)
+    lps = torch.empty(B, **f32)
+    ltw = torch.empty(B, **f32)
+    if noise_in is not None:
+        noise_in = noise_in.detach().to(**f32).contiguous()
+        assert noise_in.shape == (K, B, d), noise_in.shape
+    if seed is None:
+        seed = torch.initial_seed()
+    if offset is None:
+        offset = _philox_calls
+        _philox_calls += 1
+    net = sde.nabla_V
+    status = L.socmx_rollout_f32(
+        pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,
+        float(lmbd), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), int(row0), _lib.ptr(noise_in),
+        _lib.ptr(states), _lib.ptr(noises), _lib.ptr(controls), _lib.ptr(stop), _lib.ptr(frac),
+        _lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), _lib.stream_ptr(dev))
+    _lib.check(status, "socmx_rollout_f32")
+    return states, noises, stop, frac, lpd, lps, ltw, controls
+
+
+# --------------------------------------------------------------------------------------
+# device-agnostic torch path (CPU plumbing config, foreign controls, detach=False)
+# --------------------------------------------------------------------------------------
+
+def eager_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, noise_in=None):
+    B = x0.shape[0]
+    dev = x0.device
+    ones = torch.ones(B, device=dev)
+    stopping = hasattr(sde, "Phi")            # the reference keys on the attribute, not the config flag
+    sigma = sde.sigma
+    xs, eps_all, us, stops, fracs = [x0], [], [], [ones], []
+    lpd = torch.zeros(B, device=dev)
+    lps = torch.zeros(B, device=dev)
+    running = ones
+    x = x0
+    for k in range(t.shape[0] - 1):
+        t0 = t[k]
+        dt = t[k + 1] - t0
+        eps = noise_in[k] if noise_in is not None else torch.randn_like(x)
+        u = sde.control(t0, x, verbose=verbose)
+        step = (sde.b(t0, x) + u @ sigma.T) * dt + torch.sqrt(lmbd * dt) * (eps @ sigma.T)
+        x_prop = x + running.unsqueeze(1) * step
+        if stopping:
+            phi_b, phi_a = sde.Phi(x), sde.Phi(x_prop)
+            alive = ((phi_b > 0) & (phi_a > 0)).to(torch.float)
+            crossed = ((phi_b > 0) & (phi_a < 0)).to(torch.float)
+            part = crossed * (phi_b / (phi_b - phi_a + 1e-6) + 1e-6)
+            c = crossed.unsqueeze(1)
+            x_new = c * (x + part.unsqueeze(1) * running.unsqueeze(1) * step) + (1 - c) * x_prop
+            h = crossed * part**2 * dt + alive * dt       # squared fraction, as the reference does
+            running = sde.Phi(x_new) > 0
+            stops.append(running)
+        else:
+            x_new = x_prop
+            h = dt * ones
+            stops.append(ones)
+        fracs.append(h)
+        lpd = lpd + h / lmbd * (-sde.f(t0, x_new) - 0.5 * (u * u).sum(1))   # f at the NEW state, OLD time
+        lps = lps + torch.sqrt(h / lmbd) * (-(u * eps).sum(1))
+        xs.append(x_new)
+        eps_all.append(eps)
+        us.append(u)
+        x = x_new
+    ltw = -sde.g(x) / lmbd
+    out = (torch.stack(xs), torch.stack(eps_all), torch.stack(stops), torch.stack(fracs), lpd, lps, ltw,
+           torch.stack(us))
+    if detach:
+        return tuple(o.detach() for o in out)
+    return out[:3] + (out[3].detach(),) + out[4:]

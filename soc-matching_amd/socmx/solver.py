@@ -1,0 +1,131 @@
+"""`SOC_Solver`: reference SOC_matching/method.py:146-906, SOCM branch.
+
+Same constructor, same `.loss(...)` keyword surface and 8-tuple return
+`(objective, norm_sqd_diff, ctrl_loss_mean, ctrl_loss_std_err, trajectory,
+mean(w), std(w), stop_indicators)` (method.py:223-236, 897-906), same
+`.control_objective` (method.py:185-221).  Only `algorithm="SOCM"` without stopping
+times is implemented in this round; the other
+losses of method.py:264-478, 722-856 are row f4 and raise NotImplementedError.
+
+Data parallelism: when `self.shard` is set (see socmx.dist), `batch_size` is the
+GLOBAL batch; this rank simulates rows [row0, row0+B_local) and divides by the
+global (K+1)*B so that summing gradients over ranks reproduces the single-GPU
+gradient; mean/std of w are combined across ranks.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import loss as L
+from . import rollout as R
+
+
+class SOC_Solver(nn.Module):
+    noise_type = "diagonal"
+    sde_type = "ito"
+
+    def __init__(self, neural_sde, x0, ut, T=1.0, num_steps=100, lmbd=1.0, d=2, sigma=None):
+        super().__init__()
+        self.dim = neural_sde.dim
+        self.neural_sde = neural_sde
+        self.x0 = x0
+        self.ut = ut
+        self.T = T
+        self.ts = torch.linspace(0, T, num_steps + 1).to(x0.device)
+        self.num_steps = num_steps
+        self.dt = T / num_steps
+        self.lmbd = lmbd
+        self.d = d
+        self.y0 = torch.nn.Parameter(torch.randn(1, device=x0.device))  # RNG parity with method.py:172
+        self.sigma = sigma if sigma is not None else torch.eye(d)
+        self.shard = None        # socmx.dist.Shard or None
+        self.noise_in = None     # test hook: (K, B_local, d) noise injected into the next loss() call
+
+    # ---- method.py:175-183 -------------------------------------------------------------------
+    def control(self, t0, x0):
+        x0 = x0.reshape(-1, self.dim)
+        tx = torch.cat([t0.reshape(-1, 1).expand(x0.shape[0], 1), x0], dim=-1)
+        return -(self.neural_sde.nabla_V(tx) @ self.sigma)
+
+    # ---- method.py:185-221 -------------------------------------------------------------------
+    def control_objective(self, batch_size, total_n_samples=65536):
+        n_batches = int(total_n_samples // batch_size)
+        losses, trajectory = [], None
+        for k in range(n_batches):
+            state0 = self.x0.repeat(batch_size, 1)
+            out = R.stochastic_trajectories(self.neural_sde, state0, self.ts.to(state0), self.lmbd)
+            losses.append(-self.lmbd * (out[4] + out[6]))
+            if k == 0:
+                trajectory = out[0]
+            if k % 32 == 31:
+                print(f"Batch {k+1}/{n_batches} done")
+        losses = torch.cat(losses, 0)
+        n = n_batches * batch_size
+        return torch.mean(losses), torch.std(losses) / np.sqrt(n - 1), trajectory
+
+    # ---- method.py:223-906 -------------------------------------------------------------------
+    def loss(self, batch_size, compute_L2_error=False, optimal_control=None, compute_control_objective=False,
+             algorithm="SOCM_const_M", add_weights=False, total_n_samples=65536, verbose=False,
+             u_warm_start=None, use_warm_start=True, use_stopping_time=False):
+        if algorithm != "SOCM":
+            raise NotImplementedError(
+                f"algorithm={algorithm!r}: only 'SOCM' is implemented (other losses: SURVEY.md row f4)")
+        if use_stopping_time:
+            raise NotImplementedError("SOCM with use_stopping_time=True (TwoBoundarySigmoidMLP): SURVEY.md row f4")
+        if u_warm_start and use_warm_start:
+            raise NotImplementedError("warm start is out of scope (SURVEY.md component 9)")
+        sde = self.neural_sde
+        pb = sde.problem
+        shard = self.shard
+        B_global = batch_size
+        B, row0 = (shard.local_rows(batch_size) if shard is not None else (batch_size, 0))
+        K = self.num_steps
+        Kp = K + 1
+        d = self.dim
+
+        state0 = self.x0.repeat(B, 1)
+        ts = self.ts.to(state0)
+        noise_in, self.noise_in = self.noise_in, None
+        (states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls) = \
+            R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=True, noise_in=noise_in, row0=row0)
+
+        weight, stats = L.weights_and_stats(lpd, lps, ltw)
+        if shard is not None:
+            stats = shard.combine_weight_stats(stats)
+        w_mean, w_std = L.mean_std_from_stats(stats)
+
+        # nabla_V on all Kp*B trajectory rows (method.py:272-278): library GEMMs + autograd
+        tx = torch.cat([ts.reshape(-1, 1, 1).expand(Kp, B, 1), states], dim=-1).reshape(-1, d + 1)
+        nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)
+
+        # M and dM/ds on the pair grid (method.py:510-515, 533-573)
+        t_vec, s_vec, _, _ = L.pair_times(ts, self.T, K)
+        M_all, dM_all = sde.M.forward_with_ds(t_vec, s_vec)
+
+        inv_norm = 1.0 / (Kp * B_global)
+        objective = L.socm_objective(pb, ts, self.lmbd, K, states, noises, controls, M_all, dM_all, nabla_V,
+                                     weight, inv_norm)
+
+        if compute_L2_error:
+            target_control = optimal_control(self.ts, states, t_is_tensor=True)
+            learned_control = -(nabla_V @ self.sigma)
+            norm_sqd_diff = torch.sum((target_control - learned_control) ** 2 * weight.reshape(1, -1, 1)
+                                      / (target_control.shape[0] * target_control.shape[1]))
+        else:
+            norm_sqd_diff = None
+
+        if compute_control_objective:
+            ctrl_loss_mean, ctrl_loss_std_err, trajectory = self.control_objective(
+                batch_size, total_n_samples=total_n_samples)
+        else:
+            ctrl_loss_mean = ctrl_loss_std_err = trajectory = None
+
+        if verbose and state0.is_cuda:
+            # the reference prints NVML numbers for device 0 here (method.py:886-895); ROCm-safe equivalent
+            free, total = torch.cuda.mem_get_info(state0.device)
+            print("Total memory:", total / 1048576, "MiB")
+            print("Free memory:", free / 1048576, "MiB")
+            print("Used memory:", (total - free) / 1048576, "MiB")
+
+        return (objective, norm_sqd_diff, ctrl_loss_mean, ctrl_loss_std_err, trajectory, w_mean, w_std,
+                stop_indicators)

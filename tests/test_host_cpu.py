@@ -1,0 +1,126 @@
+"""Host-side logic on CPU: the drop-in surface (`SOC_matching.*` names) running the device-agnostic
+torch path (BASELINE config 0, "plumbing, no GPU") against the reference-generated golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import socm_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+TINY = [n for n in ALL if n.startswith("tiny_")]
+LOSS = [n for n in TINY if not n.endswith("_stopping")]
+
+
+def build_sde(name, device="cpu"):
+    """Instantiate the product's setting class from a fixture (weights loaded from the fixture)."""
+    from SOC_matching.experiment_settings.OU_quadratic import OU_Quadratic
+    from SOC_matching.experiment_settings.OU_linear import OU_Linear
+    from SOC_matching.experiment_settings.double_well import DoubleWell
+    from SOC_matching.experiment_settings.molecular_dynamics import MolecularDynamics
+
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    setting = str(z["meta_setting"])
+    d, K, B, seed, stopping = [int(v) for v in z["meta"]]
+    T, lmbd, gamma, sfV, sfM = [float(v) for v in z["meta_f"]]
+    c = lambda k: torch.from_numpy(z["const_" + k].copy()).to(device)
+    common = dict(device=device, dim=d, hdims=[int(h) for h in z["hdims"]], hdims_M=[int(h) for h in z["hdims_M"]],
+                  lmbd=lmbd, sigma=c("sigma"), gamma=gamma, scaling_factor_nabla_V=sfV, scaling_factor_M=sfM)
+    if setting.startswith("OU_quadratic"):
+        sde = OU_Quadratic(A=c("A"), P=c("P"), Q=c("Q"), **common)
+    elif setting == "OU_linear":
+        sde = OU_Linear(A=c("A"), omega=c("omega"), **common)
+    elif setting == "double_well":
+        sde = DoubleWell(kappa=c("kappa"), nu=c("nu"), **common)
+    else:
+        sde = MolecularDynamics(kappa=c("kappa"), T=T, use_stopping_time=bool(stopping), **common)
+    sde.initialize_models()
+    sde.nabla_V.load_state_dict({k[len("nablaV."):]: torch.from_numpy(z[k].copy()) for k in z.files
+                                 if k.startswith("nablaV.")})
+    if not stopping:
+        sde.M.sigmoid_layers.load_state_dict({k[len("M.sigmoid_layers."):]: torch.from_numpy(z[k].copy())
+                                              for k in z.files if k.startswith("M.sigmoid_layers.")})
+    with torch.no_grad():
+        sde.gamma.copy_(torch.from_numpy(z["gamma"].copy()))
+    aux = dict(z=z, d=d, K=K, B=B, T=T, lmbd=lmbd, x0=c("x0"), ts=torch.from_numpy(z["ts"].copy()).to(device),
+               noise=torch.from_numpy(z["noise_in"].copy()).to(device), stopping=bool(stopping))
+    return sde, aux
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_eager_rollout_matches_reference(name):
+    from SOC_matching import utils
+    sde, aux = build_sde(name)
+    z = aux["z"]
+    with torch.no_grad():
+        r = utils.stochastic_trajectories(sde, aux["x0"].repeat(aux["B"], 1), aux["ts"], aux["lmbd"],
+                                          noise_in=aux["noise"])
+    names = ["states", "noises", "stop_indicators", "fractional_timesteps", "lpd", "lps", "ltw", "controls"]
+    for n, v in zip(names, r):
+        assert v.shape == z["roll_" + n].shape, n
+        np.testing.assert_allclose(v.to(torch.float32).numpy(), z["roll_" + n], rtol=1e-4, atol=1e-5, err_msg=n)
+
+
+@pytest.mark.parametrize("name", LOSS)
+def test_socm_loss_matches_reference(name):
+    from SOC_matching.method import SOC_Solver
+    sde, aux = build_sde(name)
+    z = aux["z"]
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                        sigma=sde.sigma)
+    solver.noise_in = aux["noise"]
+    out = solver.loss(aux["B"], algorithm="SOCM", use_warm_start=False, use_stopping_time=False)
+    obj, wm, ws = out[0], out[5], out[6]
+    np.testing.assert_allclose(obj.item(), z["loss_objective"], rtol=1e-4)
+    np.testing.assert_allclose(wm.item(), z["loss_weight_mean"], rtol=1e-4)
+    np.testing.assert_allclose(ws.item(), z["loss_weight_std"], rtol=1e-4)
+    assert out[7].shape == z["roll_stop_indicators"].shape
+    obj.backward()
+    for k, p in sde.nabla_V.named_parameters():
+        g = z["grad_nablaV." + k]
+        np.testing.assert_allclose(p.grad.numpy(), g, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(g).max()), err_msg=k)
+    for k, p in sde.M.sigmoid_layers.named_parameters():
+        g = z["grad_M.sigmoid_layers." + k]
+        np.testing.assert_allclose(p.grad.numpy(), g, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(g).max()), err_msg=k)
+    np.testing.assert_allclose(sde.gamma.grad.numpy(), z["grad_gamma"], rtol=1e-3,
+                               atol=1e-5 * max(1.0, np.abs(z["grad_gamma"]).max()))
+
+
+@pytest.mark.parametrize("name", LOSS)
+def test_pair_times_match_reference_linspace(name):
+    from socmx import loss as L
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    ts = torch.from_numpy(z["ts"].copy())
+    t, s, ii, jj = L.pair_times(ts, float(z["meta_f"][0]), int(z["meta"][1]))
+    assert np.array_equal(t.numpy(), z["pairs_t"])
+    np.testing.assert_allclose(s.numpy(), z["pairs_s"], rtol=0, atol=1.2e-7)
+
+
+def test_state_dict_keys_and_seeded_init_match_reference():
+    """Same construction order => same RNG consumption => a reference seed reproduces the same weights."""
+    name = "tiny_double_well_d10"
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    from SOC_matching.experiment_settings.double_well import DoubleWell
+    d, K, B, seed, _ = [int(v) for v in z["meta"]]
+    torch.manual_seed(seed)
+    sde = DoubleWell(device="cpu", dim=d, hdims=[32, 16, 8], hdims_M=[16, 16], lmbd=1.0,
+                     kappa=torch.from_numpy(z["const_kappa"].copy()), nu=torch.from_numpy(z["const_nu"].copy()),
+                     sigma=torch.eye(d), gamma=6.0, scaling_factor_nabla_V=1.0, scaling_factor_M=0.1)
+    sde.initialize_models()
+    for k, v in sde.nabla_V.state_dict().items():
+        assert np.array_equal(v.numpy(), z["nablaV." + k]), k
+    for k, v in sde.M.state_dict().items():
+        if k.startswith("sigmoid_layers"):
+            assert np.array_equal(v.numpy(), z["M." + k]), k
+
+
+def test_other_algorithms_fail_loudly():
+    from SOC_matching.method import SOC_Solver
+    sde, aux = build_sde("tiny_ou_quadratic_easy_d2")
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                        sigma=sde.sigma)
+    with pytest.raises(NotImplementedError):
+        solver.loss(4, algorithm="SOCM_adjoint")
