@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the SOC-matching hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the one the target is quoted on):
+double_well d=10, num_steps=200, batch=128 per GPU, arch [256,128,64]/[128,128], T=1, lmbd=1,
+gamma=6, scaling_factor_M=0.1, seed 0, synthetic (seeded) inputs.  Weak scaling: every rank
+simulates its own 128 rows (global batch 128*N = configs[3] at N=8), Philox keyed by global row.
+
+One JSON line on rank 0:
+  value            trajectory-steps/s = N*B*num_steps*steps / t   (a "step" = one full rollout call
+                   producing the reference's 8-tuple, SURVEY 8(d) metric 1), inputs resident in HBM
+  socm_iters_per_sec  secondary metric: 1/time_per_iteration of a full SOCM iteration (rollout + loss
+                   + backward + gradient all-reduce + Adam), timed like main.py:280,351-352
+  roofline         dominant kernel = socmx rollout_kernel; algorithmic flops (and bytes) per launch
+                   over its HIP-event duration, against the fp32 MFMA peak (157.3 TF) / HBM (8 TB/s)
+  cpu_baseline     the oracle's eager rollout (oracle/socm_oracle.py, "port") timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "soc-matching_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+SETTING, D, NUM_STEPS, BATCH_PER_GPU, GAMMA = "double_well", 10, 200, 128, 6.0
+HDIMS, HDIMS_M = [256, 128, 64], [128, 128]
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def unet_macs(d, h):
+    i0 = d + 1
+    return (i0 * h[0] + h[0] * h[1] + h[1] * h[2] + i0 * d + h[0] * h[0] + h[1] * h[1] + h[2] * h[1]
+            + h[1] * h[0] + h[0] * d)
+
+
+def flops_per_traj_step(d, h):
+    return 2 * unet_macs(d, h) + 6 * d * d
+
+
+def bytes_per_traj_step(d):
+    return 3 * d * 4 + 8                        # state + noise + control + stop/frac
+
+
+def build(device):
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from SOC_matching.method import SOC_Solver
+    cfg = load_config([f"method.setting={SETTING}", f"method.d={D}", f"method.num_steps={NUM_STEPS}",
+                       f"method.gamma={GAMMA}", "method.scaling_factor_M=0.1", "optim.M_lr=1e-3",
+                       f"optim.batch_size={BATCH_PER_GPU}", "method.lmbd=1.0", "method.seed=0"])
+    cfg.method.device = str(device)
+    torch.manual_seed(cfg.method.seed)
+    ts = torch.linspace(0, cfg.method.T, cfg.method.num_steps + 1).to(device)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, optimal_sde, sde, _ = define_variables(cfg, ts)
+    solver = SOC_Solver(sde, x0, None, T=cfg.method.T, num_steps=cfg.method.num_steps, lmbd=cfg.method.lmbd,
+                        d=cfg.method.d, sigma=sigma)
+    return cfg, ts, x0, sde, solver
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's rollout (same per-step eager op sequence as the reference) on the host cores."""
+    from oracle import socm_oracle as O
+    torch.manual_seed(0)
+    d, K, B = D, NUM_STEPS, BATCH_PER_GPU
+    kappa, nu = torch.ones(d), torch.ones(d)
+    kappa[:3], nu[:3] = 5, 3
+    pb = dict(kind="double_well", sigma=torch.eye(d), kappa=kappa, nu=nu)
+    from socmx.nets import FullyConnectedUNet
+    net = FullyConnectedUNet(d, HDIMS)
+    vp = {k: v.detach() for k, v in net.state_dict().items()}
+    ts = torch.linspace(0, 1.0, K + 1)
+    x0 = torch.zeros(B, d)
+    best = None
+    for threads in sorted({1, os.cpu_count() or 1}):
+        torch.set_num_threads(threads)
+        noise = torch.randn(K, B, d)
+        with torch.no_grad():
+            O.stochastic_trajectories(pb, vp, x0, ts, 1.0, noise)   # warm-up
+            n, t0 = 0, time.perf_counter()
+            while True:
+                O.stochastic_trajectories(pb, vp, x0, ts, 1.0, noise)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget_s / 2 or n >= 40:
+                    break
+        rate = n * B * K / el
+        if best is None or rate > best["value"]:
+            best = dict(value=rate, unit="trajectory-steps/s", cores=threads, kind="port",
+                        sample=f"{n} rollouts of double_well d=10 K=200 B=128 (oracle eager torch-CPU, "
+                               f"{el:.1f} s, best of 1 and {os.cpu_count()} threads)",
+                        ms_per_rollout=1e3 * el / n, host_cpus=os.cpu_count())
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path for the product"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from socmx import _lib, rollout, dist as sdist
+    from socmx.train import Trainer, make_optimizer
+    _lib.lib()   # fail loudly if the HIP extension is missing
+    cfg, ts, x0, sde, solver = build(device)
+    B, K, d = BATCH_PER_GPU, NUM_STEPS, D
+    state0 = x0.repeat(B, 1)
+    row0 = rank * B
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---- metric 1: rollouts ------------------------------------------------------------------
+    def one_rollout(i):
+        return rollout.stochastic_trajectories(sde, state0, ts, cfg.method.lmbd, seed=0, offset=i, row0=row0)
+
+    for i in range(args.warmup):
+        one_rollout(i)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        # the rollout is launched on torch's current stream, so these events bracket exactly that launch
+        sde.nabla_V.packed()
+        ev[i][0].record()
+        one_rollout(args.warmup + i)
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    value = world * B * K * args.steps / elapsed
+
+    # ---- metric 2: full SOCM iterations ----------------------------------------------------------
+    if world > 1:
+        solver.shard = sdist.Shard()
+    opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
+    trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False)
+    it_steps, it_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
+    for _ in range(it_warm):
+        trainer.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(it_steps):
+        info = trainer.step()
+    barrier()
+    it_elapsed = time.perf_counter() - t0
+    t = torch.tensor([it_elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    it_elapsed = float(t.item())
+    last_loss = float(info["loss"])
+
+    if rank == 0:
+        flops = flops_per_traj_step(d, HDIMS) * B * K
+        byts = bytes_per_traj_step(d) * B * K
+        achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "trajectory-steps/sec", "value": value, "unit": "trajectory-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "double_well d=10 num_steps=200 batch=128/GPU SOCM (BASELINE configs[2]; "
+                                   "global batch 128*N)", "step": "one stochastic_trajectories call (full 8-tuple)",
+                       "parallelism": f"dp{world} (batch-sharded, no data-path collective in the rollout)"},
+            "socm_iters_per_sec": it_steps / it_elapsed, "socm_ms_per_iter": 1e3 * it_elapsed / it_steps,
+            "socm_iters_timed": it_steps, "socm_last_loss": last_loss,
+            "roofline": {"bound": "mfma", "kernel": "socmx::rollout_kernel<8,false>",
+                         "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "algorithmic_hbm_bytes_per_launch": byts,
+                         "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,
+                         "hbm_frac": byts / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         "active_workgroups": (B + 15) // 16, "cus": 256},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

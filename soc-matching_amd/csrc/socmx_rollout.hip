@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/socmx.h"
@@ -48,6 +49,7 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, u
 struct RolloutArgs {
   UnetDesc u;
   TileLayout t;
+  UnetProgram prog;
   int kind, d, B, K;
   float lmbd;
   uint64_t seed, offset;
@@ -57,6 +59,7 @@ struct RolloutArgs {
   const float *x0, *ts, *noise_in;
   float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
   int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
+  long long* prof;  // diagnostics only (PROF variant): [blocks][12] accumulated s_memtime cycles per phase
 };
 
 // drift b_i(x) -- OU_quadratic.py:51-52, OU_linear.py:43-44, double_well.py:44-48, molecular_dynamics.py:49-53
@@ -64,27 +67,38 @@ __device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x,
                                          const float* __restrict__ kappa) {
   if (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR) {
     float s = 0.f;
-    for (int j = 0; j < d; ++j) s += A_l[i * d + j] * x[j];
+    for (int j = 0; j < d; ++j) s += A_l[i * (d + 1) + j] * x[j];
     return s;
   }
   const float xi = x[i];
   return -2.f * kappa[i] * (xi * xi - 1.f) * 2.f * xi;
 }
 
-template <int NW, bool STOPPING>
+#define SOCMX_TICK(slot)                                   \
+  if (PROF) {                                              \
+    const long long now_ = clock64();                      \
+    acc_prof[slot] += now_ - last_tick;                    \
+    last_tick = now_;                                      \
+  }
+
+template <int NW, bool STOPPING, bool PROF>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int nthr = NW * 64;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
   const int tile_row0 = blockIdx.x * 16;
+  // e / d and e / in0p for e < 16*1024 without integer divides: floor((e + 0.5) * (1/n)) is exact in that range
+  const float inv_d = __builtin_amdgcn_rcpf((float)d), inv_in0p = __builtin_amdgcn_rcpf((float)a.u.in0p);
+#define SOCMX_DIV_D(e) ((int)(((float)(e) + 0.5f) * inv_d))
   float* X0 = lds + a.t.x0;
   float* GV = lds + a.t.gv;
   // small per-tile state (behind the network tiles)
-  float* sig = lds + a.lds_mats;          // (d,d)
-  float* A_l = sig + d * d;               // (d,d)  OU only
-  float* P_l = A_l + d * d;               // (d,d)  OU_quadratic only
-  float* XS = P_l + d * d;                // (16,d) current state
+  const int ds = d + 1;                   // padded row stride of the LDS matrix copies (bank spread)
+  float* sig = lds + a.lds_mats;          // (d,ds)
+  float* A_l = sig + d * ds;              // (d,ds)  OU only
+  float* P_l = A_l + d * ds;              // (d,ds)  OU_quadratic only
+  float* XS = P_l + d * ds;               // (16,d) current state
   float* XN = XS + 16 * d;                // (16,d) proposed state
   float* XF = XN + 16 * d;                // (16,d) state after the stopping re-interpolation
   float* U = XF + 16 * d;                 // (16,d) control
@@ -96,12 +110,15 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
 
   const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
   for (int e = tid; e < d * d; e += nthr) {
-    sig[e] = a.sigma[e];
-    A_l[e] = is_ou ? a.A[e] : 0.f;
-    P_l[e] = (kind == SOCMX_OU_QUADRATIC) ? a.P[e] : 0.f;
+    const int r = e / d, c = e - r * d;
+    sig[r * ds + c] = a.sigma[e];
+    A_l[r * ds + c] = is_ou ? a.A[e] : 0.f;
+    P_l[r * ds + c] = (kind == SOCMX_OU_QUADRATIC) ? a.P[e] : 0.f;
   }
+  unet_load_biases(a.packed, a.u, a.t, lds, tid, nthr);
+  Pre carry = unet_carry_init(a.packed, a.prog);
   for (int e = tid; e < 16 * d; e += nthr) {
-    const int r = e / d, i = e - r * d;
+    const int r = SOCMX_DIV_D(e), i = e - r * d;
     const int grow = min(tile_row0 + r, B - 1);  // ragged tail: replicate the last row, never stored
     const float x = a.x0[(size_t)grow * d + i];
     XS[e] = x;
@@ -113,6 +130,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   }
   float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in threads 0..15
   __syncthreads();
+  long long acc_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long last_tick = PROF ? clock64() : 0;
 
   for (int k = 0; k < K; ++k) {
     const float t0 = a.ts[k];
@@ -121,17 +140,18 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
 
     // ---- network input [t, x, 0...]  (method.py:65-67) --------------------------------
     for (int e = tid; e < 16 * a.u.in0p; e += nthr) {
-      const int r = e / a.u.in0p, c = e - r * a.u.in0p;
+      const int r = (int)(((float)e + 0.5f) * inv_in0p), c = e - r * a.u.in0p;
       X0[r * a.t.s0 + c] = (c == 0) ? t0 : (c <= d ? XS[r * d + c - 1] : 0.f);
     }
     __syncthreads();
-    unet_tile_forward<NW>(a.packed, a.u, a.t, lds);  // GV = nabla_V(t, x)
+    SOCMX_TICK(0)
+    unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, [&](int stage) { SOCMX_TICK(stage) });  // GV = nabla_V(t,x)
 
     // ---- control u = -sigma^T nabla_V (method.py:68-72) and the step's noise (utils.py:39) ---
     for (int e = tid; e < 16 * d; e += nthr) {
-      const int r = e / d, i = e - r * d;
+      const int r = SOCMX_DIV_D(e), i = e - r * d;
       float s = 0.f;
-      for (int j = 0; j < d; ++j) s += sig[j * d + i] * GV[r * a.t.sg + j];
+      for (int j = 0; j < d; ++j) s += sig[j * ds + i] * GV[r * a.t.sg + j];
       const float u = -s;
       const int grow = tile_row0 + r;
       float eps;
@@ -145,27 +165,29 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       }
     }
     __syncthreads();
+    SOCMX_TICK(7)
 
     // ---- Euler-Maruyama update (utils.py:45-48) ------------------------------------------
     for (int e = tid; e < 16 * d; e += nthr) {
-      const int r = e / d, i = e - r * d;
+      const int r = SOCMX_DIV_D(e), i = e - r * d;
       const float bi = drift_i(kind, d, i, XS + r * d, A_l, a.kappa);
       float su = 0.f, se = 0.f;
       for (int j = 0; j < d; ++j) {
-        su += sig[i * d + j] * U[r * d + j];
-        se += sig[i * d + j] * E[r * d + j];
+        su += sig[i * ds + j] * U[r * d + j];
+        se += sig[i * ds + j] * E[r * d + j];
       }
       const float upd = (bi + su) * dt + sq_ldt * se;
       UP[e] = upd;
       XN[e] = XS[e] + ST[r] * upd;
     }
     __syncthreads();
+    SOCMX_TICK(8)
 
     const float* XE = XN;  // state at the end of the step
     if (STOPPING) {
       // utils.py:42-44, 49-75 with Phi(x) = -x_0 (molecular_dynamics.py:94-99)
       for (int e = tid; e < 16 * d; e += nthr) {
-        const int r = e / d, i = e - r * d;
+        const int r = SOCMX_DIV_D(e), i = e - r * d;
         const float phi_b = -XS[r * d], phi_a = -XN[r * d];
         const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
         const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       if (kind == SOCMX_OU_QUADRATIC) {  // OU_quadratic.py:66-69
         for (int i = 0; i < d; ++i) {
           float px = 0.f;
-          for (int j = 0; j < d; ++j) px += P_l[i * d + j] * x[j];
+          for (int j = 0; j < d; ++j) px += P_l[i * ds + j] * x[j];
           f += x[i] * px;
         }
       } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
@@ -211,13 +233,16 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       if (STOPPING) ST[r] = SN[r];
     }
     for (int e = tid; e < 16 * d; e += nthr) {
-      const int r = e / d, i = e - r * d;
+      const int r = SOCMX_DIV_D(e), i = e - r * d;
       const float x = XE[e];
       XS[e] = x;
       if (tile_row0 + r < B) a.states[((size_t)(k + 1) * B + tile_row0 + r) * d + i] = x;
     }
     __syncthreads();
+    SOCMX_TICK(9)
   }
+  if (PROF && tid == 0 && a.prof)
+    for (int s = 0; s < 12; ++s) a.prof[(size_t)blockIdx.x * 12 + s] = acc_prof[s];
 
   // ---- terminal cost (utils.py:101) --------------------------------------------------------
   if (tid < 16 && tile_row0 + tid < B) {
@@ -247,6 +272,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
 struct ForwardArgs {
   UnetDesc u;
   TileLayout t;
+  UnetProgram prog;
   const float* packed;
   const float* tx;  // (N, d+1)
   float* out;       // (N, d)
@@ -266,8 +292,10 @@ __global__ __launch_bounds__(NW * 64) void unet_forward_kernel(const ForwardArgs
     const int64_t grow = min(row0 + r, a.N - 1);
     X0[r * a.t.s0 + c] = (c < in0) ? a.tx[grow * in0 + c] : 0.f;
   }
+  unet_load_biases(a.packed, a.u, a.t, lds, tid, nthr);
+  Pre carry = unet_carry_init(a.packed, a.prog);
   __syncthreads();
-  unet_tile_forward<NW>(a.packed, a.u, a.t, lds);
+  unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, [](int) {});
   for (int e = tid; e < 16 * d; e += nthr) {
     const int r = e / d, i = e - r * d;
     if (row0 + r < a.N) a.out[(row0 + r) * d + i] = GV[r * a.t.sg + i];
@@ -361,6 +389,16 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)
 
+// developer A/B switch: SOCMX_WAVES=4 runs the tile with one wave per SIMD (read once)
+static int waves_per_tile() {
+  static int w = 0;
+  if (!w) {
+    const char* e = getenv("SOCMX_WAVES");
+    w = (e && e[0] == '4') ? 4 : kWaves;
+  }
+  return w;
+}
+
 extern "C" int socmx_unet_forward_f32(const float* packed, int32_t d, const int32_t hdims[3], const float* tx,
                                       int64_t N, float* out, socmx_stream_t stream) {
   if (!packed || !hdims || !tx || !out) return SOCMX_E_NULL;
@@ -369,23 +407,26 @@ extern "C" int socmx_unet_forward_f32(const float* packed, int32_t d, const int3
   ForwardArgs a;
   const int h[3] = {hdims[0], hdims[1], hdims[2]};
   a.u = make_unet_desc(d, h);
-  a.t = make_tile_layout(a.u, kWaves);
+  const int nw = waves_per_tile();
+  a.t = make_tile_layout(a.u, nw);
+  a.prog = make_unet_program(a.u, a.t);
+  fill_wave_work(a.prog, nw);
   a.packed = packed; a.tx = tx; a.out = out; a.N = N;
   const size_t lds_bytes = (size_t)a.t.floats * sizeof(float);
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
-  auto kern = unet_forward_kernel<kWaves>;
+  void (*kern)(const ForwardArgs) = nw == 4 ? unet_forward_kernel<4> : unet_forward_kernel<8>;
   hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err != hipSuccess) return (int)err;
   const int64_t blocks = (N + 15) / 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nw * 64), lds_bytes, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
-extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3],
-                                 const float* x0, const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed,
-                                 uint64_t offset, int64_t row0, const float* noise_in, float* states, float* noises,
-                                 float* controls, float* stop_indicators, float* fractional_timesteps, float* lpd,
-                                 float* lps, float* ltw, socmx_stream_t stream) {
+static int rollout_launch(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3], const float* x0,
+                          const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed, uint64_t offset,
+                          int64_t row0, const float* noise_in, float* states, float* noises, float* controls,
+                          float* stop_indicators, float* fractional_timesteps, float* lpd, float* lps, float* ltw,
+                          long long* prof, socmx_stream_t stream) {
   if (!pb || !packed_unet || !hdims || !x0 || !ts || !states || !noises || !controls || !stop_indicators ||
       !fractional_timesteps || !lpd || !lps || !ltw || !pb->sigma)
     return SOCMX_E_NULL;
@@ -401,7 +442,10 @@ extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_un
   RolloutArgs a;
   const int h[3] = {hdims[0], hdims[1], hdims[2]};
   a.u = make_unet_desc(d, h);
-  a.t = make_tile_layout(a.u, kWaves);
+  const int nw = waves_per_tile();
+  a.t = make_tile_layout(a.u, nw);
+  a.prog = make_unet_program(a.u, a.t);
+  fill_wave_work(a.prog, nw);
   a.kind = pb->kind; a.d = d; a.B = B; a.K = K; a.lmbd = lmbd;
   a.seed = seed; a.offset = offset; a.row0 = row0;
   a.packed = packed_unet;
@@ -409,22 +453,43 @@ extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_un
   a.x0 = x0; a.ts = ts; a.noise_in = noise_in;
   a.states = states; a.noises = noises; a.controls = controls; a.stop_ind = stop_indicators;
   a.frac = fractional_timesteps; a.lpd = lpd; a.lps = lps; a.ltw = ltw;
+  a.prof = prof;
   a.lds_mats = (a.t.floats + 3) & ~3;
-  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * d + 6 * 16 * (size_t)d + 48;
+  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * (d + 1) + 6 * 16 * (size_t)d + 48;
   const size_t lds_bytes = lds_floats * sizeof(float);
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
   const int blocks = (B + 15) / 16;
-  hipError_t err;
-  if (pb->kind == SOCMX_MOLECULAR_DYNAMICS) {
-    auto kern = rollout_kernel<kWaves, true>;
-    err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (err != hipSuccess) return (int)err;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+  const bool stopping = pb->kind == SOCMX_MOLECULAR_DYNAMICS;
+  void (*kern)(const RolloutArgs);
+  if (nw == 4) {
+    if (prof) kern = stopping ? rollout_kernel<4, true, true> : rollout_kernel<4, false, true>;
+    else kern = stopping ? rollout_kernel<4, true, false> : rollout_kernel<4, false, false>;
   } else {
-    auto kern = rollout_kernel<kWaves, false>;
-    err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (err != hipSuccess) return (int)err;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWaves * 64), lds_bytes, (hipStream_t)stream, a);
+    if (prof) kern = stopping ? rollout_kernel<8, true, true> : rollout_kernel<8, false, true>;
+    else kern = stopping ? rollout_kernel<8, true, false> : rollout_kernel<8, false, false>;
   }
+  hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * 64), lds_bytes, (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3],
+                                 const float* x0, const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed,
+                                 uint64_t offset, int64_t row0, const float* noise_in, float* states, float* noises,
+                                 float* controls, float* stop_indicators, float* fractional_timesteps, float* lpd,
+                                 float* lps, float* ltw, socmx_stream_t stream) {
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, row0, noise_in, states, noises,
+                        controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
+}
+
+extern "C" int socmx_rollout_phase_cycles_f32(const socmx_problem* pb, const float* packed_unet,
+                                              const int32_t hdims[3], const float* x0, const float* ts, int32_t B,
+                                              int32_t K, float lmbd, uint64_t seed, uint64_t offset, int64_t row0,
+                                              const float* noise_in, float* states, float* noises, float* controls,
+                                              float* stop_indicators, float* fractional_timesteps, float* lpd,
+                                              float* lps, float* ltw, int64_t* cycles, socmx_stream_t stream) {
+  if (!cycles) return SOCMX_E_NULL;
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, row0, noise_in, states, noises,
+                        controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, (long long*)cycles, stream);
 }

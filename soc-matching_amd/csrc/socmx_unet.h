@@ -27,6 +27,7 @@ struct LayerDesc {
   int b_off;   // float offset of the (padded) bias
   int in_pad;  // padded fan-in  (multiple of 16)
   int out_pad; // padded fan-out (multiple of 16)
+  int b_lds;   // float offset of this layer's bias inside the LDS bias copy (TileLayout::bias)
 };
 
 struct UnetDesc {
@@ -38,6 +39,7 @@ struct UnetDesc {
   int hp[3];  // padded hdims
   LayerDesc L[9];
   int total_floats;
+  int bias_floats;  // sum of padded fan-outs
 };
 
 __host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
@@ -62,14 +64,16 @@ inline UnetDesc make_unet_desc(int d, const int h[3]) {
   for (int i = 0; i < 3; ++i) { u.h[i] = h[i]; u.hp[i] = pad16(h[i]); }
   int fin[9], fout[9];
   unet_layer_dims(d, h, fin, fout);
-  int off = 0;
+  int off = 0, boff = 0;
   for (int l = 0; l < 9; ++l) {
     u.L[l].in_pad = pad16(fin[l]);
     u.L[l].out_pad = pad16(fout[l]);
     u.L[l].w_off = off; off += u.L[l].in_pad * u.L[l].out_pad;
     u.L[l].b_off = off; off += u.L[l].out_pad;
+    u.L[l].b_lds = boff; boff += u.L[l].out_pad;
   }
   u.total_floats = off;
+  u.bias_floats = boff;
   return u;
 }
 
@@ -78,6 +82,7 @@ inline UnetDesc make_unet_desc(int d, const int h[3]) {
 struct TileLayout {
   int s0, s1, s2, s3, sg;                    // strides of X0, R1/O1, R2/O2, R3, GV
   int x0, r1, r2, r3, o2, o1, gv, scratch;   // float offsets
+  int bias;                                  // float offset of the LDS copy of all (padded) biases
   int floats;                                // total
 };
 
@@ -93,48 +98,245 @@ __host__ __device__ inline TileLayout make_tile_layout(const UnetDesc& u, int nw
   t.o1 = off; off += 16 * t.s1;
   t.gv = off; off += 16 * t.sg;
   t.scratch = off; off += 2 * 16 * 16 * nwaves;  // split-K partials: 2 GEMMs x (parts*out_pad <= 16*nwaves) x 16 rows
+  t.bias = off; off += u.bias_floats;
   t.floats = off;
   return t;
+}
+
+// One network stage: Y = relu(L1 . X1 + b1) [+ L2 . X2 + b2]; Ln = GEMM 1 of the stage that follows (its first
+// weight fragments are requested before this stage's closing barrier).  LDS operands as float offsets.
+struct StageDesc {
+  LayerDesc L1, L2, Ln;
+  int x1, s1, x2, s2, y, sy, has2;
+};
+
+// The six stages of FullyConnectedUNet.forward (models.py:233-242) as a table, so that the kernels run ONE
+// copy of the stage code in a loop (the fully inlined form is ~130 KB of ISA and thrashes the 64 KB I-cache).
+//
+// `ww[stage][wave]` is the work split, precomputed on the host so that the kernel does no integer division per
+// stage (a 32-bit division is ~25 dependent instructions on this ISA; eight of them per stage cost more than
+// the small layers' MFMAs):
+//   direct stages (neuron blocks >= waves): wave owns blocks blk0, blk0+NW, ... (cnt of them), full K range;
+//   split-K stages (fewer blocks than waves): wave owns block blk0, chunk range [kc0a,kc1a) / [kc0b,kc1b).
+//   pf[4]: fragment numbers (block*KC + chunk) of the NEXT stage's first four GEMM-1 fragments for this wave.
+constexpr int kMaxWaves = 8;
+struct WaveWork {
+  unsigned short split, blk0, cnt, active;
+  unsigned short kc0a, kc1a, kc0b, kc1b;
+  unsigned short part, parts, use_pre, pad;
+  unsigned short pf[4];
+};
+
+struct UnetProgram {
+  StageDesc st[6];
+  WaveWork ww[6][kMaxWaves];
+};
+
+__host__ __device__ inline UnetProgram make_unet_program(const UnetDesc& u, const TileLayout& t) {
+  UnetProgram p;
+  const LayerDesc* L = u.L;
+  auto set = [&](int i, int l1, int x1, int s1, int has2, int l2, int x2, int s2, int y, int sy, int ln) {
+    StageDesc& d = p.st[i];
+    d.L1 = L[l1]; d.L2 = L[l2]; d.Ln = L[ln];
+    d.x1 = x1; d.s1 = s1; d.x2 = x2; d.s2 = s2; d.y = y; d.sy = sy; d.has2 = has2;
+  };
+  set(0, 0, t.x0, t.s0, 0, 0, t.x0, t.s0, t.r1, t.s1, 1);   // r1 = relu(down_0 x)
+  set(1, 1, t.r1, t.s1, 0, 1, t.r1, t.s1, t.r2, t.s2, 2);   // r2 = relu(down_1 r1)
+  set(2, 2, t.r2, t.s2, 0, 2, t.r2, t.s2, t.r3, t.s3, 6);   // r3 = relu(down_2 r2)
+  set(3, 6, t.r3, t.s3, 1, 5, t.r2, t.s2, t.o2, t.s2, 7);   // o2 = relu(up_2 r3) + res_2 r2
+  set(4, 7, t.o2, t.s2, 1, 4, t.r1, t.s1, t.o1, t.s1, 8);   // o1 = relu(up_1 o2) + res_1 r1
+  set(5, 8, t.o1, t.s1, 1, 3, t.x0, t.s0, t.gv, t.sg, 0);   // o0 = relu(up_0 o1) + res_0 x ; then down_0 again
+  return p;
+}
+
+// first four GEMM-1 fragments wave `w` consumes in a stage whose GEMM 1 is layer Lg (mirrors fill_wave_work)
+inline void first_fragment_numbers(const LayerDesc& Lg, int NW, int w, unsigned short pf[4], bool* consumed) {
+  const int NBLK = Lg.out_pad >> 4, KC = Lg.in_pad >> 4;
+  int blk, bstride, nb, kc0, kc1;
+  bool ok;
+  if (NBLK >= NW) {
+    int cnt = w < NBLK ? (NBLK - w + NW - 1) / NW : 0;
+    nb = cnt > 4 ? 4 : cnt;
+    ok = cnt > 0 && nb != 3;                 // a 3-block group ignores the prefetch
+    if (nb < 1) nb = 1;
+    blk = w < NBLK ? w : 0; bstride = NW; kc0 = 0; kc1 = KC;
+  } else {
+    const int parts = NW / NBLK, part = w / NBLK;
+    blk = w % NBLK; bstride = 0; nb = 1;
+    kc0 = (part * KC) / parts; kc1 = ((part + 1) * KC) / parts;
+    ok = part < parts && kc1 > kc0;
+    if (!ok) { kc0 = 0; kc1 = 1; }
+  }
+  for (int f = 0; f < 4; ++f) {
+    int kc = kc0 + f / nb; if (kc > kc1 - 1) kc = kc1 - 1;
+    int b = blk + (f % nb) * bstride; if (b > NBLK - 1) b = NBLK - 1;
+    pf[f] = (unsigned short)(b * KC + kc);
+  }
+  *consumed = ok;
+}
+
+inline void fill_wave_work(UnetProgram& p, int NW) {
+  for (int si = 0; si < 6; ++si) {
+    const StageDesc& d = p.st[si];
+    const int NBLK = d.L1.out_pad >> 4, KC1 = d.L1.in_pad >> 4, KC2 = d.L2.in_pad >> 4;
+    for (int w = 0; w < NW; ++w) {
+      WaveWork& x = p.ww[si][w];
+      x = WaveWork{};
+      if (NBLK >= NW) {
+        x.split = 0; x.blk0 = (unsigned short)w;
+        x.cnt = (unsigned short)(w < NBLK ? (NBLK - w + NW - 1) / NW : 0);
+        x.active = x.cnt > 0;
+        x.kc0a = 0; x.kc1a = (unsigned short)KC1; x.kc0b = 0; x.kc1b = (unsigned short)KC2;
+      } else {
+        const int parts = NW / NBLK, part = w / NBLK;
+        x.split = 1; x.blk0 = (unsigned short)(w % NBLK); x.cnt = 1;
+        x.parts = (unsigned short)parts; x.part = (unsigned short)part; x.active = part < parts;
+        x.kc0a = (unsigned short)((part * KC1) / parts); x.kc1a = (unsigned short)(((part + 1) * KC1) / parts);
+        x.kc0b = (unsigned short)((part * KC2) / parts); x.kc1b = (unsigned short)(((part + 1) * KC2) / parts);
+        if (!x.active) { x.kc0a = x.kc1a = x.kc0b = x.kc1b = 0; }
+      }
+      bool consumed;
+      unsigned short tmp[4];
+      first_fragment_numbers(d.L1, NW, w, tmp, &consumed);   // does THIS stage consume a prefetch?
+      x.use_pre = consumed;
+      first_fragment_numbers(d.Ln, NW, w, x.pf, &consumed);  // what to request for the NEXT stage
+    }
+  }
 }
 
 #if defined(__HIPCC__)
 
 __device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.f ? 0.f : x; }
 
-// acc[j] += W[block blk0 + j*bstride] . X  over input chunks [kc0, kc1)
+// all threads: copy the padded biases of the nine layers from the packed image into LDS (once per kernel)
+__device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, const UnetDesc& u, const TileLayout& t,
+                                                 float* lds, int tid, int nthr) {
+  for (int l = 0; l < 9; ++l)
+    for (int e = tid; e < u.L[l].out_pad; e += nthr) lds[t.bias + u.L[l].b_lds + e] = Wp[u.L[l].b_off + e];
+}
+
 template <int NB>
-__device__ __forceinline__ void gemm_acc(f32x4 (&acc)[NB], const float4* __restrict__ wl, int blk0, int bstride,
-                                         int KC, const float* X, int S, int row, int g, int kc0, int kc1) {
-  const float* xrow = X + row * S + 4 * g;
-#pragma unroll 4
-  for (int kc = kc0; kc < kc1; ++kc) {
-    const float4 bx = *reinterpret_cast<const float4*>(xrow + kc * 16);
-    float4 a[NB];
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NB], const f32x4 (&a)[NB], const f32x4 bx) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) a[j] = wl[(size_t)((blk0 + j * bstride) * KC + kc) * 64];
+  for (int j = 0; j < NB; ++j) {
+    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], bx[0], acc[j], 0, 0, 0);
+    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], bx[1], acc[j], 0, 0, 0);
+    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], bx[2], acc[j], 0, 0, 0);
+    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], bx[3], acc[j], 0, 0, 0);
+  }
+}
+
+// Weight fragments come straight from L2 into VGPRs (each is used by exactly one MFMA group of one
+// wave, so an LDS round trip would be pure overhead).  L2 latency is ~500-1000 cycles while one chunk is
+// only NB x 4 MFMAs, so PD chunks are kept in flight in a statically indexed register ring: slot s is
+// refilled with chunk kc+PD right after chunk kc used it.  The first fragments of a GEMM can arrive
+// through `pre` (4 fragments requested by the PREVIOUS stage before its barrier), which takes the L2
+// latency off the stage-to-stage critical path.
+// the four prefetched fragments handed from one stage to the next (by value: stays in VGPRs)
+struct Pre {
+  f32x4 f[4];
+};
+
+template <int NB>
+struct Ring {
+  static constexpr int PD = (NB >= 4) ? 2 : (NB >= 2 ? 4 : 8);   // chunks in flight (PD*NB*4 VGPRs)
+  static constexpr int CP = (NB == 3) ? 0 : 4 / NB;              // chunks covered by the 4 `pre` fragments
+  f32x4 slot[PD][NB];
+};
+
+template <int NB>
+struct GemmPlan {
+  const f32x4* wb[NB];  // per block: fragment base (+lane), indexable by chunk*64
+  const float* xrow;     // this lane's activation row (+4g)
+  int kc0, kc1;
+};
+
+template <int NB>
+__device__ __forceinline__ GemmPlan<NB> make_plan(const float* __restrict__ Wp, const LayerDesc& L, int blk0, int bstride,
+                                                  const float* X, int S, int lane, int kc0, int kc1) {
+  GemmPlan<NB> p;
+  const int KC = L.in_pad >> 4;
+  const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + L.w_off) + lane;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, bx.x, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, bx.y, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, bx.z, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, bx.w, acc[j], 0, 0, 0);
+  for (int j = 0; j < NB; ++j) p.wb[j] = wl + (size_t)((blk0 + j * bstride) * KC) * 64;
+  p.xrow = X + (lane & 15) * S + 4 * (lane >> 4);
+  p.kc0 = kc0; p.kc1 = kc1;
+  return p;
+}
+
+// issue the loads of ring slots [from, PD); slots [0, from) are taken from `pre` (from == CP) or loaded too (from == 0)
+template <int NB, bool USE_PRE>
+__device__ __forceinline__ void ring_fill(Ring<NB>& r, const GemmPlan<NB>& p, const Pre& pre) {
+  constexpr int PD = Ring<NB>::PD, CP = USE_PRE ? Ring<NB>::CP : 0;
+  const int last = p.kc1 - 1;
+#pragma unroll
+  for (int s = 0; s < PD; ++s) {
+    if (s < CP) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) r.slot[s][j] = pre.f[s * NB + j];
+    } else {
+      const int kc = min(p.kc0 + s, last);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)kc * 64];
     }
   }
 }
 
+template <int NB>
+__device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const GemmPlan<NB>& p) {
+  constexpr int PD = Ring<NB>::PD;
+  const int last = p.kc1 - 1;
+  int kc = p.kc0;
+  f32x4 bx = *reinterpret_cast<const f32x4*>(p.xrow + min(kc, last) * 16);
+  for (; kc + PD <= p.kc1; kc += PD) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      const f32x4 bx_next = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 1, last) * 16);
+      mfma_chunk<NB>(acc, r.slot[s], bx);
+      const int nk = min(kc + s + PD, last);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)nk * 64];
+      bx = bx_next;
+    }
+  }
+  // tail: fewer than PD chunks left; they already sit in slots 0..rem-1
+#pragma unroll
+  for (int s = 0; s < PD - 1; ++s) {
+    if (kc + s < p.kc1) {
+      const f32x4 bx_next = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 1, last) * 16);
+      mfma_chunk<NB>(acc, r.slot[s], bx);
+      bx = bx_next;
+    }
+  }
+}
+
+// request the four fragments numbered pf[0..3] of layer Lg (GEMM 1 of the stage that follows)
+__device__ __forceinline__ Pre prefetch_fragments(const float* __restrict__ Wp, const LayerDesc& Lg, const WaveWork& w,
+                                                  int lane) {
+  const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + Lg.w_off) + lane;
+  Pre pre;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) pre.f[f] = wl[(size_t)w.pf[f] * 64];
+  return pre;
+}
+
 template <int NB, int NW>
-__device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const LayerDesc& L1, const float* X1, int S1,
-                                             bool has2, const LayerDesc& L2, const float* X2, int S2, float* Y,
-                                             int SY, int blk0, int lane) {
+__device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const float* bias_lds,
+                                             const LayerDesc& L1, const float* X1, int S1, bool has2,
+                                             const LayerDesc& L2, const float* X2, int S2, float* Y, int SY,
+                                             int blk0, int lane, const Pre& pre, bool use_pre) {
   const int row = lane & 15, g = lane >> 4;
+  const GemmPlan<NB> p1 = make_plan<NB>(Wp, L1, blk0, NW, X1, S1, lane, 0, L1.in_pad >> 4);
+  const GemmPlan<NB> p2 = make_plan<NB>(Wp, L2, blk0, NW, X2, S2, lane, 0, L2.in_pad >> 4);
+  Ring<NB> r1, r2;
+  if (use_pre) ring_fill<NB, true>(r1, p1, pre); else ring_fill<NB, false>(r1, p1, pre);
+  if (has2) ring_fill<NB, false>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
   f32x4 acc[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    const float4 b = *reinterpret_cast<const float4*>(Wp + L1.b_off + (blk0 + j * NW) * 16 + 4 * g);
-    acc[j] = f32x4{b.x, b.y, b.z, b.w};
+    acc[j] = *reinterpret_cast<const f32x4*>(bias_lds + L1.b_lds + (blk0 + j * NW) * 16 + 4 * g);
   }
-  gemm_acc<NB>(acc, reinterpret_cast<const float4*>(Wp + L1.w_off) + lane, blk0, NW, L1.in_pad >> 4, X1, S1, row, g,
-               0, L1.in_pad >> 4);
+  gemm_run<NB>(acc, r1, p1);
 #pragma unroll
   for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -142,71 +344,76 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
   if (has2) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const float4 b = *reinterpret_cast<const float4*>(Wp + L2.b_off + (blk0 + j * NW) * 16 + 4 * g);
-      acc[j] += f32x4{b.x, b.y, b.z, b.w};
+      acc[j] += *reinterpret_cast<const f32x4*>(bias_lds + L2.b_lds + (blk0 + j * NW) * 16 + 4 * g);
     }
-    gemm_acc<NB>(acc, reinterpret_cast<const float4*>(Wp + L2.w_off) + lane, blk0, NW, L2.in_pad >> 4, X2, S2, row,
-                 g, 0, L2.in_pad >> 4);
+    gemm_run<NB>(acc, r2, p2);
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
-    *reinterpret_cast<float4*>(Y + row * SY + (blk0 + j * NW) * 16 + 4 * g) =
-        make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    *reinterpret_cast<f32x4*>(Y + row * SY + (blk0 + j * NW) * 16 + 4 * g) = acc[j];
 }
 
 // Y = relu(W1.X1 + b1) [+ W2.X2 + b2]   for the 16-row tile; all NW waves of the workgroup call it.
+// `pre` holds this wave's first four GEMM-1 fragments on entry (if w.use_pre) and, on exit, the first four
+// fragments of the following stage's GEMM 1, requested BEFORE this stage's closing barrier.
 // Ends with a workgroup barrier (Y visible, inputs free to overwrite).
 template <int NW>
-__device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const LayerDesc& L1, const float* X1, int S1,
-                                           bool has2, const LayerDesc& L2, const float* X2, int S2, float* Y, int SY,
-                                           float* scratch) {
+__device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const float* bias_lds, const StageDesc& sd,
+                                           const WaveWork& w, float* lds, float* scratch, Pre& pre) {
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int NBLK = L1.out_pad >> 4;
-  if (NBLK >= NW) {
-    for (int blk0 = wave; blk0 < NBLK; blk0 += 4 * NW) {
-      const int cnt = (NBLK - blk0 + NW - 1) / NW;  // blocks this wave still owns (wave-uniform)
-      if (cnt >= 4)      stage_direct<4, NW>(Wp, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane);
-      else if (cnt == 3) stage_direct<3, NW>(Wp, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane);
-      else if (cnt == 2) stage_direct<2, NW>(Wp, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane);
-      else               stage_direct<1, NW>(Wp, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane);
+  const LayerDesc& L1 = sd.L1;
+  const LayerDesc& L2 = sd.L2;
+  const float* X1 = lds + sd.x1;
+  const float* X2 = lds + sd.x2;
+  float* Y = lds + sd.y;
+  const int S1 = sd.s1, S2 = sd.s2, SY = sd.sy;
+  const bool has2 = sd.has2 != 0;
+  if (!w.split) {
+    bool use_pre = w.use_pre != 0;  // the first group starts from the fragments the previous stage requested
+    int blk0 = w.blk0;
+    for (int cnt = w.cnt; cnt > 0; cnt -= 4, blk0 += 4 * NW) {
+      if (cnt >= 4)      stage_direct<4, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre);
+      else if (cnt == 3) stage_direct<3, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, false);
+      else if (cnt == 2) stage_direct<2, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre);
+      else               stage_direct<1, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre);
+      use_pre = false;
     }
+    pre = prefetch_fragments(Wp, sd.Ln, w, lane);
     __syncthreads();
   } else {
     // fewer neuron blocks than waves: split the reduction (K) dimension across waves,
     // partial sums through LDS, bias + ReLU applied after the combine.
-    const int parts = NW / NBLK;
-    const int blk = wave % NBLK, part = wave / NBLK;
+    const int parts = w.parts, blk = w.blk0, part = w.part;
     const int outp = L1.out_pad;
     const int row = lane & 15, g = lane >> 4;
     float* P1 = scratch;
     float* P2 = scratch + parts * 16 * outp;
-    if (part < parts) {
-      {
-        const int KC = L1.in_pad >> 4;
-        f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        gemm_acc<1>(acc, reinterpret_cast<const float4*>(Wp + L1.w_off) + lane, blk, 0, KC, X1, S1, row, g,
-                    (part * KC) / parts, ((part + 1) * KC) / parts);
-        *reinterpret_cast<float4*>(P1 + (part * 16 + row) * outp + blk * 16 + 4 * g) =
-            make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-      }
+    if (w.active) {
+      const GemmPlan<1> p1 = make_plan<1>(Wp, L1, blk, 0, X1, S1, lane, w.kc0a, w.kc1a);
+      const GemmPlan<1> p2 = make_plan<1>(Wp, L2, blk, 0, X2, S2, lane, w.kc0b, w.kc1b);
+      Ring<1> r1, r2;
+      const bool w1 = p1.kc1 > p1.kc0, w2 = has2 && p2.kc1 > p2.kc0;
+      if (w1) ring_fill<1, true>(r1, p1, pre);
+      if (w2) ring_fill<1, false>(r2, p2, pre);
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      if (w1) gemm_run<1>(acc, r1, p1);
+      *reinterpret_cast<f32x4*>(P1 + (part * 16 + row) * outp + blk * 16 + 4 * g) = acc[0];
       if (has2) {
-        const int KC = L2.in_pad >> 4;
-        f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        gemm_acc<1>(acc, reinterpret_cast<const float4*>(Wp + L2.w_off) + lane, blk, 0, KC, X2, S2, row, g,
-                    (part * KC) / parts, ((part + 1) * KC) / parts);
-        *reinterpret_cast<float4*>(P2 + (part * 16 + row) * outp + blk * 16 + 4 * g) =
-            make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+        f32x4 acc2[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (w2) gemm_run<1>(acc2, r2, p2);
+        *reinterpret_cast<f32x4*>(P2 + (part * 16 + row) * outp + blk * 16 + 4 * g) = acc2[0];
       }
     }
+    pre = prefetch_fragments(Wp, sd.Ln, w, lane);
     __syncthreads();
+    const float inv_outp = __builtin_amdgcn_rcpf((float)outp);
     for (int e = threadIdx.x; e < 16 * outp; e += NW * 64) {
-      const int r = e / outp, n = e - r * outp;
-      float v = Wp[L1.b_off + n];
+      const int r = (int)(((float)e + 0.5f) * inv_outp), n = e - r * outp;  // e / outp without an integer divide
+      float v = bias_lds[L1.b_lds + n];
       for (int p = 0; p < parts; ++p) v += P1[(p * 16 + r) * outp + n];
       v = relu_keep_nan(v);
       if (has2) {
-        float v2 = Wp[L2.b_off + n];
+        float v2 = bias_lds[L2.b_lds + n];
         for (int p = 0; p < parts; ++p) v2 += P2[(p * 16 + r) * outp + n];
         v += v2;
       }
@@ -216,19 +423,27 @@ __device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const L
   }
 }
 
+// `Pre` is carried across stages and across time steps (the last stage prefetches down_0 again).
+__device__ __forceinline__ Pre unet_carry_init(const float* __restrict__ Wp, const UnetProgram& prog) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return prefetch_fragments(Wp, prog.st[5].Ln, prog.ww[5][wave], lane);
+}
+
 // The whole network on the tile: X0 (already filled, [t, x, 0-pad]) -> GV (nabla_V, first d columns valid).
-template <int NW>
-__device__ __forceinline__ void unet_tile_forward(const float* __restrict__ Wp, const UnetDesc& u, const TileLayout& t,
-                                                  float* lds) {
-  const LayerDesc* L = u.L;
-  float* X0 = lds + t.x0; float* R1 = lds + t.r1; float* R2 = lds + t.r2; float* R3 = lds + t.r3;
-  float* O2 = lds + t.o2; float* O1 = lds + t.o1; float* GV = lds + t.gv; float* SC = lds + t.scratch;
-  unet_stage<NW>(Wp, L[0], X0, t.s0, false, L[0], X0, t.s0, R1, t.s1, SC);        // r1 = relu(down_0 x)
-  unet_stage<NW>(Wp, L[1], R1, t.s1, false, L[1], R1, t.s1, R2, t.s2, SC);        // r2 = relu(down_1 r1)
-  unet_stage<NW>(Wp, L[2], R2, t.s2, false, L[2], R2, t.s2, R3, t.s3, SC);        // r3 = relu(down_2 r2)
-  unet_stage<NW>(Wp, L[6], R3, t.s3, true, L[5], R2, t.s2, O2, t.s2, SC);         // o2 = relu(up_2 r3) + res_2 r2
-  unet_stage<NW>(Wp, L[7], O2, t.s2, true, L[4], R1, t.s1, O1, t.s1, SC);         // o1 = relu(up_1 o2) + res_1 r1
-  unet_stage<NW>(Wp, L[8], O1, t.s1, true, L[3], X0, t.s0, GV, t.sg, SC);         // o0 = relu(up_0 o1) + res_0 x
+// hook(i) is called after stage i = 1..6 (diagnostics).
+template <int NW, typename Hook>
+__device__ __forceinline__ void unet_tile_forward(const float* __restrict__ Wp, const UnetProgram& prog,
+                                                  const TileLayout& t, float* lds, Pre& c, Hook hook) {
+  static_assert(NW <= kMaxWaves, "work table too small");
+  float* SC = lds + t.scratch;
+  const float* BL = lds + t.bias;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 1
+  for (int si = 0; si < 6; ++si) {
+    unet_stage<NW>(Wp, BL, prog.st[si], prog.ww[si][wave], lds, SC, c);
+    hook(si + 1);
+  }
 }
 
 #endif  // __HIPCC__

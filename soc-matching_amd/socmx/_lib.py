@@ -44,6 +44,9 @@ PROTOTYPES = {
     "socmx_rollout_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                     C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
                                     _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_rollout_phase_cycles_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
+                                                 C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
+                                                 _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "socmx_weights_stats_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp]),
     "socmx_num_pairs": (C.c_int64, [C.c_int32]),
     "socmx_socm_prep_f32": (C.c_int, [C.POINTER(Problem), _fp, C.c_int32, C.c_int32, C.c_float,

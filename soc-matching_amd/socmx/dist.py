@@ -1,0 +1,63 @@
+"""Batch-dimension data parallelism over the GPUs of one node (no reference counterpart: the
+reference is single-process).
+
+Trajectories are independent (utils.py:37-101 has no cross-sample term) and the SOCM objective is a
+sum over samples (method.py:717-720), so rank r simulates rows [row0, row0+B_r) of the global batch
+with the Philox stream keyed by the GLOBAL row index, and the only communication per iteration is
+  * one all_gather of 3 floats per rank (sum w, centred sum of squares, n) -> mean/std of w,
+  * ONE all_reduce(SUM) of a flat fp32 buffer holding every gradient (+ the objective value),
+over RCCL (torch.distributed backend "nccl") on xGMI; "gloo" on CPU for tests.  The buffer is
+0.7-3 MB, i.e. latency-bound: it must stay a single collective, never one call per parameter.
+"""
+import torch
+import torch.distributed as dist
+
+from . import loss as L
+
+
+class Shard:
+    def __init__(self, rank=None, world_size=None, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world_size = dist.get_world_size(group) if world_size is None else world_size
+        self._flat = None
+
+    def local_rows(self, B_global):
+        """(B_local, row0): contiguous split, first (B % G) ranks take one extra row."""
+        base, rem = divmod(int(B_global), self.world_size)
+        B_local = base + (1 if self.rank < rem else 0)
+        row0 = self.rank * base + min(self.rank, rem)
+        if B_local < 1:
+            raise ValueError(f"batch {B_global} smaller than world size {self.world_size}")
+        return B_local, row0
+
+    def combine_weight_stats(self, stats):
+        if self.world_size == 1:
+            return stats
+        gathered = [torch.empty_like(stats) for _ in range(self.world_size)]
+        dist.all_gather(gathered, stats.contiguous(), group=self.group)
+        return L.combine_stats(torch.stack(gathered))
+
+    def allreduce_gradients(self, params, extra=None):
+        """Sum `.grad` of all params (and the optional 0-dim tensors in `extra`) across ranks with ONE
+        collective on one flat buffer.  Returns the reduced extras."""
+        params = [p for p in params if p.grad is not None]
+        extra = list(extra or [])
+        if self.world_size == 1:
+            return extra
+        n = sum(p.grad.numel() for p in params) + len(extra)
+        dev = params[0].grad.device if params else extra[0].device
+        if self._flat is None or self._flat.numel() != n or self._flat.device != dev:
+            self._flat = torch.empty(n, dtype=torch.float32, device=dev)
+        flat = self._flat
+        views, off = [], 0
+        for p in params:
+            k = p.grad.numel()
+            views.append(flat[off:off + k].view_as(p.grad))
+            off += k
+        torch._foreach_copy_(views, [p.grad for p in params])
+        for i, e in enumerate(extra):
+            flat[off + i] = e.detach()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        torch._foreach_copy_([p.grad for p in params], views)
+        return [flat[off + i].clone() for i in range(len(extra))]

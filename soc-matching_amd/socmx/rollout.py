@@ -49,7 +49,8 @@ def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noi
 # fused HIP path
 # --------------------------------------------------------------------------------------
 
-def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0):
+def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0, phase_cycles=None):
+    """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 12) -> run the instrumented kernel."""
     global _philox_calls
     L = _lib.lib()
     pb = sde.problem
@@ -76,11 +77,15 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
         offset = _philox_calls
         _philox_calls += 1
     net = sde.nabla_V
-    status = L.socmx_rollout_f32(
-        pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,
-        float(lmbd), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), int(row0), _lib.ptr(noise_in),
-        _lib.ptr(states), _lib.ptr(noises), _lib.ptr(controls), _lib.ptr(stop), _lib.ptr(frac),
-        _lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), _lib.stream_ptr(dev))
+    args = (pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,
+            float(lmbd), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), int(row0), _lib.ptr(noise_in),
+            _lib.ptr(states), _lib.ptr(noises), _lib.ptr(controls), _lib.ptr(stop), _lib.ptr(frac),
+            _lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw))
+    if phase_cycles is not None:
+        assert phase_cycles.dtype == torch.int64 and phase_cycles.is_cuda and phase_cycles.is_contiguous()
+        status = L.socmx_rollout_phase_cycles_f32(*args, phase_cycles.data_ptr(), _lib.stream_ptr(dev))
+    else:
+        status = L.socmx_rollout_f32(*args, _lib.stream_ptr(dev))
     _lib.check(status, "socmx_rollout_f32")
     return states, noises, stop, frac, lpd, lps, ltw, controls
 

@@ -1,0 +1,70 @@
+"""One SOCM training iteration with the reference's bookkeeping (main.py:280-359).
+
+`time_per_iteration` -- the quantity behind the "SOCM iters/sec" metric -- is measured exactly like
+the reference: wall clock from before `.loss()` to after `optimizer.step(); zero_grad()`
+(main.py:280, 351-352).  The normalisation constant is the EMA of the mean importance weight
+(main.py:313-322, 354-359; utils.py:389-396).
+"""
+import time
+
+import numpy as np
+import torch
+
+
+def compute_EMA(value, EMA_value, EMA_coeff=0.01, itr=0):
+    warm = int(np.floor(1 / EMA_coeff))
+    if itr == 0:
+        return value
+    if itr <= warm:
+        return (value + itr * EMA_value) / (itr + 1)
+    return EMA_coeff * value + (1 - EMA_coeff) * EMA_value
+
+
+def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4):
+    """Adam with the SOCM parameter groups of main.py:214-230."""
+    sde = solver.neural_sde
+    return torch.optim.Adam(
+        [{"params": sde.nabla_V.parameters()},
+         {"params": sde.M.sigmoid_layers.parameters(), "lr": M_lr},
+         {"params": sde.gamma, "lr": M_lr}],
+        lr=nabla_V_lr, eps=adam_eps)
+
+
+class Trainer:
+    def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
+                 ema_weight_mean_coeff=0.002, sync_timing=True):
+        self.solver, self.optimizer = solver, optimizer
+        self.batch_size = batch_size
+        self.normalization_const = normalization_const
+        self.algorithm = algorithm
+        self.coeff = ema_weight_mean_coeff
+        self.itr = 0
+        self.sync_timing = sync_timing
+
+    def step(self, **loss_kwargs):
+        solver = self.solver
+        dev = solver.x0.device
+        if self.sync_timing and dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        start = time.time()
+        out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
+                          use_stopping_time=False, **loss_kwargs)
+        objective, weight_mean = out[0], out[5]
+        loss = objective / self.normalization_const                      # main.py:313-322
+        loss.backward()                                                  # main.py:323
+        if solver.shard is not None:
+            (loss_val,) = solver.shard.allreduce_gradients(
+                [p for g in self.optimizer.param_groups for p in g["params"]], extra=[loss.detach()])
+        else:
+            loss_val = loss.detach()
+        with torch.no_grad():
+            self.optimizer.step()                                        # main.py:347-349
+            self.optimizer.zero_grad()
+            if self.sync_timing and dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            time_per_iteration = time.time() - start                    # main.py:351-352
+            self.normalization_const = compute_EMA(weight_mean.detach(), self.normalization_const,
+                                                   EMA_coeff=self.coeff, itr=self.itr)   # main.py:354-359
+        self.itr += 1
+        return dict(loss=loss_val, time_per_iteration=time_per_iteration, weight_mean=weight_mean.detach(),
+                    weight_std=out[6].detach(), out=out)
