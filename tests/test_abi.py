@@ -1,0 +1,55 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/socmx.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "socmx.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(socmx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_symbols()
+    for must in ("socmx_rollout_f32", "socmx_unet_pack_f32", "socmx_unet_forward_f32", "socmx_weights_stats_f32",
+                 "socmx_socm_prep_f32", "socmx_socm_target_fwd_f32", "socmx_socm_target_bwd_f32", "socmx_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from socmx import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: make -C soc-matching_amd/csrc"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(handle, name), f"{name} declared in socmx.h but not exported"
+    # and the Python binding knows every one of them (no stale prototype table)
+    assert sorted(_lib.PROTOTYPES) == declared_symbols()
+
+
+def test_argument_validation_needs_no_gpu():
+    from socmx import _lib
+    L = _lib.lib()
+    assert L.socmx_version() == 100
+    assert L.socmx_num_pairs(200) == 201 * 202 // 2
+    assert L.socmx_unet_packed_floats(10, _lib.i3([256, 128, 64])) > 170562      # padded image >= parameter count
+    assert L.socmx_unet_packed_floats(0, _lib.i3([256, 128, 64])) == 0
+    # NULL / bad-dimension arguments are rejected before any HIP call
+    assert L.socmx_weights_stats_f32(None, None, None, 4, None, None, None) == -1
+    assert L.socmx_socm_target_bwd_f32(0, 4, 4, 1, 1, 1, 1, 1, 1, None) == -2
+    pb = _lib.Problem(kind=7, d=2, sigma=1)
+    assert L.socmx_rollout_f32(pb, 1, _lib.i3([8, 8, 8]), 1, 1, 4, 4, 1.0, 0, 0, 0, None,
+                               1, 1, 1, 1, 1, 1, 1, 1, None) == -3
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from socmx import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libsocmx.so"))
+    with pytest.raises(_lib.SocmxError):
+        _lib.lib()
