@@ -127,10 +127,11 @@ int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, co
                       float* fractional_timesteps, float* lpd, float* lps, float* ltw,
                       socmx_stream_t stream);
 
-/* Diagnostics: the same rollout instrumented with s_memtime; cycles ((B+15)/16, 12) int64 device receives, per
+/* Diagnostics: the same rollout instrumented with s_memtime; cycles ((B+15)/16, 64) int64 device receives, per
  * workgroup, shader cycles summed over the K steps for: [0] input tile build, [1..6] the six network stages
  * (down_0, down_1, down_2, up_2+res_2, up_1+res_1, up_0+res_0), [7] control+noise, [8] EM update,
- * [9] costs/state write-back.  Results are identical to socmx_rollout_f32; it is slower. */
+ * [9] costs/state write-back, [16+8*s+{0..4}] wave 0's split of stage s: issue/prologue, GEMM 1, GEMM 2,
+ * store+prefetch, closing barrier.  Results are identical to socmx_rollout_f32; it is slower. */
 int socmx_rollout_phase_cycles_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
                                    const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
                                    uint64_t seed, uint64_t offset, int64_t row0, const float* noise_in,

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   }
   float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in threads 0..15
   __syncthreads();
-  long long acc_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long acc_prof[64];
+  for (int s = 0; s < 64; ++s) acc_prof[s] = 0;
+  long long last_sub = 0;
   long long last_tick = PROF ? clock64() : 0;
 
   for (int k = 0; k < K; ++k) {
@@ -145,7 +147,14 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     }
     __syncthreads();
     SOCMX_TICK(0)
-    unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, [&](int stage) { SOCMX_TICK(stage) });  // GV = nabla_V(t,x)
+    last_sub = last_tick;
+    unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, [&](int slot) {
+      if (PROF) {
+        const long long now_ = clock64();
+        if (slot < 16) { acc_prof[slot] += now_ - last_tick; last_tick = now_; last_sub = now_; }
+        else { acc_prof[slot] += now_ - last_sub; last_sub = now_; }   // sub-stage split (wave 0's view)
+      }
+    });  // GV = nabla_V(t,x)
 
     // ---- control u = -sigma^T nabla_V (method.py:68-72) and the step's noise (utils.py:39) ---
     for (int e = tid; e < 16 * d; e += nthr) {
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     SOCMX_TICK(9)
   }
   if (PROF && tid == 0 && a.prof)
-    for (int s = 0; s < 12; ++s) a.prof[(size_t)blockIdx.x * 12 + s] = acc_prof[s];
+    for (int s = 0; s < 64; ++s) a.prof[(size_t)blockIdx.x * 64 + s] = acc_prof[s];
 
   // ---- terminal cost (utils.py:101) --------------------------------------------------------
   if (tid < 16 && tile_row0 + tid < B) {

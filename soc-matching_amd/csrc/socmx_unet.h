@@ -310,8 +310,45 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
   }
 }
 
+// ---- descriptor residency ---------------------------------------------------------------------------
+// The stage loop reads its StageDesc / WaveWork from the kernarg segment.  Left alone, the compiler loads
+// each field lazily in the basic block that first needs it: five to eight serial `s_load` -> `s_waitcnt`
+// round trips (~200 cycles each) per stage.  Pinning every field in an SGPR at the top of the stage makes
+// it fetch the whole descriptor in one batch.
+#define SOCMX_PIN(x) asm volatile("" : "+s"(x))
+
+struct WaveWorkS {  // WaveWork widened to SGPR-resident ints
+  int split, blk0, cnt, active, kc0a, kc1a, kc0b, kc1b, part, parts, use_pre;
+  int pf[4];
+};
+
+__device__ __forceinline__ void pin_layer(LayerDesc& L) {
+  SOCMX_PIN(L.w_off); SOCMX_PIN(L.b_off); SOCMX_PIN(L.in_pad); SOCMX_PIN(L.out_pad); SOCMX_PIN(L.b_lds);
+}
+
+__device__ __forceinline__ StageDesc load_stage(const StageDesc& src) {
+  StageDesc d = src;
+  pin_layer(d.L1); pin_layer(d.L2); pin_layer(d.Ln);
+  SOCMX_PIN(d.x1); SOCMX_PIN(d.s1); SOCMX_PIN(d.x2); SOCMX_PIN(d.s2); SOCMX_PIN(d.y); SOCMX_PIN(d.sy); SOCMX_PIN(d.has2);
+  return d;
+}
+
+__device__ __forceinline__ WaveWorkS load_work(const WaveWork& src) {
+  WaveWorkS w;
+  w.split = src.split; w.blk0 = src.blk0; w.cnt = src.cnt; w.active = src.active;
+  w.kc0a = src.kc0a; w.kc1a = src.kc1a; w.kc0b = src.kc0b; w.kc1b = src.kc1b;
+  w.part = src.part; w.parts = src.parts; w.use_pre = src.use_pre;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) w.pf[f] = src.pf[f];
+  SOCMX_PIN(w.split); SOCMX_PIN(w.blk0); SOCMX_PIN(w.cnt); SOCMX_PIN(w.active);
+  SOCMX_PIN(w.kc0a); SOCMX_PIN(w.kc1a); SOCMX_PIN(w.kc0b); SOCMX_PIN(w.kc1b);
+  SOCMX_PIN(w.part); SOCMX_PIN(w.parts); SOCMX_PIN(w.use_pre);
+  SOCMX_PIN(w.pf[0]); SOCMX_PIN(w.pf[1]); SOCMX_PIN(w.pf[2]); SOCMX_PIN(w.pf[3]);
+  return w;
+}
+
 // request the four fragments numbered pf[0..3] of layer Lg (GEMM 1 of the stage that follows)
-__device__ __forceinline__ Pre prefetch_fragments(const float* __restrict__ Wp, const LayerDesc& Lg, const WaveWork& w,
+__device__ __forceinline__ Pre prefetch_fragments(const float* __restrict__ Wp, const LayerDesc& Lg, const WaveWorkS& w,
                                                   int lane) {
   const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + Lg.w_off) + lane;
   Pre pre;
@@ -320,11 +357,11 @@ __device__ __forceinline__ Pre prefetch_fragments(const float* __restrict__ Wp, 
   return pre;
 }
 
-template <int NB, int NW>
+template <int NB, int NW, typename Hook>
 __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const float* bias_lds,
                                              const LayerDesc& L1, const float* X1, int S1, bool has2,
                                              const LayerDesc& L2, const float* X2, int S2, float* Y, int SY,
-                                             int blk0, int lane, const Pre& pre, bool use_pre) {
+                                             int blk0, int lane, const Pre& pre, bool use_pre, Hook hook) {
   const int row = lane & 15, g = lane >> 4;
   const GemmPlan<NB> p1 = make_plan<NB>(Wp, L1, blk0, NW, X1, S1, lane, 0, L1.in_pad >> 4);
   const GemmPlan<NB> p2 = make_plan<NB>(Wp, L2, blk0, NW, X2, S2, lane, 0, L2.in_pad >> 4);
@@ -336,7 +373,9 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
   for (int j = 0; j < NB; ++j) {
     acc[j] = *reinterpret_cast<const f32x4*>(bias_lds + L1.b_lds + (blk0 + j * NW) * 16 + 4 * g);
   }
+  hook(0);
   gemm_run<NB>(acc, r1, p1);
+  hook(1);
 #pragma unroll
   for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -348,6 +387,7 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
     }
     gemm_run<NB>(acc, r2, p2);
   }
+  hook(2);
 #pragma unroll
   for (int j = 0; j < NB; ++j)
     *reinterpret_cast<f32x4*>(Y + row * SY + (blk0 + j * NW) * 16 + 4 * g) = acc[j];
@@ -357,10 +397,14 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
 // `pre` holds this wave's first four GEMM-1 fragments on entry (if w.use_pre) and, on exit, the first four
 // fragments of the following stage's GEMM 1, requested BEFORE this stage's closing barrier.
 // Ends with a workgroup barrier (Y visible, inputs free to overwrite).
-template <int NW>
+template <int NW, typename Hook>
 __device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const float* bias_lds, const StageDesc& sd,
-                                           const WaveWork& w, float* lds, float* scratch, Pre& pre) {
+                                           const WaveWorkS& w, float* lds, float* scratch, Pre& pre, Hook hook) {
   const int lane = threadIdx.x & 63;
+  // Settle the fragments the previous stage requested BEFORE this stage issues any load of its own: the wait
+  // the compiler puts in front of this statement then only covers those (long since landed) loads; placed
+  // later it would also drain this stage's fresh ring loads -- a full L2 round trip per stage.
+  asm volatile("" : "+v"(pre.f[0]), "+v"(pre.f[1]), "+v"(pre.f[2]), "+v"(pre.f[3]));
   const LayerDesc& L1 = sd.L1;
   const LayerDesc& L2 = sd.L2;
   const float* X1 = lds + sd.x1;
@@ -372,14 +416,16 @@ __device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const f
     bool use_pre = w.use_pre != 0;  // the first group starts from the fragments the previous stage requested
     int blk0 = w.blk0;
     for (int cnt = w.cnt; cnt > 0; cnt -= 4, blk0 += 4 * NW) {
-      if (cnt >= 4)      stage_direct<4, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre);
-      else if (cnt == 3) stage_direct<3, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, false);
-      else if (cnt == 2) stage_direct<2, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre);
-      else               stage_direct<1, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre);
+      if (cnt >= 4)      stage_direct<4, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre, hook);
+      else if (cnt == 3) stage_direct<3, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, false, hook);
+      else if (cnt == 2) stage_direct<2, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre, hook);
+      else               stage_direct<1, NW>(Wp, bias_lds, L1, X1, S1, has2, L2, X2, S2, Y, SY, blk0, lane, pre, use_pre, hook);
       use_pre = false;
     }
     pre = prefetch_fragments(Wp, sd.Ln, w, lane);
+    hook(3);
     __syncthreads();
+    hook(4);
   } else {
     // fewer neuron blocks than waves: split the reduction (K) dimension across waves,
     // partial sums through LDS, bias + ReLU applied after the combine.
@@ -427,7 +473,7 @@ __device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const f
 __device__ __forceinline__ Pre unet_carry_init(const float* __restrict__ Wp, const UnetProgram& prog) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  return prefetch_fragments(Wp, prog.st[5].Ln, prog.ww[5][wave], lane);
+  return prefetch_fragments(Wp, prog.st[5].Ln, load_work(prog.ww[5][wave]), lane);
 }
 
 // The whole network on the tile: X0 (already filled, [t, x, 0-pad]) -> GV (nabla_V, first d columns valid).
@@ -441,7 +487,9 @@ __device__ __forceinline__ void unet_tile_forward(const float* __restrict__ Wp, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll 1
   for (int si = 0; si < 6; ++si) {
-    unet_stage<NW>(Wp, BL, prog.st[si], prog.ww[si][wave], lds, SC, c);
+    const StageDesc sd = load_stage(prog.st[si]);
+    const WaveWorkS ww = load_work(prog.ww[si][wave]);
+    unet_stage<NW>(Wp, BL, sd, ww, lds, SC, c, [&](int sub) { hook(16 + si * 8 + sub); });
     hook(si + 1);
   }
 }

@@ -50,7 +50,7 @@ def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noi
 # --------------------------------------------------------------------------------------
 
 def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0, phase_cycles=None):
-    """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 12) -> run the instrumented kernel."""
+    """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 64) -> run the instrumented kernel."""
     global _philox_calls
     L = _lib.lib()
     pb = sde.problem
