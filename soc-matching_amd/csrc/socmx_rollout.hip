@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/socmx.h"
 #include "socmx_unet.h"
@@ -81,18 +82,31 @@ __device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x,
     last_tick = now_;                                      \
   }
 
-template <int NW, bool STOPPING, bool PROF>
+struct DynamicNet {};  // descriptors come from the kernel arguments (any architecture)
+typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
+
+template <int NW, bool STOPPING, bool PROF, class NET>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr bool kStatic = !std::is_same<NET, DynamicNet>::value;
+  TileLayout tl;
+  UnetDesc ud;
+  if constexpr (kStatic) {
+    constexpr TileLayout tc = NET::layout(NW);
+    constexpr UnetDesc uc = NET::desc();
+    tl = tc; ud = uc;
+  } else {
+    tl = a.t; ud = a.u;
+  }
   const int tid = threadIdx.x;
   const int nthr = NW * 64;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
   const int tile_row0 = blockIdx.x * 16;
   // e / d and e / in0p for e < 16*1024 without integer divides: floor((e + 0.5) * (1/n)) is exact in that range
-  const float inv_d = __builtin_amdgcn_rcpf((float)d), inv_in0p = __builtin_amdgcn_rcpf((float)a.u.in0p);
+  const float inv_d = __builtin_amdgcn_rcpf((float)d), inv_in0p = __builtin_amdgcn_rcpf((float)ud.in0p);
 #define SOCMX_DIV_D(e) ((int)(((float)(e) + 0.5f) * inv_d))
-  float* X0 = lds + a.t.x0;
-  float* GV = lds + a.t.gv;
+  float* X0 = lds + tl.x0;
+  float* GV = lds + tl.gv;
   // small per-tile state (behind the network tiles)
   const int ds = d + 1;                   // padded row stride of the LDS matrix copies (bank spread)
   float* sig = lds + a.lds_mats;          // (d,ds)
@@ -115,8 +129,10 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     A_l[r * ds + c] = is_ou ? a.A[e] : 0.f;
     P_l[r * ds + c] = (kind == SOCMX_OU_QUADRATIC) ? a.P[e] : 0.f;
   }
-  unet_load_biases(a.packed, a.u, a.t, lds, tid, nthr);
-  Pre carry = unet_carry_init(a.packed, a.prog);
+  unet_load_biases(a.packed, ud, tl, lds, tid, nthr);
+  Pre carry;
+  if constexpr (kStatic) carry = unet_carry_init_static<NW, NET>(a.packed);
+  else carry = unet_carry_init(a.packed, a.prog);
   for (int e = tid; e < 16 * d; e += nthr) {
     const int r = SOCMX_DIV_D(e), i = e - r * d;
     const int grow = min(tile_row0 + r, B - 1);  // ragged tail: replicate the last row, never stored
@@ -141,26 +157,28 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
 
     // ---- network input [t, x, 0...]  (method.py:65-67) --------------------------------
-    for (int e = tid; e < 16 * a.u.in0p; e += nthr) {
-      const int r = (int)(((float)e + 0.5f) * inv_in0p), c = e - r * a.u.in0p;
-      X0[r * a.t.s0 + c] = (c == 0) ? t0 : (c <= d ? XS[r * d + c - 1] : 0.f);
+    for (int e = tid; e < 16 * ud.in0p; e += nthr) {
+      const int r = (int)(((float)e + 0.5f) * inv_in0p), c = e - r * ud.in0p;
+      X0[r * tl.s0 + c] = (c == 0) ? t0 : (c <= d ? XS[r * d + c - 1] : 0.f);
     }
     __syncthreads();
     SOCMX_TICK(0)
     last_sub = last_tick;
-    unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, [&](int slot) {
+    auto hook = [&](int slot) {
       if (PROF) {
         const long long now_ = clock64();
         if (slot < 16) { acc_prof[slot] += now_ - last_tick; last_tick = now_; last_sub = now_; }
         else { acc_prof[slot] += now_ - last_sub; last_sub = now_; }   // sub-stage split (wave 0's view)
       }
-    });  // GV = nabla_V(t,x)
+    };
+    if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, hook);   // GV = nabla_V(t, x)
+    else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);  // GV = nabla_V(t,x)
 
     // ---- control u = -sigma^T nabla_V (method.py:68-72) and the step's noise (utils.py:39) ---
     for (int e = tid; e < 16 * d; e += nthr) {
       const int r = SOCMX_DIV_D(e), i = e - r * d;
       float s = 0.f;
-      for (int j = 0; j < d; ++j) s += sig[j * ds + i] * GV[r * a.t.sg + j];
+      for (int j = 0; j < d; ++j) s += sig[j * ds + i] * GV[r * tl.sg + j];
       const float u = -s;
       const int grow = tile_row0 + r;
       float eps;
@@ -469,13 +487,21 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
   const int blocks = (B + 15) / 16;
   const bool stopping = pb->kind == SOCMX_MOLECULAR_DYNAMICS;
+  // the reference's default architecture runs the fully specialised instantiation (SOCMX_GENERIC=1 forces the
+  // table-driven one, for A/B runs and tests)
+  static const bool force_generic = getenv("SOCMX_GENERIC") != nullptr;
+  const bool is_default = !force_generic && nw == 8 && a.u.in0p == 16 && a.u.hp[0] == 256 && a.u.hp[1] == 128 &&
+                          a.u.hp[2] == 64 && a.u.outp == 16;
   void (*kern)(const RolloutArgs);
-  if (nw == 4) {
-    if (prof) kern = stopping ? rollout_kernel<4, true, true> : rollout_kernel<4, false, true>;
-    else kern = stopping ? rollout_kernel<4, true, false> : rollout_kernel<4, false, false>;
+  if (is_default) {
+    if (prof) kern = stopping ? rollout_kernel<8, true, true, DefaultNet> : rollout_kernel<8, false, true, DefaultNet>;
+    else kern = stopping ? rollout_kernel<8, true, false, DefaultNet> : rollout_kernel<8, false, false, DefaultNet>;
+  } else if (nw == 4) {
+    if (prof) kern = stopping ? rollout_kernel<4, true, true, DynamicNet> : rollout_kernel<4, false, true, DynamicNet>;
+    else kern = stopping ? rollout_kernel<4, true, false, DynamicNet> : rollout_kernel<4, false, false, DynamicNet>;
   } else {
-    if (prof) kern = stopping ? rollout_kernel<8, true, true> : rollout_kernel<8, false, true>;
-    else kern = stopping ? rollout_kernel<8, true, false> : rollout_kernel<8, false, false>;
+    if (prof) kern = stopping ? rollout_kernel<8, true, true, DynamicNet> : rollout_kernel<8, false, true, DynamicNet>;
+    else kern = stopping ? rollout_kernel<8, true, false, DynamicNet> : rollout_kernel<8, false, false, DynamicNet>;
   }
   hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err != hipSuccess) return (int)err;

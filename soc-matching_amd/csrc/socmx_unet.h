@@ -42,7 +42,7 @@ struct UnetDesc {
   int bias_floats;  // sum of padded fan-outs
 };
 
-__host__ __device__ inline int pad16(int x) { return (x + 15) & ~15; }
+__host__ __device__ constexpr int pad16(int x) { return (x + 15) & ~15; }
 
 // layer (fan_in, fan_out) in SOCMX_L_* order
 inline void unet_layer_dims(int d, const int h[3], int fin[9], int fout[9]) {
@@ -58,22 +58,31 @@ inline void unet_layer_dims(int d, const int h[3], int fin[9], int fout[9]) {
   fin[8] = h[0]; fout[8] = d;     // up_0
 }
 
-inline UnetDesc make_unet_desc(int d, const int h[3]) {
-  UnetDesc u;
-  u.d = d; u.in0 = d + 1; u.in0p = pad16(d + 1); u.outp = pad16(d);
-  for (int i = 0; i < 3; ++i) { u.h[i] = h[i]; u.hp[i] = pad16(h[i]); }
-  int fin[9], fout[9];
-  unet_layer_dims(d, h, fin, fout);
+// Everything the kernels need depends only on the PADDED widths; this form is constexpr so that the
+// specialised kernels (socmx_rollout.hip, StaticNet) fold every offset into an immediate.
+__host__ __device__ constexpr UnetDesc make_unet_desc_padded(int d, int in0p, int h0p, int h1p, int h2p, int outp) {
+  UnetDesc u{};
+  u.d = d; u.in0 = d + 1; u.in0p = in0p; u.outp = outp;
+  u.h[0] = h0p; u.h[1] = h1p; u.h[2] = h2p;
+  u.hp[0] = h0p; u.hp[1] = h1p; u.hp[2] = h2p;
+  const int fin[9] = {in0p, h0p, h1p, in0p, h0p, h1p, h2p, h1p, h0p};   // SOCMX_L_* order
+  const int fout[9] = {h0p, h1p, h2p, outp, h0p, h1p, h1p, h0p, outp};
   int off = 0, boff = 0;
   for (int l = 0; l < 9; ++l) {
-    u.L[l].in_pad = pad16(fin[l]);
-    u.L[l].out_pad = pad16(fout[l]);
-    u.L[l].w_off = off; off += u.L[l].in_pad * u.L[l].out_pad;
-    u.L[l].b_off = off; off += u.L[l].out_pad;
-    u.L[l].b_lds = boff; boff += u.L[l].out_pad;
+    u.L[l].in_pad = fin[l];
+    u.L[l].out_pad = fout[l];
+    u.L[l].w_off = off; off += fin[l] * fout[l];
+    u.L[l].b_off = off; off += fout[l];
+    u.L[l].b_lds = boff; boff += fout[l];
   }
   u.total_floats = off;
   u.bias_floats = boff;
+  return u;
+}
+
+inline UnetDesc make_unet_desc(int d, const int h[3]) {
+  UnetDesc u = make_unet_desc_padded(d, pad16(d + 1), pad16(h[0]), pad16(h[1]), pad16(h[2]), pad16(d));
+  for (int i = 0; i < 3; ++i) u.h[i] = h[i];
   return u;
 }
 
@@ -86,8 +95,8 @@ struct TileLayout {
   int floats;                                // total
 };
 
-__host__ __device__ inline TileLayout make_tile_layout(const UnetDesc& u, int nwaves) {
-  TileLayout t;
+__host__ __device__ constexpr TileLayout make_tile_layout(const UnetDesc& u, int nwaves) {
+  TileLayout t{};
   t.s0 = u.in0p + 4; t.s1 = u.hp[0] + 4; t.s2 = u.hp[1] + 4; t.s3 = u.hp[2] + 4; t.sg = u.outp + 4;
   int off = 0;
   t.x0 = off; off += 16 * t.s0;
@@ -124,7 +133,7 @@ struct WaveWork {
   unsigned short split, blk0, cnt, active;
   unsigned short kc0a, kc1a, kc0b, kc1b;
   unsigned short part, parts, use_pre, pad;
-  unsigned short pf[4];
+  unsigned short pf[8];
 };
 
 struct UnetProgram {
@@ -132,28 +141,37 @@ struct UnetProgram {
   WaveWork ww[6][kMaxWaves];
 };
 
+__host__ __device__ constexpr StageDesc make_stage(const UnetDesc& u, int l1, int x1, int s1, int has2, int l2, int x2,
+                                                   int s2, int y, int sy, int ln) {
+  StageDesc d{};
+  d.L1 = u.L[l1]; d.L2 = u.L[l2]; d.Ln = u.L[ln];
+  d.x1 = x1; d.s1 = s1; d.x2 = x2; d.s2 = s2; d.y = y; d.sy = sy; d.has2 = has2;
+  return d;
+}
+
+// stage i of the network (0..5); constexpr so the specialised kernels see immediates
+__host__ __device__ constexpr StageDesc unet_stage_desc(const UnetDesc& u, const TileLayout& t, int i) {
+  switch (i) {
+    case 0: return make_stage(u, 0, t.x0, t.s0, 0, 0, t.x0, t.s0, t.r1, t.s1, 1);   // r1 = relu(down_0 x)
+    case 1: return make_stage(u, 1, t.r1, t.s1, 0, 1, t.r1, t.s1, t.r2, t.s2, 2);   // r2 = relu(down_1 r1)
+    case 2: return make_stage(u, 2, t.r2, t.s2, 0, 2, t.r2, t.s2, t.r3, t.s3, 6);   // r3 = relu(down_2 r2)
+    case 3: return make_stage(u, 6, t.r3, t.s3, 1, 5, t.r2, t.s2, t.o2, t.s2, 7);   // o2 = relu(up_2 r3) + res_2 r2
+    case 4: return make_stage(u, 7, t.o2, t.s2, 1, 4, t.r1, t.s1, t.o1, t.s1, 8);   // o1 = relu(up_1 o2) + res_1 r1
+    default: return make_stage(u, 8, t.o1, t.s1, 1, 3, t.x0, t.s0, t.gv, t.sg, 0);  // o0 = relu(up_0 o1) + res_0 x; then down_0
+  }
+}
+
 __host__ __device__ inline UnetProgram make_unet_program(const UnetDesc& u, const TileLayout& t) {
   UnetProgram p;
-  const LayerDesc* L = u.L;
-  auto set = [&](int i, int l1, int x1, int s1, int has2, int l2, int x2, int s2, int y, int sy, int ln) {
-    StageDesc& d = p.st[i];
-    d.L1 = L[l1]; d.L2 = L[l2]; d.Ln = L[ln];
-    d.x1 = x1; d.s1 = s1; d.x2 = x2; d.s2 = s2; d.y = y; d.sy = sy; d.has2 = has2;
-  };
-  set(0, 0, t.x0, t.s0, 0, 0, t.x0, t.s0, t.r1, t.s1, 1);   // r1 = relu(down_0 x)
-  set(1, 1, t.r1, t.s1, 0, 1, t.r1, t.s1, t.r2, t.s2, 2);   // r2 = relu(down_1 r1)
-  set(2, 2, t.r2, t.s2, 0, 2, t.r2, t.s2, t.r3, t.s3, 6);   // r3 = relu(down_2 r2)
-  set(3, 6, t.r3, t.s3, 1, 5, t.r2, t.s2, t.o2, t.s2, 7);   // o2 = relu(up_2 r3) + res_2 r2
-  set(4, 7, t.o2, t.s2, 1, 4, t.r1, t.s1, t.o1, t.s1, 8);   // o1 = relu(up_1 o2) + res_1 r1
-  set(5, 8, t.o1, t.s1, 1, 3, t.x0, t.s0, t.gv, t.sg, 0);   // o0 = relu(up_0 o1) + res_0 x ; then down_0 again
+  for (int i = 0; i < 6; ++i) p.st[i] = unet_stage_desc(u, t, i);
   return p;
 }
 
-// first four GEMM-1 fragments wave `w` consumes in a stage whose GEMM 1 is layer Lg (mirrors fill_wave_work)
-inline void first_fragment_numbers(const LayerDesc& Lg, int NW, int w, unsigned short pf[4], bool* consumed) {
+// first eight GEMM-1 fragments wave `w` consumes in a stage whose GEMM 1 is layer Lg
+__host__ __device__ constexpr bool first_fragment_numbers(const LayerDesc& Lg, int NW, int w, unsigned short (&pf)[8]) {
   const int NBLK = Lg.out_pad >> 4, KC = Lg.in_pad >> 4;
-  int blk, bstride, nb, kc0, kc1;
-  bool ok;
+  int blk = 0, bstride = 0, nb = 1, kc0 = 0, kc1 = 1;
+  bool ok = false;
   if (NBLK >= NW) {
     int cnt = w < NBLK ? (NBLK - w + NW - 1) / NW : 0;
     nb = cnt > 4 ? 4 : cnt;
@@ -167,41 +185,42 @@ inline void first_fragment_numbers(const LayerDesc& Lg, int NW, int w, unsigned 
     ok = part < parts && kc1 > kc0;
     if (!ok) { kc0 = 0; kc1 = 1; }
   }
-  for (int f = 0; f < 4; ++f) {
+  for (int f = 0; f < 8; ++f) {
     int kc = kc0 + f / nb; if (kc > kc1 - 1) kc = kc1 - 1;
     int b = blk + (f % nb) * bstride; if (b > NBLK - 1) b = NBLK - 1;
     pf[f] = (unsigned short)(b * KC + kc);
   }
-  *consumed = ok;
+  return ok;
+}
+
+// work split of wave w in stage d (constexpr: the specialised kernels evaluate it with constant d and NW, so
+// only shifts/masks of the wave id remain)
+__host__ __device__ constexpr WaveWork wave_work_of(const StageDesc& d, int NW, int w) {
+  WaveWork x{};
+  const int NBLK = d.L1.out_pad >> 4, KC1 = d.L1.in_pad >> 4, KC2 = d.L2.in_pad >> 4;
+  if (NBLK >= NW) {
+    x.split = 0; x.blk0 = (unsigned short)w;
+    x.cnt = (unsigned short)(w < NBLK ? (NBLK - w + NW - 1) / NW : 0);
+    x.active = x.cnt > 0;
+    x.kc0a = 0; x.kc1a = (unsigned short)KC1; x.kc0b = 0; x.kc1b = (unsigned short)KC2;
+  } else {
+    const int parts = NW / NBLK, part = w / NBLK;
+    x.split = 1; x.blk0 = (unsigned short)(w % NBLK); x.cnt = 1;
+    x.parts = (unsigned short)parts; x.part = (unsigned short)part; x.active = part < parts;
+    if (x.active) {
+      x.kc0a = (unsigned short)((part * KC1) / parts); x.kc1a = (unsigned short)(((part + 1) * KC1) / parts);
+      x.kc0b = (unsigned short)((part * KC2) / parts); x.kc1b = (unsigned short)(((part + 1) * KC2) / parts);
+    }
+  }
+  unsigned short tmp[8] = {};
+  x.use_pre = first_fragment_numbers(d.L1, NW, w, tmp);   // does THIS stage consume a prefetch?
+  first_fragment_numbers(d.Ln, NW, w, x.pf);              // what to request for the NEXT stage
+  return x;
 }
 
 inline void fill_wave_work(UnetProgram& p, int NW) {
-  for (int si = 0; si < 6; ++si) {
-    const StageDesc& d = p.st[si];
-    const int NBLK = d.L1.out_pad >> 4, KC1 = d.L1.in_pad >> 4, KC2 = d.L2.in_pad >> 4;
-    for (int w = 0; w < NW; ++w) {
-      WaveWork& x = p.ww[si][w];
-      x = WaveWork{};
-      if (NBLK >= NW) {
-        x.split = 0; x.blk0 = (unsigned short)w;
-        x.cnt = (unsigned short)(w < NBLK ? (NBLK - w + NW - 1) / NW : 0);
-        x.active = x.cnt > 0;
-        x.kc0a = 0; x.kc1a = (unsigned short)KC1; x.kc0b = 0; x.kc1b = (unsigned short)KC2;
-      } else {
-        const int parts = NW / NBLK, part = w / NBLK;
-        x.split = 1; x.blk0 = (unsigned short)(w % NBLK); x.cnt = 1;
-        x.parts = (unsigned short)parts; x.part = (unsigned short)part; x.active = part < parts;
-        x.kc0a = (unsigned short)((part * KC1) / parts); x.kc1a = (unsigned short)(((part + 1) * KC1) / parts);
-        x.kc0b = (unsigned short)((part * KC2) / parts); x.kc1b = (unsigned short)(((part + 1) * KC2) / parts);
-        if (!x.active) { x.kc0a = x.kc1a = x.kc0b = x.kc1b = 0; }
-      }
-      bool consumed;
-      unsigned short tmp[4];
-      first_fragment_numbers(d.L1, NW, w, tmp, &consumed);   // does THIS stage consume a prefetch?
-      x.use_pre = consumed;
-      first_fragment_numbers(d.Ln, NW, w, x.pf, &consumed);  // what to request for the NEXT stage
-    }
-  }
+  for (int si = 0; si < 6; ++si)
+    for (int w = 0; w < NW; ++w) p.ww[si][w] = wave_work_of(p.st[si], NW, w);
 }
 
 #if defined(__HIPCC__)
@@ -217,13 +236,12 @@ __device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, c
 
 template <int NB>
 __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NB], const f32x4 (&a)[NB], const f32x4 bx) {
+  // k-step outer, block inner: consecutive MFMAs hit different accumulators (the dependent-accumulator latency
+  // of v_mfma_f32_16x16x4_f32 is 40 cycles against a 32-cycle issue interval)
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], bx[0], acc[j], 0, 0, 0);
-    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], bx[1], acc[j], 0, 0, 0);
-    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], bx[2], acc[j], 0, 0, 0);
-    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], bx[3], acc[j], 0, 0, 0);
-  }
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], bx[i], acc[j], 0, 0, 0);
 }
 
 // Weight fragments come straight from L2 into VGPRs (each is used by exactly one MFMA group of one
@@ -234,13 +252,13 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NB], const f32x4 (&a)[NB
 // latency off the stage-to-stage critical path.
 // the four prefetched fragments handed from one stage to the next (by value: stays in VGPRs)
 struct Pre {
-  f32x4 f[4];
+  f32x4 f[8];   // PD*NB = 8 for NB in {1,2,4}: the whole first ring of the next stage's GEMM 1
 };
 
 template <int NB>
 struct Ring {
   static constexpr int PD = (NB >= 4) ? 2 : (NB >= 2 ? 4 : 8);   // chunks in flight (PD*NB*4 VGPRs)
-  static constexpr int CP = (NB == 3) ? 0 : 4 / NB;              // chunks covered by the 4 `pre` fragments
+  static constexpr int CP = (NB == 3) ? 0 : 8 / NB;              // chunks covered by the 8 `pre` fragments (= PD)
   f32x4 slot[PD][NB];
 };
 
@@ -319,7 +337,7 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
 
 struct WaveWorkS {  // WaveWork widened to SGPR-resident ints
   int split, blk0, cnt, active, kc0a, kc1a, kc0b, kc1b, part, parts, use_pre;
-  int pf[4];
+  int pf[8];
 };
 
 __device__ __forceinline__ void pin_layer(LayerDesc& L) {
@@ -339,21 +357,22 @@ __device__ __forceinline__ WaveWorkS load_work(const WaveWork& src) {
   w.kc0a = src.kc0a; w.kc1a = src.kc1a; w.kc0b = src.kc0b; w.kc1b = src.kc1b;
   w.part = src.part; w.parts = src.parts; w.use_pre = src.use_pre;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) w.pf[f] = src.pf[f];
+  for (int f = 0; f < 8; ++f) w.pf[f] = src.pf[f];
   SOCMX_PIN(w.split); SOCMX_PIN(w.blk0); SOCMX_PIN(w.cnt); SOCMX_PIN(w.active);
   SOCMX_PIN(w.kc0a); SOCMX_PIN(w.kc1a); SOCMX_PIN(w.kc0b); SOCMX_PIN(w.kc1b);
   SOCMX_PIN(w.part); SOCMX_PIN(w.parts); SOCMX_PIN(w.use_pre);
   SOCMX_PIN(w.pf[0]); SOCMX_PIN(w.pf[1]); SOCMX_PIN(w.pf[2]); SOCMX_PIN(w.pf[3]);
+  SOCMX_PIN(w.pf[4]); SOCMX_PIN(w.pf[5]); SOCMX_PIN(w.pf[6]); SOCMX_PIN(w.pf[7]);
   return w;
 }
 
-// request the four fragments numbered pf[0..3] of layer Lg (GEMM 1 of the stage that follows)
+// request the eight fragments numbered pf[0..7] of layer Lg (GEMM 1 of the stage that follows)
 __device__ __forceinline__ Pre prefetch_fragments(const float* __restrict__ Wp, const LayerDesc& Lg, const WaveWorkS& w,
                                                   int lane) {
   const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + Lg.w_off) + lane;
   Pre pre;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) pre.f[f] = wl[(size_t)w.pf[f] * 64];
+  for (int f = 0; f < 8; ++f) pre.f[f] = wl[(size_t)w.pf[f] * 64];
   return pre;
 }
 
@@ -404,7 +423,10 @@ __device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const f
   // Settle the fragments the previous stage requested BEFORE this stage issues any load of its own: the wait
   // the compiler puts in front of this statement then only covers those (long since landed) loads; placed
   // later it would also drain this stage's fresh ring loads -- a full L2 round trip per stage.
+  hook(5);
   asm volatile("" : "+v"(pre.f[0]), "+v"(pre.f[1]), "+v"(pre.f[2]), "+v"(pre.f[3]));
+  asm volatile("" : "+v"(pre.f[4]), "+v"(pre.f[5]), "+v"(pre.f[6]), "+v"(pre.f[7]));
+  hook(6);
   const LayerDesc& L1 = sd.L1;
   const LayerDesc& L2 = sd.L2;
   const float* X1 = lds + sd.x1;
@@ -492,6 +514,59 @@ __device__ __forceinline__ void unet_tile_forward(const float* __restrict__ Wp, 
     unet_stage<NW>(Wp, BL, sd, ww, lds, SC, c, [&](int sub) { hook(16 + si * 8 + sub); });
     hook(si + 1);
   }
+}
+
+// ---- fully specialised form -----------------------------------------------------------------------------
+// For a network whose padded widths are template constants every descriptor above is a compile-time value:
+// no descriptor loads, no runtime NB dispatch, offsets folded into immediates.  The per-stage bookkeeping of
+// the table-driven loop (~100 scalar instructions per wave per stage) costs more than the MFMAs of the small
+// layers, so the reference's default architecture gets this instantiation (socmx_rollout.hip picks it).
+template <int IN0P, int H0P, int H1P, int H2P, int OUTP>
+struct StaticNet {
+  static constexpr int in0p = IN0P, outp = OUTP;
+  __host__ __device__ static constexpr UnetDesc desc() { return make_unet_desc_padded(0, IN0P, H0P, H1P, H2P, OUTP); }
+  __host__ __device__ static constexpr TileLayout layout(int nw) { return make_tile_layout(desc(), nw); }
+};
+
+template <int NW, class NET, int SI, typename Hook>
+__device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, float* lds, Pre& c, int wave, Hook hook) {
+  constexpr UnetDesc u = NET::desc();
+  constexpr TileLayout t = NET::layout(NW);
+  constexpr StageDesc sd = unet_stage_desc(u, t, SI);
+  const WaveWork w0 = wave_work_of(sd, NW, wave);
+  WaveWorkS w;
+  w.split = w0.split; w.blk0 = w0.blk0; w.cnt = w0.cnt; w.active = w0.active;
+  w.kc0a = w0.kc0a; w.kc1a = w0.kc1a; w.kc0b = w0.kc0b; w.kc1b = w0.kc1b;
+  w.part = w0.part; w.parts = w0.parts; w.use_pre = w0.use_pre;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
+  unet_stage<NW>(Wp, lds + t.bias, sd, w, lds, lds + t.scratch, c, [&](int sub) { hook(16 + SI * 8 + sub); });
+  hook(SI + 1);
+}
+
+template <int NW, class NET, typename Hook>
+__device__ __forceinline__ void unet_tile_forward_static(const float* __restrict__ Wp, float* lds, Pre& c, Hook hook) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unet_stage_static<NW, NET, 0>(Wp, lds, c, wave, hook);
+  unet_stage_static<NW, NET, 1>(Wp, lds, c, wave, hook);
+  unet_stage_static<NW, NET, 2>(Wp, lds, c, wave, hook);
+  unet_stage_static<NW, NET, 3>(Wp, lds, c, wave, hook);
+  unet_stage_static<NW, NET, 4>(Wp, lds, c, wave, hook);
+  unet_stage_static<NW, NET, 5>(Wp, lds, c, wave, hook);
+}
+
+template <int NW, class NET>
+__device__ __forceinline__ Pre unet_carry_init_static(const float* __restrict__ Wp) {
+  constexpr UnetDesc u = NET::desc();
+  constexpr TileLayout t = NET::layout(NW);
+  constexpr StageDesc sd = unet_stage_desc(u, t, 5);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const WaveWork w0 = wave_work_of(sd, NW, wave);
+  WaveWorkS w{};
+#pragma unroll
+  for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
+  return prefetch_fragments(Wp, sd.Ln, w, lane);
 }
 
 #endif  // __HIPCC__

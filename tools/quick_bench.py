@@ -57,8 +57,8 @@ for name in which:
         names = ["x0build", "down_0", "down_1", "down_2", "up2+res2", "up1+res1", "up0+res0", "ctrl+noise", "EM", "cost+wb"]
         print(f"{name}: cycles/step per phase: " + ", ".join(f"{n}={v:.0f}" for n, v in zip(names, c)) + f"  total={c[:10].sum():.0f}")
         for si in range(6):
-            sub = c[16 + si * 8: 16 + si * 8 + 5]
-            print(f"   stage {si+1} ({names[si+1]}): issue={sub[0]:.0f} gemm1={sub[1]:.0f} gemm2={sub[2]:.0f} store+prefetch={sub[3]:.0f} barrier={sub[4]:.0f}")
+            sub = c[16 + si * 8: 16 + si * 8 + 7]
+            print(f"   stage {si+1} ({names[si+1]}): desc={sub[5]:.0f} prewait={sub[6]:.0f} issue={sub[0]:.0f} gemm1={sub[1]:.0f} gemm2={sub[2]:.0f} store+prefetch={sub[3]:.0f} barrier={sub[4]:.0f}")
     if name != "burst" and "--loss" in sys.argv or name in ("cfg2", "cfg3"):
         solver = SOC_Solver(sde, x0, None, T=1.0, num_steps=K, lmbd=1.0, d=d, sigma=sigma)
         opt = make_optimizer(solver, M_lr=1e-3)
