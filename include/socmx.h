@@ -60,9 +60,13 @@ enum {
 };
 
 /* Closed-form problem constants; unused members may be NULL. All device, fp32. */
+#define SOCMX_SIGMA_IDENTITY 1 /* flags: sigma is exactly the identity (lets the rollout skip the sigma products) */
+
 typedef struct socmx_problem {
   int32_t kind;
   int32_t d;
+  int32_t flags;            /* SOCMX_SIGMA_IDENTITY or 0; a hint: 0 is always correct */
+  int32_t reserved;
   const float* sigma;       /* (d,d) */
   const float* sigma_inv_t; /* (d,d) transpose(inverse(sigma)); only the loss entry points read it */
   const float* A;           /* (d,d)  OU_*            */

@@ -59,6 +59,7 @@ struct RolloutArgs {
   const float *sigma, *A, *P, *Q, *omega, *kappa, *nu;
   const float *x0, *ts, *noise_in;
   float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
+  int sigma_identity;  // problem->flags & SOCMX_SIGMA_IDENTITY
   int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
   long long* prof;  // diagnostics only (PROF variant): [blocks][12] accumulated s_memtime cycles per phase
 };
@@ -85,7 +86,7 @@ __device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x,
 struct DynamicNet {};  // descriptors come from the kernel arguments (any architecture)
 typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
 
-template <int NW, bool STOPPING, bool PROF, class NET>
+template <int NW, bool STOPPING, bool PROF, class NET, bool FAST>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool kStatic = !std::is_same<NET, DynamicNet>::value;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   float* ST = UP + 16 * d;                // (16,)  stop_inds (1 = still running)
   float* SN = ST + 16;                    // (16,)  next stop_inds
   float* FD = SN + 16;                    // (16,)  fractional time step
+  float* NZ = FD + 16;                    // (2,16,16) FAST path: double-buffered noise of steps k, k+1
 
   const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
   for (int e = tid; e < d * d; e += nthr) {
@@ -133,6 +135,133 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   Pre carry;
   if constexpr (kStatic) carry = unet_carry_init_static<NW, NET>(a.packed);
   else carry = unet_carry_init(a.packed, a.prog);
+
+  if constexpr (FAST) {
+    // ---- sigma = I, d <= 15: the whole SDE step of a row lives in one 16-lane group --------------------
+    // thread (r = tid>>4, i = tid&15), tid < 256: state x_i, control, noise, update, costs in registers; row
+    // sums by 16-lane butterflies; ONE barrier per step besides the network's (method.py:64-80, utils.py:37-101).
+    const bool act = tid < 256;
+    const int r = (tid >> 4) & 15, i = tid & 15;
+    const int ic = min(i, d - 1);
+    const bool lane_ok = act && i < d;
+    const int grow = tile_row0 + r;
+    const bool store = lane_ok && grow < B;
+    const size_t rowoff = (size_t)grow * d + i;
+    auto gsum = [](float v) {
+      v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+      return v;
+    };
+    float x = lane_ok ? a.x0[(size_t)min(grow, B - 1) * d + i] : 0.f;
+    const float kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
+    float stop = 1.f, lpd = 0.f, lps = 0.f;
+    if (store) a.states[rowoff] = x;
+    if (act && i == 0 && grow < B) a.stop_ind[grow] = 1.f;
+    if (act) {
+      if (i < 15) X0[r * tl.s0 + 1 + i] = x;   // columns 1..15; lanes i >= d hold x = 0
+      if (i == 0) X0[r * tl.s0] = a.ts[0];
+    }
+    // The step's noise does not depend on the network: while waves 0..3 integrate step k, waves 4..7 (idle in
+    // this phase) draw / fetch the noise of step k+1 into the other half of NZ.
+    constexpr bool kSplitNoise = (NW >= 8);
+    const bool producer = kSplitNoise ? (tid >= 256 && tid < 512) : act;
+    const int pr = (tid >> 4) & 15, pi = tid & 15, pgrow = tile_row0 + pr;
+    auto draw = [&](int k) -> float {
+      if (pi >= d || k >= K) return 0.f;
+      if (a.noise_in) return a.noise_in[((size_t)k * B + min(pgrow, B - 1)) * d + pi];
+      return philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + pgrow), (uint32_t)k, pi);
+    };
+    if (producer) NZ[pr * 16 + pi] = draw(0);
+    long long acc_prof[64];
+    if (PROF) for (int s = 0; s < 64; ++s) acc_prof[s] = 0;
+    long long last_tick = PROF ? clock64() : 0, last_sub = last_tick;
+    for (int k = 0; k < K; ++k) {
+      const float t0 = a.ts[k], t1 = a.ts[k + 1];
+      const float dt = t1 - t0;                 // utils.py:38
+      const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
+      __syncthreads();
+      SOCMX_TICK(0)
+      auto hook = [&](int slot) {
+        if (PROF) {
+          const long long now_ = clock64();
+          if (slot < 16) { acc_prof[slot] += now_ - last_tick; last_tick = now_; last_sub = now_; }
+          else { acc_prof[slot] += now_ - last_sub; last_sub = now_; }
+        }
+      };
+      if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, hook);   // GV = nabla_V(t, x)
+      else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);
+      if (act) {
+        const float u = lane_ok ? -GV[r * tl.sg + i] : 0.f;              // u = -sigma^T nabla_V, sigma = I
+        const float eps = NZ[(k & 1) * 256 + r * 16 + i];                 // drawn during the previous step
+        float bi;
+        if (is_ou) {                                                      // b = A x
+          bi = 0.f;
+          for (int j = 0; j < d; ++j) bi += A_l[ic * ds + j] * __shfl(x, j, 16);
+          if (!lane_ok) bi = 0.f;
+        } else {
+          bi = -2.f * kap * (x * x - 1.f) * 2.f * x;                      // double_well.py:44-48
+        }
+        const float upd = (bi + u) * dt + sq_ldt * eps;                   // utils.py:45-47
+        const float xn = x + stop * upd;                                  // utils.py:48
+        float xe = xn, step = dt, stop_new = 1.f;
+        if (STOPPING) {                                                   // utils.py:42-44, 49-75; Phi = -x_0
+          const float phi_b = -__shfl(x, 0, 16), phi_a = -__shfl(xn, 0, 16);
+          const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
+          const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
+          const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
+          xe = js * (x + fr * stop * upd) + (1.f - js) * xn;
+          step = js * (fr * fr) * dt + ns * dt;                           // step_fraction squared (utils.py:70-72)
+          stop_new = (-__shfl(xe, 0, 16) > 0.f) ? 1.f : 0.f;
+        }
+        float f = 0.f;                                                    // f at the NEW state, OLD time (utils.py:92-96)
+        if (kind == SOCMX_OU_QUADRATIC) {
+          float px = 0.f;
+          for (int j = 0; j < d; ++j) px += P_l[ic * ds + j] * __shfl(xe, j, 16);
+          f = gsum(lane_ok ? xe * px : 0.f);
+        } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
+          f = 1.f;
+        }
+        const float uu = gsum(u * u), ue = gsum(u * eps);
+        lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
+        lps = lps + sqrtf(step / a.lmbd) * (-ue);
+        if (store) {
+          a.controls[(size_t)k * B * d + rowoff] = u;
+          a.noises[(size_t)k * B * d + rowoff] = eps;
+          a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
+        }
+        if (i == 0 && grow < B) {
+          a.frac[(size_t)k * B + grow] = step;
+          a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? stop_new : 1.f;
+        }
+        x = lane_ok ? xe : 0.f;
+        if (STOPPING) stop = stop_new;
+        if (i < 15) X0[r * tl.s0 + 1 + i] = x;                            // next step's network input [t, x, 0..]
+        if (i == 0) X0[r * tl.s0] = t1;
+      }
+      if (producer) NZ[((k + 1) & 1) * 256 + pr * 16 + pi] = draw(k + 1);
+      SOCMX_TICK(9)
+    }
+    if (PROF && tid == 0 && a.prof)
+      for (int s = 0; s < 64; ++s) a.prof[(size_t)blockIdx.x * 64 + s] = acc_prof[s];
+    if (act) {                                                            // terminal cost (utils.py:101)
+      float gval = 0.f;
+      if (kind == SOCMX_OU_QUADRATIC) {
+        float qx = 0.f;
+        for (int j = 0; j < d; ++j) qx += a.Q[ic * d + j] * __shfl(x, j, 16);
+        gval = gsum(lane_ok ? x * qx : 0.f);
+      } else if (kind == SOCMX_OU_LINEAR) {
+        gval = gsum(lane_ok ? a.omega[ic] * x : 0.f);
+      } else if (kind == SOCMX_DOUBLE_WELL) {
+        const float q = x * x - 1.f;
+        gval = gsum(lane_ok ? a.nu[ic] * (q * q) : 0.f);
+      }
+      if (i == 0 && grow < B) {
+        a.lpd[grow] = lpd;
+        a.lps[grow] = lps;
+        a.ltw[grow] = -gval / a.lmbd;
+      }
+    }
+    return;
+  }
   for (int e = tid; e < 16 * d; e += nthr) {
     const int r = SOCMX_DIV_D(e), i = e - r * d;
     const int grow = min(tile_row0 + r, B - 1);  // ragged tail: replicate the last row, never stored
@@ -475,6 +604,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   fill_wave_work(a.prog, nw);
   a.kind = pb->kind; a.d = d; a.B = B; a.K = K; a.lmbd = lmbd;
   a.seed = seed; a.offset = offset; a.row0 = row0;
+  a.sigma_identity = (pb->flags & SOCMX_SIGMA_IDENTITY) ? 1 : 0;
   a.packed = packed_unet;
   a.sigma = pb->sigma; a.A = pb->A; a.P = pb->P; a.Q = pb->Q; a.omega = pb->omega; a.kappa = pb->kappa; a.nu = pb->nu;
   a.x0 = x0; a.ts = ts; a.noise_in = noise_in;
@@ -482,7 +612,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.frac = fractional_timesteps; a.lpd = lpd; a.lps = lps; a.ltw = ltw;
   a.prof = prof;
   a.lds_mats = (a.t.floats + 3) & ~3;
-  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * (d + 1) + 6 * 16 * (size_t)d + 48;
+  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * (d + 1) + 6 * 16 * (size_t)d + 48 + 512;
   const size_t lds_bytes = lds_floats * sizeof(float);
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
   const int blocks = (B + 15) / 16;
@@ -492,17 +622,24 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   static const bool force_generic = getenv("SOCMX_GENERIC") != nullptr;
   const bool is_default = !force_generic && nw == 8 && a.u.in0p == 16 && a.u.hp[0] == 256 && a.u.hp[1] == 128 &&
                           a.u.hp[2] == 64 && a.u.outp == 16;
+  // sigma = I and d <= 15: the SDE step runs in 16-lane groups with one barrier per step (FAST)
+  static const bool force_slow = getenv("SOCMX_NOFAST") != nullptr;
+  const bool fast = !force_slow && a.sigma_identity && d <= 15;
   void (*kern)(const RolloutArgs);
-  if (is_default) {
-    if (prof) kern = stopping ? rollout_kernel<8, true, true, DefaultNet> : rollout_kernel<8, false, true, DefaultNet>;
-    else kern = stopping ? rollout_kernel<8, true, false, DefaultNet> : rollout_kernel<8, false, false, DefaultNet>;
-  } else if (nw == 4) {
-    if (prof) kern = stopping ? rollout_kernel<4, true, true, DynamicNet> : rollout_kernel<4, false, true, DynamicNet>;
-    else kern = stopping ? rollout_kernel<4, true, false, DynamicNet> : rollout_kernel<4, false, false, DynamicNet>;
-  } else {
-    if (prof) kern = stopping ? rollout_kernel<8, true, true, DynamicNet> : rollout_kernel<8, false, true, DynamicNet>;
-    else kern = stopping ? rollout_kernel<8, true, false, DynamicNet> : rollout_kernel<8, false, false, DynamicNet>;
-  }
+#define SOCMX_PICK(NWV, NETV)                                                                                   \
+  do {                                                                                                          \
+    if (fast) {                                                                                                 \
+      if (prof) kern = stopping ? rollout_kernel<NWV, true, true, NETV, true> : rollout_kernel<NWV, false, true, NETV, true>;   \
+      else kern = stopping ? rollout_kernel<NWV, true, false, NETV, true> : rollout_kernel<NWV, false, false, NETV, true>; \
+    } else {                                                                                                    \
+      if (prof) kern = stopping ? rollout_kernel<NWV, true, true, NETV, false> : rollout_kernel<NWV, false, true, NETV, false>; \
+      else kern = stopping ? rollout_kernel<NWV, true, false, NETV, false> : rollout_kernel<NWV, false, false, NETV, false>; \
+    }                                                                                                           \
+  } while (0)
+  if (is_default) SOCMX_PICK(8, DefaultNet);
+  else if (nw == 4) SOCMX_PICK(4, DynamicNet);
+  else SOCMX_PICK(8, DynamicNet);
+#undef SOCMX_PICK
   hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err != hipSuccess) return (int)err;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * 64), lds_bytes, (hipStream_t)stream, a);

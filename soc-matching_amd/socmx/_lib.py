@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsocmx.so")
 
 OU_QUADRATIC, OU_LINEAR, DOUBLE_WELL, MOLECULAR_DYNAMICS = 0, 1, 2, 3
+SIGMA_IDENTITY = 1
 
 # order of socmx_unet.weight[] / bias[] (include/socmx.h, SOCMX_L_*)
 UNET_LAYERS = ("down_0", "down_1", "down_2", "res_0", "res_1", "res_2", "up_2", "up_1", "up_0")
@@ -22,7 +23,8 @@ _fp = C.c_void_p  # device pointers travel as plain addresses
 
 
 class Problem(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("sigma", _fp), ("sigma_inv_t", _fp),
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("sigma", _fp), ("sigma_inv_t", _fp),
                 ("A", _fp), ("P", _fp), ("Q", _fp), ("omega", _fp), ("kappa", _fp), ("nu", _fp)]
 
 

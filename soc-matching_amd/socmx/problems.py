@@ -60,7 +60,8 @@ class Problem:
             for k, v in self.tensors().items():
                 keep[k] = None if v is None else v.detach().to(torch.float32).contiguous()
             keep["sigma_inv_t"] = self.sigma_inv_t().to(torch.float32).contiguous()
-            s = _lib.Problem(kind=self.kind, d=self.d)
+            ident = bool(torch.equal(keep["sigma"].cpu(), torch.eye(self.d)))   # one host sync, at setup time
+            s = _lib.Problem(kind=self.kind, d=self.d, flags=_lib.SIGMA_IDENTITY if ident else 0)
             for k, v in keep.items():
                 setattr(s, k, _lib.ptr(v))
             self._cache[key] = (s, keep)
