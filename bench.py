@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-burst", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,6 +164,29 @@ def main():
     elapsed = float(t.item())
     value = world * B * K * args.steps / elapsed
 
+    # ---- the same kernel with the chip full: one evaluation-burst launch (65,536 rows = 4,096 workgroups,
+    #      what control_objective / normalization_constant issue, utils.py:131-231) --------------------------
+    burst = None
+    if rank == 0 and not args.no_burst:
+        Bb = 65536
+        big = x0.reshape(1, -1).expand(Bb, -1)
+        rollout.stochastic_trajectories(sde, big, ts, cfg.method.lmbd, seed=1, offset=0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        e0.record()
+        for i in range(3):
+            rollout.stochastic_trajectories(sde, big, ts, cfg.method.lmbd, seed=1, offset=1 + i)
+        e1.record()
+        torch.cuda.synchronize(device)
+        bms = e0.elapsed_time(e1) / 3
+        bfl = flops_per_traj_step(d, HDIMS) * Bb * K
+        burst = {"workload": "double_well d=10 num_steps=200, 65536 rows in one launch (evaluation burst)",
+                 "kernel_ms": bms, "trajectory_steps_per_s": Bb * K / (bms * 1e-3),
+                 "bound": "mfma", "achieved": bfl / (bms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                 "frac": bfl / (bms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+        del big
+        torch.cuda.empty_cache()
+
     # ---- metric 2: full SOCM iterations ----------------------------------------------------------
     if world > 1:
         solver.shard = sdist.Shard()
@@ -187,6 +211,17 @@ def main():
         flops = flops_per_traj_step(d, HDIMS) * B * K
         byts = bytes_per_traj_step(d) * B * K
         achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/):
+        # WRITE_SIZE + 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-byte-per-lane reads), in bytes
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")))
+            for kname, v in pm.items():
+                if "rollout_kernel" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
+                    traffic_src = "profiles/r1/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         line = {
             "metric": "trajectory-steps/sec", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,15 +232,19 @@ def main():
                        "parallelism": f"dp{world} (batch-sharded, no data-path collective in the rollout)"},
             "socm_iters_per_sec": it_steps / it_elapsed, "socm_ms_per_iter": 1e3 * it_elapsed / it_steps,
             "socm_iters_timed": it_steps, "socm_last_loss": last_loss,
-            "roofline": {"bound": "mfma", "kernel": "socmx::rollout_kernel<8,false>",
+            "roofline": {"bound": "mfma", "kernel": "socmx::rollout_kernel<8,false,false,StaticNet<16,256,128,64,16>,true>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "B=128 gives 8 row tiles: at most 8 of 256 CUs can work (frac <= 0.031 by construction); "
+                                 "see roofline_full_chip for the same kernel with 4096 workgroups",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": byts,
                          "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,
                          "hbm_frac": byts / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                          "active_workgroups": (B + 15) // 16, "cus": 256},
         }
+        if burst is not None:
+            line["roofline_full_chip"] = burst
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

@@ -175,8 +175,8 @@ int socmx_socm_prep_f32(const socmx_problem* problem, const float* ts, int32_t K
  * r[i,m,:]      = sigma^T ( nablaV[i,m] - target[i,m] )
  * objective    += inv_norm * sum_{i,m} w[m] |r[i,m]|^2             (inv_norm = 1/((K+1) B_global))
  * G[i,m,:]      = d objective / d nablaV[i,m,:] = 2 w[m] inv_norm sigma r[i,m]   ( = - d objective/d target )
- * objective (1,) is ACCUMULATED with one atomic per workgroup: zero it first.  target (K+1,B,d) may be NULL.
- * nablaV, G: (K+1,B,d).  1 <= d <= 128.
+ * objective (1,) is ACCUMULATED with one atomic per workgroup: zero it first.
+ * target, nablaV, G: (K+1,B,d); target is an output (written by the MFMA contraction, read by the residual pass).
  */
 int socmx_socm_target_fwd_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* M_all,
                               const float* dM_all, const float* qT, const float* vT, const float* gTT,

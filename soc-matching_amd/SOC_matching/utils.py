@@ -11,7 +11,7 @@ import pickle
 import numpy as np
 import torch
 
-from socmx.rollout import stochastic_trajectories  # noqa: F401
+from socmx.rollout import stochastic_trajectories, burst_eligible  # noqa: F401
 from socmx.train import compute_EMA  # noqa: F401
 from socmx.ground_truth import riccati as solution_Ricatti_grid  # noqa: F401
 
@@ -19,6 +19,13 @@ from socmx.ground_truth import riccati as solution_Ricatti_grid  # noqa: F401
 def control_objective(sde, x0, ts, lmbd, batch_size, total_n_samples=65536, verbose=False):
     """Mean and standard error of the control cost -lmbd (lpd + ltw) over n_batches rollouts."""
     n_batches = int(total_n_samples // batch_size)
+    if burst_eligible(sde, x0):
+        # fused-kernel path: the n_batches rollouts are independent, so they run as ONE launch of
+        # n_batches*batch_size rows (4096 workgroups at the defaults: the one regime where the chip is full)
+        n = n_batches * batch_size
+        out = stochastic_trajectories(sde, x0.reshape(1, -1).expand(n, -1), ts.to(x0), lmbd, verbose=verbose)
+        costs = -lmbd * (out[4] + out[6])
+        return torch.mean(costs), torch.std(costs) / np.sqrt(n - 1)
     costs = []
     for k in range(n_batches):
         out = stochastic_trajectories(sde, x0.repeat(batch_size, 1), ts.to(x0), lmbd, verbose=verbose)
@@ -31,6 +38,21 @@ def control_objective(sde, x0, ts, lmbd, batch_size, total_n_samples=65536, verb
 
 def normalization_constant(sde, x0, ts, cfg, n_batches_normalization=512, ground_truth_control=None):
     """E[w] over n_batches rollouts of the initial control (+ weighted L2 error vs a ground truth)."""
+    if burst_eligible(sde, x0):
+        # one launch for all batches (x0 here is the (B,d) repeated initial state, main.py:115)
+        B = x0.shape[0]
+        n = B * n_batches_normalization
+        states, _, _, _, lpd, lps, ltw, controls = stochastic_trajectories(
+            sde, x0.repeat(n_batches_normalization, 1), ts.to(x0), cfg.method.lmbd)
+        lw = lpd + lps + ltw
+        w = torch.exp(lw)
+        err = None
+        if ground_truth_control is not None:
+            gt = ground_truth_control(ts, states, t_is_tensor=True)[:-1].detach()
+            # mean over batches of sum(.)/(K*B)  ==  sum over all rows / (K*B*n_batches)
+            err = torch.sum((gt - controls) ** 2 * w.reshape(1, -1, 1)) / (gt.shape[0] * n)
+        print(f"Average and std. dev. of log_weights for all batches: {torch.mean(lw)} {torch.std(lw)}")
+        return torch.mean(w), torch.std(w) / np.sqrt(n - 1), err
     logw, w_all = [], []
     err = 0 if ground_truth_control is not None else None
     for k in range(n_batches_normalization):

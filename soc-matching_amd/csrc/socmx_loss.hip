@@ -150,97 +150,117 @@ __host__ __device__ inline int64_t pair_row_offset(int i, int K) {
   return (int64_t)i * (K + 1) - (int64_t)i * (i - 1) / 2;
 }
 
-template <int KO>
-__global__ void socm_target_fwd_kernel(const TargetArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// target[i,m,:] = sum_{j>=i} ( M_ij q_j[m] - dM_ij v_j[m] ) + M_iK gT[m]  as per-row GEMMs on the fp32 MFMA:
+//   D (16 k-rows x 16 batch columns) += A (M_ij[k][l], 16 x 4) . B (q_j[l][m], 4 x 16)      v_mfma_f32_16x16x4_f32
+// One wave owns (row pair (i, K-i), 16-column batch tile, 16-row k-block): every wave runs K+2 pair matrices
+// (balanced triangular work), KP2 x B/16 x ceil(d/16) waves fill the chip, and the next (pair, l-block)'s four
+// operand fragments are loaded while the current one is multiplied.  Lanes outside d x d are fed zeros.
+constexpr int kTargetWaves = 8;  // waves per workgroup: the (pair, l-block) iterations of a row are dealt round-robin
+
+__global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(const TargetArgs a) {
+  __shared__ f32x4 part[kTargetWaves][64];
   const int d = a.d, K = a.K, B = a.B;
-  const int dpad = a.KG * KO;
-  float* Mt = lds;                    // [d][dpad]  Mt[l][k] = M_ij[k][l]
-  float* dMt = Mt + d * dpad;         // [d][dpad]
-  float* diff = dMt + d * dpad;       // [64][d+1]
-  float* R = diff + 64 * (d + 1);     // [64][d+1]
-  float* red = R + 64 * (d + 1);      // [32]
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int ml = tid & 63;
-  const int kg = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int k0 = kg * KO;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int m = blockIdx.y * 16 + c16;
+  const int mc = m < B ? m : B - 1;
+  const int kb = blockIdx.z * 16;          // first k-row of this wave's block
+  const int krow = kb + c16;               // A-fragment row of this lane
+  const int nlb = (d + 15) >> 4;           // 16-wide l-blocks
+  const int dd = d * d;
+  for (int rep = 0; rep < 2; ++rep) {
+    const int i = rep == 0 ? (int)blockIdx.x : K - (int)blockIdx.x;
+    if (rep == 1 && i <= (int)blockIdx.x) break;
+    const float* Mrow = a.M_all + (size_t)pair_row_offset(i, K) * dd;
+    const float* dMrow = a.dM_all + (size_t)pair_row_offset(i, K) * dd;
+    const int niter = (K - i + 1) * nlb;   // flattened (pair, l-block) iterations
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float am[4], ad[4], bq[4], bv[4];
+    auto load = [&](int t, float (&xm)[4], float (&xd)[4], float (&xq)[4], float (&xv)[4]) {
+      const int jr = t / nlb, lb = (t - jr * nlb) * 16;
+      const int j = i + jr;
+      const float* Mp = Mrow + (size_t)jr * dd;
+      const float* dMp = dMrow + (size_t)jr * dd;
+      const float* qs = (j < K) ? a.qT + (size_t)j * d * B : a.gTT;
+      const float* vs = a.vT + (size_t)(j < K ? j : 0) * d * B;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int l = lb + 4 * s + g4;
+        const bool okl = l < d, oka = okl && krow < d;
+        xm[s] = oka ? Mp[krow * d + l] : 0.f;
+        xd[s] = (oka && j < K) ? -dMp[krow * d + l] : 0.f;
+        xq[s] = okl ? qs[(size_t)l * B + mc] : 0.f;
+        xv[s] = (okl && j < K) ? vs[(size_t)l * B + mc] : 0.f;
+      }
+    };
+    if (wave < niter) load(wave, am, ad, bq, bv);
+    for (int t = wave; t < niter; t += kTargetWaves) {
+      float nm[4], nd[4], nq[4], nv[4];
+      if (t + kTargetWaves < niter) load(t + kTargetWaves, nm, nd, nq, nv);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s], bq[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ad[s], bv[s], acc, 0, 0, 0);
+      }
+      if (t + kTargetWaves < niter) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { am[s] = nm[s]; ad[s] = nd[s]; bq[s] = nq[s]; bv[s] = nv[s]; }
+      }
+    }
+    // combine the waves' partial tiles (fixed order: deterministic)
+    __syncthreads();
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      acc = part[0][lane];
+#pragma unroll
+      for (int w = 1; w < kTargetWaves; ++w) acc += part[w][lane];
+    }
+    // D: lane holds k = kb + 4*g4 + r (r = 0..3) of batch column m
+    if (wave == 0 && m < B) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = kb + 4 * g4 + r;
+        if (k < d) a.target[((size_t)i * B + m) * d + k] = acc[r];
+      }
+    }
+  }
+}
+
+// r = sigma^T (nablaV - target), objective += inv_norm * sum w |r|^2, G = 2 w inv_norm sigma r.
+// Workgroup = one row i x 64 batch lanes; wave shuffle -> LDS -> one atomic per workgroup.
+__global__ __launch_bounds__(64) void socm_residual_kernel(const TargetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int d = a.d, B = a.B;
+  float* diff = lds;                 // [64][d+1]
+  float* R = diff + 64 * (d + 1);    // [64][d+1]
+  const int ml = threadIdx.x;
+  const int i = blockIdx.x;
   const int m = blockIdx.y * 64 + ml;
   const bool valid = m < B;
   const int mc = valid ? m : B - 1;
   const float wm = a.w[mc];
-  float obj_part = 0.f;
-
-  for (int rep = 0; rep < 2; ++rep) {
-    // rows are processed in pairs (i, K-i): every workgroup does K+2 pair matrices in total
-    const int i = rep == 0 ? (int)blockIdx.x : K - (int)blockIdx.x;
-    if (rep == 1 && i <= (int)blockIdx.x) break;
-    float acc[KO];
-#pragma unroll
-    for (int kk = 0; kk < KO; ++kk) acc[kk] = 0.f;
-    const int64_t p0 = pair_row_offset(i, K);
-    for (int j = i; j <= K; ++j) {
-      const float* Mp = a.M_all + (size_t)(p0 + (j - i)) * d * d;
-      const float* dMp = a.dM_all + (size_t)(p0 + (j - i)) * d * d;
-      __syncthreads();
-      for (int e = tid; e < d * d; e += nthr) {
-        const int k = e / d, l = e - k * d;
-        Mt[l * dpad + k] = Mp[e];
-        dMt[l * dpad + k] = (j < K) ? dMp[e] : 0.f;
-      }
-      __syncthreads();
-      const float* qs = (j < K) ? a.qT + (size_t)j * d * B : a.gTT;
-      const float* vs = a.vT + (size_t)(j < K ? j : 0) * d * B;
-      for (int l = 0; l < d; ++l) {
-        const float ql = qs[(size_t)l * B + mc];
-        const float vl = (j < K) ? vs[(size_t)l * B + mc] : 0.f;
-        const float* mrow = Mt + l * dpad + k0;
-        const float* drow = dMt + l * dpad + k0;
-#pragma unroll
-        for (int kk = 0; kk < KO; kk += 4) {
-          const float4 mv = *reinterpret_cast<const float4*>(mrow + kk);
-          const float4 dv = *reinterpret_cast<const float4*>(drow + kk);
-          acc[kk + 0] += mv.x * ql - dv.x * vl;
-          acc[kk + 1] += mv.y * ql - dv.y * vl;
-          acc[kk + 2] += mv.z * ql - dv.z * vl;
-          acc[kk + 3] += mv.w * ql - dv.w * vl;
-        }
-      }
-    }
-    // ---- residual r = sigma^T (nablaV - target), objective, G ---------------------------------
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < KO; ++kk) {
-      const int k = k0 + kk;
-      if (k < d) {
-        const float nv = a.nablaV[((size_t)i * B + mc) * d + k];
-        diff[ml * (d + 1) + k] = nv - acc[kk];
-        if (a.target && valid) a.target[((size_t)i * B + m) * d + k] = acc[kk];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < KO; ++kk) {
-      const int c = k0 + kk;
-      if (c < d) {
-        float r = 0.f;
-        for (int k = 0; k < d; ++k) r += a.sigma[k * d + c] * diff[ml * (d + 1) + k];
-        R[ml * (d + 1) + c] = r;
-        if (valid) obj_part += wm * r * r;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < KO; ++kk) {
-      const int k = k0 + kk;
-      if (k < d && valid) {
-        float s = 0.f;
-        for (int c = 0; c < d; ++c) s += a.sigma[k * d + c] * R[ml * (d + 1) + c];
-        a.G[((size_t)i * B + m) * d + k] = 2.f * wm * a.inv_norm * s;
-      }
+  const size_t row = ((size_t)i * B + mc) * d;
+  for (int k = 0; k < d; ++k) diff[ml * (d + 1) + k] = a.nablaV[row + k] - a.target[row + k];
+  float obj = 0.f;
+  for (int c = 0; c < d; ++c) {
+    float r = 0.f;
+    for (int k = 0; k < d; ++k) r += a.sigma[k * d + c] * diff[ml * (d + 1) + k];
+    R[ml * (d + 1) + c] = r;
+    if (valid) obj += wm * r * r;
+  }
+  if (valid) {
+    for (int k = 0; k < d; ++k) {
+      float s = 0.f;
+      for (int c = 0; c < d; ++c) s += a.sigma[k * d + c] * R[ml * (d + 1) + c];
+      a.G[row + k] = 2.f * wm * a.inv_norm * s;
     }
   }
-  const float tot = block_sum(obj_part, red);
-  if (tid == 0) atomicAdd(a.objective, tot * a.inv_norm);
+  obj = wave_sum(obj);
+  if (ml == 0) atomicAdd(a.objective, obj * a.inv_norm);
 }
 
 // ---- backward: gradients w.r.t. the pair matrices ---------------------------------------------------
@@ -342,23 +362,24 @@ extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int
                                          const float* dM_all, const float* qT, const float* vT, const float* gTT,
                                          const float* nablaV, const float* w, float inv_norm, float* target,
                                          float* G, float* objective, socmx_stream_t stream) {
-  if (!pb || !M_all || !dM_all || !qT || !vT || !gTT || !nablaV || !w || !G || !objective || !pb->sigma)
+  if (!pb || !M_all || !dM_all || !qT || !vT || !gTT || !nablaV || !w || !G || !objective || !target || !pb->sigma)
     return SOCMX_E_NULL;
   const int d = pb->d;
-  if (d < 1 || d > 128 || K < 1 || B < 1) return SOCMX_E_DIM;
-  constexpr int KO = 8;
+  if (d < 1 || d > 1024 || K < 1 || B < 1) return SOCMX_E_DIM;
   TargetArgs a;
-  a.d = d; a.K = K; a.B = B; a.KG = (d + KO - 1) / KO; a.inv_norm = inv_norm;
+  a.d = d; a.K = K; a.B = B; a.KG = 0; a.inv_norm = inv_norm;
   a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.qT = qT; a.vT = vT; a.gTT = gTT;
   a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective;
-  const int dpad = a.KG * KO;
-  const size_t lds = ((size_t)2 * d * dpad + 2 * 64 * (d + 1) + 32) * sizeof(float);
-  if (lds > 160 * 1024) return SOCMX_E_LDS;
-  auto kern = socm_target_fwd_kernel<KO>;
-  hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((K + 2) / 2, (B + 15) / 16, (d + 15) / 16);
+  hipLaunchKernelGGL(socm_target_mfma_kernel, grid, dim3(64 * kTargetWaves), 0, (hipStream_t)stream, a);
+  hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
-  dim3 grid((K + 2) / 2, (B + 63) / 64);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * a.KG), lds, (hipStream_t)stream, a);
+  const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
+  if (lds > 160 * 1024) return SOCMX_E_LDS;
+  auto kern = socm_residual_kernel;
+  err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(kern, dim3(K + 1, (B + 63) / 64), dim3(64), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -124,7 +124,7 @@ class _TargetResidualHip(torch.autograd.Function):
         c = lambda t: t.detach().to(torch.float32).contiguous()
         M_all, dM_all, nablaV, w = map(c, (M_all, dM_all, nablaV, w))
         G = torch.empty_like(nablaV)
-        target = torch.empty_like(nablaV) if want_target else None
+        target = torch.empty_like(nablaV)   # the contraction's output; the residual kernel reads it back
         obj = torch.zeros(1, dtype=torch.float32, device=dev)
         _lib.check(L.socmx_socm_target_fwd_f32(
             pb.c_struct(), K, B, _lib.ptr(M_all), _lib.ptr(dM_all), _lib.ptr(ops["qT"]), _lib.ptr(ops["vT"]),

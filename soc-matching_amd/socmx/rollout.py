@@ -38,6 +38,11 @@ def _eligible_for_hip(sde, x0, detach):
     )
 
 
+def burst_eligible(sde, x0):
+    """True when an evaluation burst (utils.py:131-231, method.py:185-221) can run as one fused launch."""
+    return _eligible_for_hip(sde, x0, True)
+
+
 def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noise_in=None, seed=None,
                             offset=None, row0=0):
     if _eligible_for_hip(sde, x0, detach):

@@ -50,6 +50,12 @@ class SOC_Solver(nn.Module):
     # ---- method.py:185-221 -------------------------------------------------------------------
     def control_objective(self, batch_size, total_n_samples=65536):
         n_batches = int(total_n_samples // batch_size)
+        if R.burst_eligible(self.neural_sde, self.x0.reshape(1, -1)) and self.shard is None:
+            # all n_batches rollouts as ONE launch; `trajectory` is the first batch, as in the reference
+            n = n_batches * batch_size
+            out = R.stochastic_trajectories(self.neural_sde, self.x0.reshape(1, -1).expand(n, -1), self.ts, self.lmbd)
+            losses = -self.lmbd * (out[4] + out[6])
+            return torch.mean(losses), torch.std(losses) / np.sqrt(n - 1), out[0][:, :batch_size].contiguous()
         losses, trajectory = [], None
         for k in range(n_batches):
             state0 = self.x0.repeat(batch_size, 1)

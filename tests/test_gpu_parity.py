@@ -220,3 +220,28 @@ def test_full_size_properties_cfg3():
     with torch.no_grad():
         u_ref = -(sde.nabla_V(tx).reshape(K, B, d) @ sde.sigma)
     np.testing.assert_allclose(_np(controls), _np(u_ref), rtol=1e-4, atol=1e-4)
+
+
+def test_eval_burst_single_launch_matches_looped_statistics():
+    """f1: control_objective / normalization_constant as one fused launch vs the reference-style loop
+    (statistical agreement: different noise streams)."""
+    from SOC_matching import utils
+    from socmx.config import load_config
+    sde, aux = build_sde("tiny_double_well_d10", DEV)
+    ts, x0, lm = aux["ts"], aux["x0"], aux["lmbd"]
+    torch.manual_seed(0)
+    mean_b, err_b = utils.control_objective(sde, x0, ts, lm, 64, total_n_samples=8192)
+    # reference-style loop through the same kernel, batch by batch
+    costs = []
+    for k in range(8192 // 64):
+        out = utils.stochastic_trajectories(sde, x0.repeat(64, 1), ts, lm, seed=99, offset=k)
+        costs.append(-lm * (out[4] + out[6]))
+    costs = torch.cat(costs)
+    mean_l, err_l = costs.mean(), costs.std() / np.sqrt(costs.numel() - 1)
+    assert abs(mean_b.item() - mean_l.item()) < 4 * (err_b.item() + err_l.item())
+    np.testing.assert_allclose(err_b.item(), err_l.item(), rtol=0.2)
+    cfg = load_config(["method.lmbd=%g" % lm])
+    nc, nc_err, _ = utils.normalization_constant(sde, x0.repeat(64, 1), ts, cfg, n_batches_normalization=64)
+    w = torch.exp(torch.cat([sum(utils.stochastic_trajectories(sde, x0.repeat(64, 1), ts, lm, seed=7, offset=k)[4:7])
+                              for k in range(64)]))
+    assert abs(nc.item() - w.mean().item()) < 4 * (nc_err.item() + (w.std() / np.sqrt(w.numel() - 1)).item())

@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_r1
 mkdir -p $OUT
-CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-burst"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o r1 -- $CMD > $OUT/trace_bench.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "rollout_kernel|socm_target|socm_prep" -f csv -d $OUT/pmc_fetch -o r1 -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "rollout_kernel|socm_target|socm_prep" -f csv -d $OUT/pmc_write -o r1 -- $CMD > $OUT/pmc_write.log 2>&1
