@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-burst", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and take the sharded code path even at world_size 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +124,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path for the product"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from socmx import _lib, rollout, dist as sdist
@@ -136,7 +140,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -159,7 +163,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     value = world * B * K * args.steps / elapsed
@@ -188,7 +192,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- metric 2: full SOCM iterations ----------------------------------------------------------
-    if world > 1:
+    if use_dist:
         solver.shard = sdist.Shard()
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
     trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False)
@@ -202,7 +206,7 @@ def main():
     barrier()
     it_elapsed = time.perf_counter() - t0
     t = torch.tensor([it_elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     it_elapsed = float(t.item())
     last_loss = float(info["loss"])
@@ -249,7 +253,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -32,7 +32,7 @@ class Shard:
         return B_local, row0
 
     def combine_weight_stats(self, stats):
-        if self.world_size == 1:
+        if self.world_size == 1 and not dist.is_initialized():
             return stats
         gathered = [torch.empty_like(stats) for _ in range(self.world_size)]
         dist.all_gather(gathered, stats.contiguous(), group=self.group)
@@ -43,7 +43,7 @@ class Shard:
         collective on one flat buffer.  Returns the reduced extras."""
         params = [p for p in params if p.grad is not None]
         extra = list(extra or [])
-        if self.world_size == 1:
+        if self.world_size == 1 and not dist.is_initialized():
             return extra
         n = sum(p.grad.numel() for p in params) + len(extra)
         dev = params[0].grad.device if params else extra[0].device

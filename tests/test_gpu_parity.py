@@ -245,3 +245,32 @@ def test_eval_burst_single_launch_matches_looped_statistics():
     w = torch.exp(torch.cat([sum(utils.stochastic_trajectories(sde, x0.repeat(64, 1), ts, lm, seed=7, offset=k)[4:7])
                               for k in range(64)]))
     assert abs(nc.item() - w.mean().item()) < 4 * (nc_err.item() + (w.std() / np.sqrt(w.numel() - 1)).item())
+
+
+def test_specialised_and_generic_kernels_agree(tmp_path):
+    """The constexpr-specialised + fused-SDE instantiation (default arch, sigma = I) against the table-driven
+    generic one (SOCMX_GENERIC / SOCMX_NOFAST are read once per process, hence subprocesses)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, os, numpy as np, torch\n"
+        f"sys.path[:0] = [{root!r}, os.path.join({root!r}, 'soc-matching_amd'), os.path.join({root!r}, 'tests')]\n"
+        "from test_host_cpu import build_sde\n"
+        "from SOC_matching import utils\n"
+        "out = {}\n"
+        "for name in ('cfg3_double_well_d10_K200', 'cfg1_ou_quadratic_easy_d2_K50'):\n"
+        "    sde, aux = build_sde(name, 'cuda:0')\n"
+        "    r = utils.stochastic_trajectories(sde, aux['x0'].repeat(40, 1), aux['ts'], aux['lmbd'], seed=3, offset=1)\n"
+        "    for i, t in enumerate(r): out[f'{name}_{i}'] = t.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    outs = []
+    for tag, env in (("fast", {}), ("generic", {"SOCMX_GENERIC": "1", "SOCMX_NOFAST": "1"})):
+        path = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ, **env)
+        res = subprocess.run([sys.executable, "-c", script, path], env=e, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(np.load(path))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-5, err_msg=k)
