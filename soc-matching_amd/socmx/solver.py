@@ -4,8 +4,10 @@ Same constructor, same `.loss(...)` keyword surface and 8-tuple return
 `(objective, norm_sqd_diff, ctrl_loss_mean, ctrl_loss_std_err, trajectory,
 mean(w), std(w), stop_indicators)` (method.py:223-236, 897-906), same
 `.control_objective` (method.py:185-221).  Only `algorithm="SOCM"` without stopping
-times is implemented in this round; the other
-losses of method.py:264-478, 722-856 are row f4 and raise NotImplementedError.
+times runs on the HIP loss kernels; the stopping-time
+variant (molecular_dynamics, per-sample TwoBoundarySigmoidMLP) is a torch restatement on
+the same rollout buffers; the other losses of method.py:264-478, 722-856 are row f4 and
+raise NotImplementedError.
 
 Data parallelism: when `self.shard` is set (see socmx.dist), `batch_size` is the
 GLOBAL batch; this rank simulates rows [row0, row0+B_local) and divides by the
@@ -69,6 +71,31 @@ class SOC_Solver(nn.Module):
         n = n_batches * batch_size
         return torch.mean(losses), torch.std(losses) / np.sqrt(n - 1), trajectory
 
+    # ---- stopping-time SOCM (molecular_dynamics): method.py:484-507, 523-530, 548-564, 597-613, 633-660,
+    #      692-715.  Per-sample M(t,s;tau) from TwoBoundarySigmoidMLP; same restated contraction as the plain SOCM
+    #      loss with dt -> fractional time steps, never forming the reference's (Kp,Kp,B,d,d) tensors.
+    def _socm_stopping_objective(self, pb, ts, t_vec, s_vec, ii, jj, states, noises, controls, stop_indicators,
+                                 frac, nabla_V, weight):
+        if self.shard is not None:
+            raise NotImplementedError("stopping-time SOCM is single-process only")
+        sde = self.neural_sde
+        K = self.num_steps
+        Kp, B, d = states.shape
+        tau = ((sde.Phi(states) > 0).to(torch.int).sum(dim=0) - 1) / (Kp - 1)            # method.py:525-530
+        tau_vec = tau.unsqueeze(0).expand(t_vec.shape[0], B)
+        # dM/ds as a forward-mode tangent (the reference: functorch.jacrev over the batch-summed output)
+        M_all, dM_all = torch.func.jvp(lambda s_: sde.M(t_vec, s_, tau_vec), (s_vec,), (torch.ones_like(s_vec),))
+        dM_all = torch.nan_to_num(dM_all)                                                   # method.py:553-555
+        v, q, gT = L.socm_operands(pb, ts, self.lmbd, states, noises, controls, frac=frac)
+        last = jj == K
+        jq = torch.clamp(jj, max=K - 1)
+        qx = torch.where(last.reshape(-1, 1, 1), gT.unsqueeze(0), q[jq])                    # (Np,B,d)
+        vx = torch.where(last.reshape(-1, 1, 1), torch.zeros_like(gT).unsqueeze(0), v[jq])
+        contrib = torch.einsum("pmkl,pml->pmk", M_all, qx) - torch.einsum("pmkl,pml->pmk", dM_all, vx)
+        target = torch.zeros(Kp, B, d, device=states.device, dtype=contrib.dtype).index_add(0, ii, contrib)
+        r = stop_indicators.unsqueeze(2) * ((nabla_V - target) @ pb.sigma)
+        return torch.sum(r * r * weight.reshape(1, -1, 1)) / torch.sum(stop_indicators)
+
     # ---- method.py:223-906 -------------------------------------------------------------------
     def loss(self, batch_size, compute_L2_error=False, optimal_control=None, compute_control_objective=False,
              algorithm="SOCM_const_M", add_weights=False, total_n_samples=65536, verbose=False,
@@ -76,8 +103,6 @@ class SOC_Solver(nn.Module):
         if algorithm != "SOCM":
             raise NotImplementedError(
                 f"algorithm={algorithm!r}: only 'SOCM' is implemented (other losses: SURVEY.md row f4)")
-        if use_stopping_time:
-            raise NotImplementedError("SOCM with use_stopping_time=True (TwoBoundarySigmoidMLP): SURVEY.md row f4")
         if u_warm_start and use_warm_start:
             raise NotImplementedError("warm start is out of scope (SURVEY.md component 9)")
         sde = self.neural_sde
@@ -105,12 +130,15 @@ class SOC_Solver(nn.Module):
         nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)
 
         # M and dM/ds on the pair grid (method.py:510-515, 533-573)
-        t_vec, s_vec, _, _ = L.pair_times(ts, self.T, K)
-        M_all, dM_all = sde.M.forward_with_ds(t_vec, s_vec)
-
-        inv_norm = 1.0 / (Kp * B_global)
-        objective = L.socm_objective(pb, ts, self.lmbd, K, states, noises, controls, M_all, dM_all, nabla_V,
-                                     weight, inv_norm)
+        t_vec, s_vec, ii, jj = L.pair_times(ts, self.T, K)
+        if use_stopping_time:
+            objective = self._socm_stopping_objective(pb, ts, t_vec, s_vec, ii, jj, states, noises, controls,
+                                                      stop_indicators, fractional_timesteps, nabla_V, weight)
+        else:
+            M_all, dM_all = sde.M.forward_with_ds(t_vec, s_vec)
+            inv_norm = 1.0 / (Kp * B_global)
+            objective = L.socm_objective(pb, ts, self.lmbd, K, states, noises, controls, M_all, dM_all, nabla_V,
+                                         weight, inv_norm)
 
         if compute_L2_error:
             target_control = optimal_control(self.ts, states, t_is_tensor=True)

@@ -23,11 +23,12 @@ def compute_EMA(value, EMA_value, EMA_coeff=0.01, itr=0):
 def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4):
     """Adam with the SOCM parameter groups of main.py:214-230."""
     sde = solver.neural_sde
-    return torch.optim.Adam(
-        [{"params": sde.nabla_V.parameters()},
-         {"params": sde.M.sigmoid_layers.parameters(), "lr": M_lr},
-         {"params": sde.gamma, "lr": M_lr}],
-        lr=nabla_V_lr, eps=adam_eps)
+    groups = [{"params": sde.nabla_V.parameters()},
+              {"params": sde.M.sigmoid_layers.parameters(), "lr": M_lr},
+              {"params": sde.gamma, "lr": M_lr}]
+    if getattr(sde, "use_stopping_time", False):
+        groups.append({"params": sde.gamma2, "lr": M_lr})   # gamma3 is NOT optimised in the reference (main.py:190-212)
+    return torch.optim.Adam(groups, lr=nabla_V_lr, eps=adam_eps)
 
 
 class Trainer:
@@ -48,7 +49,8 @@ class Trainer:
             torch.cuda.synchronize(dev)
         start = time.time()
         out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
-                          use_stopping_time=False, **loss_kwargs)
+                          use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)),
+                          **loss_kwargs)
         objective, weight_mean = out[0], out[5]
         loss = objective / self.normalization_const                      # main.py:313-322
         loss.backward()                                                  # main.py:323

@@ -274,3 +274,19 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:
         np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-5, err_msg=k)
+
+
+def test_stopping_time_socm_loss_on_gpu_vs_golden():
+    from SOC_matching.method import SOC_Solver
+    name = "tiny_molecular_dynamics_d1_stopping"
+    sde, aux = build_sde(name, DEV)
+    z = aux["z"]
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                        sigma=sde.sigma)
+    solver.noise_in = aux["noise"]
+    out = solver.loss(aux["B"], algorithm="SOCM", use_warm_start=False, use_stopping_time=True)
+    # stopping decisions are sign tests on fp32 values: require the same stopping pattern, then the loss
+    assert np.array_equal(_np(out[7]), z["roll_stop_indicators"])
+    np.testing.assert_allclose(out[0].item(), z["loss_objective"], rtol=5e-4)
+    out[0].backward()
+    np.testing.assert_allclose(_np(sde.gamma.grad), z["grad_gamma"], rtol=5e-3, atol=1e-6)

@@ -40,11 +40,13 @@ def build_sde(name, device="cpu"):
     sde.initialize_models()
     sde.nabla_V.load_state_dict({k[len("nablaV."):]: torch.from_numpy(z[k].copy()) for k in z.files
                                  if k.startswith("nablaV.")})
-    if not stopping:
-        sde.M.sigmoid_layers.load_state_dict({k[len("M.sigmoid_layers."):]: torch.from_numpy(z[k].copy())
-                                              for k in z.files if k.startswith("M.sigmoid_layers.")})
+    sde.M.sigmoid_layers.load_state_dict({k[len("M.sigmoid_layers."):]: torch.from_numpy(z[k].copy())
+                                          for k in z.files if k.startswith("M.sigmoid_layers.")})
     with torch.no_grad():
         sde.gamma.copy_(torch.from_numpy(z["gamma"].copy()))
+        if stopping:
+            sde.gamma2.copy_(torch.from_numpy(z["gamma2"].copy()))
+            sde.gamma3.copy_(torch.from_numpy(z["gamma3"].copy()))
     aux = dict(z=z, d=d, K=K, B=B, T=T, lmbd=lmbd, x0=c("x0"), ts=torch.from_numpy(z["ts"].copy()).to(device),
                noise=torch.from_numpy(z["noise_in"].copy()).to(device), stopping=bool(stopping))
     return sde, aux
@@ -115,6 +117,28 @@ def test_state_dict_keys_and_seeded_init_match_reference():
     for k, v in sde.M.state_dict().items():
         if k.startswith("sigmoid_layers"):
             assert np.array_equal(v.numpy(), z["M." + k]), k
+
+
+def test_stopping_time_socm_loss_matches_reference():
+    """molecular_dynamics with use_stopping_time=True (per-sample TwoBoundarySigmoidMLP), README's MD command."""
+    from SOC_matching.method import SOC_Solver
+    name = "tiny_molecular_dynamics_d1_stopping"
+    sde, aux = build_sde(name)
+    z = aux["z"]
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                        sigma=sde.sigma)
+    solver.noise_in = aux["noise"]
+    out = solver.loss(aux["B"], algorithm="SOCM", use_warm_start=False, use_stopping_time=True)
+    np.testing.assert_allclose(out[0].item(), z["loss_objective"], rtol=1e-4)
+    out[0].backward()
+    for k, p in sde.nabla_V.named_parameters():
+        g = z["grad_nablaV." + k]
+        np.testing.assert_allclose(p.grad.numpy(), g, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(g).max()), err_msg=k)
+    for k, p in sde.M.sigmoid_layers.named_parameters():
+        g = z["grad_M.sigmoid_layers." + k]
+        np.testing.assert_allclose(p.grad.numpy(), g, rtol=2e-3, atol=1e-5 * max(1.0, np.abs(g).max()), err_msg=k)
+    np.testing.assert_allclose(sde.gamma.grad.numpy(), z["grad_gamma"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(sde.gamma2.grad.numpy(), z["grad_gamma2"], rtol=2e-3, atol=1e-6)
 
 
 def test_other_algorithms_fail_loudly():
