@@ -7,8 +7,8 @@
 
 Uses Hydra (`@hydra.main(config_path="configs", config_name="soc")`) when it is installed, otherwise
 the same `configs/soc.yaml` through PyYAML with Hydra-style `a.b=value` overrides.  Differences from the
-reference, all forced by the scope of this repository: only `method.algorithm=SOCM` without
-stopping time / warm start; the NVML print at iteration 0 is replaced by a ROCm-safe memory report; with
+reference: no warm start, no `multiagent_8`, no Hydra multirun (`-m` with a comma list: run the
+algorithms one by one); the NVML print at iteration 0 is replaced by a ROCm-safe memory report; with
 WORLD_SIZE > 1 the global batch is sharded across ranks (socmx.dist) and only rank 0 prints and saves.
 """
 import os
@@ -69,9 +69,13 @@ def run(cfg):
 
     solver = SOC_Solver(neural_sde, x0, ground_truth_control, T=cfg.method.T, num_steps=cfg.method.num_steps,
                         lmbd=cfg.method.lmbd, d=cfg.method.d, sigma=sigma)
-    solver.gamma = cfg.method.gamma
+    if algorithm == "SOCM_exp":                                          # main.py:166-171
+        solver.gamma = torch.nn.Parameter(torch.tensor([cfg.method.gamma]).to(cfg.method.device))
+    else:
+        solver.gamma = cfg.method.gamma
     solver.shard = shard
-    optimizer = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
+    optimizer = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps,
+                               algorithm=algorithm, y0_lr=cfg.optim.y0_lr)
     optimizer.zero_grad()
     trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm)
 
@@ -106,7 +110,14 @@ def run(cfg):
             log(f"{itr} - {vals['time_per_iteration']:5.3f}s/it (EMA {ema['time_per_iteration']:5.3f}s/it): "
                 f"{vals['loss'].item():5.5f} {ema['loss'].item():5.5f}{extra} "
                 f"{ema['weight_mean'].item():5.6E} {ema['weight_std'].item():5.6E}")
-            log(f"soc_solver.neural_sde.M.gamma: {neural_sde.M.gamma.item()}")
+            if algorithm == "moment":
+                log(f"soc_solver.y0: {solver.y0.item()}")
+            elif algorithm == "SOCM_exp":
+                log(f"soc_solver.gamma: {solver.gamma.item()}")
+            elif algorithm == "SOCM":
+                log(f"soc_solver.neural_sde.M.gamma: {neural_sde.M.gamma.item()}")
+        if algorithm == "moment" and itr == 5000:                        # main.py:437-441
+            optimizer.param_groups[-1]["lr"] = 1e-4
         if checkpoint:
             log(f"Control loss mean: {out[2]:5.5f}, Control loss std. error: {out[3]:5.5f}")
             info["control_objective_mean"].append(out[2].detach())

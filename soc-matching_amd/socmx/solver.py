@@ -3,11 +3,11 @@
 Same constructor, same `.loss(...)` keyword surface and 8-tuple return
 `(objective, norm_sqd_diff, ctrl_loss_mean, ctrl_loss_std_err, trajectory,
 mean(w), std(w), stop_indicators)` (method.py:223-236, 897-906), same
-`.control_objective` (method.py:185-221).  Only `algorithm="SOCM"` without stopping
-times runs on the HIP loss kernels; the stopping-time
-variant (molecular_dynamics, per-sample TwoBoundarySigmoidMLP) is a torch restatement on
-the same rollout buffers; the other losses of method.py:264-478, 722-856 are row f4 and
-raise NotImplementedError.
+`.control_objective` (method.py:185-221).  `algorithm="SOCM"` without stopping times runs on
+the HIP loss kernels; the stopping-time variant
+(molecular_dynamics, per-sample TwoBoundarySigmoidMLP) and the other eight losses of
+method.py:264-478, 722-856 (row f4, `socmx.baselines`) are torch restatements on the same
+fused-rollout buffers (`rel_entropy` differentiates through the eager rollout instead).
 
 Data parallelism: when `self.shard` is set (see socmx.dist), `batch_size` is the
 GLOBAL batch; this rank simulates rows [row0, row0+B_local) and divides by the
@@ -18,8 +18,12 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import baselines
 from . import loss as L
 from . import rollout as R
+
+ALGORITHMS = ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-variance", "variance",
+              "moment", "rel_entropy")
 
 
 class SOC_Solver(nn.Module):
@@ -100,9 +104,12 @@ class SOC_Solver(nn.Module):
     def loss(self, batch_size, compute_L2_error=False, optimal_control=None, compute_control_objective=False,
              algorithm="SOCM_const_M", add_weights=False, total_n_samples=65536, verbose=False,
              u_warm_start=None, use_warm_start=True, use_stopping_time=False):
-        if algorithm != "SOCM":
-            raise NotImplementedError(
-                f"algorithm={algorithm!r}: only 'SOCM' is implemented (other losses: SURVEY.md row f4)")
+        if algorithm not in ALGORITHMS:
+            raise NotImplementedError(f"algorithm={algorithm!r}: expected one of {ALGORITHMS}")
+        if use_stopping_time and algorithm in ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint"):
+            raise NotImplementedError(f"{algorithm} has no stopping-time form in the reference either")
+        if self.shard is not None and algorithm != "SOCM":
+            raise NotImplementedError("batch sharding is implemented for algorithm='SOCM' only")
         if u_warm_start and use_warm_start:
             raise NotImplementedError("warm start is out of scope (SURVEY.md component 9)")
         sde = self.neural_sde
@@ -117,8 +124,21 @@ class SOC_Solver(nn.Module):
         state0 = self.x0.repeat(B, 1)
         ts = self.ts.to(state0)
         noise_in, self.noise_in = self.noise_in, None
+        detach = algorithm != "rel_entropy"     # rel_entropy differentiates THROUGH the rollout (method.py:240)
         (states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls) = \
-            R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=True, noise_in=noise_in, row0=row0)
+            R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0)
+        if algorithm == "rel_entropy":          # method.py:264-270
+            objective = torch.mean(-self.lmbd * (lpd + ltw))
+            weight = torch.exp(lpd + lps + ltw).detach()
+            norm_sqd_diff = None
+            if compute_L2_error:
+                tc = optimal_control(self.ts, states, t_is_tensor=True)[:-1].detach()
+                norm_sqd_diff = torch.sum((tc - controls.detach()) ** 2 * weight.reshape(1, -1, 1)
+                                          / (tc.shape[0] * tc.shape[1]))
+            cm = ce = traj = None
+            if compute_control_objective:
+                cm, ce, traj = self.control_objective(batch_size, total_n_samples=total_n_samples)
+            return (objective, norm_sqd_diff, cm, ce, traj, torch.mean(weight), torch.std(weight), stop_indicators)
 
         weight, stats = L.weights_and_stats(lpd, lps, ltw)
         if shard is not None:
@@ -129,16 +149,31 @@ class SOC_Solver(nn.Module):
         tx = torch.cat([ts.reshape(-1, 1, 1).expand(Kp, B, 1), states], dim=-1).reshape(-1, d + 1)
         nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)
 
-        # M and dM/ds on the pair grid (method.py:510-515, 533-573)
-        t_vec, s_vec, ii, jj = L.pair_times(ts, self.T, K)
-        if use_stopping_time:
-            objective = self._socm_stopping_objective(pb, ts, t_vec, s_vec, ii, jj, states, noises, controls,
-                                                      stop_indicators, fractional_timesteps, nabla_V, weight)
-        else:
-            M_all, dM_all = sde.M.forward_with_ds(t_vec, s_vec)
-            inv_norm = 1.0 / (Kp * B_global)
-            objective = L.socm_objective(pb, ts, self.lmbd, K, states, noises, controls, M_all, dM_all, nabla_V,
-                                         weight, inv_norm)
+        frac = fractional_timesteps if use_stopping_time else None
+        if algorithm == "SOCM":
+            # M and dM/ds on the pair grid (method.py:510-515, 533-573)
+            t_vec, s_vec, ii, jj = L.pair_times(ts, self.T, K)
+            if use_stopping_time:
+                objective = self._socm_stopping_objective(pb, ts, t_vec, s_vec, ii, jj, states, noises, controls,
+                                                          stop_indicators, fractional_timesteps, nabla_V, weight)
+            else:
+                M_all, dM_all = sde.M.forward_with_ds(t_vec, s_vec)
+                inv_norm = 1.0 / (Kp * B_global)
+                objective = L.socm_objective(pb, ts, self.lmbd, K, states, noises, controls, M_all, dM_all, nabla_V,
+                                             weight, inv_norm)
+        elif algorithm == "SOCM_const_M":
+            objective = baselines.socm_const_m(pb, ts, self.lmbd, states, noises, controls, nabla_V, weight)
+        elif algorithm == "SOCM_exp":
+            objective = baselines.socm_exp(pb, ts, self.T, self.lmbd, self.gamma, states, noises, controls, nabla_V,
+                                           weight)
+        elif algorithm == "SOCM_adjoint":
+            objective = baselines.socm_adjoint(pb, ts, self.dt, states, nabla_V, weight)
+        elif algorithm == "cross_entropy":
+            objective = baselines.cross_entropy(pb, ts, self.lmbd, states, noises, controls, nabla_V, weight, frac=frac)
+        else:  # variance, log-variance, moment
+            objective = baselines.variance_family(
+                algorithm, pb, ts, self.lmbd, states, noises, controls, nabla_V, weight, self.y0,
+                add_weights=add_weights, frac=frac, stop_indicators=stop_indicators if use_stopping_time else None)
 
         if compute_L2_error:
             target_control = optimal_control(self.ts, states, t_is_tensor=True)

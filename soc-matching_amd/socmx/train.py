@@ -20,14 +20,21 @@ def compute_EMA(value, EMA_value, EMA_coeff=0.01, itr=0):
     return EMA_coeff * value + (1 - EMA_coeff) * EMA_value
 
 
-def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4):
-    """Adam with the SOCM parameter groups of main.py:214-230."""
+def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm="SOCM", y0_lr=1e-2):
+    """Adam with the per-algorithm parameter groups of main.py:174-238."""
     sde = solver.neural_sde
-    groups = [{"params": sde.nabla_V.parameters()},
-              {"params": sde.M.sigmoid_layers.parameters(), "lr": M_lr},
-              {"params": sde.gamma, "lr": M_lr}]
-    if getattr(sde, "use_stopping_time", False):
-        groups.append({"params": sde.gamma2, "lr": M_lr})   # gamma3 is NOT optimised in the reference (main.py:190-212)
+    if algorithm == "SOCM":
+        groups = [{"params": sde.nabla_V.parameters()},
+                  {"params": sde.M.sigmoid_layers.parameters(), "lr": M_lr},
+                  {"params": sde.gamma, "lr": M_lr}]
+        if getattr(sde, "use_stopping_time", False):
+            groups.append({"params": sde.gamma2, "lr": M_lr})   # gamma3 is NOT optimised in the reference (main.py:190-212)
+    elif algorithm == "moment":
+        groups = [{"params": sde.parameters()}, {"params": solver.y0, "lr": y0_lr}]
+    elif algorithm == "SOCM_exp":
+        groups = [{"params": sde.parameters()}, {"params": solver.gamma, "lr": M_lr}]
+    else:
+        groups = [{"params": solver.parameters()}]
     return torch.optim.Adam(groups, lr=nabla_V_lr, eps=adam_eps)
 
 
@@ -52,7 +59,12 @@ class Trainer:
                           use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)),
                           **loss_kwargs)
         objective, weight_mean = out[0], out[5]
-        loss = objective / self.normalization_const                      # main.py:313-322
+        if self.algorithm in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
+            loss = objective / self.normalization_const                  # main.py:313-320
+        elif self.algorithm == "variance":
+            loss = objective / self.normalization_const ** 2             # main.py:321-322
+        else:
+            loss = objective
         loss.backward()                                                  # main.py:323
         if solver.shard is not None:
             (loss_val,) = solver.shard.allreduce_gradients(

@@ -149,7 +149,7 @@ def build_setting(classes, setting, d, hdims, hdims_M, gamma, sf_V, sf_M, lmbd, 
 
 
 def make_one(name, setting, d, K, B, hdims, hdims_M, gamma, seed, T=1.0, lmbd=1.0,
-             sf_V=1.0, sf_M=0.1, use_stopping_time=False, with_loss=True, with_pairs=True):
+             sf_V=1.0, sf_M=0.1, use_stopping_time=False, with_loss=True, with_pairs=True, with_algs=False):
     utils, method, models, classes = _import_reference()
     torch.manual_seed(seed)
     torch.set_num_threads(1)
@@ -232,6 +232,29 @@ def make_one(name, setting, d, K, B, hdims, hdims_M, gamma, seed, T=1.0, lmbd=1.
             out["pairs_M"] = M_all.detach().numpy().copy()
             out["pairs_dM"] = dM_all.detach().numpy().copy()
 
+    if with_algs:
+        # ---- the other losses on the same rollout (method.py:264-270, 289-478, 722-856): objective + nabla_V grads
+        for alg in ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-variance", "variance",
+                    "moment", "rel_entropy"):
+            for p_ in sde.parameters():
+                p_.grad = None
+            solver = method.SOC_Solver(sde, x0, None, T=T, num_steps=K, lmbd=lmbd, d=d, sigma=sigma)
+            with torch.no_grad():
+                solver.y0.fill_(0.37)
+            solver.gamma = torch.nn.Parameter(torch.tensor([gamma])) if alg == "SOCM_exp" else gamma
+            with _NoiseFeeder(noise):
+                res = solver.loss(B, compute_L2_error=False, optimal_control=None, compute_control_objective=False,
+                                  algorithm=alg, verbose=False, u_warm_start=None, use_warm_start=False,
+                                  use_stopping_time=False)
+            res[0].backward()
+            out[f"alg.{alg}.objective"] = res[0].detach().numpy().copy()
+            for k, p_ in sde.nabla_V.named_parameters():
+                out[f"alg.{alg}.grad_nablaV.{k}"] = p_.grad.numpy().copy()
+            if alg == "SOCM_exp":
+                out[f"alg.{alg}.grad_gamma"] = solver.gamma.grad.numpy().copy()
+            if alg == "moment":
+                out[f"alg.{alg}.grad_y0"] = solver.y0.grad.numpy().copy()
+
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB"
@@ -244,10 +267,10 @@ DEFAULT = dict(hdims=[256, 128, 64], hdims_M=[128, 128])
 FIXTURES = [
     # name, setting, d, K, B, arch, gamma, seed, extra
     ("tiny_ou_quadratic_easy_d2", "OU_quadratic_easy", 2, 12, 8, TINY, 2.0, 1, {}),
-    ("tiny_ou_quadratic_hard_d4", "OU_quadratic_hard", 4, 12, 8, TINY, 1.0, 2, {}),
+    ("tiny_ou_quadratic_hard_d4", "OU_quadratic_hard", 4, 12, 8, TINY, 1.0, 2, dict(with_algs=True)),
     ("tiny_ou_quadratic_dense_d3", "OU_quadratic_dense", 3, 10, 8, TINY, 1.5, 7, {}),
-    ("tiny_ou_linear_d6", "OU_linear", 6, 14, 8, TINY, 2.0, 3, {}),
-    ("tiny_double_well_d10", "double_well", 10, 40, 8, TINY, 6.0, 4, {}),
+    ("tiny_ou_linear_d6", "OU_linear", 6, 14, 8, TINY, 2.0, 3, dict(with_algs=True)),
+    ("tiny_double_well_d10", "double_well", 10, 40, 8, TINY, 6.0, 4, dict(with_algs=True)),
     ("tiny_molecular_dynamics_d1", "molecular_dynamics", 1, 24, 16, TINY, 1.0, 5,
      dict(T=2.0, lmbd=2.0)),
     ("tiny_molecular_dynamics_d1_stopping", "molecular_dynamics", 1, 24, 16, TINY, 1.0, 5,

@@ -141,10 +141,44 @@ def test_stopping_time_socm_loss_matches_reference():
     np.testing.assert_allclose(sde.gamma2.grad.numpy(), z["grad_gamma2"], rtol=2e-3, atol=1e-6)
 
 
-def test_other_algorithms_fail_loudly():
+OTHER_ALGS = ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-variance", "variance", "moment",
+              "rel_entropy")
+
+
+@pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10"])
+@pytest.mark.parametrize("alg", OTHER_ALGS)
+def test_other_losses_match_reference(name, alg):
+    """Row f4: the reference's eight other losses, objective and nabla_V gradients, same injected noise."""
+    from SOC_matching.method import SOC_Solver
+    sde, aux = build_sde(name)
+    z = aux["z"]
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                        sigma=sde.sigma)
+    with torch.no_grad():
+        solver.y0.fill_(0.37)
+    gamma0 = float(z["meta_f"][2])
+    solver.gamma = torch.nn.Parameter(torch.tensor([gamma0])) if alg == "SOCM_exp" else gamma0
+    solver.noise_in = aux["noise"]
+    out = solver.loss(aux["B"], algorithm=alg, use_warm_start=False, use_stopping_time=False)
+    want = z[f"alg.{alg}.objective"]
+    np.testing.assert_allclose(out[0].item(), want, rtol=2e-4, atol=1e-7)
+    out[0].backward()
+    num = den = 0.0
+    for k, p in sde.nabla_V.named_parameters():
+        g = z[f"alg.{alg}.grad_nablaV.{k}"]
+        num += float(((p.grad.numpy() - g) ** 2).sum())
+        den += float((g ** 2).sum())
+    assert (num / max(den, 1e-30)) ** 0.5 < 2e-3, (alg, (num / max(den, 1e-30)) ** 0.5)
+    if alg == "SOCM_exp":
+        np.testing.assert_allclose(solver.gamma.grad.numpy(), z[f"alg.{alg}.grad_gamma"], rtol=2e-3, atol=1e-6)
+    if alg == "moment":
+        np.testing.assert_allclose(solver.y0.grad.numpy(), z[f"alg.{alg}.grad_y0"], rtol=2e-3)
+
+
+def test_unknown_algorithm_fails_loudly():
     from SOC_matching.method import SOC_Solver
     sde, aux = build_sde("tiny_ou_quadratic_easy_d2")
     solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
                         sigma=sde.sigma)
     with pytest.raises(NotImplementedError):
-        solver.loss(4, algorithm="SOCM_adjoint")
+        solver.loss(4, algorithm="SOCM_typo")
