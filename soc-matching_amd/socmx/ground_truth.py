@@ -1,11 +1,18 @@
-"""Closed-form optimal controls for the linear settings.
+"""Ground-truth optimal controls.
 
 * LQ (OU_quadratic): backward Riccati recursion F' = -(A^T F + F A - 2 F S S^T F + P), F(T)=Q on the
   simulation grid, u*(t,x) = -2 S^T F(t) x  (reference utils.py:234-254, models.py:10-52).
 * OU_linear: u*(t) = -S^T exp(A^T (T-t)) omega  (reference settings.py:52-63, models.py:55-95).
-Both are exposed as `sde.u(t, x, t_is_tensor=False)` callables on an un-learned NeuralSDE, which the
+* double_well: the problem decouples per coordinate; each coordinate's value function follows from a 1-D
+  linear PDE for psi = exp(-V) solved backward in time with an implicit (tridiagonal) step on a symmetrised
+  finite-volume generator, u* = -(2/beta) sigma_ii d/dx(-log psi)  (reference double_well.py:132-233,
+  table lookup models.py:98-150).  Vectorised here: the reference fills the tridiagonal matrix and the
+  control table with Python double loops (5.5 M iterations per coordinate at the README resolution) and
+  repeats the solve for every coordinate; coordinates sharing (kappa_i, nu_i, sigma_ii) share one solve.
+All are exposed as `sde.u(t, x, t_is_tensor=False)` callables on an un-learned NeuralSDE, which the
 eager rollout path consumes (the fused kernel handles the learned control only).
 """
+import numpy as np
 import torch
 
 
@@ -72,3 +79,68 @@ def linear_optimal_sde(cls, ts, sigma, A, omega, cfg):
     C = -torch.einsum("ij,aj->ai", sigma.T, expo @ omega)
     return cls(device=cfg.method.device, dim=cfg.method.d, u=ConstantControl(C, ts, T), lmbd=cfg.method.lmbd,
                A=A, omega=omega, sigma=sigma)
+
+
+# ---- double well ------------------------------------------------------------------------------------------
+
+def double_well_table_1d(kappa_i, nu_i, sigma_ii, T, delta_t, delta_x, xb):
+    """u*(t_n, x_i) on the reference's grid: (N+1, nx-1) float64.  beta = 2 as in the reference."""
+    from scipy.linalg import solve_banded
+    beta = 2.0
+    nx = int(2.0 * xb / delta_x)
+    N = int(T / delta_t)
+    V = lambda x: kappa_i * (x * x - 1.0) ** 2
+    i = np.arange(nx)
+    xc = -xb + (i + 0.5) * delta_x                      # cell centres
+    # off-diagonal between cells i and i+1 (symmetric), interface at -xb + (i+1) dx
+    xi = -xb + (i[:-1] + 1) * delta_x
+    off = -np.exp(beta * 0.5 * (V(xc[1:]) + V(xc[:-1]) - 2 * V(xi))) / delta_x**2
+    diag = np.zeros(nx)
+    diag[1:] += np.exp(beta * (V(xc[1:]) - V(-xb + i[1:] * delta_x))) / delta_x**2          # left interface
+    diag[:-1] += np.exp(beta * (V(xc[:-1]) - V(-xb + (i[:-1] + 1) * delta_x))) / delta_x**2  # right interface
+    off, diag = -off / beta, -diag / beta
+    band = -delta_t * np.vstack([np.append([0.0], off), diag - N / T, np.append(off, [0.0])])
+    xv = np.linspace(-xb, xb, nx, endpoint=True)
+    D, Dinv = np.exp(beta * V(xv) / 2), np.exp(-beta * V(xv) / 2)
+    psi = np.zeros((N + 1, nx))
+    psi[N] = np.exp(-nu_i * (xv * xv - 1.0) ** 2)
+    for n in range(N - 1, -1, -1):
+        psi[n] = D * solve_banded((1, 1), band, Dinv * psi[n + 1])
+    logp = np.log(psi)
+    return -2.0 / beta * sigma_ii * (logp[:, :-1] - logp[:, 1:]) / delta_x
+
+
+class LowDimControl:
+    """Per-coordinate table lookup u_j(t, x_j) (reference models.py:98-150): time index ceil(t/delta_t), space
+    index floor((x+xb)/delta_x) clamped to the table."""
+
+    def __init__(self, ut, T, xb, dim, delta_t, delta_x):
+        self.ut, self.T, self.xb, self.dim, self.delta_t, self.delta_x = ut, T, xb, dim, delta_t, delta_x
+
+    def _lookup(self, t_idx, x):
+        ix = torch.floor((x + self.xb) / self.delta_x).to(torch.int64).clamp_(0, self.ut.shape[1] - 1)
+        j = torch.arange(self.dim, device=x.device).expand_as(ix)
+        return self.ut[t_idx.expand_as(ix), ix, j]
+
+    def __call__(self, t, x, t_is_tensor=False):
+        if not t_is_tensor:
+            x2 = x.reshape(-1, self.dim)
+            ti = torch.ceil(torch.as_tensor(t, device=x.device).reshape(1, 1) / self.delta_t).to(torch.int64)
+            return self._lookup(ti, x2)
+        ti = torch.ceil(t.reshape(-1, 1, 1) / self.delta_t).to(torch.int64)
+        return self._lookup(ti, x)
+
+
+def double_well_optimal_sde(cls, kappa, nu, sigma, cfg, xb=2.75):
+    m = cfg.method
+    tables, cache = [], {}
+    for j in range(m.d):
+        key = (float(kappa[j]), float(nu[j]), float(sigma[j, j]))
+        if key not in cache:
+            cache[key] = torch.from_numpy(double_well_table_1d(*key, m.T, m.delta_t_optimal, m.delta_x_optimal, xb))
+        tables.append(cache[key])
+    ut = torch.stack(tables, dim=2).to(m.device)
+    print(f"ut_discrete.shape: {ut.shape}")
+    sde = cls(device=m.device, dim=m.d, lmbd=m.lmbd, kappa=kappa, nu=nu, sigma=sigma)
+    sde.u = LowDimControl(ut, m.T, xb, m.d, m.delta_t_optimal, m.delta_x_optimal)
+    return sde

@@ -4,9 +4,9 @@ u_warm_start)`.
 
 Constants and the ORDER of RNG draws follow the reference (x0 / xi are drawn right after seeding,
 before the networks are initialised) so that a run with the reference's seed starts from the same
-problem instance and the same weights.  Ground-truth controls: closed forms for the OU settings
-(socmx.ground_truth); `None` for double_well / molecular_dynamics in this round (the reference
-solves a 1-D PDE there, double_well.py:99-233 -- SURVEY row f2).  Warm start (splines) is out of
+problem instance and the same weights.  Ground-truth controls (socmx.ground_truth): closed forms for the OU
+settings, the vectorised 1-D PDE solve for double_well; `None` for molecular_dynamics as in the reference
+(settings.py:112-114).  Warm start (splines) is out of
 scope: `u_warm_start` is always None and `method.use_warm_start=True` raises.
 """
 import torch
@@ -51,6 +51,7 @@ def define_variables(cfg, ts):
         kappa[:3] = 5
         nu[:3] = 3
         sigma = eye
+        optimal_sde = ground_truth.double_well_optimal_sde(DoubleWell, kappa, nu, sigma, cfg)
         sde = DoubleWell(kappa=kappa, nu=nu, sigma=sigma, **common)
     elif setting == "molecular_dynamics":
         print("molecular_dynamics")

@@ -91,7 +91,8 @@ def test_zero_control_ou_mean_matches_euler_maruyama_closed_form():
 
 def test_main_runs_a_tiny_training_on_cpu(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "soc-matching_amd", "main.py"), "method.setting=double_well", "method.d=3",
-           "method.use_gpu=False", "method.num_iterations=4", "method.num_steps=6", "arch.hdims=[16,16,8]",
+           "method.use_gpu=False", "method.num_iterations=4", "method.num_steps=40", "arch.hdims=[16,16,8]",
+           "method.delta_t_optimal=0.02", "method.delta_x_optimal=0.02",
            "arch.hdims_M=[8,8]", "method.n_samples_control=32", "+method.n_batches_normalization=2",
            "optim.batch_size=8", "method.gamma=2.0", "method.compute_control_objective_every=2"]
     res = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300)
@@ -100,4 +101,38 @@ def test_main_runs_a_tiny_training_on_cpu(tmp_path):
     run_dir = tmp_path / "outputs" / "runs"
     folders = [p for p in run_dir.iterdir() if p.is_dir()]
     assert len(folders) == 1 and (folders[0] / "last.pkl").exists()     # reference checkpoint convention
-    assert folders[0].name.startswith("SOCM_double_well_1.0_1.0_6_False_0_8_")
+    assert folders[0].name.startswith("SOCM_double_well_1.0_1.0_40_False_0_8_")
+
+
+def test_double_well_pde_ground_truth_matches_reference():
+    """f2: vectorised 1-D PDE solve + table lookup against the reference's double-loop solver (coarse grid)."""
+    from socmx import ground_truth as G
+    z = np.load(os.path.join(ROOT, "tests", "golden", "dw_pde_reference.npz"))
+    T, delta_t, delta_x, xb = [float(v) for v in z["params"]]
+    d = z["kappa"].shape[0]
+    tabs = [G.double_well_table_1d(float(z["kappa"][j]), float(z["nu"][j]), 1.0, T, delta_t, delta_x, xb) for j in range(d)]
+    ut = np.stack(tabs, axis=2)
+    assert ut.shape == z["ut"].shape
+    np.testing.assert_allclose(ut, z["ut"], rtol=1e-8, atol=1e-9)
+    ctrl = G.LowDimControl(torch.from_numpy(ut), T, xb, d, delta_t, delta_x)
+    ts, xs = torch.from_numpy(z["ts"]), torch.from_numpy(z["xs"])
+    np.testing.assert_array_equal(ctrl(ts, xs, t_is_tensor=True).numpy(), z["u_tensor"])
+    np.testing.assert_array_equal(ctrl(torch.tensor(float(z["t_scalar"])), xs[3]).numpy(), z["u_scalar"])
+
+
+def test_double_well_optimal_control_lowers_the_cost():
+    """Known answer: rollouts under the PDE control must beat the zero control on the control objective."""
+    from socmx.config import load_config
+    from SOC_matching.experiment_settings.settings import define_variables
+    from SOC_matching import utils
+    cfg = load_config(["method.setting=double_well", "method.d=3", "method.use_gpu=False", "method.device=cpu",
+                       "arch.hdims=[16,16,8]", "arch.hdims_M=[8,8]", "method.num_steps=100",
+                       "method.delta_t_optimal=0.01", "method.delta_x_optimal=0.01"])
+    torch.manual_seed(0)
+    ts = torch.linspace(0, 1.0, 101)
+    x0, sigma, optimal_sde, sde, _ = define_variables(cfg, ts)
+    assert optimal_sde is not None
+    opt, _ = utils.control_objective(optimal_sde, x0, ts, 1.0, 256, total_n_samples=1024)
+    optimal_sde.u = lambda t, x, t_is_tensor=False: torch.zeros_like(x)
+    zero, _ = utils.control_objective(optimal_sde, x0, ts, 1.0, 256, total_n_samples=1024)
+    assert opt.item() < zero.item() - 0.2
