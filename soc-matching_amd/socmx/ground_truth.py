@@ -139,7 +139,7 @@ def double_well_optimal_sde(cls, kappa, nu, sigma, cfg, xb=2.75):
         if key not in cache:
             cache[key] = torch.from_numpy(double_well_table_1d(*key, m.T, m.delta_t_optimal, m.delta_x_optimal, xb))
         tables.append(cache[key])
-    ut = torch.stack(tables, dim=2).to(m.device)
+    ut = torch.stack(tables, dim=2).to(torch.float32).to(m.device)   # fp32 like every other rollout operand
     print(f"ut_discrete.shape: {ut.shape}")
     sde = cls(device=m.device, dim=m.d, lmbd=m.lmbd, kappa=kappa, nu=nu, sigma=sigma)
     sde.u = LowDimControl(ut, m.T, xb, m.d, m.delta_t_optimal, m.delta_x_optimal)
