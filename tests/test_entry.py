@@ -122,19 +122,20 @@ def test_double_well_pde_ground_truth_matches_reference():
     np.testing.assert_array_equal(ctrl(torch.tensor(float(z["t_scalar"])), xs[3]).numpy(), z["u_scalar"])
 
 
-def test_double_well_optimal_control_lowers_the_cost():
-    """Known answer: rollouts under the PDE control must beat the zero control on the control objective."""
+def test_double_well_optimal_control_is_a_known_answer():
+    """Under the PDE control the importance weights become (nearly) deterministic and
+    -log E[w] = control cost = V(x0); both improve with the grid (measured 0.126 / 0.431 vs 0.431 here)."""
     from socmx.config import load_config
     from SOC_matching.experiment_settings.settings import define_variables
     from SOC_matching import utils
     cfg = load_config(["method.setting=double_well", "method.d=3", "method.use_gpu=False", "method.device=cpu",
-                       "arch.hdims=[16,16,8]", "arch.hdims_M=[8,8]", "method.num_steps=100",
-                       "method.delta_t_optimal=0.01", "method.delta_x_optimal=0.01"])
+                       "arch.hdims=[16,16,8]", "arch.hdims_M=[8,8]", "method.num_steps=400",
+                       "method.delta_t_optimal=0.002", "method.delta_x_optimal=0.002"])
     torch.manual_seed(0)
-    ts = torch.linspace(0, 1.0, 101)
+    ts = torch.linspace(0, 1.0, 401)
     x0, sigma, optimal_sde, sde, _ = define_variables(cfg, ts)
-    assert optimal_sde is not None
-    opt, e1 = utils.control_objective(optimal_sde, x0, ts, 1.0, 1024, total_n_samples=8192)
-    optimal_sde.u = lambda t, x, t_is_tensor=False: torch.zeros_like(x)
-    zero, e2 = utils.control_objective(optimal_sde, x0, ts, 1.0, 1024, total_n_samples=8192)
-    assert opt.item() < zero.item() - 2 * (e1.item() + e2.item()), (opt.item(), zero.item(), e1.item(), e2.item())
+    r = utils.stochastic_trajectories(optimal_sde, x0.repeat(1024, 1), ts, 1.0)
+    lw = r[4] + r[5] + r[6]
+    cost = (-(r[4] + r[6])).mean().item()
+    assert lw.std().item() < 0.2                         # zero control: 0.48
+    assert abs(-torch.log(torch.exp(lw).mean()).item() - cost) < 0.03
