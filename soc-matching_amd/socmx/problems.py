@@ -32,6 +32,11 @@ class Problem:
         self.A, self.P, self.Q, self.omega, self.kappa, self.nu = A, P, Q, omega, kappa, nu
         self._cache = {}
 
+    def __getstate__(self):  # ctypes structs / device-side copies are rebuilt on demand; keep the solver picklable
+        st = self.__dict__.copy()
+        st["_cache"] = {}
+        return st
+
     # ---- constants -------------------------------------------------------
     @property
     def has_phi(self):

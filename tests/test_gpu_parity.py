@@ -290,3 +290,22 @@ def test_stopping_time_socm_loss_on_gpu_vs_golden():
     np.testing.assert_allclose(out[0].item(), z["loss_objective"], rtol=5e-4)
     out[0].backward()
     np.testing.assert_allclose(_np(sde.gamma.grad), z["grad_gamma"], rtol=5e-3, atol=1e-6)
+
+
+def test_solver_pickles_after_hip_calls(tmp_path):
+    """f3: main.py pickles the whole solver (reference main.py:445-471); ctypes handles must not leak into it."""
+    import pickle
+    from SOC_matching.method import SOC_Solver
+    sde, aux = build_sde("tiny_double_well_d10", DEV)
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                        sigma=sde.sigma)
+    solver.training_info = {"loss": [torch.tensor(1.0, device=DEV)]}
+    out = solver.loss(aux["B"], algorithm="SOCM", use_warm_start=False)
+    out[0].backward()
+    path = tmp_path / "last.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(solver, f)
+    with open(path, "rb") as f:
+        back = pickle.load(f)
+    out2 = back.loss(aux["B"], algorithm="SOCM", use_warm_start=False)      # still usable (handles rebuilt lazily)
+    assert torch.isfinite(out2[0])
