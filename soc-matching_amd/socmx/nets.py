@@ -31,6 +31,45 @@ _UNET_SPEC = (
 )
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b with a batched split-K weight gradient.
+
+    On the trajectory rows (R = (K+1)*B ~ 25k) the weight gradient dW = dY^T X is a GEMM with tiny M, N
+    (<= 256) and a huge reduction dimension; the library runs it on (M/32)*(N/32) <= 64 workgroups without
+    split-K (53-96 us per layer on MI355X).  Splitting R into S slabs as a bmm fills the chip (13-41 us)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gb = gy.sum(0) if ctx.needs_input_grad[2] else None
+        return gx, _wgrad_splitk(gy, x), gb
+
+
+def _wgrad_splitk(gy, x, S=16):
+    """gy^T x for (R, out) x (R, in) with R >> out, in: S row slabs as one bmm (+ a short tail GEMM)."""
+    R = x.shape[0]
+    main = (R // S) * S
+    if main == 0:
+        return gy.t() @ x
+    gw = torch.bmm(gy[:main].view(S, main // S, -1).transpose(1, 2), x[:main].view(S, main // S, -1)).sum(0)
+    if main < R:
+        gw = gw + gy[main:].t() @ x[main:]
+    return gw
+
+
+def _linear(seq, x, splitk):
+    lin = seq[0]
+    y = _LinearSplitK.apply(x, lin.weight, lin.bias) if splitk else lin(x)
+    return torch.relu(y) if len(seq) > 1 else y
+
+
 def _scale_(seq, factor):
     for m in seq:
         if isinstance(m, nn.Linear):
@@ -54,12 +93,14 @@ class FullyConnectedUNet(nn.Module):
         self._packed_version = None
 
     def forward(self, x):
-        r1 = self.down_0(x)
-        r2 = self.down_1(r1)
-        r3 = self.down_2(r2)
-        o2 = self.up_2(r3) + self.res_2(r2)
-        o1 = self.up_1(o2) + self.res_1(r1)
-        return self.up_0(o1) + self.res_0(x)
+        # many rows on the GPU with gradients on: same math, split-K weight gradients (see _LinearSplitK)
+        sk = x.is_cuda and x.shape[0] >= 8192 and torch.is_grad_enabled() and x.is_contiguous()
+        r1 = _linear(self.down_0, x, sk)
+        r2 = _linear(self.down_1, r1, sk)
+        r3 = _linear(self.down_2, r2, sk)
+        o2 = _linear(self.up_2, r3, sk) + _linear(self.res_2, r2, sk)
+        o1 = _linear(self.up_1, o2, sk) + _linear(self.res_1, r1, sk)
+        return _linear(self.up_0, o1, sk) + _linear(self.res_0, x, sk)
 
     # ---- HIP side ---------------------------------------------------------------
     def _version(self):
@@ -135,14 +176,17 @@ class SigmoidMLP(nn.Module):
         """(M, dM/ds) with the s-derivative as an analytic forward tangent
         (the reference differentiates with functorch.jacrev: method.py:510-515)."""
         l0, l2, l4 = self.sigmoid_layers[0], self.sigmoid_layers[2], self.sigmoid_layers[4]
-        a1 = torch.addmm(l0.bias, torch.stack((t, s), dim=1), l0.weight.T)
+        sk = t.is_cuda and t.shape[0] >= 8192 and torch.is_grad_enabled()
+        lin = (lambda x, w, b: _LinearSplitK.apply(x, w, b)) if sk else (lambda x, w, b: torch.addmm(b, x, w.T))
+        a1 = lin(torch.stack((t, s), dim=1), l0.weight, l0.bias)
         h1 = torch.relu(a1)
-        a2 = torch.addmm(l2.bias, h1, l2.weight.T)
+        a2 = lin(h1, l2.weight, l2.bias)
         h2 = torch.relu(a2)
-        net = torch.addmm(l4.bias, h2, l4.weight.T).reshape(-1, self.dim, self.dim)
+        net = lin(h2, l4.weight, l4.bias).reshape(-1, self.dim, self.dim)
+        zero2, zero4 = torch.zeros_like(l2.bias), torch.zeros_like(l4.bias)   # tangent path: no bias
         t1 = (a1 > 0).to(a1.dtype) * l0.weight[:, 1]
-        t2 = (a2 > 0).to(a2.dtype) * (t1 @ l2.weight.T)
-        dnet = (t2 @ l4.weight.T).reshape(-1, self.dim, self.dim)
+        t2 = (a2 > 0).to(a2.dtype) * lin(t1, l2.weight, zero2)
+        dnet = lin(t2, l4.weight, zero4).reshape(-1, self.dim, self.dim)
         decay = torch.exp(-self.gamma * (s - t)).reshape(-1, 1, 1)
         eye = torch.eye(self.dim, device=t.device, dtype=t.dtype)
         M = decay * eye + (1.0 - decay) * net
