@@ -35,7 +35,9 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
         groups = [{"params": sde.parameters()}, {"params": solver.gamma, "lr": M_lr}]
     else:
         groups = [{"params": solver.parameters()}]
-    return torch.optim.Adam(groups, lr=nabla_V_lr, eps=adam_eps)
+    # one fused multi-tensor kernel per group on the GPU (same update rule; ~20 launches fewer per iteration)
+    on_gpu = next(sde.parameters()).is_cuda
+    return torch.optim.Adam(groups, lr=nabla_V_lr, eps=adam_eps, fused=True if on_gpu else None)
 
 
 class Trainer:
