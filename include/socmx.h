@@ -20,6 +20,8 @@
  *   socmx_socm_target_fwd_f32    SOC_matching/method.py:591-720 (least-squares target, residual,
  *                                 weighted reduction to the scalar objective)
  *   socmx_socm_target_bwd_f32    autograd of the above w.r.t. M, dM/ds (nabla_V grad comes out of fwd)
+ *   socmx_socm_target_{fwd,bwd}_net_f32   the same with SOC_matching/models.py:263-275 (SigmoidMLP.forward: the
+ *                                 exp(-gamma (s-t)) blend of I and the network output) and its d/ds fused in
  *
  * Conventions
  *   - every function returns int: 0 = ok, < 0 = invalid argument (SOCMX_E_*), > 0 = hipError_t;
@@ -188,6 +190,28 @@ int socmx_socm_target_fwd_f32(const socmx_problem* problem, int32_t K, int32_t B
 int socmx_socm_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* G, const float* q,
                               const float* v, const float* gT, float* gM, float* gdM,
                               socmx_stream_t stream);
+
+/*
+ * Fused pair-matrix variants for the reference's SigmoidMLP parametrisation (models.py:263-275):
+ *     e = exp(-gamma (s_j - t_i)),   M = e I + (1-e) net,   dM/ds = gamma e (net - I) + (1-e) dnet
+ * net, dnet (Np,d,d) are the raw outputs of `sigmoid_layers` and of its forward tangent in s; delta (Np,) = s - t;
+ * gamma (1,) is read on the device (it is a trained parameter: method.py:134, 160).  M and dM/ds are never written
+ * to HBM: the forward forms them in registers while loading its MFMA operands, the backward chains through them in
+ * its epilogue.  Same outputs as socmx_socm_target_fwd_f32 applied to the materialised (M, dM).
+ */
+int socmx_socm_target_fwd_net_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* net,
+                                  const float* dnet, const float* delta, const float* gamma, const float* qT,
+                                  const float* vT, const float* gTT, const float* nablaV, const float* w,
+                                  float inv_norm, float* target, float* G, float* objective,
+                                  socmx_stream_t stream);
+
+/* g_net = d obj/d net, g_dnet = d obj/d dnet (Np,d,d), scaled by gout[0] (upstream gradient of the objective on
+ * the device; NULL = 1).  g_gamma_part (Np * ceil(d/16)^2,) holds partial sums of d obj/d gamma: the caller adds
+ * them up (deterministic, no atomics). */
+int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* G, const float* q,
+                                  const float* v, const float* gT, const float* gout, const float* net,
+                                  const float* dnet, const float* delta, const float* gamma, float* g_net,
+                                  float* g_dnet, float* g_gamma_part, socmx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,10 @@ struct TargetArgs {
   const float *qT, *vT, *gTT;    // (K,d,B), (K,d,B), (d,B)
   const float *nablaV, *w;       // (Kp,B,d), (B,)
   float *target, *G, *objective; // (Kp,B,d) or NULL, (Kp,B,d), (1,)
+  // NET variant: M_all / dM_all hold the raw network outputs net, d(net)/ds and the pair matrices
+  //   M = e I + (1-e) net,  dM = gamma e (net - I) + (1-e) dnet,  e = exp(-gamma (s-t))       (models.py:263-275)
+  // are formed in registers while the A fragments are loaded.
+  const float *delta, *gamma;    // (Np,) s-t per pair, (1,) on the device
 };
 
 __host__ __device__ inline int64_t pair_row_offset(int i, int K) {
@@ -159,6 +163,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // operand fragments are loaded while the current one is multiplied.  Lanes outside d x d are fed zeros.
 constexpr int kTargetWaves = 8;  // waves per workgroup: the (pair, l-block) iterations of a row are dealt round-robin
 
+template <bool NET>
 __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(const TargetArgs a) {
   __shared__ f32x4 part[kTargetWaves][64];
   const int d = a.d, K = a.K, B = a.B;
@@ -176,6 +181,8 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
     if (rep == 1 && i <= (int)blockIdx.x) break;
     const float* Mrow = a.M_all + (size_t)pair_row_offset(i, K) * dd;
     const float* dMrow = a.dM_all + (size_t)pair_row_offset(i, K) * dd;
+    const float* drow = NET ? a.delta + pair_row_offset(i, K) : nullptr;
+    const float gam = NET ? a.gamma[0] : 0.f;
     const int niter = (K - i + 1) * nlb;   // flattened (pair, l-block) iterations
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float am[4], ad[4], bq[4], bv[4];
@@ -186,12 +193,22 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       const float* dMp = dMrow + (size_t)jr * dd;
       const float* qs = (j < K) ? a.qT + (size_t)j * d * B : a.gTT;
       const float* vs = a.vT + (size_t)(j < K ? j : 0) * d * B;
+      float e = 0.f;
+      if (NET) e = expf(-gam * drow[jr]);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int l = lb + 4 * s + g4;
         const bool okl = l < d, oka = okl && krow < d;
-        xm[s] = oka ? Mp[krow * d + l] : 0.f;
-        xd[s] = (oka && j < K) ? -dMp[krow * d + l] : 0.f;
+        if (NET) {
+          const float nt = oka ? Mp[krow * d + l] : 0.f;
+          const float dn = (oka && j < K) ? dMp[krow * d + l] : 0.f;
+          const float eye = (krow == l) ? 1.f : 0.f;
+          xm[s] = oka ? e * eye + (1.f - e) * nt : 0.f;
+          xd[s] = (oka && j < K) ? -(gam * e * (nt - eye) + (1.f - e) * dn) : 0.f;
+        } else {
+          xm[s] = oka ? Mp[krow * d + l] : 0.f;
+          xd[s] = (oka && j < K) ? -dMp[krow * d + l] : 0.f;
+        }
         xq[s] = okl ? qs[(size_t)l * B + mc] : 0.f;
         xv[s] = (okl && j < K) ? vs[(size_t)l * B + mc] : 0.f;
       }
@@ -267,52 +284,84 @@ __global__ __launch_bounds__(64) void socm_residual_kernel(const TargetArgs a) {
 struct TargetBwdArgs {
   int d, K, B;
   const float *G, *q, *v, *gT;   // (Kp,B,d), (K,B,d), (K,B,d), (B,d)
-  float *gM, *gdM;               // (Np,d,d)
+  const float *gout;             // (1,) upstream gradient of the objective on the device, or NULL (= 1)
+  float *gM, *gdM;               // (Np,d,d): d obj/dM, d obj/d(dM)   -- NET: d obj/d net, d obj/d dnet
+  const float *net, *dnet, *delta, *gamma;   // NET only
+  float *ggamma_part;            // NET only: (Np * kblocks * lblocks,) partial sums of d obj/d gamma
 };
 
-// thread <-> one column (j,l) of row i; accumulates over the batch the KC rows k0..k0+KC-1:
+// One wave per (pair (i,j), 16x16 block of the d x d matrix); the batch is the MFMA reduction dimension:
 //   gM[i,j][k][l] = -sum_m G[i,m,k] q[j,m,l]     gdM[i,j][k][l] = +sum_m G[i,m,k] v[j,m,l]
-template <int KC>
-__global__ __launch_bounds__(256) void socm_target_bwd_kernel(const TargetBwdArgs a) {
+//   D (16 k x 16 l) += A (G[i,m,k], 16 x 4 m) . B (q[j,m,l], 4 m x 16 l)                    v_mfma_f32_16x16x4_f32
+// Consecutive waves take consecutive j of one row i, so the A operand stays in L1/L2.  NET = true chains the
+// derivative of M = e I + (1-e) net, dM = gamma e (net - I) + (1-e) dnet in the epilogue.
+template <bool NET>
+__global__ __launch_bounds__(256) void socm_target_bwd_mfma_kernel(const TargetBwdArgs a) {
   const int d = a.d, K = a.K, B = a.B;
-  const int i = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;  // column inside row i: (j-i)*d + l
-  const int ncols = (K + 1 - i) * d;
-  if (blockIdx.x * blockDim.x >= ncols) return;
-  const bool valid = c < ncols;
-  const int cc = valid ? c : ncols - 1;
-  const int jr = cc / d, l = cc - jr * d;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t np = (int64_t)(K + 1) * (K + 2) / 2;
+  const int64_t p = (int64_t)blockIdx.x * 4 + wave;
+  if (p >= np) return;
+  // invert the i-major triangular numbering: rows counted from the end have 1, 2, 3, ... pairs
+  const int64_t pe = np - 1 - p;
+  int r = (int)((sqrtf(8.f * (float)pe + 1.f) - 1.f) * 0.5f);
+  while ((int64_t)(r + 1) * (r + 2) / 2 <= pe) ++r;
+  while ((int64_t)r * (r + 1) / 2 > pe) --r;
+  const int i = K - r;
+  const int jr = (int)(p - pair_row_offset(i, K));
   const int j = i + jr;
   const bool last = (j == K);
-  const float* qcol = last ? a.gT + l : a.q + (size_t)j * B * d + l;
-  const float* vcol = a.v + (size_t)(last ? 0 : j) * B * d + l;
-  const float* Grow = a.G + (size_t)i * B * d;
-  float* outM = a.gM + (size_t)(pair_row_offset(i, K) + jr) * d * d + l;
-  float* outD = a.gdM + (size_t)(pair_row_offset(i, K) + jr) * d * d + l;
-  for (int k0 = 0; k0 < d; k0 += KC) {
-    float aq[KC], av[KC];
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = blockIdx.y * 16, lb = blockIdx.z * 16;
+  const int k = kb + c16, l = lb + c16;
+  const bool okk = k < d, okl = l < d;
+  const float* Ap = a.G + (size_t)i * B * d + (okk ? k : d - 1);
+  const float* Bq = (last ? a.gT : a.q + (size_t)j * B * d) + (okl ? l : d - 1);
+  const float* Bv = a.v + (size_t)(last ? 0 : j) * B * d + (okl ? l : d - 1);
+  f32x4 accq = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+  for (int m0 = 0; m0 < B; m0 += 16) {   // 12 loads in flight, then 8 MFMAs
+    float af[4], qf[4], vf[4];
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk) { aq[kk] = 0.f; av[kk] = 0.f; }
-    for (int m = 0; m < B; ++m) {
-      const float ql = qcol[(size_t)m * d];
-      const float vl = last ? 0.f : vcol[(size_t)m * d];
-      const float* g = Grow + (size_t)m * d + k0;  // wave-uniform address -> scalar loads
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + 4 * u + g4;
+      const bool okm = m < B;
+      const size_t off = (size_t)(okm ? m : B - 1) * d;
+      const float av = Ap[off], qv = Bq[off], vv = Bv[off];
+      af[u] = (okm && okk) ? av : 0.f;
+      qf[u] = okl ? qv : 0.f;
+      vf[u] = (okl && !last) ? vv : 0.f;
+    }
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk) {
-        const float gk = (k0 + kk < d) ? g[kk] : 0.f;
-        aq[kk] += gk * ql;
-        av[kk] += gk * vl;
+    for (int u = 0; u < 4; ++u) {
+      accq = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u], qf[u], accq, 0, 0, 0);
+      accv = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u], vf[u], accv, 0, 0, 0);
+    }
+  }
+  const float go = a.gout ? a.gout[0] : 1.f;
+  const size_t base = (size_t)p * d * d;
+  float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
+  if (NET) { gam = a.gamma[0]; dl = a.delta[p]; e = expf(-gam * dl); }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int kk = kb + 4 * g4 + rr;
+    if (kk < d && okl) {
+      const size_t idx = base + (size_t)kk * d + l;
+      const float gm = -accq[rr] * go, gd = accv[rr] * go;
+      if (NET) {
+        const float nmi = a.net[idx] - (kk == l ? 1.f : 0.f);
+        a.gM[idx] = (1.f - e) * gm + gam * e * gd;
+        a.gdM[idx] = (1.f - e) * gd;
+        part += gm * dl * e * nmi + gd * (e * (1.f - gam * dl) * nmi + dl * e * a.dnet[idx]);
+      } else {
+        a.gM[idx] = gm;
+        a.gdM[idx] = gd;
       }
     }
-    if (valid) {
-#pragma unroll
-      for (int kk = 0; kk < KC; ++kk) {
-        if (k0 + kk < d) {
-          outM[(size_t)(k0 + kk) * d] = -aq[kk];
-          outD[(size_t)(k0 + kk) * d] = av[kk];
-        }
-      }
-    }
+  }
+  if (NET) {
+    part = wave_sum(part);
+    if (lane == 0) a.ggamma_part[((size_t)p * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z] = part;
   }
 }
 
@@ -358,10 +407,10 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
   return (int)hipGetLastError();
 }
 
-extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all,
-                                         const float* dM_all, const float* qT, const float* vT, const float* gTT,
-                                         const float* nablaV, const float* w, float inv_norm, float* target,
-                                         float* G, float* objective, socmx_stream_t stream) {
+static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all, const float* dM_all,
+                             const float* delta, const float* gamma, const float* qT, const float* vT,
+                             const float* gTT, const float* nablaV, const float* w, float inv_norm, float* target,
+                             float* G, float* objective, socmx_stream_t stream) {
   if (!pb || !M_all || !dM_all || !qT || !vT || !gTT || !nablaV || !w || !G || !objective || !target || !pb->sigma)
     return SOCMX_E_NULL;
   const int d = pb->d;
@@ -370,8 +419,12 @@ extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int
   a.d = d; a.K = K; a.B = B; a.KG = 0; a.inv_norm = inv_norm;
   a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.qT = qT; a.vT = vT; a.gTT = gTT;
   a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective;
+  a.delta = delta; a.gamma = gamma;
   dim3 grid((K + 2) / 2, (B + 15) / 16, (d + 15) / 16);
-  hipLaunchKernelGGL(socm_target_mfma_kernel, grid, dim3(64 * kTargetWaves), 0, (hipStream_t)stream, a);
+  if (delta)
+    hipLaunchKernelGGL(socm_target_mfma_kernel<true>, grid, dim3(64 * kTargetWaves), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(socm_target_mfma_kernel<false>, grid, dim3(64 * kTargetWaves), 0, (hipStream_t)stream, a);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
@@ -383,14 +436,54 @@ extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int
   return (int)hipGetLastError();
 }
 
-extern "C" int socmx_socm_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* G, const float* q,
-                                         const float* v, const float* gT, float* gM, float* gdM,
-                                         socmx_stream_t stream) {
+extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all,
+                                         const float* dM_all, const float* qT, const float* vT, const float* gTT,
+                                         const float* nablaV, const float* w, float inv_norm, float* target,
+                                         float* G, float* objective, socmx_stream_t stream) {
+  return launch_target_fwd(pb, K, B, M_all, dM_all, nullptr, nullptr, qT, vT, gTT, nablaV, w, inv_norm, target, G,
+                           objective, stream);
+}
+
+extern "C" int socmx_socm_target_fwd_net_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* net,
+                                             const float* dnet, const float* delta, const float* gamma,
+                                             const float* qT, const float* vT, const float* gTT,
+                                             const float* nablaV, const float* w, float inv_norm, float* target,
+                                             float* G, float* objective, socmx_stream_t stream) {
+  if (!delta || !gamma) return SOCMX_E_NULL;
+  return launch_target_fwd(pb, K, B, net, dnet, delta, gamma, qT, vT, gTT, nablaV, w, inv_norm, target, G,
+                           objective, stream);
+}
+
+static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, const float* q, const float* v,
+                             const float* gT, const float* gout, const float* net, const float* dnet,
+                             const float* delta, const float* gamma, float* gM, float* gdM, float* ggamma_part,
+                             socmx_stream_t stream) {
   if (!G || !q || !v || !gT || !gM || !gdM) return SOCMX_E_NULL;
   if (d < 1 || K < 1 || B < 1) return SOCMX_E_DIM;
   TargetBwdArgs a;
-  a.d = d; a.K = K; a.B = B; a.G = G; a.q = q; a.v = v; a.gT = gT; a.gM = gM; a.gdM = gdM;
-  dim3 grid(((K + 1) * d + 255) / 256, K + 1);
-  hipLaunchKernelGGL(socm_target_bwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  a.d = d; a.K = K; a.B = B; a.G = G; a.q = q; a.v = v; a.gT = gT; a.gout = gout; a.gM = gM; a.gdM = gdM;
+  a.net = net; a.dnet = dnet; a.delta = delta; a.gamma = gamma; a.ggamma_part = ggamma_part;
+  const int64_t np = socmx_num_pairs(K);
+  dim3 grid((unsigned)((np + 3) / 4), (d + 15) / 16, (d + 15) / 16);
+  if (net)
+    hipLaunchKernelGGL(socm_target_bwd_mfma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(socm_target_bwd_mfma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+extern "C" int socmx_socm_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* G, const float* q,
+                                         const float* v, const float* gT, float* gM, float* gdM,
+                                         socmx_stream_t stream) {
+  return launch_target_bwd(d, K, B, G, q, v, gT, nullptr, nullptr, nullptr, nullptr, nullptr, gM, gdM, nullptr,
+                           stream);
+}
+
+extern "C" int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* G, const float* q,
+                                             const float* v, const float* gT, const float* gout, const float* net,
+                                             const float* dnet, const float* delta, const float* gamma,
+                                             float* g_net, float* g_dnet, float* g_gamma_part,
+                                             socmx_stream_t stream) {
+  if (!net || !dnet || !delta || !gamma || !g_gamma_part) return SOCMX_E_NULL;
+  return launch_target_bwd(d, K, B, G, q, v, gT, gout, net, dnet, delta, gamma, g_net, g_dnet, g_gamma_part, stream);
 }

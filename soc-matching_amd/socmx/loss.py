@@ -156,6 +156,59 @@ class _TargetResidualHip(torch.autograd.Function):
         return gM, gdM, gV, None, None, None, None, None, None
 
 
+class _TargetResidualNetHip(torch.autograd.Function):
+    """Same objective with M = e I + (1-e) net, dM = gamma e (net - I) + (1-e) dnet formed inside the kernels
+    (socmx_socm_target_{fwd,bwd}_net_f32): M and dM/ds never exist in HBM."""
+
+    @staticmethod
+    def forward(ctx, net, dnet, gamma, nablaV, w, delta, ops, pb, K, inv_norm):
+        L = _lib.lib()
+        dev = net.device
+        B, d = ops["gT"].shape
+        c = lambda t: t.detach().to(torch.float32).contiguous()
+        net, dnet, nablaV, w, delta = map(c, (net, dnet, nablaV, w, delta))
+        gam = gamma.detach().to(torch.float32).reshape(1).contiguous()
+        G = torch.empty_like(nablaV)
+        target = torch.empty_like(nablaV)
+        obj = torch.zeros(1, dtype=torch.float32, device=dev)
+        _lib.check(L.socmx_socm_target_fwd_net_f32(
+            pb.c_struct(), K, B, _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(ops["qT"]),
+            _lib.ptr(ops["vT"]), _lib.ptr(ops["gTT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm),
+            _lib.ptr(target), _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_net_f32")
+        ctx.save_for_backward(G, ops["q"], ops["v"], ops["gT"], net, dnet, delta, gam)
+        ctx.dims = (d, K, B, net.shape[0])
+        ctx.gamma_shape = gamma.shape
+        return obj[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        G, q, v, gT, net, dnet, delta, gam = ctx.saved_tensors
+        d, K, B, Np = ctx.dims
+        g_net = g_dnet = g_gamma = gV = None
+        gout = gout.detach().to(torch.float32).reshape(1).contiguous()
+        if any(ctx.needs_input_grad[:3]):
+            nb = (d + 15) // 16
+            g_net = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
+            g_dnet = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
+            part = torch.empty(Np * nb * nb, dtype=torch.float32, device=G.device)
+            _lib.check(L.socmx_socm_target_bwd_net_f32(
+                d, K, B, _lib.ptr(G), _lib.ptr(q), _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gout), _lib.ptr(net),
+                _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(g_net), _lib.ptr(g_dnet), _lib.ptr(part),
+                _lib.stream_ptr(G.device)), "socmx_socm_target_bwd_net_f32")
+            if ctx.needs_input_grad[2]:
+                g_gamma = part.sum().reshape(ctx.gamma_shape)
+        if ctx.needs_input_grad[3]:
+            gV = G * gout
+        return g_net, g_dnet, g_gamma, gV, None, None, None, None, None, None
+
+
+def socm_objective_net(pb, ts, lmbd, K, states, noises, controls, net, dnet, gamma, delta, nablaV, w, inv_norm):
+    """SOCM objective from the raw SigmoidMLP outputs (GPU only; raises if libsocmx.so is missing)."""
+    ops = socm_operands_hip(pb, ts, lmbd, states, noises, controls)
+    return _TargetResidualNetHip.apply(net, dnet, gamma, nablaV, w, delta, ops, pb, K, inv_norm)
+
+
 def socm_objective(pb, ts, lmbd, K, states, noises, controls, M_all, dM_all, nablaV, w, inv_norm,
                    want_target=False):
     """The SOCM objective from the rollout buffers and the network outputs.

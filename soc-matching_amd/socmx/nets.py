@@ -172,9 +172,11 @@ class SigmoidMLP(nn.Module):
         eye = torch.eye(self.dim, device=t.device, dtype=t.dtype)
         return decay * eye + (1.0 - decay) * self.net(t, s)
 
-    def forward_with_ds(self, t, s):
+    def forward_with_ds(self, t, s, raw=False):
         """(M, dM/ds) with the s-derivative as an analytic forward tangent
-        (the reference differentiates with functorch.jacrev: method.py:510-515)."""
+        (the reference differentiates with functorch.jacrev: method.py:510-515).
+        raw=True returns (net, d net/ds) instead: the exp(-gamma (s-t)) blend is then fused into the HIP
+        contraction (loss.socm_objective_net)."""
         l0, l2, l4 = self.sigmoid_layers[0], self.sigmoid_layers[2], self.sigmoid_layers[4]
         sk = t.is_cuda and t.shape[0] >= 8192 and torch.is_grad_enabled()
         lin = (lambda x, w, b: _LinearSplitK.apply(x, w, b)) if sk else (lambda x, w, b: torch.addmm(b, x, w.T))
@@ -187,6 +189,8 @@ class SigmoidMLP(nn.Module):
         t1 = (a1 > 0).to(a1.dtype) * l0.weight[:, 1]
         t2 = (a2 > 0).to(a2.dtype) * lin(t1, l2.weight, zero2)
         dnet = lin(t2, l4.weight, zero4).reshape(-1, self.dim, self.dim)
+        if raw:
+            return net, dnet
         decay = torch.exp(-self.gamma * (s - t)).reshape(-1, 1, 1)
         eye = torch.eye(self.dim, device=t.device, dtype=t.dtype)
         M = decay * eye + (1.0 - decay) * net

@@ -21,6 +21,7 @@ import torch.nn as nn
 from . import baselines
 from . import loss as L
 from . import rollout as R
+from .nets import SigmoidMLP
 
 ALGORITHMS = ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-variance", "variance",
               "moment", "rel_entropy")
@@ -54,6 +55,15 @@ class SOC_Solver(nn.Module):
         return -(self.neural_sde.nabla_V(tx) @ self.sigma)
 
     # ---- method.py:185-221 -------------------------------------------------------------------
+    def _pair_grid(self, ts, K):
+        """(t, s, i, j, s-t) of the (t_i <= s_j) pairs; the time grid is fixed, so this is built once per device."""
+        key = (K, ts.device, ts.dtype)
+        cache = self.__dict__.setdefault("_pair_grid_cache", {})
+        if key not in cache:
+            t_vec, s_vec, ii, jj = L.pair_times(ts, self.T, K)
+            cache[key] = (t_vec, s_vec, ii, jj, (s_vec - t_vec).contiguous())
+        return cache[key]
+
     def control_objective(self, batch_size, total_n_samples=65536):
         n_batches = int(total_n_samples // batch_size)
         if R.burst_eligible(self.neural_sde, self.x0.reshape(1, -1)) and self.shard is None:
@@ -152,15 +162,21 @@ class SOC_Solver(nn.Module):
         frac = fractional_timesteps if use_stopping_time else None
         if algorithm == "SOCM":
             # M and dM/ds on the pair grid (method.py:510-515, 533-573)
-            t_vec, s_vec, ii, jj = L.pair_times(ts, self.T, K)
+            t_vec, s_vec, ii, jj, delta = self._pair_grid(ts, K)
             if use_stopping_time:
                 objective = self._socm_stopping_objective(pb, ts, t_vec, s_vec, ii, jj, states, noises, controls,
                                                           stop_indicators, fractional_timesteps, nabla_V, weight)
             else:
-                M_all, dM_all = sde.M.forward_with_ds(t_vec, s_vec)
                 inv_norm = 1.0 / (Kp * B_global)
-                objective = L.socm_objective(pb, ts, self.lmbd, K, states, noises, controls, M_all, dM_all, nabla_V,
-                                             weight, inv_norm)
+                if state0.is_cuda and type(sde.M) is SigmoidMLP:
+                    # the exp(-gamma (s-t)) blend and its d/ds are formed inside the HIP contraction
+                    net, dnet = sde.M.forward_with_ds(t_vec, s_vec, raw=True)
+                    objective = L.socm_objective_net(pb, ts, self.lmbd, K, states, noises, controls, net, dnet,
+                                                     sde.M.gamma, delta, nabla_V, weight, inv_norm)
+                else:
+                    M_all, dM_all = sde.M.forward_with_ds(t_vec, s_vec)
+                    objective = L.socm_objective(pb, ts, self.lmbd, K, states, noises, controls, M_all, dM_all,
+                                                 nabla_V, weight, inv_norm)
         elif algorithm == "SOCM_const_M":
             objective = baselines.socm_const_m(pb, ts, self.lmbd, states, noises, controls, nabla_V, weight)
         elif algorithm == "SOCM_exp":

@@ -166,6 +166,47 @@ def test_target_kernels_vs_oracle(name):
         np.testing.assert_allclose(_np(got), wn, rtol=1e-3, atol=1e-5 * max(1e-3, np.abs(wn).max()), err_msg=nm)
 
 
+@pytest.mark.parametrize("name", LOSS)
+def test_fused_pair_matrix_kernels_vs_materialised(name):
+    """socmx_socm_target_{fwd,bwd}_net_f32 (M, dM/ds formed in registers from net, dnet, gamma) against the torch
+    blend (models.py:263-275 restated) feeding the oracle-checked materialised kernels: objective and the
+    gradients w.r.t. net, dnet, gamma, nabla_V."""
+    from socmx import loss as L
+    sde, aux = build_sde(name, DEV)
+    pb, vp, mp, gamma, oaux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"), requires_grad=True)
+    _, parts = O.socm_loss(pb, vp, mp, gamma, oaux["x0"], oaux["ts"], oaux["T"], oaux["lmbd"],
+                           oaux["B"], oaux["noise"], derivative="analytic", return_parts=True)
+    K, B, d = aux["K"], aux["B"], aux["d"]
+    to = lambda t: t.detach().to(DEV).contiguous()
+    t_vec, s_vec, _, _ = L.pair_times(aux["ts"], aux["T"], K)
+    delta = (s_vec - t_vec).contiguous()
+    g = torch.Generator().manual_seed(5)
+    Np = (K + 1) * (K + 2) // 2
+    inv_norm = 1.0 / ((K + 1) * B)
+    args = (sde.problem, aux["ts"], aux["lmbd"], K, to(parts["states"]), to(parts["noises"]), to(parts["controls"]))
+    w = to(parts["weight"])
+    grads = {}
+    for mode in ("fused", "materialised"):
+        net = (0.3 * torch.randn(Np, d, d, generator=torch.Generator().manual_seed(5))).to(DEV).requires_grad_(True)
+        dnet = (0.3 * torch.randn(Np, d, d, generator=torch.Generator().manual_seed(6))).to(DEV).requires_grad_(True)
+        gam = torch.tensor(1.7, device=DEV, requires_grad=True)
+        nablaV = to(parts["nabla_V"]).requires_grad_(True)
+        if mode == "fused":
+            out = L.socm_objective_net(*args, net, dnet, gam, delta, nablaV, w, inv_norm)
+        else:
+            e = torch.exp(-gam * delta).reshape(-1, 1, 1)
+            eye = torch.eye(d, device=DEV)
+            M = e * eye + (1.0 - e) * net
+            dM = gam * e * (net - eye) + (1.0 - e) * dnet
+            out = L.socm_objective(*args, M, dM, nablaV, w, inv_norm)
+        (3.0 * out).backward()          # a non-unit upstream gradient exercises the gout path
+        grads[mode] = (out.item(), _np(net.grad), _np(dnet.grad), _np(gam.grad), _np(nablaV.grad))
+    f, m = grads["fused"], grads["materialised"]
+    np.testing.assert_allclose(f[0], m[0], rtol=1e-5)
+    for a, b, nm in zip(f[1:], m[1:], ("g_net", "g_dnet", "g_gamma", "g_nablaV")):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=2e-6 * max(1e-3, np.abs(b).max()), err_msg=nm)
+
+
 @pytest.mark.parametrize("name", LOSS + ["cfg1_ou_quadratic_easy_d2_K50", "cfg3_double_well_d10_K200"])
 def test_full_socm_loss_on_gpu_vs_golden(name):
     from SOC_matching.method import SOC_Solver
