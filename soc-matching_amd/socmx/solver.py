@@ -64,6 +64,20 @@ class SOC_Solver(nn.Module):
             cache[key] = (t_vec, s_vec, ii, jj, (s_vec - t_vec).contiguous())
         return cache[key]
 
+    def __getstate__(self):   # HIP streams and derived caches are per-process: rebuilt on demand after unpickling
+        st = self.__dict__.copy()
+        st.pop("_side_streams", None)
+        st.pop("_pair_grid_cache", None)
+        return st
+
+    def _side_stream(self, device):
+        if not getattr(self, "overlap_M", True):
+            return None
+        streams = self.__dict__.setdefault("_side_streams", {})
+        if device not in streams:
+            streams[device] = torch.cuda.Stream(device)
+        return streams[device]
+
     def control_objective(self, batch_size, total_n_samples=65536):
         n_batches = int(total_n_samples // batch_size)
         if R.burst_eligible(self.neural_sde, self.x0.reshape(1, -1)) and self.shard is None:
@@ -135,8 +149,24 @@ class SOC_Solver(nn.Module):
         ts = self.ts.to(state0)
         noise_in, self.noise_in = self.noise_in, None
         detach = algorithm != "rel_entropy"     # rel_entropy differentiates THROUGH the rollout (method.py:240)
+        # The pair-grid network (M) does not depend on the trajectories: with B=128 the rollout occupies 8 of the
+        # 256 CUs, so its forward is issued on a second HIP stream and runs beside the rollout kernel.
+        fused_M = (algorithm == "SOCM" and not use_stopping_time and state0.is_cuda and type(sde.M) is SigmoidMLP)
+        # (short pair grids are launch-bound on the host: the extra stream bookkeeping costs more than it hides)
+        side = self._side_stream(state0.device) if fused_M and Kp * (Kp + 1) // 2 >= 4096 else None
+        if side is not None:
+            t_vec, s_vec, ii, jj, delta = self._pair_grid(ts, K)    # built on this stream the first time: before fork
+            fork = torch.cuda.Event()
+            fork.record()                       # after the previous optimizer step, before the rollout launch
         (states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls) = \
             R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0)
+        if side is not None:
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                net, dnet = sde.M.forward_with_ds(t_vec, s_vec, raw=True)
+            main = torch.cuda.current_stream(state0.device)
+            net.record_stream(main)
+            dnet.record_stream(main)
         if algorithm == "rel_entropy":          # method.py:264-270
             objective = torch.mean(-self.lmbd * (lpd + ltw))
             weight = torch.exp(lpd + lps + ltw).detach()
@@ -168,9 +198,12 @@ class SOC_Solver(nn.Module):
                                                           stop_indicators, fractional_timesteps, nabla_V, weight)
             else:
                 inv_norm = 1.0 / (Kp * B_global)
-                if state0.is_cuda and type(sde.M) is SigmoidMLP:
+                if fused_M:
                     # the exp(-gamma (s-t)) blend and its d/ds are formed inside the HIP contraction
-                    net, dnet = sde.M.forward_with_ds(t_vec, s_vec, raw=True)
+                    if side is None:
+                        net, dnet = sde.M.forward_with_ds(t_vec, s_vec, raw=True)
+                    else:
+                        torch.cuda.current_stream(state0.device).wait_stream(side)
                     objective = L.socm_objective_net(pb, ts, self.lmbd, K, states, noises, controls, net, dnet,
                                                      sde.M.gamma, delta, nabla_V, weight, inv_norm)
                 else:
