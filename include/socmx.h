@@ -213,6 +213,15 @@ int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* 
                                   const float* dnet, const float* delta, const float* gamma, float* g_net,
                                   float* g_dnet, float* g_gamma_part, socmx_stream_t stream);
 
+/*
+ * Column sums of a tall row-major (R, C) matrix: out[c] = sum_r x[r][c].  Bias gradients of the nn.Linear layers
+ * (models.py:212-228, 253-257) over the (K+1)*B trajectory rows / the Np pair rows; no reference counterpart beyond
+ * autograd's reduction.  partial is a caller-owned workspace of socmx_colsum_blocks(R, C) * C floats; the result
+ * is deterministic (fixed summation order).
+ */
+int32_t socmx_colsum_blocks(int64_t R, int32_t C);
+int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* partial, float* out, socmx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

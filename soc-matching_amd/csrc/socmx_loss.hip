@@ -365,6 +365,63 @@ __global__ __launch_bounds__(256) void socm_target_bwd_mfma_kernel(const TargetB
   }
 }
 
+// ---- column sums (bias gradients) ---------------------------------------------------------------------
+// out[c] = sum_r x[r][c] for a tall (R, C) row-major matrix: HBM-bound, one pass.  Stage 1: workgroup b sums the
+// rows b, b+nblk, ... (lanes along the columns: coalesced; 256/CW row lanes per workgroup) into partial[b][:];
+// stage 2 adds the nblk partials in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t R, int C, int CW,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % CW, rl = threadIdx.x / CW, nrl = 256 / CW;
+  const int64_t step = (int64_t)gridDim.x * nrl;
+  for (int c0 = 0; c0 < C; c0 += CW) {
+    const int cc = c0 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (cc < C) {
+      int64_t r = (int64_t)blockIdx.x * nrl + rl;
+      for (; r + 3 * step < R; r += 4 * step) {
+        a0 += x[r * C + cc];
+        a1 += x[(r + step) * C + cc];
+        a2 += x[(r + 2 * step) * C + cc];
+        a3 += x[(r + 3 * step) * C + cc];
+      }
+      for (; r < R; r += step) a0 += x[r * C + cc];
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && cc < C) {
+      float s = red[c];
+      for (int k = 1; k < nrl; ++k) s += red[k * CW + c];
+      partial[(size_t)blockIdx.x * C + cc] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// 16 columns x 16 partial lanes per workgroup: lane (c, b) adds partials b, b+16, ... then the 16 lanes of a column
+// are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                           float* __restrict__ out) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), bl = threadIdx.x >> 4;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int b = bl;
+    for (; b + 16 < nblk; b += 32) {
+      a0 += partial[(size_t)b * C + c];
+      a1 += partial[(size_t)(b + 16) * C + c];
+    }
+    if (b < nblk) a0 += partial[(size_t)b * C + c];
+  }
+  red[threadIdx.x] = a0 + a1;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    float s = red[threadIdx.x];
+    for (int k = 1; k < 16; ++k) s += red[k * 16 + threadIdx.x];
+    out[c] = s;
+  }
+}
+
 }  // namespace socmx
 
 // =================================================================================================
@@ -486,4 +543,26 @@ extern "C" int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, co
                                              socmx_stream_t stream) {
   if (!net || !dnet || !delta || !gamma || !g_gamma_part) return SOCMX_E_NULL;
   return launch_target_bwd(d, K, B, G, q, v, gT, gout, net, dnet, delta, gamma, g_net, g_dnet, g_gamma_part, stream);
+}
+
+extern "C" int32_t socmx_colsum_blocks(int64_t R, int32_t C) {
+  if (R < 1 || C < 1) return 0;
+  const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
+  const int nrl = 256 / cw;
+  const int64_t want = (R + (int64_t)nrl * 8 - 1) / ((int64_t)nrl * 8);   // >= 8 rows per row lane
+  return (int32_t)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+}
+
+extern "C" int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* partial, float* out,
+                                socmx_stream_t stream) {
+  if (!x || !partial || !out) return SOCMX_E_NULL;
+  if (R < 1 || C < 1) return SOCMX_E_DIM;
+  const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
+  const int nblk = socmx_colsum_blocks(R, C);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, R, (int)C, cw, partial);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+                     (int)C, out);
+  return (int)hipGetLastError();
 }

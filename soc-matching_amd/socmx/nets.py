@@ -48,8 +48,23 @@ class _LinearSplitK(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gy @ weight if ctx.needs_input_grad[0] else None
-        gb = gy.sum(0) if ctx.needs_input_grad[2] else None
+        gb = _colsum(gy) if ctx.needs_input_grad[2] else None
         return gx, _wgrad_splitk(gy, x), gb
+
+
+def _colsum(gy):
+    """Bias gradient gy.sum(0) of a tall contiguous fp32 (R, C) matrix: socmx_colsum_f32 on the GPU (one HBM pass at
+    several TB/s; the generic reduction kernel runs this shape at ~1.3 TB/s)."""
+    if not (gy.is_cuda and gy.dtype == torch.float32 and gy.dim() == 2 and gy.shape[0] >= 4096):
+        return gy.sum(0)
+    L = _lib.lib()
+    R, C = gy.shape
+    nblk = L.socmx_colsum_blocks(R, C)
+    partial = torch.empty(nblk * C, dtype=torch.float32, device=gy.device)
+    out = torch.empty(C, dtype=torch.float32, device=gy.device)
+    _lib.check(L.socmx_colsum_f32(_lib.ptr(gy), R, C, _lib.ptr(partial), _lib.ptr(out), _lib.stream_ptr(gy.device)),
+               "socmx_colsum_f32")
+    return out
 
 
 def _wgrad_splitk(gy, x, S=16):
@@ -64,9 +79,58 @@ def _wgrad_splitk(gy, x, S=16):
     return gw
 
 
-def _linear(seq, x, splitk):
+class _LinearDgrad(torch.autograd.Function):
+    """y = x W^T + b whose backward yields only the input gradient (the weight gradient goes through _WgradTap)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        (weight,) = ctx.saved_tensors
+        return (gy @ weight if ctx.needs_input_grad[0] else None), None, None
+
+
+class _WgradTap(torch.autograd.Function):
+    """Side branch that receives dL/dy and produces dW, db.  It is applied under a second HIP stream, so autograd
+    runs its backward on that stream (with the engine's own event synchronisation on both sides): the weight
+    gradients of layer l overlap with the input-gradient chain of layers l-1, l-2, ... on the main stream."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x)
+        return torch.empty(1, dtype=x.dtype, device=x.device).expand(x.shape[0], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        x.record_stream(torch.cuda.current_stream(x.device))   # allocated on the main stream, read on this one
+        gy = gy.contiguous()
+        return None, _wgrad_splitk(gy, x), _colsum(gy)
+
+
+class _Join(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, tap):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def _linear(seq, x, splitk, wgrad_stream=None):
     lin = seq[0]
-    y = _LinearSplitK.apply(x, lin.weight, lin.bias) if splitk else lin(x)
+    if splitk and wgrad_stream is not None:
+        # the parameters enter the graph only through the tap, applied first: their AccumulateGrad nodes then live
+        # on the second stream too and the engine puts no wait on the main stream until backward() ends
+        with torch.cuda.stream(wgrad_stream):
+            tap = _WgradTap.apply(x.detach(), lin.weight, lin.bias)
+        y = _Join.apply(_LinearDgrad.apply(x, lin.weight.detach(), lin.bias.detach()), tap)
+    else:
+        y = _LinearSplitK.apply(x, lin.weight, lin.bias) if splitk else lin(x)
     return torch.relu(y) if len(seq) > 1 else y
 
 
@@ -91,16 +155,21 @@ class FullyConnectedUNet(nn.Module):
             _scale_(getattr(self, name), scaling_factor)
         self._packed = None
         self._packed_version = None
+        self.wgrad_stream = None   # set by the solver: second HIP stream for the weight gradients (see _WgradTap)
 
     def forward(self, x):
         # many rows on the GPU with gradients on: same math, split-K weight gradients (see _LinearSplitK)
         sk = x.is_cuda and x.shape[0] >= 8192 and torch.is_grad_enabled() and x.is_contiguous()
-        r1 = _linear(self.down_0, x, sk)
-        r2 = _linear(self.down_1, r1, sk)
-        r3 = _linear(self.down_2, r2, sk)
-        o2 = _linear(self.up_2, r3, sk) + _linear(self.res_2, r2, sk)
-        o1 = _linear(self.up_1, o2, sk) + _linear(self.res_1, r1, sk)
-        return _linear(self.up_0, o1, sk) + _linear(self.res_0, x, sk)
+        ws = self.wgrad_stream if sk else None
+        if ws is None or isinstance(ws, torch.cuda.Stream):
+            ws = (ws, ws)
+        wa, wb = ws[0], ws[-1]          # two streams: the nine weight gradients alternate between them
+        r1 = _linear(self.down_0, x, sk, wa)
+        r2 = _linear(self.down_1, r1, sk, wb)
+        r3 = _linear(self.down_2, r2, sk, wa)
+        o2 = _linear(self.up_2, r3, sk, wb) + _linear(self.res_2, r2, sk, wa)
+        o1 = _linear(self.up_1, o2, sk, wb) + _linear(self.res_1, r1, sk, wa)
+        return _linear(self.up_0, o1, sk, wb) + _linear(self.res_0, x, sk, wa)
 
     # ---- HIP side ---------------------------------------------------------------
     def _version(self):
@@ -136,6 +205,7 @@ class FullyConnectedUNet(nn.Module):
         st = self.__dict__.copy()
         st["_packed"] = None
         st["_packed_version"] = None
+        st["wgrad_stream"] = None
         return st
 
 

@@ -70,13 +70,13 @@ class SOC_Solver(nn.Module):
         st.pop("_pair_grid_cache", None)
         return st
 
-    def _side_stream(self, device):
+    def _side_stream(self, device, which=0):
         if not getattr(self, "overlap_M", True):
             return None
         streams = self.__dict__.setdefault("_side_streams", {})
-        if device not in streams:
-            streams[device] = torch.cuda.Stream(device)
-        return streams[device]
+        if (device, which) not in streams:
+            streams[(device, which)] = torch.cuda.Stream(device)
+        return streams[(device, which)]
 
     def control_objective(self, batch_size, total_n_samples=65536):
         n_batches = int(total_n_samples // batch_size)
@@ -187,6 +187,9 @@ class SOC_Solver(nn.Module):
 
         # nabla_V on all Kp*B trajectory rows (method.py:272-278): library GEMMs + autograd
         tx = torch.cat([ts.reshape(-1, 1, 1).expand(Kp, B, 1), states], dim=-1).reshape(-1, d + 1)
+        if state0.is_cuda and hasattr(sde.nabla_V, "wgrad_stream"):
+            s1, s2 = self._side_stream(state0.device, 1), self._side_stream(state0.device, 2)
+            sde.nabla_V.wgrad_stream = None if s1 is None else (s1, s2)
         nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)
 
         frac = fractional_timesteps if use_stopping_time else None

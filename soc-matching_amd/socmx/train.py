@@ -42,8 +42,11 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
-                 ema_weight_mean_coeff=0.002, sync_timing=True):
+                 ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=True):
         self.solver, self.optimizer = solver, optimizer
+        if gemm_select and solver.x0.is_cuda:
+            from . import gemm_select as _gs
+            _gs.enable()          # pick the fastest library GEMM per shape (see gemm_select.py)
         self.batch_size = batch_size
         self.normalization_const = normalization_const
         self.algorithm = algorithm

@@ -166,6 +166,19 @@ def test_target_kernels_vs_oracle(name):
         np.testing.assert_allclose(_np(got), wn, rtol=1e-3, atol=1e-5 * max(1e-3, np.abs(wn).max()), err_msg=nm)
 
 
+@pytest.mark.parametrize("R,C", [(1, 1), (5, 3), (4097, 10), (25728, 256), (25728, 64), (20301, 100), (9000, 300)])
+def test_colsum_kernel(R, C):
+    from socmx import _lib
+    L = _lib.lib()
+    x = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C)).to(DEV)
+    nblk = L.socmx_colsum_blocks(R, C)
+    partial = torch.empty(nblk * C, device=DEV)
+    out = torch.empty(C, device=DEV)
+    _lib.check(L.socmx_colsum_f32(_lib.ptr(x), R, C, _lib.ptr(partial), _lib.ptr(out), _lib.stream_ptr(x.device)), "colsum")
+    want = x.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(_np(out), want, rtol=1e-5, atol=1e-5 * max(1.0, R ** 0.5))
+
+
 @pytest.mark.parametrize("name", LOSS)
 def test_fused_pair_matrix_kernels_vs_materialised(name):
     """socmx_socm_target_{fwd,bwd}_net_f32 (M, dM/ds formed in registers from net, dnet, gamma) against the torch
@@ -231,6 +244,17 @@ def test_full_socm_loss_on_gpu_vs_golden(name):
     assert relnorm([(p, z["grad_M.sigmoid_layers." + k]) for k, p in sde.M.sigmoid_layers.named_parameters()]) < 1e-3
     np.testing.assert_allclose(_np(sde.gamma.grad), z["grad_gamma"], rtol=2e-3,
                                atol=1e-5 * max(1.0, np.abs(z["grad_gamma"]).max()))
+
+
+def test_full_socm_loss_with_gemm_selection_on():
+    """Trainer switches on per-shape library-GEMM selection (socmx.gemm_select); parity must hold with it."""
+    from socmx import gemm_select
+    assert gemm_select.enable()
+    try:
+        test_full_socm_loss_on_gpu_vs_golden("cfg3_double_well_d10_K200")
+        test_full_socm_loss_on_gpu_vs_golden("tiny_ou_linear_d6")
+    finally:
+        gemm_select.disable()
 
 
 def test_full_size_properties_cfg3():
