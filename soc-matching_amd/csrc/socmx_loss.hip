@@ -550,7 +550,7 @@ extern "C" int32_t socmx_colsum_blocks(int64_t R, int32_t C) {
   const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
   const int nrl = 256 / cw;
   const int64_t want = (R + (int64_t)nrl * 8 - 1) / ((int64_t)nrl * 8);   // >= 8 rows per row lane
-  return (int32_t)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  return (int32_t)(want < 1 ? 1 : (want > 512 ? 512 : want));
 }
 
 extern "C" int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* partial, float* out,

@@ -79,58 +79,9 @@ def _wgrad_splitk(gy, x, S=16):
     return gw
 
 
-class _LinearDgrad(torch.autograd.Function):
-    """y = x W^T + b whose backward yields only the input gradient (the weight gradient goes through _WgradTap)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(weight)
-        return torch.addmm(bias, x, weight.t())
-
-    @staticmethod
-    def backward(ctx, gy):
-        (weight,) = ctx.saved_tensors
-        return (gy @ weight if ctx.needs_input_grad[0] else None), None, None
-
-
-class _WgradTap(torch.autograd.Function):
-    """Side branch that receives dL/dy and produces dW, db.  It is applied under a second HIP stream, so autograd
-    runs its backward on that stream (with the engine's own event synchronisation on both sides): the weight
-    gradients of layer l overlap with the input-gradient chain of layers l-1, l-2, ... on the main stream."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x)
-        return torch.empty(1, dtype=x.dtype, device=x.device).expand(x.shape[0], weight.shape[0])
-
-    @staticmethod
-    def backward(ctx, gy):
-        (x,) = ctx.saved_tensors
-        x.record_stream(torch.cuda.current_stream(x.device))   # allocated on the main stream, read on this one
-        gy = gy.contiguous()
-        return None, _wgrad_splitk(gy, x), _colsum(gy)
-
-
-class _Join(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, y, tap):
-        return y.view_as(y)
-
-    @staticmethod
-    def backward(ctx, g):
-        return g, g
-
-
-def _linear(seq, x, splitk, wgrad_stream=None):
+def _linear(seq, x, splitk):
     lin = seq[0]
-    if splitk and wgrad_stream is not None:
-        # the parameters enter the graph only through the tap, applied first: their AccumulateGrad nodes then live
-        # on the second stream too and the engine puts no wait on the main stream until backward() ends
-        with torch.cuda.stream(wgrad_stream):
-            tap = _WgradTap.apply(x.detach(), lin.weight, lin.bias)
-        y = _Join.apply(_LinearDgrad.apply(x, lin.weight.detach(), lin.bias.detach()), tap)
-    else:
-        y = _LinearSplitK.apply(x, lin.weight, lin.bias) if splitk else lin(x)
+    y = _LinearSplitK.apply(x, lin.weight, lin.bias) if splitk else lin(x)
     return torch.relu(y) if len(seq) > 1 else y
 
 
@@ -155,21 +106,16 @@ class FullyConnectedUNet(nn.Module):
             _scale_(getattr(self, name), scaling_factor)
         self._packed = None
         self._packed_version = None
-        self.wgrad_stream = None   # set by the solver: second HIP stream for the weight gradients (see _WgradTap)
 
     def forward(self, x):
         # many rows on the GPU with gradients on: same math, split-K weight gradients (see _LinearSplitK)
         sk = x.is_cuda and x.shape[0] >= 8192 and torch.is_grad_enabled() and x.is_contiguous()
-        ws = self.wgrad_stream if sk else None
-        if ws is None or isinstance(ws, torch.cuda.Stream):
-            ws = (ws, ws)
-        wa, wb = ws[0], ws[-1]          # two streams: the nine weight gradients alternate between them
-        r1 = _linear(self.down_0, x, sk, wa)
-        r2 = _linear(self.down_1, r1, sk, wb)
-        r3 = _linear(self.down_2, r2, sk, wa)
-        o2 = _linear(self.up_2, r3, sk, wb) + _linear(self.res_2, r2, sk, wa)
-        o1 = _linear(self.up_1, o2, sk, wb) + _linear(self.res_1, r1, sk, wa)
-        return _linear(self.up_0, o1, sk, wb) + _linear(self.res_0, x, sk, wa)
+        r1 = _linear(self.down_0, x, sk)
+        r2 = _linear(self.down_1, r1, sk)
+        r3 = _linear(self.down_2, r2, sk)
+        o2 = _linear(self.up_2, r3, sk) + _linear(self.res_2, r2, sk)
+        o1 = _linear(self.up_1, o2, sk) + _linear(self.res_1, r1, sk)
+        return _linear(self.up_0, o1, sk) + _linear(self.res_0, x, sk)
 
     # ---- HIP side ---------------------------------------------------------------
     def _version(self):
@@ -205,7 +151,6 @@ class FullyConnectedUNet(nn.Module):
         st = self.__dict__.copy()
         st["_packed"] = None
         st["_packed_version"] = None
-        st["wgrad_stream"] = None
         return st
 
 

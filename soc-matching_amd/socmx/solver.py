@@ -68,6 +68,7 @@ class SOC_Solver(nn.Module):
         st = self.__dict__.copy()
         st.pop("_side_streams", None)
         st.pop("_pair_grid_cache", None)
+        st.pop("_pending_M", None)
         return st
 
     def _side_stream(self, device, which=0):
@@ -187,9 +188,6 @@ class SOC_Solver(nn.Module):
 
         # nabla_V on all Kp*B trajectory rows (method.py:272-278): library GEMMs + autograd
         tx = torch.cat([ts.reshape(-1, 1, 1).expand(Kp, B, 1), states], dim=-1).reshape(-1, d + 1)
-        if state0.is_cuda and hasattr(sde.nabla_V, "wgrad_stream"):
-            s1, s2 = self._side_stream(state0.device, 1), self._side_stream(state0.device, 2)
-            sde.nabla_V.wgrad_stream = None if s1 is None else (s1, s2)
         nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)
 
         frac = fractional_timesteps if use_stopping_time else None
@@ -207,6 +205,12 @@ class SOC_Solver(nn.Module):
                         net, dnet = sde.M.forward_with_ds(t_vec, s_vec, raw=True)
                     else:
                         torch.cuda.current_stream(state0.device).wait_stream(side)
+                        if getattr(self, "defer_M_backward", False) and shard is None:
+                            # Trainer finishes the M-network's backward + Adam update on the second stream, beside
+                            # the NEXT rollout (which needs only nabla_V): cut the graph at (net, dnet)
+                            cut = (net.detach().requires_grad_(True), dnet.detach().requires_grad_(True))
+                            self._pending_M = (net, dnet) + cut
+                            net, dnet = cut
                     objective = L.socm_objective_net(pb, ts, self.lmbd, K, states, noises, controls, net, dnet,
                                                      sde.M.gamma, delta, nabla_V, weight, inv_norm)
                 else:

@@ -42,17 +42,56 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
-                 ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=True):
+                 ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=True, overlap_M_backward=True):
         self.solver, self.optimizer = solver, optimizer
-        if gemm_select and solver.x0.is_cuda:
-            from . import gemm_select as _gs
-            _gs.enable()          # pick the fastest library GEMM per shape (see gemm_select.py)
         self.batch_size = batch_size
         self.normalization_const = normalization_const
         self.algorithm = algorithm
         self.coeff = ema_weight_mean_coeff
         self.itr = 0
         self.sync_timing = sync_timing
+        if gemm_select and solver.x0.is_cuda:
+            from . import gemm_select as _gs
+            _gs.enable()          # pick the fastest library GEMM per shape (see gemm_select.py)
+        # SOCM on one GPU: the pair-grid network's backward and its Adam groups run on the solver's second stream
+        # and overlap with the next iteration's rollout (same arithmetic, same order of updates per parameter)
+        self.defer_M = (overlap_M_backward and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None
+                        and not getattr(solver.neural_sde, "use_stopping_time", False))
+        sde = solver.neural_sde
+        ids_M = {id(p) for p in sde.M.parameters()} | {id(sde.gamma)} if self.defer_M else set()
+        self._groups_side = [g for g in optimizer.param_groups if all(id(p) in ids_M for p in g["params"])]
+        self._groups_main = [g for g in optimizer.param_groups if not all(id(p) in ids_M for p in g["params"])]
+
+    def _step_groups(self, groups):
+        opt = self.optimizer
+        saved = opt.param_groups
+        opt.param_groups = groups
+        try:
+            opt.step()
+        finally:
+            opt.param_groups = saved
+
+    def _finish_M_on_side_stream(self, pending, dev):
+        """Backward of the pair-grid network from the gradients at the cut, then its Adam groups, on the second
+        stream.  The next forward of that network is issued on the same stream, hence ordered after the update."""
+        solver = self.solver
+        side = solver._side_stream(dev)
+        main = torch.cuda.current_stream(dev)
+        net, dnet, net_cut, dnet_cut = pending
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            side.wait_event(done)
+            grads = [net_cut.grad, dnet_cut.grad]
+            for g in grads:
+                g.record_stream(side)
+            with torch.enable_grad():
+                torch.autograd.backward([net, dnet], grads)
+            for grp in self._groups_side:
+                for p in grp["params"]:
+                    if p.grad is not None:
+                        p.grad.record_stream(side)       # gamma's gradient was produced on the main stream
+            self._step_groups(self._groups_side)
 
     def step(self, **loss_kwargs):
         solver = self.solver
@@ -60,9 +99,13 @@ class Trainer:
         if self.sync_timing and dev.type == "cuda":
             torch.cuda.synchronize(dev)
         start = time.time()
-        out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
-                          use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)),
-                          **loss_kwargs)
+        solver.defer_M_backward = self.defer_M       # only for this call: direct users of .loss() get the full graph
+        try:
+            out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
+                              use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)),
+                              **loss_kwargs)
+        finally:
+            solver.defer_M_backward = False
         objective, weight_mean = out[0], out[5]
         if self.algorithm in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
             loss = objective / self.normalization_const                  # main.py:313-320
@@ -76,8 +119,13 @@ class Trainer:
                 [p for g in self.optimizer.param_groups for p in g["params"]], extra=[loss.detach()])
         else:
             loss_val = loss.detach()
+        pending = solver.__dict__.pop("_pending_M", None)
         with torch.no_grad():
-            self.optimizer.step()                                        # main.py:347-349
+            if pending is not None:
+                self._step_groups(self._groups_main)                     # nabla_V: needed by the next rollout
+                self._finish_M_on_side_stream(pending, dev)
+            else:
+                self.optimizer.step()                                    # main.py:347-349
             self.optimizer.zero_grad()
             if self.sync_timing and dev.type == "cuda":
                 torch.cuda.synchronize(dev)

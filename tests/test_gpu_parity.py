@@ -257,6 +257,31 @@ def test_full_socm_loss_with_gemm_selection_on():
         gemm_select.disable()
 
 
+def test_trainer_overlapped_M_backward_matches_sequential():
+    """Trainer finishes the pair-grid network's backward + Adam groups on a second stream beside the next rollout;
+    that is scheduling only: parameters after a few iterations equal the sequential schedule's."""
+    from SOC_matching.method import SOC_Solver
+    from socmx.train import Trainer, make_optimizer
+    results = []
+    for overlap in (True, False):
+        sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+        solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                            sigma=sde.sigma)
+        opt = make_optimizer(solver, M_lr=1e-3)
+        tr = Trainer(solver, opt, 64, sync_timing=False, gemm_select=False, overlap_M_backward=overlap)
+        assert tr.defer_M == overlap
+        losses = []
+        for it in range(4):
+            solver.noise_in = torch.randn(aux["K"], 64, aux["d"], generator=torch.Generator().manual_seed(it)).to(DEV)
+            losses.append(tr.step()["loss"])
+        torch.cuda.synchronize()
+        results.append(([l.item() for l in losses], {k: _np(v) for k, v in sde.state_dict().items()}))
+    (la, pa), (lb, pb_) = results
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    for k in pa:
+        np.testing.assert_allclose(pa[k], pb_[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
 def test_full_size_properties_cfg3():
     """BASELINE config 3 at full size (double_well d=10, K=200, B=128): size-independent properties."""
     from SOC_matching import utils

@@ -14,8 +14,6 @@ opt = make_optimizer(solver, M_lr=1e-3)
 tr = Trainer(solver, opt, Bn.BATCH_PER_GPU, sync_timing=False)
 for mode in ("overlap", "no-overlap", "overlap"):
     solver.overlap_M = mode == "overlap"
-    if not solver.overlap_M:
-        sde.nabla_V.wgrad_stream = None
     for _ in range(5):
         tr.step()
     torch.cuda.synchronize()
