@@ -147,8 +147,9 @@ int socmx_rollout_phase_cycles_f32(const socmx_problem* problem, const float* pa
 
 /* ---- importance weights --------------------------------------------------- */
 
-/* w[m] = exp(lpd+lps+ltw) (method.py:258-262); stats[0..2] = (sum w, sum (w - mean)^2, B): mean and
- * unbiased std (method.py:903-904) follow on the host; shards combine with Chan's parallel-variance rule. */
+/* w[m] = exp(lpd+lps+ltw) (method.py:258-262); stats (5,) = (sum w, sum (w - mean)^2, B, mean, unbiased std):
+ * stats[3..4] are torch.mean / torch.std of method.py:903-904 for this shard; across shards stats[0..2] combine
+ * with Chan's parallel-variance rule on the host. */
 int socmx_weights_stats_f32(const float* lpd, const float* lps, const float* ltw, int32_t B,
                             float* w, float* stats, socmx_stream_t stream);
 
@@ -163,8 +164,8 @@ int64_t socmx_num_pairs(int32_t K);
  *   v[j,m,:] = -( sqrt(lmbd) sqrt(dt_j) S^-T noise[j,m] + dt_j S^-T control[j,m] )
  *   q[j,m,:] = dt_j nabla_f(X[j,m]) + nabla_b(X[j,m])^T v[j,m]      ((nabla_b^T v)_l = sum_n d b_n/d x_l v_n)
  *   gT[m,:]  = nabla_g(X[K,m])
- * written twice: batch-major  v,q (K,B,d), gT (B,d)   -- read by socmx_socm_target_bwd_f32
- *                batch-fastest vT,qT (K,d,B), gTT (d,B) -- read by socmx_socm_target_fwd_f32 (lanes run along m)
+ * batch-major  v,q (K,B,d), gT (B,d): read by socmx_socm_target_fwd_f32 and socmx_socm_target_bwd_f32.
+ * vT,qT (K,d,B), gTT (d,B) are optional batch-fastest copies (NULL = not written; no kernel of this library reads them).
  * frac (K,B) may be NULL (=> dt_j = ts[j+1]-ts[j]), else per-sample fractional time steps.
  */
 int socmx_socm_prep_f32(const socmx_problem* problem, const float* ts, int32_t K, int32_t B, float lmbd,
@@ -181,7 +182,7 @@ int socmx_socm_prep_f32(const socmx_problem* problem, const float* ts, int32_t K
  * target, nablaV, G: (K+1,B,d); target is an output (written by the MFMA contraction, read by the residual pass).
  */
 int socmx_socm_target_fwd_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* M_all,
-                              const float* dM_all, const float* qT, const float* vT, const float* gTT,
+                              const float* dM_all, const float* q, const float* v, const float* gT,
                               const float* nablaV, const float* w, float inv_norm, float* target,
                               float* G, float* objective, socmx_stream_t stream);
 
@@ -200,8 +201,8 @@ int socmx_socm_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* G, c
  * its epilogue.  Same outputs as socmx_socm_target_fwd_f32 applied to the materialised (M, dM).
  */
 int socmx_socm_target_fwd_net_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* net,
-                                  const float* dnet, const float* delta, const float* gamma, const float* qT,
-                                  const float* vT, const float* gTT, const float* nablaV, const float* w,
+                                  const float* dnet, const float* delta, const float* gamma, const float* q,
+                                  const float* v, const float* gT, const float* nablaV, const float* w,
                                   float inv_norm, float* target, float* G, float* objective,
                                   socmx_stream_t stream);
 

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void weights_stats_kernel(const float* __restr
     stats[0] = total;
     stats[1] = m2;
     stats[2] = (float)B;
+    stats[3] = mean;                                   // torch.mean(weight)            method.py:903
+    stats[4] = sqrtf(m2 / (float)(B - 1));             // torch.std(weight), unbiased   method.py:904 (NaN for B = 1)
   }
 }
 
@@ -71,7 +73,7 @@ struct PrepArgs {
   const float *sit, *A, *P, *Q, *omega, *kappa, *nu;
   const float *ts, *states, *noises, *controls, *frac;
   float *v, *q, *gT;      // (K,B,d), (K,B,d), (B,d)      batch-major  (backward kernel)
-  float *vT, *qT, *gTT;   // (K,d,B), (K,d,B), (d,B)      batch-fastest (forward kernel)
+  float *vT, *qT, *gTT;   // (K,d,B), (K,d,B), (d,B)      batch-fastest copies, optional (NULL = not written)
 };
 
 // one thread per (j, m); j == K handles the terminal row (nabla_g)
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void socm_prep_kernel(const PrepArgs a) {
         g = 2.f * a.nu[l] * (x[l] * x[l] - 1.f) * 2.f * x[l];
       }
       a.gT[(size_t)m * d + l] = g;
-      a.gTT[(size_t)l * B + m] = g;
+      if (a.gTT) a.gTT[(size_t)l * B + m] = g;
     }
     return;
   }
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void socm_prep_kernel(const PrepArgs a) {
     }
     const float vl = -(a.sqrt_lmbd * sdt * se + dt * su);
     a.v[((size_t)j * B + m) * d + l] = vl;
-    a.vT[((size_t)j * d + l) * B + m] = vl;
+    if (a.vT) a.vT[((size_t)j * d + l) * B + m] = vl;
   }
   // q = dt nabla_f + nabla_b^T v   (second pass reads this thread's own v back)
   const float* vv = a.v + ((size_t)j * B + m) * d;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void socm_prep_kernel(const PrepArgs a) {
       ql = -(8.f * kap * x[l] * x[l] + 4.f * kap * (x[l] * x[l] - 1.f)) * vv[l];
     }
     a.q[((size_t)j * B + m) * d + l] = ql;
-    a.qT[((size_t)j * d + l) * B + m] = ql;
+    if (a.qT) a.qT[((size_t)j * d + l) * B + m] = ql;
   }
 }
 
@@ -141,7 +143,7 @@ struct TargetArgs {
   float inv_norm;
   const float *sigma;
   const float *M_all, *dM_all;   // (Np,d,d)
-  const float *qT, *vT, *gTT;    // (K,d,B), (K,d,B), (d,B)
+  const float *q, *v, *gT;       // (K,B,d), (K,B,d), (B,d)   batch-major
   const float *nablaV, *w;       // (Kp,B,d), (B,)
   float *target, *G, *objective; // (Kp,B,d) or NULL, (Kp,B,d), (1,)
   // NET variant: M_all / dM_all hold the raw network outputs net, d(net)/ds and the pair matrices
@@ -157,91 +159,160 @@ __host__ __device__ inline int64_t pair_row_offset(int i, int K) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // target[i,m,:] = sum_{j>=i} ( M_ij q_j[m] - dM_ij v_j[m] ) + M_iK gT[m]  as per-row GEMMs on the fp32 MFMA:
-//   D (16 k-rows x 16 batch columns) += A (M_ij[k][l], 16 x 4) . B (q_j[l][m], 4 x 16)      v_mfma_f32_16x16x4_f32
+//   D (16 k-rows x 16 batch columns) += A (M_ij[k][l], 16 x 4) . B (q_j[m][l], 4 x 16)      v_mfma_f32_16x16x4_f32
 // One wave owns (row pair (i, K-i), 16-column batch tile, 16-row k-block): every wave runs K+2 pair matrices
 // (balanced triangular work), KP2 x B/16 x ceil(d/16) waves fill the chip, and the next (pair, l-block)'s four
-// operand fragments are loaded while the current one is multiplied.  Lanes outside d x d are fed zeros.
+// operand fragments are loaded while the current one is multiplied.
+// Operand slots: MFMA number s of an l-block takes l = lb + 4*g4 + s from lane group g4 -- for A and for B alike,
+// so the reduction is unchanged while every lane reads FOUR CONSECUTIVE floats of a row of M (row-major k,l) and of
+// q (batch-major m,l): one 16-byte load per operand instead of four strided 4-byte loads.  Lanes outside d x d are
+// fed zeros; a 16-byte read that would cross the end of a buffer falls back to guarded scalar reads.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// four consecutive floats at base[off..off+3]; SAFE = false clamps every index below `limit` (end of the buffer)
+template <bool SAFE>
+__device__ __forceinline__ f32x4 load4(const float* base, int off, int limit) {
+  if (SAFE) {
+    const f32x4u t = *reinterpret_cast<const f32x4u*>(base + off);
+    return f32x4{t[0], t[1], t[2], t[3]};
+  }
+  f32x4 r;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) r[s] = base[min(off + s, limit - 1)];
+  return r;
+}
+
 constexpr int kTargetWaves = 8;  // waves per workgroup: the (pair, l-block) iterations of a row are dealt round-robin
 
-template <bool NET>
+// CT = 16-column batch tiles per wave: the A fragments (and, for NET, the blend that forms them) are built once
+// per (pair, l-block) and multiplied into CT accumulators, so the per-iteration bookkeeping (~300 issue cycles)
+// is amortised over 8*CT MFMAs.  NLB1 = (d <= 16): a single l-block, no division in the iteration -> pair map.
+template <bool NET, int CT, bool NLB1>
 __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(const TargetArgs a) {
-  __shared__ f32x4 part[kTargetWaves][64];
+  __shared__ f32x4 part[kTargetWaves][CT][64];
   const int d = a.d, K = a.K, B = a.B;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
-  const int m = blockIdx.y * 16 + c16;
-  const int mc = m < B ? m : B - 1;
+  int mcol[CT], boff0[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    mcol[c] = (blockIdx.y * CT + c) * 16 + c16;
+    boff0[c] = min(mcol[c], B - 1) * d;
+  }
   const int kb = blockIdx.z * 16;          // first k-row of this wave's block
   const int krow = kb + c16;               // A-fragment row of this lane
-  const int nlb = (d + 15) >> 4;           // 16-wide l-blocks
+  const int nlb = NLB1 ? 1 : (d + 15) >> 4;  // 16-wide l-blocks
   const int dd = d * d;
+  const float gam = NET ? a.gamma[0] : 0.f;
   for (int rep = 0; rep < 2; ++rep) {
     const int i = rep == 0 ? (int)blockIdx.x : K - (int)blockIdx.x;
     if (rep == 1 && i <= (int)blockIdx.x) break;
-    const float* Mrow = a.M_all + (size_t)pair_row_offset(i, K) * dd;
-    const float* dMrow = a.dM_all + (size_t)pair_row_offset(i, K) * dd;
     const float* drow = NET ? a.delta + pair_row_offset(i, K) : nullptr;
-    const float gam = NET ? a.gamma[0] : 0.f;
     const int niter = (K - i + 1) * nlb;   // flattened (pair, l-block) iterations
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float am[4], ad[4], bq[4], bv[4];
-    auto load = [&](int t, float (&xm)[4], float (&xd)[4], float (&xq)[4], float (&xv)[4]) {
-      const int jr = t / nlb, lb = (t - jr * nlb) * 16;
-      const int j = i + jr;
-      const float* Mp = Mrow + (size_t)jr * dd;
-      const float* dMp = dMrow + (size_t)jr * dd;
-      const float* qs = (j < K) ? a.qT + (size_t)j * d * B : a.gTT;
-      const float* vs = a.vT + (size_t)(j < K ? j : 0) * d * B;
-      float e = 0.f;
-      if (NET) e = expf(-gam * drow[jr]);
+    f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t prow_dd = pair_row_offset(i, K) * dd;
+    // Raw operands travel through the prefetch ring; anything computed FROM them (zero padding, the NET blend)
+    // happens at consumption time, so that issuing a load never makes the wave wait for it.
+    struct Slot { f32x4 nt, dn, q[CT], v[CT]; float dl; };
+    auto geom = [&](int t, int& jr, int& j, int& l0, int& nl) {
+      jr = NLB1 ? t : t / nlb;
+      const int lb = NLB1 ? 0 : (t - jr * nlb) * 16;
+      j = i + jr;
+      l0 = min(lb + 4 * g4, d - 1);                 // this lane's four l: l0 .. l0+3 (clamped into the row)
+      nl = max(0, min(4, d - (lb + 4 * g4)));       // how many of them exist
+    };
+    auto load = [&](int t, Slot& sl) {
+      int jr, j, l0, nl;
+      geom(t, jr, j, l0, nl);
+      const float* Ap = a.M_all + prow_dd + (int64_t)jr * dd;         // wave-uniform bases + small lane offsets
+      const float* Dp = a.dM_all + prow_dd + (int64_t)jr * dd;
+      const int aoff = min(krow, d - 1) * d + l0;
+      const float* qs = (j < K) ? a.q + (size_t)j * B * d : a.gT;
+      const float* vs = a.v + (size_t)(j < K ? j : 0) * B * d;
+      // a 16-byte read can cross the end of a buffer only in the last pair matrix / the last operand rows:
+      // those (wave-uniform) iterations take clamped scalar reads
+      if (j + 1 < K) {
+        sl.nt = load4<true>(Ap, aoff, 0);
+        sl.dn = load4<true>(Dp, aoff, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          sl.q[c] = load4<true>(qs, boff0[c] + l0, 0);
+          sl.v[c] = load4<true>(vs, boff0[c] + l0, 0);
+        }
+      } else {
+        sl.nt = load4<false>(Ap, aoff, dd);
+        sl.dn = load4<false>(Dp, aoff, dd);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          sl.q[c] = load4<false>(qs, boff0[c] + l0, B * d);
+          sl.v[c] = load4<false>(vs, boff0[c] + l0, B * d);
+        }
+      }
+      sl.dl = NET ? drow[jr] : 0.f;
+    };
+    auto consume = [&](int t, const Slot& sl) {
+      int jr, j, l0, nl;
+      geom(t, jr, j, l0, nl);
+      const int na = krow < d ? nl : 0;
+      const float e = NET ? expf(-gam * sl.dl) : 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int l = lb + 4 * s + g4;
-        const bool okl = l < d, oka = okl && krow < d;
+        float xm, xd;
         if (NET) {
-          const float nt = oka ? Mp[krow * d + l] : 0.f;
-          const float dn = (oka && j < K) ? dMp[krow * d + l] : 0.f;
-          const float eye = (krow == l) ? 1.f : 0.f;
-          xm[s] = oka ? e * eye + (1.f - e) * nt : 0.f;
-          xd[s] = (oka && j < K) ? -(gam * e * (nt - eye) + (1.f - e) * dn) : 0.f;
+          const float eye = (krow == l0 + s) ? 1.f : 0.f;
+          xm = e * eye + (1.f - e) * sl.nt[s];
+          xd = -(gam * e * (sl.nt[s] - eye) + (1.f - e) * sl.dn[s]);
         } else {
-          xm[s] = oka ? Mp[krow * d + l] : 0.f;
-          xd[s] = (oka && j < K) ? -dMp[krow * d + l] : 0.f;
+          xm = sl.nt[s];
+          xd = -sl.dn[s];
         }
-        xq[s] = okl ? qs[(size_t)l * B + mc] : 0.f;
-        xv[s] = (okl && j < K) ? vs[(size_t)l * B + mc] : 0.f;
+        xm = (s < na) ? xm : 0.f;
+        xd = (s < na && j < K) ? xd : 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const float xq = (s < nl) ? sl.q[c][s] : 0.f;
+          const float xv = (s < nl && j < K) ? sl.v[c][s] : 0.f;
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm, xq, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd, xv, acc[c], 0, 0, 0);
+        }
       }
     };
-    if (wave < niter) load(wave, am, ad, bq, bv);
-    for (int t = wave; t < niter; t += kTargetWaves) {
-      float nm[4], nd[4], nq[4], nv[4];
-      if (t + kTargetWaves < niter) load(t + kTargetWaves, nm, nd, nq, nv);
+    // PF iterations of this wave are in flight: one (pair, l-block) is 8*CT MFMAs, shorter than a trip to L2/HBM
+    constexpr int PF = CT >= 4 ? 2 : (CT >= 2 ? 3 : 4);
+    Slot ring[PF];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s], bq[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ad[s], bv[s], acc, 0, 0, 0);
-      }
-      if (t + kTargetWaves < niter) {
+    for (int p = 0; p < PF; ++p)
+      if (wave + p * kTargetWaves < niter) load(wave + p * kTargetWaves, ring[p]);
+    for (int t = wave; t < niter; t += PF * kTargetWaves) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { am[s] = nm[s]; ad[s] = nd[s]; bq[s] = nq[s]; bv[s] = nv[s]; }
+      for (int p = 0; p < PF; ++p) {
+        const int tt = t + p * kTargetWaves;
+        if (tt < niter) {
+          consume(tt, ring[p]);
+          if (tt + PF * kTargetWaves < niter) load(tt + PF * kTargetWaves, ring[p]);
+        }
       }
     }
     // combine the waves' partial tiles (fixed order: deterministic)
     __syncthreads();
-    part[wave][lane] = acc;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) part[wave][c][lane] = acc[c];
     __syncthreads();
-    if (wave == 0) {
-      acc = part[0][lane];
+    // D: lane holds k = kb + 4*g4 + r (r = 0..3) of batch column m; wave c finishes column tile c
+    if (wave < CT) {
+      f32x4 tot = part[0][wave][lane];
 #pragma unroll
-      for (int w = 1; w < kTargetWaves; ++w) acc += part[w][lane];
-    }
-    // D: lane holds k = kb + 4*g4 + r (r = 0..3) of batch column m
-    if (wave == 0 && m < B) {
+      for (int w = 1; w < kTargetWaves; ++w) tot += part[w][wave][lane];
+      const int m = (blockIdx.y * CT + wave) * 16 + c16;
+      if (m < B) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = kb + 4 * g4 + r;
-        if (k < d) a.target[((size_t)i * B + m) * d + k] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+          const int k = kb + 4 * g4 + r;
+          if (k < d) a.target[((size_t)i * B + m) * d + k] = tot[r];
+        }
       }
     }
   }
@@ -443,8 +514,7 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
                                    const float* states, const float* noises, const float* controls,
                                    const float* frac, float* v, float* q, float* gT, float* vT, float* qT,
                                    float* gTT, socmx_stream_t stream) {
-  if (!pb || !ts || !states || !noises || !controls || !v || !q || !gT || !vT || !qT || !gTT || !pb->sigma_inv_t)
-    return SOCMX_E_NULL;
+  if (!pb || !ts || !states || !noises || !controls || !v || !q || !gT || !pb->sigma_inv_t) return SOCMX_E_NULL;
   if (pb->d < 1 || K < 1 || B < 1) return SOCMX_E_DIM;
   switch (pb->kind) {
     case SOCMX_OU_QUADRATIC: if (!pb->A || !pb->P || !pb->Q) return SOCMX_E_NULL; break;
@@ -465,23 +535,35 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
 }
 
 static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all, const float* dM_all,
-                             const float* delta, const float* gamma, const float* qT, const float* vT,
-                             const float* gTT, const float* nablaV, const float* w, float inv_norm, float* target,
+                             const float* delta, const float* gamma, const float* q, const float* v,
+                             const float* gT, const float* nablaV, const float* w, float inv_norm, float* target,
                              float* G, float* objective, socmx_stream_t stream) {
-  if (!pb || !M_all || !dM_all || !qT || !vT || !gTT || !nablaV || !w || !G || !objective || !target || !pb->sigma)
+  if (!pb || !M_all || !dM_all || !q || !v || !gT || !nablaV || !w || !G || !objective || !target || !pb->sigma)
     return SOCMX_E_NULL;
   const int d = pb->d;
   if (d < 1 || d > 1024 || K < 1 || B < 1) return SOCMX_E_DIM;
   TargetArgs a;
   a.d = d; a.K = K; a.B = B; a.KG = 0; a.inv_norm = inv_norm;
-  a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.qT = qT; a.vT = vT; a.gTT = gTT;
+  a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.q = q; a.v = v; a.gT = gT;
   a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective;
   a.delta = delta; a.gamma = gamma;
-  dim3 grid((K + 2) / 2, (B + 15) / 16, (d + 15) / 16);
-  if (delta)
-    hipLaunchKernelGGL(socm_target_mfma_kernel<true>, grid, dim3(64 * kTargetWaves), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(socm_target_mfma_kernel<false>, grid, dim3(64 * kTargetWaves), 0, (hipStream_t)stream, a);
+  const int ct = B > 32 ? 4 : (B > 16 ? 2 : 1);        // 16-column batch tiles per wave
+  dim3 grid((K + 2) / 2, (B + 16 * ct - 1) / (16 * ct), (d + 15) / 16);
+  const dim3 blk(64 * kTargetWaves);
+  const hipStream_t st = (hipStream_t)stream;
+#define SOCMX_TARGET_LAUNCH(NETV, CTV, N1V) \
+  hipLaunchKernelGGL((socm_target_mfma_kernel<NETV, CTV, N1V>), grid, blk, 0, st, a)
+  const bool nlb1 = d <= 16;
+  if (delta) {
+    if (ct == 4)      { if (nlb1) SOCMX_TARGET_LAUNCH(true, 4, true); else SOCMX_TARGET_LAUNCH(true, 4, false); }
+    else if (ct == 2) { if (nlb1) SOCMX_TARGET_LAUNCH(true, 2, true); else SOCMX_TARGET_LAUNCH(true, 2, false); }
+    else              { if (nlb1) SOCMX_TARGET_LAUNCH(true, 1, true); else SOCMX_TARGET_LAUNCH(true, 1, false); }
+  } else {
+    if (ct == 4)      { if (nlb1) SOCMX_TARGET_LAUNCH(false, 4, true); else SOCMX_TARGET_LAUNCH(false, 4, false); }
+    else if (ct == 2) { if (nlb1) SOCMX_TARGET_LAUNCH(false, 2, true); else SOCMX_TARGET_LAUNCH(false, 2, false); }
+    else              { if (nlb1) SOCMX_TARGET_LAUNCH(false, 1, true); else SOCMX_TARGET_LAUNCH(false, 1, false); }
+  }
+#undef SOCMX_TARGET_LAUNCH
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
@@ -494,20 +576,20 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
 }
 
 extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all,
-                                         const float* dM_all, const float* qT, const float* vT, const float* gTT,
+                                         const float* dM_all, const float* q, const float* v, const float* gT,
                                          const float* nablaV, const float* w, float inv_norm, float* target,
                                          float* G, float* objective, socmx_stream_t stream) {
-  return launch_target_fwd(pb, K, B, M_all, dM_all, nullptr, nullptr, qT, vT, gTT, nablaV, w, inv_norm, target, G,
+  return launch_target_fwd(pb, K, B, M_all, dM_all, nullptr, nullptr, q, v, gT, nablaV, w, inv_norm, target, G,
                            objective, stream);
 }
 
 extern "C" int socmx_socm_target_fwd_net_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* net,
                                              const float* dnet, const float* delta, const float* gamma,
-                                             const float* qT, const float* vT, const float* gTT,
+                                             const float* q, const float* v, const float* gT,
                                              const float* nablaV, const float* w, float inv_norm, float* target,
                                              float* G, float* objective, socmx_stream_t stream) {
   if (!delta || !gamma) return SOCMX_E_NULL;
-  return launch_target_fwd(pb, K, B, net, dnet, delta, gamma, qT, vT, gTT, nablaV, w, inv_norm, target, G,
+  return launch_target_fwd(pb, K, B, net, dnet, delta, gamma, q, v, gT, nablaV, w, inv_norm, target, G,
                            objective, stream);
 }
 

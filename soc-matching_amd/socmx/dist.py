@@ -34,8 +34,9 @@ class Shard:
     def combine_weight_stats(self, stats):
         if self.world_size == 1 and not dist.is_initialized():
             return stats
+        stats = stats[:3].contiguous()       # (sum w, M2, n); a single-shard GPU kernel also appends mean, std
         gathered = [torch.empty_like(stats) for _ in range(self.world_size)]
-        dist.all_gather(gathered, stats.contiguous(), group=self.group)
+        dist.all_gather(gathered, stats, group=self.group)
         return L.combine_stats(torch.stack(gathered))
 
     def allreduce_gradients(self, params, extra=None):

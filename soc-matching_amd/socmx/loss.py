@@ -95,22 +95,21 @@ def target_residual_torch(pb, K, M_all, dM_all, q, v, gT, nablaV, w, inv_norm):
 
 
 def socm_operands_hip(pb, ts, lmbd, states, noises, controls, frac=None):
-    """socmx_socm_prep_f32: operands in both layouts (batch-major for bwd, batch-fastest for fwd)."""
+    """socmx_socm_prep_f32: v, q (K,B,d) and gT (B,d), batch-major (read by the forward and the backward kernels)."""
     L = _lib.lib()
     K, B, d = noises.shape
     dev = states.device
     f32 = dict(dtype=torch.float32, device=dev)
     v, q = torch.empty(K, B, d, **f32), torch.empty(K, B, d, **f32)
-    vT, qT = torch.empty(K, d, B, **f32), torch.empty(K, d, B, **f32)
-    gT, gTT = torch.empty(B, d, **f32), torch.empty(d, B, **f32)
+    gT = torch.empty(B, d, **f32)
     tsc = ts.detach().to(**f32).contiguous()
     _lib.check(L.socmx_socm_prep_f32(
         pb.c_struct(), _lib.ptr(tsc), K, B, float(lmbd), _lib.ptr(states.contiguous()),
         _lib.ptr(noises.contiguous()), _lib.ptr(controls.contiguous()),
         _lib.ptr(frac.contiguous()) if frac is not None else None,
-        _lib.ptr(v), _lib.ptr(q), _lib.ptr(gT), _lib.ptr(vT), _lib.ptr(qT), _lib.ptr(gTT),
+        _lib.ptr(v), _lib.ptr(q), _lib.ptr(gT), None, None, None,
         _lib.stream_ptr(dev)), "socmx_socm_prep_f32")
-    return dict(v=v, q=q, gT=gT, vT=vT, qT=qT, gTT=gTT)
+    return dict(v=v, q=q, gT=gT)
 
 
 class _TargetResidualHip(torch.autograd.Function):
@@ -127,8 +126,8 @@ class _TargetResidualHip(torch.autograd.Function):
         target = torch.empty_like(nablaV)   # the contraction's output; the residual kernel reads it back
         obj = torch.zeros(1, dtype=torch.float32, device=dev)
         _lib.check(L.socmx_socm_target_fwd_f32(
-            pb.c_struct(), K, B, _lib.ptr(M_all), _lib.ptr(dM_all), _lib.ptr(ops["qT"]), _lib.ptr(ops["vT"]),
-            _lib.ptr(ops["gTT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm), _lib.ptr(target),
+            pb.c_struct(), K, B, _lib.ptr(M_all), _lib.ptr(dM_all), _lib.ptr(ops["q"]), _lib.ptr(ops["v"]),
+            _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm), _lib.ptr(target),
             _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_f32")
         ctx.save_for_backward(G, ops["q"], ops["v"], ops["gT"])
         ctx.dims = (d, K, B, M_all.shape[0])
@@ -172,8 +171,8 @@ class _TargetResidualNetHip(torch.autograd.Function):
         target = torch.empty_like(nablaV)
         obj = torch.zeros(1, dtype=torch.float32, device=dev)
         _lib.check(L.socmx_socm_target_fwd_net_f32(
-            pb.c_struct(), K, B, _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(ops["qT"]),
-            _lib.ptr(ops["vT"]), _lib.ptr(ops["gTT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm),
+            pb.c_struct(), K, B, _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(ops["q"]),
+            _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm),
             _lib.ptr(target), _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_net_f32")
         ctx.save_for_backward(G, ops["q"], ops["v"], ops["gT"], net, dnet, delta, gam)
         ctx.dims = (d, K, B, net.shape[0])
@@ -226,13 +225,13 @@ def socm_objective(pb, ts, lmbd, K, states, noises, controls, M_all, dM_all, nab
 # --------------------------------------------------------------------------------------
 
 def weights_and_stats(lpd, lps, ltw):
-    """w = exp(lpd+lps+ltw) (method.py:258-262) and stats = (sum w, sum (w-mean_local)^2, n): mean and
-    unbiased std (method.py:903-904) follow from it, and shards combine with Chan's formula."""
+    """w = exp(lpd+lps+ltw) (method.py:258-262) and stats = (sum w, sum (w-mean_local)^2, n[, mean, std]): mean
+    and unbiased std (method.py:903-904) follow from the first three, and shards combine with Chan's formula."""
     if lpd.is_cuda:
         L = _lib.lib()
         B = lpd.shape[0]
         w = torch.empty_like(lpd)
-        stats = torch.empty(3, dtype=torch.float32, device=lpd.device)
+        stats = torch.empty(5, dtype=torch.float32, device=lpd.device)
         _lib.check(L.socmx_weights_stats_f32(_lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), B, _lib.ptr(w),
                                              _lib.ptr(stats), _lib.stream_ptr(lpd.device)),
                    "socmx_weights_stats_f32")
@@ -251,4 +250,6 @@ def combine_stats(all_stats):
 
 
 def mean_std_from_stats(stats):
+    if stats.numel() == 5:          # single shard on the GPU: the kernel already wrote mean and unbiased std
+        return stats[3], stats[4]
     return stats[0] / stats[2], torch.sqrt(stats[1] / (stats[2] - 1))
