@@ -220,6 +220,63 @@ def test_fused_pair_matrix_kernels_vs_materialised(name):
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=2e-6 * max(1e-3, np.abs(b).max()), err_msg=nm)
 
 
+@pytest.mark.parametrize("d,K,B", [(20, 7, 24), (40, 5, 70), (64, 4, 16), (3, 9, 130)])
+def test_contraction_kernels_multi_block_shapes(d, K, B):
+    """d > 16 takes several 16-wide k/l blocks per pair matrix, B > 32 four batch tiles per wave (ragged last tile):
+    none of the reference-generated fixtures is that large, so the HIP contraction (materialised and fused forms,
+    forward and backward) is compared with the dense torch formulation of the same restated math (fp64 on the CPU)."""
+    from socmx import loss as L
+    from socmx.problems import Problem
+    from socmx import _lib
+    g = torch.Generator().manual_seed(d * 1000 + K)
+    rn = lambda *sh: torch.randn(*sh, generator=g)
+    sigma = torch.eye(d) + 0.1 * rn(d, d)
+    A = -torch.eye(d) + 0.1 * rn(d, d)
+    pb64 = Problem(_lib.OU_LINEAR, d, sigma.double(), A=A.double(), omega=torch.ones(d).double())
+    pb = Problem(_lib.OU_LINEAR, d, sigma.to(DEV), A=A.to(DEV), omega=torch.ones(d).to(DEV))
+    ts = torch.linspace(0, 1, K + 1)
+    states, noises, controls = rn(K + 1, B, d), rn(K, B, d), rn(K, B, d)
+    Np = (K + 1) * (K + 2) // 2
+    net0, dnet0 = 0.3 * rn(Np, d, d), 0.3 * rn(Np, d, d)
+    nablaV0, w = rn(K + 1, B, d), torch.rand(B, generator=g) + 0.5
+    t_vec, s_vec, _, _ = L.pair_times(ts, 1.0, K)
+    delta = (s_vec - t_vec)
+    inv_norm = 1.0 / ((K + 1) * B)
+
+    def blend(net, dnet, gam, dl, eye):
+        e = torch.exp(-gam * dl).reshape(-1, 1, 1)
+        return e * eye + (1.0 - e) * net, gam * e * (net - eye) + (1.0 - e) * dnet
+
+    # fp64 dense reference on the CPU
+    net, dnet = net0.double().requires_grad_(True), dnet0.double().requires_grad_(True)
+    gam = torch.tensor(1.3, dtype=torch.float64, requires_grad=True)
+    nV = nablaV0.double().requires_grad_(True)
+    M, dM = blend(net, dnet, gam, delta.double(), torch.eye(d, dtype=torch.float64))
+    v, q, gT = L.socm_operands(pb64, ts.double(), 1.0, states.double(), noises.double(), controls.double())
+    ref, ref_t = L.target_residual_torch(pb64, K, M, dM, q, v, gT, nV, w.double(), inv_norm)
+    (2.0 * ref).backward()
+    want = [t.grad.numpy() for t in (net, dnet, gam, nV)]
+
+    to = lambda t: t.to(DEV).contiguous()
+    args = (pb, to(ts), 1.0, K, to(states), to(noises), to(controls))
+    for mode in ("fused", "materialised"):
+        net, dnet = to(net0).requires_grad_(True), to(dnet0).requires_grad_(True)
+        gam = torch.tensor(1.3, device=DEV, requires_grad=True)
+        nV = to(nablaV0).requires_grad_(True)
+        if mode == "fused":
+            out = L.socm_objective_net(*args, net, dnet, gam, to(delta), nV, to(w), inv_norm)
+        else:
+            M, dM = blend(net, dnet, gam, to(delta), torch.eye(d, device=DEV))
+            out, tgt = L.socm_objective(*args, M, dM, nV, to(w), inv_norm, want_target=True)
+            tw = ref_t.detach().numpy()
+            np.testing.assert_allclose(_np(tgt), tw, rtol=1e-4, atol=2e-5 * np.abs(tw).max(), err_msg="target")
+        np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-4, err_msg=mode)
+        (2.0 * out).backward()
+        for got, wn, nm in zip((net.grad, dnet.grad, gam.grad, nV.grad), want, ("g_net", "g_dnet", "g_gamma", "g_nablaV")):
+            np.testing.assert_allclose(_np(got), wn, rtol=2e-3, atol=2e-5 * max(1e-6, np.abs(wn).max()),
+                                       err_msg=f"{mode} {nm}")
+
+
 @pytest.mark.parametrize("name", LOSS + ["cfg1_ou_quadratic_easy_d2_K50", "cfg3_double_well_d10_K200"])
 def test_full_socm_loss_on_gpu_vs_golden(name):
     from SOC_matching.method import SOC_Solver
