@@ -137,6 +137,98 @@ __global__ __launch_bounds__(256) void socm_prep_kernel(const PrepArgs a) {
   }
 }
 
+// Tiled form for d <= 128: a workgroup owns 64 consecutive (j,m) rows -- one contiguous 64*d run of states, noises
+// and controls -- staged through LDS (row stride d+1: a wave reads 64 different rows of one column without bank
+// conflicts); thread = (row, quarter of the output columns), so sigma^-T / A / P are wave-uniform scalar loads.
+// Outputs go back through LDS and leave as one coalesced run.  (The per-thread form above walks d*d strided
+// global reads per row: 27 ms at d = 64, K = 400, B = 512.)
+__global__ __launch_bounds__(256) void socm_prep_tiled_kernel(const PrepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int d = a.d, B = a.B, K = a.K, S = d + 1;
+  float* E = lds;             // noise tile, later the q tile
+  float* U = E + 64 * S;      // control tile
+  float* X = U + 64 * S;      // state tile
+  float* V = X + 64 * S;      // v
+  const int64_t nrows = (int64_t)K * B;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int nr = (int)min((int64_t)64, nrows - row0);
+  for (int e = threadIdx.x; e < nr * d; e += 256) {
+    const int r = e / d, c = e - r * d;
+    E[r * S + c] = a.noises[row0 * d + e];
+    U[r * S + c] = a.controls[row0 * d + e];
+    X[r * S + c] = a.states[row0 * d + e];
+  }
+  __syncthreads();
+  const int r = threadIdx.x & 63, lq = threadIdx.x >> 6;
+  const int lbeg = (d * lq) >> 2, lend = (d * (lq + 1)) >> 2;
+  const bool live = r < nr;
+  const int64_t idx = row0 + (live ? r : 0);
+  const int j = (int)(idx / B);
+  const float dt = a.frac ? a.frac[idx] : (a.ts[j + 1] - a.ts[j]);
+  const float sdt = sqrtf(dt);
+  const bool is_ou = (a.kind == SOCMX_OU_QUADRATIC || a.kind == SOCMX_OU_LINEAR);
+  for (int l = lbeg; l < lend; ++l) {
+    float se = 0.f, su = 0.f;
+    for (int c = 0; c < d; ++c) {
+      const float sc = a.sit[l * d + c];
+      se += sc * E[r * S + c];
+      su += sc * U[r * S + c];
+    }
+    V[r * S + l] = -(a.sqrt_lmbd * sdt * se + dt * su);
+  }
+  __syncthreads();
+  for (int l = lbeg; l < lend; ++l) {
+    float ql;
+    if (is_ou) {
+      float sacc = 0.f;
+      for (int n = 0; n < d; ++n) sacc += a.A[n * d + l] * V[r * S + n];   // (A^T v)_l
+      ql = sacc;
+      if (a.kind == SOCMX_OU_QUADRATIC) {
+        float px = 0.f;
+        for (int c = 0; c < d; ++c) px += a.P[l * d + c] * X[r * S + c];
+        ql += dt * 2.f * px;
+      }
+    } else {
+      const float kap = a.kappa[l], xl = X[r * S + l];
+      ql = -(8.f * kap * xl * xl + 4.f * kap * (xl * xl - 1.f)) * V[r * S + l];
+    }
+    E[r * S + l] = ql;        // the noise tile is consumed (barrier above): q is staged there
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nr * d; e += 256) {
+    const int rr = e / d, c = e - rr * d;
+    a.v[row0 * d + e] = V[rr * S + c];
+    a.q[row0 * d + e] = E[rr * S + c];
+    if (a.vT || a.qT) {
+      const int64_t id2 = row0 + rr;
+      const int jj = (int)(id2 / B), mm = (int)(id2 - (int64_t)jj * B);
+      if (a.vT) a.vT[((size_t)jj * d + c) * B + mm] = V[rr * S + c];
+      if (a.qT) a.qT[((size_t)jj * d + c) * B + mm] = E[rr * S + c];
+    }
+  }
+}
+
+// terminal rows only (j == K): gT = nabla_g(X_K); thread per batch row
+__global__ __launch_bounds__(256) void socm_prep_terminal_kernel(const PrepArgs a) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int d = a.d, B = a.B, K = a.K;
+  if (m >= B) return;
+  const float* x = a.states + ((size_t)K * B + m) * d;
+  for (int l = 0; l < d; ++l) {
+    float g = 0.f;
+    if (a.kind == SOCMX_OU_QUADRATIC) {
+      for (int c = 0; c < d; ++c) g += a.Q[l * d + c] * x[c];
+      g *= 2.f;
+    } else if (a.kind == SOCMX_OU_LINEAR) {
+      g = a.omega[l];
+    } else if (a.kind == SOCMX_DOUBLE_WELL) {
+      g = 2.f * a.nu[l] * (x[l] * x[l] - 1.f) * 2.f * x[l];
+    }
+    a.gT[(size_t)m * d + l] = g;
+    if (a.gTT) a.gTT[(size_t)l * B + m] = g;
+  }
+}
+
 // ---- target + residual (forward) --------------------------------------------------------------------
 struct TargetArgs {
   int d, K, B, KG;        // KG = k-groups (waves) per workgroup; each thread owns KO outputs
@@ -529,6 +621,18 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
   a.nu = pb->nu;
   a.ts = ts; a.states = states; a.noises = noises; a.controls = controls; a.frac = frac;
   a.v = v; a.q = q; a.gT = gT; a.vT = vT; a.qT = qT; a.gTT = gTT;
+  const size_t tile_lds = (size_t)4 * 64 * (pb->d + 1) * sizeof(float);
+  if (pb->d <= 128 && tile_lds <= 160 * 1024) {
+    auto kern = socm_prep_tiled_kernel;
+    hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds);
+    if (err != hipSuccess) return (int)err;
+    const int64_t rows = (int64_t)K * B;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 63) / 64)), dim3(256), tile_lds, (hipStream_t)stream, a);
+    err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(socm_prep_terminal_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   const int64_t n = (int64_t)(K + 1) * B;
   hipLaunchKernelGGL(socm_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
