@@ -295,6 +295,7 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
   const int kb = blockIdx.z * 16;          // first k-row of this wave's block
   const int krow = kb + c16;               // A-fragment row of this lane
   const int nlb = NLB1 ? 1 : (d + 15) >> 4;  // 16-wide l-blocks
+  const int nlb_shift = (nlb & (nlb - 1)) == 0 ? __builtin_ctz(nlb) : -1;
   const int dd = d * d;
   const float gam = NET ? a.gamma[0] : 0.f;
   for (int rep = 0; rep < 2; ++rep) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
     // happens at consumption time, so that issuing a load never makes the wave wait for it.
     struct Slot { f32x4 nt, dn, q[CT], v[CT]; float dl; };
     auto geom = [&](int t, int& jr, int& j, int& l0, int& nl) {
-      jr = NLB1 ? t : t / nlb;
+      jr = NLB1 ? t : (nlb_shift >= 0 ? t >> nlb_shift : t / nlb);   // a runtime integer division is ~30 instructions
       const int lb = NLB1 ? 0 : (t - jr * nlb) * 16;
       j = i + jr;
       l0 = min(lb + 4 * g4, d - 1);                 // this lane's four l: l0 .. l0+3 (clamped into the row)
@@ -363,17 +364,17 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
         }
         xm = (s < na) ? xm : 0.f;
         xd = (s < na && j < K) ? xd : 0.f;
+        // consecutive MFMAs go to different accumulators (a dependent pair costs 40 cycles instead of 32)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const float xq = (s < nl) ? sl.q[c][s] : 0.f;
-          const float xv = (s < nl && j < K) ? sl.v[c][s] : 0.f;
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm, xq, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd, xv, acc[c], 0, 0, 0);
-        }
+        for (int c = 0; c < CT; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm, (s < nl) ? sl.q[c][s] : 0.f, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd, (s < nl && j < K) ? sl.v[c][s] : 0.f, acc[c], 0, 0, 0);
       }
     };
     // PF iterations of this wave are in flight: one (pair, l-block) is 8*CT MFMAs, shorter than a trip to L2/HBM
-    constexpr int PF = CT >= 4 ? 2 : (CT >= 2 ? 3 : 4);
+    constexpr int PF = CT >= 4 ? 3 : (CT >= 2 ? 3 : 4);
     Slot ring[PF];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
@@ -407,6 +408,139 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
         }
       }
     }
+  }
+}
+
+// Wide form for 16 < d <= 64 and B >= 256 (the MFMA-bound regime, e.g. d = 64, K = 400, B = 512: 676 GFLOP):
+// a workgroup owns a row pair (i, K-i) and 8 x CT x 16 batch columns; its 8 waves split the COLUMNS, each wave keeps
+// all KB k-blocks x CT column tiles of the output in registers (KB*CT accumulators) and walks the (pair, l-block)
+// iterations in order.  Per iteration a wave loads 2*KB A fragments (shared by the 8 waves: one L2/HBM fetch,
+// L1 hits for the rest) and 2*CT B fragments for KB*CT*8 MFMAs; every pair matrix is fetched from HBM once.
+template <bool NET, int KB, int CT>
+__global__ __launch_bounds__(64 * kTargetWaves) void socm_target_wide_kernel(const TargetArgs a) {
+  const int d = a.d, K = a.K, B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  int mcol[CT], boff0[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    mcol[c] = ((blockIdx.y * kTargetWaves + wave) * CT + c) * 16 + c16;
+    boff0[c] = min(mcol[c], B - 1) * d;
+  }
+  const int nlb = (d + 15) >> 4;
+  const int dd = d * d;
+  const float gam = NET ? a.gamma[0] : 0.f;
+  for (int rep = 0; rep < 2; ++rep) {
+    const int i = rep == 0 ? (int)blockIdx.x : K - (int)blockIdx.x;
+    if (rep == 1 && i <= (int)blockIdx.x) break;
+    const float* drow = NET ? a.delta + pair_row_offset(i, K) : nullptr;
+    const int npair = K - i + 1;
+    f32x4 acc[KB][CT];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[kb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t prow_dd = pair_row_offset(i, K) * dd;
+    struct Slot { f32x4 nt[KB], dn[KB], q[CT], v[CT]; float dl; };
+    auto load = [&](int jr, int lb, Slot& sl) {
+      const int j = i + jr;
+      const int l0 = min(lb + 4 * g4, d - 1);
+      const float* Ap = a.M_all + prow_dd + (int64_t)jr * dd;
+      const float* Dp = a.dM_all + prow_dd + (int64_t)jr * dd;
+      const float* qs = (j < K) ? a.q + (size_t)j * B * d : a.gT;
+      const float* vs = a.v + (size_t)(j < K ? j : 0) * B * d;
+      if (j + 1 < K) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int aoff = min(kb * 16 + c16, d - 1) * d + l0;
+          sl.nt[kb] = load4<true>(Ap, aoff, 0);
+          sl.dn[kb] = load4<true>(Dp, aoff, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          sl.q[c] = load4<true>(qs, boff0[c] + l0, 0);
+          sl.v[c] = load4<true>(vs, boff0[c] + l0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int aoff = min(kb * 16 + c16, d - 1) * d + l0;
+          sl.nt[kb] = load4<false>(Ap, aoff, dd);
+          sl.dn[kb] = load4<false>(Dp, aoff, dd);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          sl.q[c] = load4<false>(qs, boff0[c] + l0, B * d);
+          sl.v[c] = load4<false>(vs, boff0[c] + l0, B * d);
+        }
+      }
+      sl.dl = NET ? drow[jr] : 0.f;
+    };
+    auto consume = [&](int jr, int lb, const Slot& sl) {
+      const int j = i + jr;
+      const int l0 = min(lb + 4 * g4, d - 1);
+      const int nl = max(0, min(4, d - (lb + 4 * g4)));
+      const float e = NET ? expf(-gam * sl.dl) : 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float xq[CT], xv[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          xq[c] = (s < nl) ? sl.q[c][s] : 0.f;
+          xv[c] = (s < nl && j < K) ? sl.v[c][s] : 0.f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int krow = kb * 16 + c16;
+          const bool oka = (s < nl) && krow < d;
+          float xm, xd;
+          if (NET) {
+            const float eye = (krow == l0 + s) ? 1.f : 0.f;
+            xm = e * eye + (1.f - e) * sl.nt[kb][s];
+            xd = -(gam * e * (sl.nt[kb][s] - eye) + (1.f - e) * sl.dn[kb][s]);
+          } else {
+            xm = sl.nt[kb][s];
+            xd = -sl.dn[kb][s];
+          }
+          xm = oka ? xm : 0.f;
+          xd = (oka && j < K) ? xd : 0.f;
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm, xq[c], acc[kb][c], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd, xv[c], acc[kb][c], 0, 0, 0);
+        }
+      }
+    };
+    // the next iteration's operands are requested before the current one is multiplied (its KB*CT*8 MFMAs cover
+    // the round trip); (jr, lb) advance as counters (no division)
+    auto advance = [&](int& jr, int& lb) { lb += 16; if (lb >= nlb * 16) { lb = 0; ++jr; } };
+    Slot cur, nxt;
+    int cjr = 0, clb = 0;
+    load(cjr, clb, cur);
+    while (cjr < npair) {
+      int njr = cjr, nlb2 = clb;
+      advance(njr, nlb2);
+      const bool more = njr < npair;
+      if (more) load(njr, nlb2, nxt);
+      consume(cjr, clb, cur);
+      if (more) cur = nxt;
+      cjr = njr; clb = nlb2;
+    }
+    // D: lane holds k = kb*16 + 4*g4 + r (r = 0..3) of batch column mcol[c]
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (mcol[c] < B) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = kb * 16 + 4 * g4 + r;
+            if (k < d) a.target[((size_t)i * B + mcol[c]) * d + k] = acc[kb][c][r];
+          }
+        }
   }
 }
 
@@ -525,6 +659,114 @@ __global__ __launch_bounds__(256) void socm_target_bwd_mfma_kernel(const TargetB
   if (NET) {
     part = wave_sum(part);
     if (lane == 0) a.ggamma_part[((size_t)p * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z] = part;
+  }
+}
+
+// d > 16: one workgroup (4 waves) per pair; wave w owns k-block 4*blockIdx.y + w and LB l-blocks, i.e. 2*LB
+// accumulators: an A fragment (G rows) is loaded once per 16 batch rows and multiplied into all of them, the B
+// fragments (q, v rows) are shared by the four waves through L1.  Operands of the next 16 batch rows are requested
+// before the current ones are multiplied.
+template <bool NET, int LB>
+__global__ __launch_bounds__(256) void socm_target_bwd_wide_kernel(const TargetBwdArgs a) {
+  const int d = a.d, K = a.K, B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t np = (int64_t)(K + 1) * (K + 2) / 2;
+  const int64_t p = blockIdx.x;
+  const int64_t pe = np - 1 - p;
+  int r = (int)((sqrtf(8.f * (float)pe + 1.f) - 1.f) * 0.5f);
+  while ((int64_t)(r + 1) * (r + 2) / 2 <= pe) ++r;
+  while ((int64_t)r * (r + 1) / 2 > pe) --r;
+  const int i = K - r;
+  const int j = i + (int)(p - pair_row_offset(i, K));
+  const bool last = (j == K);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = (blockIdx.y * 4 + wave) * 16;
+  if (kb >= d) return;                                   // (no barriers in this kernel)
+  const int lb0 = blockIdx.z * LB * 16;
+  const int k = kb + c16;
+  const bool okk = k < d;
+  const float* Ap = a.G + (size_t)i * B * d + (okk ? k : d - 1);
+  const float* Bq = last ? a.gT : a.q + (size_t)j * B * d;
+  const float* Bv = a.v + (size_t)(last ? 0 : j) * B * d;
+  int lcol[LB];
+  bool okl[LB];
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int l = lb0 + b * 16 + c16;
+    okl[b] = l < d;
+    lcol[b] = okl[b] ? l : d - 1;
+  }
+  f32x4 accq[LB], accv[LB];
+#pragma unroll
+  for (int b = 0; b < LB; ++b) { accq[b] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  struct Chunk { float af[4], qf[LB][4], vf[LB][4]; };
+  auto load = [&](int m0, Chunk& c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = min(m0 + 4 * u + g4, B - 1);
+      const size_t off = (size_t)m * d;
+      c.af[u] = Ap[off];
+#pragma unroll
+      for (int b = 0; b < LB; ++b) {
+        c.qf[b][u] = Bq[off + lcol[b]];
+        c.vf[b][u] = Bv[off + lcol[b]];
+      }
+    }
+  };
+  auto consume = [&](int m0, const Chunk& c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool okm = m0 + 4 * u + g4 < B;
+      const float af = (okm && okk) ? c.af[u] : 0.f;
+#pragma unroll
+      for (int b = 0; b < LB; ++b)
+        accq[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, okl[b] ? c.qf[b][u] : 0.f, accq[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < LB; ++b)
+        accv[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, (okl[b] && !last) ? c.vf[b][u] : 0.f, accv[b], 0, 0, 0);
+    }
+  };
+  Chunk c0, c1;
+  load(0, c0);
+  for (int m0 = 0; m0 < B; m0 += 32) {
+    if (m0 + 16 < B) load(m0 + 16, c1);
+    consume(m0, c0);
+    if (m0 + 16 >= B) break;
+    if (m0 + 32 < B) load(m0 + 32, c0);
+    consume(m0 + 16, c1);
+  }
+  const float go = a.gout ? a.gout[0] : 1.f;
+  const size_t base = (size_t)p * d * d;
+  float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
+  if (NET) { gam = a.gamma[0]; dl = a.delta[p]; e = expf(-gam * dl); }
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int l = lb0 + b * 16 + c16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int kk = kb + 4 * g4 + rr;
+      if (kk < d && okl[b]) {
+        const size_t idx = base + (size_t)kk * d + l;
+        const float gm = -accq[b][rr] * go, gd = accv[b][rr] * go;
+        if (NET) {
+          const float nmi = a.net[idx] - (kk == l ? 1.f : 0.f);
+          a.gM[idx] = (1.f - e) * gm + gam * e * gd;
+          a.gdM[idx] = (1.f - e) * gd;
+          part += gm * dl * e * nmi + gd * (e * (1.f - gam * dl) * nmi + dl * e * a.dnet[idx]);
+        } else {
+          a.gM[idx] = gm;
+          a.gdM[idx] = gd;
+        }
+      }
+    }
+  }
+  if (NET) {
+    part = wave_sum(part);
+    // the caller's buffer has one slot per (pair, k-block, l-block): this wave covers LB of them (sum in the first)
+    const int nb = (d + 15) >> 4;
+    if (lane < LB && (int)blockIdx.z * LB + lane < nb)
+      a.ggamma_part[((size_t)p * nb + (kb >> 4)) * nb + blockIdx.z * LB + lane] = lane == 0 ? part : 0.f;
   }
 }
 
@@ -651,6 +893,20 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.q = q; a.v = v; a.gT = gT;
   a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective;
   a.delta = delta; a.gamma = gamma;
+  const hipStream_t st0 = (hipStream_t)stream;
+  bool launched = false;
+  if (d > 16 && d <= 64 && B >= 256) {                 // wide form: all k-blocks and 8 x 2 batch tiles per workgroup
+    dim3 wgrid((K + 2) / 2, (B + 16 * 2 * kTargetWaves - 1) / (16 * 2 * kTargetWaves));
+    const dim3 wblk(64 * kTargetWaves);
+    if (delta) {
+      if (d <= 32) hipLaunchKernelGGL((socm_target_wide_kernel<true, 2, 2>), wgrid, wblk, 0, st0, a);
+      else         hipLaunchKernelGGL((socm_target_wide_kernel<true, 4, 2>), wgrid, wblk, 0, st0, a);
+    } else {
+      if (d <= 32) hipLaunchKernelGGL((socm_target_wide_kernel<false, 2, 2>), wgrid, wblk, 0, st0, a);
+      else         hipLaunchKernelGGL((socm_target_wide_kernel<false, 4, 2>), wgrid, wblk, 0, st0, a);
+    }
+    launched = true;
+  }
   const int ct = B > 32 ? 4 : (B > 16 ? 2 : 1);        // 16-column batch tiles per wave
   dim3 grid((K + 2) / 2, (B + 16 * ct - 1) / (16 * ct), (d + 15) / 16);
   const dim3 blk(64 * kTargetWaves);
@@ -658,7 +914,8 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
 #define SOCMX_TARGET_LAUNCH(NETV, CTV, N1V) \
   hipLaunchKernelGGL((socm_target_mfma_kernel<NETV, CTV, N1V>), grid, blk, 0, st, a)
   const bool nlb1 = d <= 16;
-  if (delta) {
+  if (launched) {
+  } else if (delta) {
     if (ct == 4)      { if (nlb1) SOCMX_TARGET_LAUNCH(true, 4, true); else SOCMX_TARGET_LAUNCH(true, 4, false); }
     else if (ct == 2) { if (nlb1) SOCMX_TARGET_LAUNCH(true, 2, true); else SOCMX_TARGET_LAUNCH(true, 2, false); }
     else              { if (nlb1) SOCMX_TARGET_LAUNCH(true, 1, true); else SOCMX_TARGET_LAUNCH(true, 1, false); }
@@ -707,6 +964,20 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
   a.d = d; a.K = K; a.B = B; a.G = G; a.q = q; a.v = v; a.gT = gT; a.gout = gout; a.gM = gM; a.gdM = gdM;
   a.net = net; a.dnet = dnet; a.delta = delta; a.gamma = gamma; a.ggamma_part = ggamma_part;
   const int64_t np = socmx_num_pairs(K);
+  if (d > 16) {
+    const int nblk = (d + 15) / 16;
+    const int lbw = nblk >= 4 ? 4 : 2;                               // l-blocks per wave
+    dim3 wgrid((unsigned)np, (nblk + 3) / 4, (nblk + lbw - 1) / lbw);
+    const hipStream_t st = (hipStream_t)stream;
+    if (net) {
+      if (lbw == 4) hipLaunchKernelGGL((socm_target_bwd_wide_kernel<true, 4>), wgrid, dim3(256), 0, st, a);
+      else          hipLaunchKernelGGL((socm_target_bwd_wide_kernel<true, 2>), wgrid, dim3(256), 0, st, a);
+    } else {
+      if (lbw == 4) hipLaunchKernelGGL((socm_target_bwd_wide_kernel<false, 4>), wgrid, dim3(256), 0, st, a);
+      else          hipLaunchKernelGGL((socm_target_bwd_wide_kernel<false, 2>), wgrid, dim3(256), 0, st, a);
+    }
+    return (int)hipGetLastError();
+  }
   dim3 grid((unsigned)((np + 3) / 4), (d + 15) / 16, (d + 15) / 16);
   if (net)
     hipLaunchKernelGGL(socm_target_bwd_mfma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
