@@ -283,6 +283,10 @@ FIXTURES = [
      dict(with_pairs=False)),
     # a 20-row batch so that a 16-row tile plus a ragged 4-row tail is exercised
     ("tiny_ou_linear_d5_B20", "OU_linear", 5, 9, 20, TINY, 2.0, 8, {}),
+    # d > 16 (BASELINE configs[4] is d = 64): dense sigma, several 16-wide blocks per pair matrix, the general SDE step
+    ("tiny_ou_linear_d20", "OU_linear", 20, 8, 8, TINY, 2.0, 9, dict(with_pairs=False)),
+    ("tiny_ou_linear_d64", "OU_linear", 64, 5, 4, dict(hdims=[32, 16, 8], hdims_M=[8, 8]), 2.0, 10,
+     dict(with_pairs=False)),
 ]
 
 
