@@ -274,6 +274,9 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if (tile_row0 + tid < B) a.stop_ind[tile_row0 + tid] = 1.f;  // stop_indicators[0] = ones (utils.py:28)
   }
   float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in threads 0..15
+  const bool mm = d >= 16;                                  // matrix products of the SDE step on the MFMA
+  const int mwave = __builtin_amdgcn_readfirstlane(tid >> 6), mc16 = tid & 15, mg4 = (tid & 63) >> 4;
+  const int mblocks = (d + 15) >> 4;
   __syncthreads();
   long long acc_prof[64];
   for (int s = 0; s < 64; ++s) acc_prof[s] = 0;
@@ -304,37 +307,102 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);  // GV = nabla_V(t,x)
 
     // ---- control u = -sigma^T nabla_V (method.py:68-72) and the step's noise (utils.py:39) ---
-    for (int e = tid; e < 16 * d; e += nthr) {
-      const int r = SOCMX_DIV_D(e), i = e - r * d;
-      float s = 0.f;
-      for (int j = 0; j < d; ++j) s += sig[j * ds + i] * GV[r * tl.sg + j];
-      const float u = -s;
-      const int grow = tile_row0 + r;
-      float eps;
-      if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
-      else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
-      U[e] = u;
-      E[e] = eps;
-      if (grow < B) {
-        a.controls[((size_t)k * B + grow) * d + i] = u;
-        a.noises[((size_t)k * B + grow) * d + i] = eps;
+    if (mm) {
+      // d >= 16: the (16 rows x d) . (d x d) products run on the MFMA with both operands read from LDS
+      // (one ds_read_b32 pair per MFMA instead of two LDS reads per multiply-add)
+      for (int e = tid; e < 16 * d; e += nthr) {
+        const int r = SOCMX_DIV_D(e), i = e - r * d;
+        const int grow = tile_row0 + r;
+        float eps;
+        if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
+        else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
+        E[e] = eps;
+        if (grow < B) a.noises[((size_t)k * B + grow) * d + i] = eps;
+      }
+      for (int ib = mwave; ib < mblocks; ib += NW) {
+        const int i = ib * 16 + mc16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < d; j0 += 4) {
+          const int j = j0 + mg4;
+          const bool okj = j < d;
+          const float av = (okj && i < d) ? sig[min(j, d - 1) * ds + min(i, d - 1)] : 0.f;   // (sigma^T)[i][j]
+          const float bv = okj ? GV[mc16 * tl.sg + min(j, d - 1)] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        const int grow = tile_row0 + mc16;            // D: lane holds rows i = ib*16 + 4*g4 + rr of batch column c16
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int io = ib * 16 + 4 * mg4 + rr;
+          if (io < d) {
+            const float u = -acc[rr];
+            U[mc16 * d + io] = u;
+            if (grow < B) a.controls[((size_t)k * B + grow) * d + io] = u;
+          }
+        }
+      }
+    } else {
+      for (int e = tid; e < 16 * d; e += nthr) {
+        const int r = SOCMX_DIV_D(e), i = e - r * d;
+        float s = 0.f;
+        for (int j = 0; j < d; ++j) s += sig[j * ds + i] * GV[r * tl.sg + j];
+        const float u = -s;
+        const int grow = tile_row0 + r;
+        float eps;
+        if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
+        else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
+        U[e] = u;
+        E[e] = eps;
+        if (grow < B) {
+          a.controls[((size_t)k * B + grow) * d + i] = u;
+          a.noises[((size_t)k * B + grow) * d + i] = eps;
+        }
       }
     }
     __syncthreads();
     SOCMX_TICK(7)
 
     // ---- Euler-Maruyama update (utils.py:45-48) ------------------------------------------
-    for (int e = tid; e < 16 * d; e += nthr) {
-      const int r = SOCMX_DIV_D(e), i = e - r * d;
-      const float bi = drift_i(kind, d, i, XS + r * d, A_l, a.kappa);
-      float su = 0.f, se = 0.f;
-      for (int j = 0; j < d; ++j) {
-        su += sig[i * ds + j] * U[r * d + j];
-        se += sig[i * ds + j] * E[r * d + j];
+    if (mm) {
+      for (int ib = mwave; ib < mblocks; ib += NW) {
+        const int i = ib * 16 + mc16, ic = min(i, d - 1);
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // A x + sigma u ; sigma eps
+        for (int j0 = 0; j0 < d; j0 += 4) {
+          const int j = j0 + mg4, jc = min(j, d - 1);
+          const bool ok = j < d && i < d;
+          const float sv = ok ? sig[ic * ds + jc] : 0.f;
+          const float bu = U[mc16 * d + jc], be = E[mc16 * d + jc];
+          if (is_ou) {
+            const float aa = ok ? A_l[ic * ds + jc] : 0.f;
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, XS[mc16 * d + jc], acc1, 0, 0, 0);
+          }
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, be, acc2, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, bu, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int io = ib * 16 + 4 * mg4 + rr;
+          if (io < d) {
+            const int e = mc16 * d + io;
+            const float bi = is_ou ? 0.f : drift_i(kind, d, io, XS + mc16 * d, A_l, a.kappa);
+            const float upd = (bi + acc1[rr]) * dt + sq_ldt * acc2[rr];
+            UP[e] = upd;
+            XN[e] = XS[e] + ST[mc16] * upd;
+          }
+        }
       }
-      const float upd = (bi + su) * dt + sq_ldt * se;
-      UP[e] = upd;
-      XN[e] = XS[e] + ST[r] * upd;
+    } else {
+      for (int e = tid; e < 16 * d; e += nthr) {
+        const int r = SOCMX_DIV_D(e), i = e - r * d;
+        const float bi = drift_i(kind, d, i, XS + r * d, A_l, a.kappa);
+        float su = 0.f, se = 0.f;
+        for (int j = 0; j < d; ++j) {
+          su += sig[i * ds + j] * U[r * d + j];
+          se += sig[i * ds + j] * E[r * d + j];
+        }
+        const float upd = (bi + su) * dt + sq_ldt * se;
+        UP[e] = upd;
+        XN[e] = XS[e] + ST[r] * upd;
+      }
     }
     __syncthreads();
     SOCMX_TICK(8)
