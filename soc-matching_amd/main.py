@@ -126,6 +126,7 @@ def run(cfg):
             info["trajectories"].append(out[4])
             solver.num_iterations = itr + 1
             if rank == 0:
+                trainer.join()                               # second-stream M update lands before we read it
                 keep, solver.shard = solver.shard, None      # process groups do not pickle
                 save_results(solver, folder_name, get_file_name(folder_name, num_iterations=itr + 1))
                 save_results(solver, folder_name, get_file_name(folder_name, num_iterations=itr + 1, last=True))

@@ -62,6 +62,16 @@ class Trainer:
         self._groups_side = [g for g in optimizer.param_groups if all(id(p) in ids_M for p in g["params"])]
         self._groups_main = [g for g in optimizer.param_groups if not all(id(p) in ids_M for p in g["params"])]
 
+    def join(self):
+        """Make the current stream wait for the second stream's pending M-network update.  Needed only by code that
+        reads M / gamma outside `step()` / `solver.loss()` while `sync_timing=False` (with the default
+        `sync_timing=True` every step ends with a device synchronisation, like the reference's timing does)."""
+        dev = self.solver.x0.device
+        if self.defer_M and dev.type == "cuda":
+            side = self.solver._side_stream(dev)
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+
     def _step_groups(self, groups):
         opt = self.optimizer
         saved = opt.param_groups

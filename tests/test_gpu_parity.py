@@ -456,3 +456,30 @@ def test_solver_pickles_after_hip_calls(tmp_path):
         back = pickle.load(f)
     out2 = back.loss(aux["B"], algorithm="SOCM", use_warm_start=False)      # still usable (handles rebuilt lazily)
     assert torch.isfinite(out2[0])
+
+
+@pytest.mark.parametrize("overrides", [
+    ["method.setting=OU_quadratic_easy", "method.d=2", "method.num_steps=20"],
+    ["method.setting=OU_linear", "method.d=4", "method.num_steps=20"],
+    ["method.setting=double_well", "method.d=3", "method.num_steps=40", "method.delta_t_optimal=0.02",
+     "method.delta_x_optimal=0.02"],
+    ["method.setting=molecular_dynamics", "method.d=1", "method.num_steps=30", "method.use_stopping_time=True",
+     "method.T=2.0", "method.lmbd=2.0"],
+    ["method.setting=double_well", "method.d=3", "method.num_steps=40", "method.delta_t_optimal=0.02",
+     "method.delta_x_optimal=0.02", "method.algorithm=log-variance"],
+])
+def test_main_trains_on_the_gpu(tmp_path, overrides):
+    """The reference's entry point end to end on the GPU (main.py:33-481 flow): normalisation-constant burst,
+    a few iterations through Trainer (two-stream schedule), control-objective bursts, checkpoint."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "soc-matching_amd", "main.py"), "method.use_gpu=True",
+           "method.num_iterations=6", "arch.hdims=[32,16,8]", "arch.hdims_M=[16,16]", "method.n_samples_control=256",
+           "+method.n_batches_normalization=2", "optim.batch_size=32", "method.gamma=2.0",
+           "method.compute_control_objective_every=3"] + overrides
+    res = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "nan" not in res.stdout.lower(), res.stdout[-3000:]
+    folders = [p for p in (tmp_path / "outputs" / "runs").iterdir() if p.is_dir()]
+    assert len(folders) == 1 and (folders[0] / "last.pkl").exists()
