@@ -223,6 +223,11 @@ int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* 
 int32_t socmx_colsum_blocks(int64_t R, int32_t C);
 int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* partial, float* out, socmx_stream_t stream);
 
+/* ReLU backward fused with the bias-gradient reduction of a Linear+ReLU layer (models.py:212-228, 253-257):
+ * gz = gy * (y > 0) with y the layer's ReLU output, out[c] = sum_r gz[r][c].  gz must not alias gy. */
+int socmx_relu_bwd_colsum_f32(const float* gy, const float* y, int64_t R, int32_t C, float* gz, float* partial,
+                              float* out, socmx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

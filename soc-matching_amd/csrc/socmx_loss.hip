@@ -774,7 +774,11 @@ __global__ __launch_bounds__(256) void socm_target_bwd_wide_kernel(const TargetB
 // out[c] = sum_r x[r][c] for a tall (R, C) row-major matrix: HBM-bound, one pass.  Stage 1: workgroup b sums the
 // rows b, b+nblk, ... (lanes along the columns: coalesced; 256/CW row lanes per workgroup) into partial[b][:];
 // stage 2 adds the nblk partials in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t R, int C, int CW,
+// MASKED: x = gy, y = the ReLU output saved by the forward; gz = gy * (y > 0) is written out and summed
+// (ReLU backward fused with the bias-gradient reduction: one pass instead of two kernels and three passes)
+template <bool MASKED>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             float* __restrict__ gz, int64_t R, int C, int CW,
                                                              float* __restrict__ partial) {
   __shared__ float red[256];
   const int c = threadIdx.x % CW, rl = threadIdx.x / CW, nrl = 256 / CW;
@@ -784,13 +788,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (cc < C) {
       int64_t r = (int64_t)blockIdx.x * nrl + rl;
+      auto at = [&](int64_t rr) -> float {
+        const int64_t idx = rr * C + cc;
+        float v = x[idx];
+        if (MASKED) {
+          v = y[idx] > 0.f ? v : 0.f;
+          gz[idx] = v;
+        }
+        return v;
+      };
       for (; r + 3 * step < R; r += 4 * step) {
-        a0 += x[r * C + cc];
-        a1 += x[(r + step) * C + cc];
-        a2 += x[(r + 2 * step) * C + cc];
-        a3 += x[(r + 3 * step) * C + cc];
+        a0 += at(r);
+        a1 += at(r + step);
+        a2 += at(r + 2 * step);
+        a3 += at(r + 3 * step);
       }
-      for (; r < R; r += step) a0 += x[r * C + cc];
+      for (; r < R; r += step) a0 += at(r);
     }
     red[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -1016,7 +1029,23 @@ extern "C" int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* par
   if (R < 1 || C < 1) return SOCMX_E_DIM;
   const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
   const int nblk = socmx_colsum_blocks(R, C);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, R, (int)C, cw, partial);
+  hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr,
+                     R, (int)C, cw, partial);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+                     (int)C, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int socmx_relu_bwd_colsum_f32(const float* gy, const float* y, int64_t R, int32_t C, float* gz,
+                                         float* partial, float* out, socmx_stream_t stream) {
+  if (!gy || !y || !gz || !partial || !out) return SOCMX_E_NULL;
+  if (R < 1 || C < 1) return SOCMX_E_DIM;
+  const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
+  const int nblk = socmx_colsum_blocks(R, C);
+  hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, gy, y, gz, R, (int)C,
+                     cw, partial);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk,

@@ -52,6 +52,31 @@ class _LinearSplitK(torch.autograd.Function):
         return gx, _wgrad_splitk(gy, x), gb
 
 
+class _LinearReluSplitK(torch.autograd.Function):
+    """relu(x W^T + b): ReLU in the GEMM epilogue (hipBLASLt), its backward fused with the bias-gradient reduction
+    (socmx_relu_bwd_colsum_f32), split-K weight gradient as in _LinearSplitK."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        R, C = gy.shape
+        gz = torch.empty_like(gy)
+        partial = torch.empty(L.socmx_colsum_blocks(R, C) * C, dtype=torch.float32, device=gy.device)
+        gb = torch.empty(C, dtype=torch.float32, device=gy.device)
+        _lib.check(L.socmx_relu_bwd_colsum_f32(_lib.ptr(gy), _lib.ptr(y), R, C, _lib.ptr(gz), _lib.ptr(partial),
+                                               _lib.ptr(gb), _lib.stream_ptr(gy.device)), "socmx_relu_bwd_colsum_f32")
+        gx = gz @ weight if ctx.needs_input_grad[0] else None
+        return gx, _wgrad_splitk(gz, x), gb
+
+
 def _colsum(gy):
     """Bias gradient gy.sum(0) of a tall contiguous fp32 (R, C) matrix: socmx_colsum_f32 on the GPU (one HBM pass at
     several TB/s; the generic reduction kernel runs this shape at ~1.3 TB/s)."""
@@ -81,6 +106,8 @@ def _wgrad_splitk(gy, x, S=16):
 
 def _linear(seq, x, splitk):
     lin = seq[0]
+    if splitk and len(seq) > 1:
+        return _LinearReluSplitK.apply(x, lin.weight, lin.bias)
     y = _LinearSplitK.apply(x, lin.weight, lin.bias) if splitk else lin(x)
     return torch.relu(y) if len(seq) > 1 else y
 
@@ -195,14 +222,16 @@ class SigmoidMLP(nn.Module):
         l0, l2, l4 = self.sigmoid_layers[0], self.sigmoid_layers[2], self.sigmoid_layers[4]
         sk = t.is_cuda and t.shape[0] >= 8192 and torch.is_grad_enabled()
         lin = (lambda x, w, b: _LinearSplitK.apply(x, w, b)) if sk else (lambda x, w, b: torch.addmm(b, x, w.T))
-        a1 = lin(torch.stack((t, s), dim=1), l0.weight, l0.bias)
-        h1 = torch.relu(a1)
-        a2 = lin(h1, l2.weight, l2.bias)
-        h2 = torch.relu(a2)
+        if sk:      # fused Linear+ReLU (the ReLU mask of the tangent path is h > 0, same set as a > 0)
+            h1 = _LinearReluSplitK.apply(torch.stack((t, s), dim=1), l0.weight, l0.bias)
+            h2 = _LinearReluSplitK.apply(h1, l2.weight, l2.bias)
+        else:
+            h1 = torch.relu(lin(torch.stack((t, s), dim=1), l0.weight, l0.bias))
+            h2 = torch.relu(lin(h1, l2.weight, l2.bias))
         net = lin(h2, l4.weight, l4.bias).reshape(-1, self.dim, self.dim)
         zero2, zero4 = torch.zeros_like(l2.bias), torch.zeros_like(l4.bias)   # tangent path: no bias
-        t1 = (a1 > 0).to(a1.dtype) * l0.weight[:, 1]
-        t2 = (a2 > 0).to(a2.dtype) * lin(t1, l2.weight, zero2)
+        t1 = (h1 > 0).to(h1.dtype) * l0.weight[:, 1]
+        t2 = (h2 > 0).to(h2.dtype) * lin(t1, l2.weight, zero2)
         dnet = lin(t2, l4.weight, zero4).reshape(-1, self.dim, self.dim)
         if raw:
             return net, dnet
