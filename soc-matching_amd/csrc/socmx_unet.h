@@ -129,6 +129,7 @@ struct StageDesc {
 //   split-K stages (fewer blocks than waves): wave owns block blk0, chunk range [kc0a,kc1a) / [kc0b,kc1b).
 //   pf[4]: fragment numbers (block*KC + chunk) of the NEXT stage's first four GEMM-1 fragments for this wave.
 constexpr int kMaxWaves = 8;
+constexpr int kSimds = 4;      // SIMDs (MFMA pipes) per CU; wave w runs on SIMD w % 4
 struct WaveWork {
   unsigned short split, blk0, cnt, active;
   unsigned short kc0a, kc1a, kc0b, kc1b;
@@ -172,7 +173,7 @@ __host__ __device__ constexpr bool first_fragment_numbers(const LayerDesc& Lg, i
   const int NBLK = Lg.out_pad >> 4, KC = Lg.in_pad >> 4;
   int blk = 0, bstride = 0, nb = 1, kc0 = 0, kc1 = 1;
   bool ok = false;
-  if (NBLK >= NW) {
+  if (NBLK >= NW || NBLK >= kSimds) {   // one block per SIMD already saturates the four MFMA pipes: no split-K
     int cnt = w < NBLK ? (NBLK - w + NW - 1) / NW : 0;
     nb = cnt > 4 ? 4 : cnt;
     ok = cnt > 0 && nb != 3;                 // a 3-block group ignores the prefetch
@@ -198,7 +199,7 @@ __host__ __device__ constexpr bool first_fragment_numbers(const LayerDesc& Lg, i
 __host__ __device__ constexpr WaveWork wave_work_of(const StageDesc& d, int NW, int w) {
   WaveWork x{};
   const int NBLK = d.L1.out_pad >> 4, KC1 = d.L1.in_pad >> 4, KC2 = d.L2.in_pad >> 4;
-  if (NBLK >= NW) {
+  if (NBLK >= NW || NBLK >= kSimds) {   // one block per SIMD already saturates the four MFMA pipes: no split-K
     x.split = 0; x.blk0 = (unsigned short)w;
     x.cnt = (unsigned short)(w < NBLK ? (NBLK - w + NW - 1) / NW : 0);
     x.active = x.cnt > 0;
