@@ -13,6 +13,7 @@
 // operand load is a contiguous 256-byte wave access, the d x d pair matrices are shared through LDS
 // (transposed, 16-byte broadcast reads), and block/wave reductions feed one atomic per workgroup.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <math.h>
 #include <stdint.h>
 
@@ -544,6 +545,196 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_wide_kernel(con
   }
 }
 
+// Wide form, A operand staged through LDS.  Same work split as socm_target_wide_kernel (row pair x 8 waves x CT=2
+// column tiles, all KB k-blocks per wave), but the pair matrices are fetched ONCE per workgroup: threads 0..255 each
+// own one 16-byte piece (row k, four l) of net and dnet, keep three iterations of them in flight in registers,
+// form M / -dM/ds (zero padding, NET blend) once and write them to a three-stage LDS ring; the eight waves read their
+// MFMA A fragments from there (ds_read_b128).  One barrier per iteration.  The B fragments (q, v: different for every
+// wave) stay on a three-deep register ring.
+constexpr int kAStride = 20;   // floats per staged row (16 + 4 pad: 80-byte stride spreads the 16 rows over the banks)
+
+template <bool NET, int KB>
+__global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(const TargetArgs a) {
+  constexpr int CT = 2, ROWS = KB * 16;
+  __shared__ __attribute__((aligned(16))) float As[3][2][ROWS][kAStride];
+  const int d = a.d, K = a.K, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  int mcol[CT], boff0[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    mcol[c] = ((blockIdx.y * kTargetWaves + wave) * CT + c) * 16 + c16;
+    boff0[c] = min(mcol[c], B - 1) * d;
+  }
+  const int nlb = (d + 15) >> 4;
+  const int nlb_shift = (nlb & (nlb - 1)) == 0 ? __builtin_ctz(nlb) : -1;
+  const int dd = d * d;
+  const float gam = NET ? a.gamma[0] : 0.f;
+  // loader role: tid < 4*ROWS -> (row ak, 16-byte piece aq)
+  const bool loader = tid < 4 * ROWS;
+  const int ak = tid >> 2, aq = tid & 3;
+  {
+    // one row per workgroup, longest rows first (blockIdx.x = i): the dispatcher hands out rows as CUs free up, which
+    // balances the triangular work better than fixed (i, K-i) pairs when there are fewer pairs than 2 x CUs
+    const int i = blockIdx.x;
+    const float* drow = NET ? a.delta + pair_row_offset(i, K) : nullptr;
+    const int nit = (K - i + 1) * nlb;
+    const int64_t prow_dd = pair_row_offset(i, K) * dd;
+    f32x4 acc[KB][CT];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[kb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto geom = [&](int it, int& jr, int& lb) {
+      jr = nlb_shift >= 0 ? it >> nlb_shift : it / nlb;
+      lb = (it - jr * nlb) * 16;
+    };
+    struct APend { f32x4 nt, dn; float dl; };
+    struct BSlot { f32x4 q[CT], v[CT]; };
+    auto loadA = [&](int it, APend& p) {          // loader threads only
+      int jr, lb;
+      geom(it, jr, lb);
+      const int j = i + jr;
+      const int l0 = min(lb + 4 * aq, d - 1);
+      const float* Ap = a.M_all + prow_dd + (int64_t)jr * dd;
+      const float* Dp = a.dM_all + prow_dd + (int64_t)jr * dd;
+      const int aoff = min(ak, d - 1) * d + l0;
+      if (j + 1 < K) {
+        p.nt = load4<true>(Ap, aoff, 0);
+        p.dn = load4<true>(Dp, aoff, 0);
+      } else {
+        p.nt = load4<false>(Ap, aoff, dd);
+        p.dn = load4<false>(Dp, aoff, dd);
+      }
+      p.dl = NET ? drow[jr] : 0.f;
+    };
+    auto stageA = [&](int it, const APend& p, int st) {   // blend + zero padding, then one 16-byte LDS write each
+      int jr, lb;
+      geom(it, jr, lb);
+      const int j = i + jr;
+      const int lq = lb + 4 * aq;
+      const int l0 = min(lq, d - 1);
+      const int nl = max(0, min(4, d - lq));
+      const int na = ak < d ? nl : 0;
+      const float e = NET ? expf(-gam * p.dl) : 0.f;
+      f32x4 xm, xd;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        float m_, d_;
+        if (NET) {
+          const float eye = (ak == l0 + s2) ? 1.f : 0.f;
+          m_ = e * eye + (1.f - e) * p.nt[s2];
+          d_ = -(gam * e * (p.nt[s2] - eye) + (1.f - e) * p.dn[s2]);
+        } else {
+          m_ = p.nt[s2];
+          d_ = -p.dn[s2];
+        }
+        xm[s2] = (s2 < na) ? m_ : 0.f;
+        xd[s2] = (s2 < na && j < K) ? d_ : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(&As[st][0][ak][4 * aq]) = xm;
+      *reinterpret_cast<f32x4*>(&As[st][1][ak][4 * aq]) = xd;
+    };
+    auto loadB = [&](int it, BSlot& b) {
+      int jr, lb;
+      geom(it, jr, lb);
+      const int j = i + jr;
+      const int l0 = min(lb + 4 * g4, d - 1);
+      const float* qs = (j < K) ? a.q + (size_t)j * B * d : a.gT;
+      const float* vs = a.v + (size_t)(j < K ? j : 0) * B * d;
+      if (j + 1 < K) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          b.q[c] = load4<true>(qs, boff0[c] + l0, 0);
+          b.v[c] = load4<true>(vs, boff0[c] + l0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          b.q[c] = load4<false>(qs, boff0[c] + l0, B * d);
+          b.v[c] = load4<false>(vs, boff0[c] + l0, B * d);
+        }
+      }
+    };
+    auto consume = [&](int it, const BSlot& b, int st) {
+      int jr, lb;
+      geom(it, jr, lb);
+      const int j = i + jr;
+      const int nl = max(0, min(4, d - (lb + 4 * g4)));
+      f32x4 xm[KB], xd[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        xm[kb] = *reinterpret_cast<const f32x4*>(&As[st][0][kb * 16 + c16][4 * g4]);
+        xd[kb] = *reinterpret_cast<const f32x4*>(&As[st][1][kb * 16 + c16][4 * g4]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        float xq[CT], xv[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          xq[c] = (s2 < nl) ? b.q[c][s2] : 0.f;
+          xv[c] = (s2 < nl && j < K) ? b.v[c][s2] : 0.f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm[kb][s2], xq[c], acc[kb][c], 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[kb][s2], xv[c], acc[kb][c], 0, 0, 0);
+      }
+    };
+    // prologue: stages 0, 1 filled; A loads of iterations 2, 3, 4 and B loads of 0, 1, 2 in flight
+    APend pend[3];
+    BSlot bs[3];
+    __syncthreads();                               // previous row's readers are done with the ring
+    if (loader) {
+      loadA(0, pend[0]);
+      if (1 < nit) loadA(1, pend[1]);
+      stageA(0, pend[0], 0);
+      if (1 < nit) stageA(1, pend[1], 1);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int it = 2 + u;                     // pend slot = it % 3
+        if (it < nit) loadA(it, pend[it % 3]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (u < nit) loadB(u, bs[u]);
+    for (int it0 = 0; it0 < nit; it0 += 3) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int it = it0 + u;                   // it % 3 == u
+        if (it < nit) {
+          __syncthreads();                        // stage of `it` (and it+1) written; readers of it-1 finished
+          if (loader && it + 2 < nit) {
+            stageA(it + 2, pend[(u + 2) % 3], (u + 2) % 3);
+            if (it + 5 < nit) loadA(it + 5, pend[(u + 2) % 3]);
+          }
+          consume(it, bs[u], u);
+          if (it + 3 < nit) loadB(it + 3, bs[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (mcol[c] < B) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = kb * 16 + 4 * g4 + r;
+            if (k < d) a.target[((size_t)i * B + mcol[c]) * d + k] = acc[kb][c][r];
+          }
+        }
+  }
+}
+
 // r = sigma^T (nablaV - target), objective += inv_norm * sum w |r|^2, G = 2 w inv_norm sigma r.
 // Workgroup = one row i x 64 batch lanes; wave shuffle -> LDS -> one atomic per workgroup.
 __global__ __launch_bounds__(64) void socm_residual_kernel(const TargetArgs a) {
@@ -911,7 +1102,17 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   if (d > 16 && d <= 64 && B >= 256) {                 // wide form: all k-blocks and 8 x 2 batch tiles per workgroup
     dim3 wgrid((K + 2) / 2, (B + 16 * 2 * kTargetWaves - 1) / (16 * 2 * kTargetWaves));
     const dim3 wblk(64 * kTargetWaves);
-    if (delta) {
+    static const bool use_regs = getenv("SOCMX_TARGET_WIDE_REGS") != nullptr;   // A/B switch: register-only form
+    if (!use_regs) {
+      wgrid.x = K + 1;
+      if (delta) {
+        if (d <= 32) hipLaunchKernelGGL((socm_target_lds_kernel<true, 2>), wgrid, wblk, 0, st0, a);
+        else         hipLaunchKernelGGL((socm_target_lds_kernel<true, 4>), wgrid, wblk, 0, st0, a);
+      } else {
+        if (d <= 32) hipLaunchKernelGGL((socm_target_lds_kernel<false, 2>), wgrid, wblk, 0, st0, a);
+        else         hipLaunchKernelGGL((socm_target_lds_kernel<false, 4>), wgrid, wblk, 0, st0, a);
+      }
+    } else if (delta) {
       if (d <= 32) hipLaunchKernelGGL((socm_target_wide_kernel<true, 2, 2>), wgrid, wblk, 0, st0, a);
       else         hipLaunchKernelGGL((socm_target_wide_kernel<true, 4, 2>), wgrid, wblk, 0, st0, a);
     } else {
