@@ -961,6 +961,120 @@ __global__ __launch_bounds__(256) void socm_target_bwd_wide_kernel(const TargetB
   }
 }
 
+// d <= 64, d % 4 == 0: the same contraction with the three operand tiles of 16 batch rows (G_i, q_j, v_j: 16 x d floats
+// each) staged through a double-buffered LDS tile by coalesced 16-byte loads -- 3 global loads per thread and 16 batch
+// rows instead of 36 four-byte loads per lane; the waves read their MFMA fragments from LDS (rows padded to 80 floats).
+constexpr int kBwdStride = 80;   // row r starts 16 banks after row r-1: the four rows a wave reads per MFMA cover each bank twice (the minimum)
+
+template <bool NET>
+__global__ __launch_bounds__(256) void socm_target_bwd_lds_kernel(const TargetBwdArgs a) {
+  constexpr int LB = 4;
+  __shared__ __attribute__((aligned(16))) float Ts[2][3][16][kBwdStride];   // [stage][G, q, v][batch row][column]
+  const int d = a.d, K = a.K, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t np = (int64_t)(K + 1) * (K + 2) / 2;
+  const int64_t p = blockIdx.x;
+  const int64_t pe = np - 1 - p;
+  int r = (int)((sqrtf(8.f * (float)pe + 1.f) - 1.f) * 0.5f);
+  while ((int64_t)(r + 1) * (r + 2) / 2 <= pe) ++r;
+  while ((int64_t)r * (r + 1) / 2 > pe) --r;
+  const int i = K - r;
+  const int j = i + (int)(p - pair_row_offset(i, K));
+  const bool last = (j == K);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = wave * 16;
+  const bool wave_on = kb < d;
+  const float* Gp = a.G + (size_t)i * B * d;
+  const float* Qp = last ? a.gT : a.q + (size_t)j * B * d;
+  const float* Vp = a.v + (size_t)(last ? 0 : j) * B * d;
+  // loader role: (batch row mr of the chunk, 16-byte piece pc of the row)
+  const int mr = tid >> 4, pc = tid & 15;
+  const bool piece_on = 4 * pc < d;
+  f32x4 pg, pq, pv;                       // the chunk after next, in flight
+  auto gload = [&](int m0) {
+    const int m = min(m0 + mr, B - 1);
+    const size_t off = (size_t)m * d + 4 * pc;
+    if (piece_on) {
+      pg = load4<true>(Gp, (int)off, 0);
+      pq = load4<true>(Qp, (int)off, 0);
+      pv = load4<true>(Vp, (int)off, 0);
+    }
+  };
+  auto stage = [&](int m0, int st) {      // rows past the batch and (for the terminal pair) v are zeroed here
+    const bool okm = m0 + mr < B;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (piece_on) {
+      *reinterpret_cast<f32x4*>(&Ts[st][0][mr][4 * pc]) = okm ? pg : z;
+      *reinterpret_cast<f32x4*>(&Ts[st][1][mr][4 * pc]) = okm ? pq : z;
+      *reinterpret_cast<f32x4*>(&Ts[st][2][mr][4 * pc]) = (okm && !last) ? pv : z;
+    }
+  };
+  f32x4 accq[LB], accv[LB];
+#pragma unroll
+  for (int b = 0; b < LB; ++b) { accq[b] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int nch = (B + 15) >> 4;
+  gload(0);
+  stage(0, 0);
+  if (nch > 1) gload(16);
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();                      // stage c%2 visible; everyone is done reading stage (c+1)%2
+    if (c + 1 < nch) {
+      stage((c + 1) * 16, (c + 1) & 1);
+      if (c + 2 < nch) gload((c + 2) * 16);
+    }
+    if (wave_on) {
+      const int st = c & 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int mrow = 4 * u + g4;
+        const float af = (kb + c16 < d) ? Ts[st][0][mrow][kb + c16] : 0.f;
+#pragma unroll
+        for (int b = 0; b < LB; ++b) {
+          const int l = b * 16 + c16;
+          accq[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, l < d ? Ts[st][1][mrow][min(l, d - 1)] : 0.f, accq[b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < LB; ++b) {
+          const int l = b * 16 + c16;
+          accv[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, l < d ? Ts[st][2][mrow][min(l, d - 1)] : 0.f, accv[b], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_on) return;
+  const float go = a.gout ? a.gout[0] : 1.f;
+  const size_t base = (size_t)p * d * d;
+  float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
+  if (NET) { gam = a.gamma[0]; dl = a.delta[p]; e = expf(-gam * dl); }
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int l = b * 16 + c16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int kk = kb + 4 * g4 + rr;
+      if (kk < d && l < d) {
+        const size_t idx = base + (size_t)kk * d + l;
+        const float gm = -accq[b][rr] * go, gd = accv[b][rr] * go;
+        if (NET) {
+          const float nmi = a.net[idx] - (kk == l ? 1.f : 0.f);
+          a.gM[idx] = (1.f - e) * gm + gam * e * gd;
+          a.gdM[idx] = (1.f - e) * gd;
+          part += gm * dl * e * nmi + gd * (e * (1.f - gam * dl) * nmi + dl * e * a.dnet[idx]);
+        } else {
+          a.gM[idx] = gm;
+          a.gdM[idx] = gd;
+        }
+      }
+    }
+  }
+  if (NET) {
+    part = wave_sum(part);
+    const int nb = (d + 15) >> 4;         // the caller's buffer has one slot per (pair, k-block, l-block)
+    if (lane < nb) a.ggamma_part[((size_t)p * nb + wave) * nb + lane] = lane == 0 ? part : 0.f;
+  }
+}
+
 // ---- column sums (bias gradients) ---------------------------------------------------------------------
 // out[c] = sum_r x[r][c] for a tall (R, C) row-major matrix: HBM-bound, one pass.  Stage 1: workgroup b sums the
 // rows b, b+nblk, ... (lanes along the columns: coalesced; 256/CW row lanes per workgroup) into partial[b][:];
@@ -1178,6 +1292,14 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
   a.d = d; a.K = K; a.B = B; a.G = G; a.q = q; a.v = v; a.gT = gT; a.gout = gout; a.gM = gM; a.gdM = gdM;
   a.net = net; a.dnet = dnet; a.delta = delta; a.gamma = gamma; a.ggamma_part = ggamma_part;
   const int64_t np = socmx_num_pairs(K);
+  static const bool bwd_regs = getenv("SOCMX_TARGET_BWD_REGS") != nullptr;       // A/B switch: register-only form
+  if (d > 16 && d <= 64 && d % 4 == 0 && !bwd_regs) {
+    // (reads of whole 16-byte pieces stay inside the rows because d % 4 == 0)
+    dim3 lgrid((unsigned)np);
+    if (net) hipLaunchKernelGGL(socm_target_bwd_lds_kernel<true>, lgrid, dim3(256), 0, (hipStream_t)stream, a);
+    else     hipLaunchKernelGGL(socm_target_bwd_lds_kernel<false>, lgrid, dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   if (d > 16) {
     const int nblk = (d + 15) / 16;
     const int lbw = nblk >= 4 ? 4 : 2;                               // l-blocks per wave
