@@ -409,6 +409,18 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
         "    sde, aux = build_sde(name, 'cuda:0')\n"
         "    r = utils.stochastic_trajectories(sde, aux['x0'].repeat(40, 1), aux['ts'], aux['lmbd'], seed=3, offset=1)\n"
         "    for i, t in enumerate(r): out[f'{name}_{i}'] = t.cpu().numpy()\n"
+        "# d = 64 with the default hidden widths: the second constexpr instantiation (dense sigma: general SDE step)\n"
+        "from socmx.config import load_config\n"
+        "from socmx.settings import define_variables\n"
+        "import contextlib, io\n"
+        "cfg = load_config(['method.setting=OU_linear', 'method.d=64', 'method.num_steps=12'])\n"
+        "cfg.method.device = 'cuda:0'\n"
+        "torch.manual_seed(0)\n"
+        "ts = torch.linspace(0, 1.0, 13).to('cuda:0')\n"
+        "with contextlib.redirect_stdout(io.StringIO()):\n"
+        "    x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)\n"
+        "r = utils.stochastic_trajectories(sde, x0.repeat(40, 1), ts, 1.0, seed=5, offset=2)\n"
+        "for i, t in enumerate(r): out[f'ou_linear_d64_{i}'] = t.cpu().numpy()\n"
         "np.savez(sys.argv[1], **out)\n")
     outs = []
     for tag, env in (("fast", {}), ("generic", {"SOCMX_GENERIC": "1", "SOCMX_NOFAST": "1"})):
