@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """Side-by-side CPU timing of the REFERENCE rollout and the oracle's rollout.
 
-Authoring-container tooling: imports /root/reference (never shipped).  Establishes that the oracle
+Test tooling for the authoring container (lives beside the fixture generator): imports /root/reference (never shipped).  Establishes that the oracle
 ("port" cpu_baseline of bench.py) costs what the reference costs on the same host, so that the number
 bench.py reports on the GPU box stands in for the reference's CPU path.
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/calibrate_cpu_baseline.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/calibrate_cpu_baseline.py
 """
 import os
 import statistics
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "golden")]
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, HERE]
 import torch
 
 import make_golden as G                       # the fixture generator's reference-import recipe
