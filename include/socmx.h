@@ -22,6 +22,8 @@
  *   socmx_socm_target_bwd_f32    autograd of the above w.r.t. M, dM/ds (nabla_V grad comes out of fwd)
  *   socmx_socm_target_{fwd,bwd}_net_f32   the same with SOC_matching/models.py:263-275 (SigmoidMLP.forward: the
  *                                 exp(-gamma (s-t)) blend of I and the network output) and its d/ds fused in
+ *   socmx_colsum_f32, socmx_relu_bwd_colsum_f32   autograd of the nn.Linear(+ReLU) layers of models.py:212-228,
+ *                                 253-257 on the trajectory / pair rows: bias gradient, ReLU backward
  *
  * Conventions
  *   - every function returns int: 0 = ok, < 0 = invalid argument (SOCMX_E_*), > 0 = hipError_t;
@@ -29,7 +31,8 @@
  *     (a hipStream_t passed as void*); safe to capture in a hipGraph;
  *   - every pointer marked "device" is caller-owned device memory (e.g. torch tensor storage),
  *     fp32, contiguous, row-major in the shape given; structs themselves live on the host;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant: no global mutable state (a few getenv() switches for A/B runs are read once per process:
+ *     SOCMX_GENERIC, SOCMX_NOFAST, SOCMX_WAVES, SOCMX_TARGET_WIDE_REGS, SOCMX_TARGET_BWD_REGS).
  *
  * Reference-side binding: see INTEGRATION.md (ctypes stub).
  */
