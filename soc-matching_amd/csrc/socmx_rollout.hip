@@ -83,7 +83,7 @@ __device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x,
     last_tick = now_;                                      \
   }
 
-struct DynamicNet {};  // descriptors come from the kernel arguments (any architecture)
+struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
 typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
 typedef StaticNet<80, 256, 128, 64, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
 
@@ -188,10 +188,16 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           else { acc_prof[slot] += now_ - last_sub; last_sub = now_; }
         }
       };
-      if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, hook);   // GV = nabla_V(t, x)
-      else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);
+      float gv = 0.f;                                                     // nabla_V[r][i] of this thread
+      if constexpr (kStatic && NET::outp == 16) {
+        unet_tile_forward_static<NW, NET>(a.packed, lds, carry, hook, &gv);      // last stage -> register, no barrier
+      } else {
+        if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, hook);   // GV = nabla_V(t, x)
+        else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);
+        if (act) gv = GV[r * tl.sg + i];
+      }
       if (act) {
-        const float u = lane_ok ? -GV[r * tl.sg + i] : 0.f;              // u = -sigma^T nabla_V, sigma = I
+        const float u = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
         const float eps = NZ[(k & 1) * 256 + r * 16 + i];                 // drawn during the previous step
         float bi;
         if (is_ou) {                                                      // b = A x

@@ -417,9 +417,13 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
 // `pre` holds this wave's first four GEMM-1 fragments on entry (if w.use_pre) and, on exit, the first four
 // fragments of the following stage's GEMM 1, requested BEFORE this stage's closing barrier.
 // Ends with a workgroup barrier (Y visible, inputs free to overwrite).
+// `to_reg` (split-K stages with a 16-wide output only): thread e < 256 keeps Y[e / 16][e % 16] in *to_reg instead of
+// writing the tile to LDS, and the closing barrier is dropped -- the caller consumes the value in the same thread
+// mapping (the fused SDE step: row = tid >> 4, component = tid & 15) and synchronises before LDS is reused.
 template <int NW, typename Hook>
 __device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const float* bias_lds, const StageDesc& sd,
-                                           const WaveWorkS& w, float* lds, float* scratch, Pre& pre, Hook hook) {
+                                           const WaveWorkS& w, float* lds, float* scratch, Pre& pre, Hook hook,
+                                           float* to_reg = nullptr) {
   const int lane = threadIdx.x & 63;
   // Settle the fragments the previous stage requested BEFORE this stage issues any load of its own: the wait
   // the compiler puts in front of this statement then only covers those (long since landed) loads; placed
@@ -475,6 +479,22 @@ __device__ __forceinline__ void unet_stage(const float* __restrict__ Wp, const f
     }
     pre = prefetch_fragments(Wp, sd.Ln, w, lane);
     __syncthreads();
+    if (to_reg) {                                   // outp == 16: element e = threadIdx.x, no LDS round trip
+      const int e = threadIdx.x;
+      if (e < 256) {
+        const int r = e >> 4, n = e & 15;
+        float v = bias_lds[L1.b_lds + n];
+        for (int p = 0; p < parts; ++p) v += P1[(p * 16 + r) * 16 + n];
+        v = relu_keep_nan(v);
+        if (has2) {
+          float v2 = bias_lds[L2.b_lds + n];
+          for (int p = 0; p < parts; ++p) v2 += P2[(p * 16 + r) * 16 + n];
+          v += v2;
+        }
+        *to_reg = v;
+      }
+      return;
+    }
     const float inv_outp = __builtin_amdgcn_rcpf((float)outp);
     for (int e = threadIdx.x; e < 16 * outp; e += NW * 64) {
       const int r = (int)(((float)e + 0.5f) * inv_outp), n = e - r * outp;  // e / outp without an integer divide
@@ -530,7 +550,8 @@ struct StaticNet {
 };
 
 template <int NW, class NET, int SI, typename Hook>
-__device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, float* lds, Pre& c, int wave, Hook hook) {
+__device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, float* lds, Pre& c, int wave, Hook hook,
+                                                  float* to_reg = nullptr) {
   constexpr UnetDesc u = NET::desc();
   constexpr TileLayout t = NET::layout(NW);
   constexpr StageDesc sd = unet_stage_desc(u, t, SI);
@@ -541,19 +562,22 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
   w.part = w0.part; w.parts = w0.parts; w.use_pre = w0.use_pre;
 #pragma unroll
   for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
-  unet_stage<NW>(Wp, lds + t.bias, sd, w, lds, lds + t.scratch, c, [&](int sub) { hook(16 + SI * 8 + sub); });
+  unet_stage<NW>(Wp, lds + t.bias, sd, w, lds, lds + t.scratch, c, [&](int sub) { hook(16 + SI * 8 + sub); }, to_reg);
   hook(SI + 1);
 }
 
+// gv_reg != nullptr (output width 16 only): the last stage hands nabla_V[tid >> 4][tid & 15] to thread tid < 256 in a
+// register instead of the GV tile (see unet_stage)
 template <int NW, class NET, typename Hook>
-__device__ __forceinline__ void unet_tile_forward_static(const float* __restrict__ Wp, float* lds, Pre& c, Hook hook) {
+__device__ __forceinline__ void unet_tile_forward_static(const float* __restrict__ Wp, float* lds, Pre& c, Hook hook,
+                                                         float* gv_reg = nullptr) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unet_stage_static<NW, NET, 0>(Wp, lds, c, wave, hook);
   unet_stage_static<NW, NET, 1>(Wp, lds, c, wave, hook);
   unet_stage_static<NW, NET, 2>(Wp, lds, c, wave, hook);
   unet_stage_static<NW, NET, 3>(Wp, lds, c, wave, hook);
   unet_stage_static<NW, NET, 4>(Wp, lds, c, wave, hook);
-  unet_stage_static<NW, NET, 5>(Wp, lds, c, wave, hook);
+  unet_stage_static<NW, NET, 5>(Wp, lds, c, wave, hook, NET::outp == 16 ? gv_reg : nullptr);
 }
 
 template <int NW, class NET>
