@@ -369,6 +369,50 @@ def test_full_size_properties_cfg3():
     np.testing.assert_allclose(_np(controls), _np(u_ref), rtol=1e-4, atol=1e-4)
 
 
+def test_full_size_loss_cfg3_against_the_dense_formulation():
+    """BASELINE config 3 at full size (K=200, B=128, Np=20,301 pairs): the whole SOCM loss of the product path (HIP
+    rollout buffers -> prep -> fused MFMA contraction -> residual; autograd through the two networks) against the
+    dense-GEMM torch formulation of the same restated math in fp64 on the device: objective and every parameter
+    gradient.  (The reference's own (Kp,Kp,B,d,d) form needs 2.1 GB per intermediate at this size.)"""
+    from SOC_matching.method import SOC_Solver
+    from socmx import loss as L
+    sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+    B, K, d = 128, aux["K"], aux["d"]
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=K, lmbd=aux["lmbd"], d=d, sigma=sde.sigma)
+    solver.noise_in = torch.randn(K, B, d, generator=torch.Generator().manual_seed(21)).to(DEV)
+    noise = solver.noise_in
+    out = solver.loss(B, algorithm="SOCM", use_warm_start=False, use_stopping_time=False)
+    obj_hip = out[0].item()
+    out[0].backward()
+    got = {k: p.grad.double().clone() for k, p in sde.named_parameters()}
+    for p in sde.parameters():
+        p.grad = None
+    # fp64 dense reference from the same trajectories (re-run with the same injected noise: deterministic)
+    from SOC_matching import utils
+    states, noises, _, _, lpd, lps, ltw, controls = utils.stochastic_trajectories(
+        sde, aux["x0"].repeat(B, 1), aux["ts"], aux["lmbd"], noise_in=noise)
+    del out                                          # (parameters stay fp32; the contraction below runs in fp64)
+    ts = aux["ts"].to(DEV)
+    w = torch.exp(lpd + lps + ltw).double()
+    tx = torch.cat([ts.reshape(-1, 1, 1).expand(K + 1, B, 1), states], -1).reshape(-1, d + 1)
+    nabla_V = sde.nabla_V(tx).reshape(K + 1, B, d).double()
+    t_vec, s_vec, _, _ = L.pair_times(ts, aux["T"], K)
+    M, dM = sde.M.forward_with_ds(t_vec, s_vec)
+    pb64 = sde.problem.to(DEV)
+    pb64 = type(pb64)(pb64.kind, pb64.d, **{k: (v.double() if v is not None else None) for k, v in pb64.tensors().items()})
+    v, q, gT = L.socm_operands(pb64, ts.double(), aux["lmbd"], states.double(), noises.double(), controls.double())
+    ref, _ = L.target_residual_torch(pb64, K, M.double(), dM.double(), q, v, gT, nabla_V, w, 1.0 / ((K + 1) * B))
+    np.testing.assert_allclose(obj_hip, ref.item(), rtol=2e-5)
+    ref.backward()
+    num = den = 0.0
+    for k, p in sde.named_parameters():
+        if p.grad is None:
+            continue
+        num += float(((got[k] - p.grad.double()) ** 2).sum())
+        den += float((p.grad.double() ** 2).sum())
+    assert (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+
+
 def test_eval_burst_single_launch_matches_looped_statistics():
     """f1: control_objective / normalization_constant as one fused launch vs the reference-style loop
     (statistical agreement: different noise streams)."""
