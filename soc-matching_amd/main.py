@@ -101,6 +101,9 @@ def run(cfg):
                     weight_std=step["weight_std"])
         if compute_L2_error:
             vals["norm_sqd_diff"] = (out[1] / norm_before).detach()
+        for k in ("grad_norm_sqd", "EMA_grad_norm_sqd", "sqd_norm_EMA_grad"):      # main.py:408-410
+            if k in step:
+                info[k].append(step[k].detach())
         for k, v in vals.items():
             ema[k] = v if itr == 0 else compute_EMA(v, ema[k], EMA_coeff=0.01, itr=itr)
             info[k].append(v)

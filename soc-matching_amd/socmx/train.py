@@ -42,7 +42,8 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
-                 ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=True, overlap_M_backward=True):
+                 ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=True, overlap_M_backward=True,
+                 grad_telemetry=True):
         self.solver, self.optimizer = solver, optimizer
         self.batch_size = batch_size
         self.normalization_const = normalization_const
@@ -50,6 +51,9 @@ class Trainer:
         self.coeff = ema_weight_mean_coeff
         self.itr = 0
         self.sync_timing = sync_timing
+        self.grad_telemetry = grad_telemetry     # main.py:325-345 bookkeeping (part of the reference's timed iteration)
+        self._ema_grad = None
+        self._ema_grad_norm_sqd = None
         if gemm_select and solver.x0.is_cuda:
             from . import gemm_select as _gs
             _gs.enable()          # pick the fastest library GEMM per shape (see gemm_select.py)
@@ -61,6 +65,28 @@ class Trainer:
         ids_M = {id(p) for p in sde.M.parameters()} | {id(sde.gamma)} if self.defer_M else set()
         self._groups_side = [g for g in optimizer.param_groups if all(id(p) in ids_M for p in g["params"])]
         self._groups_main = [g for g in optimizer.param_groups if not all(id(p) in ids_M for p in g["params"])]
+
+    @torch.no_grad()
+    def _grad_telemetry(self):
+        """main.py:325-345, inside the timed region like there: squared norm of the nabla_V gradient, its EMA, and the
+        squared norm of the EMA of the gradient -- as multi-tensor ops (about ten launches instead of ~160)."""
+        grads = [p.grad for p in self.solver.neural_sde.nabla_V.parameters() if p.grad is not None]
+        if not grads:
+            return {}
+        sq = lambda ts: torch.stack(torch._foreach_norm(ts)).square().sum()
+        grad_norm_sqd = sq(grads)
+        itr, c = self.itr, 0.01                              # EMA_coeff of main.py:102
+        if itr == 0 or self._ema_grad is None:
+            self._ema_grad = grads                           # like the reference: the first EMA IS the first gradient
+            self._ema_grad_norm_sqd = grad_norm_sqd
+        else:
+            warm = int(np.floor(1 / c))
+            a, b = (itr / (itr + 1), 1.0 / (itr + 1)) if itr <= warm else (1 - c, c)     # compute_EMA, utils.py:389-396
+            torch._foreach_mul_(self._ema_grad, a)
+            torch._foreach_add_(self._ema_grad, grads, alpha=b)
+            self._ema_grad_norm_sqd = compute_EMA(grad_norm_sqd, self._ema_grad_norm_sqd, EMA_coeff=c, itr=itr)
+        return dict(grad_norm_sqd=grad_norm_sqd, EMA_grad_norm_sqd=self._ema_grad_norm_sqd,
+                    sqd_norm_EMA_grad=sq(self._ema_grad))
 
     def join(self):
         """Make the current stream wait for the second stream's pending M-network update.  Needed only by code that
@@ -90,8 +116,14 @@ class Trainer:
         net, dnet, net_cut, dnet_cut = pending
         done = torch.cuda.Event()
         done.record(main)
+        telemetry = {}
         with torch.cuda.stream(side), torch.no_grad():
             side.wait_event(done)
+            if self.grad_telemetry:       # reads the nabla_V gradients only: off the main stream's critical path
+                for p_ in solver.neural_sde.nabla_V.parameters():
+                    if p_.grad is not None:
+                        p_.grad.record_stream(side)
+                telemetry = self._grad_telemetry()
             grads = [net_cut.grad, dnet_cut.grad]
             for g in grads:
                 g.record_stream(side)
@@ -102,6 +134,7 @@ class Trainer:
                     if p.grad is not None:
                         p.grad.record_stream(side)       # gamma's gradient was produced on the main stream
             self._step_groups(self._groups_side)
+        return telemetry
 
     def step(self, **loss_kwargs):
         solver = self.solver
@@ -130,10 +163,13 @@ class Trainer:
         else:
             loss_val = loss.detach()
         pending = solver.__dict__.pop("_pending_M", None)
+        telemetry = {}
+        if self.grad_telemetry and pending is None:
+            telemetry = self._grad_telemetry()
         with torch.no_grad():
             if pending is not None:
                 self._step_groups(self._groups_main)                     # nabla_V: needed by the next rollout
-                self._finish_M_on_side_stream(pending, dev)
+                telemetry = self._finish_M_on_side_stream(pending, dev)  # (gradient telemetry rides on that stream)
             else:
                 self.optimizer.step()                                    # main.py:347-349
             self.optimizer.zero_grad()
@@ -144,4 +180,4 @@ class Trainer:
                                                    EMA_coeff=self.coeff, itr=self.itr)   # main.py:354-359
         self.itr += 1
         return dict(loss=loss_val, time_per_iteration=time_per_iteration, weight_mean=weight_mean.detach(),
-                    weight_std=out[6].detach(), out=out)
+                    weight_std=out[6].detach(), out=out, **telemetry)

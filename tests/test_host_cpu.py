@@ -185,3 +185,32 @@ def test_unknown_algorithm_fails_loudly():
                         sigma=sde.sigma)
     with pytest.raises(NotImplementedError):
         solver.loss(4, algorithm="SOCM_typo")
+
+
+def test_trainer_gradient_telemetry_follows_the_reference_bookkeeping():
+    """Trainer.step reports grad_norm_sqd / EMA_grad_norm_sqd / sqd_norm_EMA_grad exactly as main.py:325-345 computes
+    them (per-parameter norms, compute_EMA on every gradient), here re-derived with plain per-tensor ops."""
+    from SOC_matching.method import SOC_Solver
+    from socmx.train import Trainer, make_optimizer, compute_EMA
+    sde, aux = build_sde("tiny_ou_linear_d6", "cpu")
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
+    opt = make_optimizer(solver, M_lr=1e-3)
+    tr = Trainer(solver, opt, aux["B"], sync_timing=False)
+    ema_grad = ema_norm = None
+    for itr in range(4):
+        seen = {}
+        hook = opt.register_step_pre_hook(lambda *_: seen.update(
+            g=[p.grad.detach().clone() for p in sde.nabla_V.parameters()]))
+        solver.noise_in = torch.randn(aux["K"], aux["B"], aux["d"], generator=torch.Generator().manual_seed(itr))
+        step = tr.step()
+        hook.remove()
+        grad = seen["g"]
+        gns = sum(torch.norm(g) ** 2 for g in grad)
+        if itr == 0:
+            ema_grad, ema_norm = grad, gns
+        else:
+            ema_grad = [compute_EMA(g, e, EMA_coeff=0.01, itr=itr) for g, e in zip(grad, ema_grad)]
+            ema_norm = compute_EMA(gns, ema_norm, EMA_coeff=0.01, itr=itr)
+        np.testing.assert_allclose(step["grad_norm_sqd"].item(), gns.item(), rtol=1e-5)
+        np.testing.assert_allclose(step["EMA_grad_norm_sqd"].item(), ema_norm.item(), rtol=1e-5)
+        np.testing.assert_allclose(step["sqd_norm_EMA_grad"].item(), sum(torch.norm(e) ** 2 for e in ema_grad).item(), rtol=1e-5)
