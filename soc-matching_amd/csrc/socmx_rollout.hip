@@ -61,7 +61,8 @@ struct RolloutArgs {
   float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
   int sigma_identity;  // problem->flags & SOCMX_SIGMA_IDENTITY
   int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
-  long long* prof;  // diagnostics only (PROF variant): [blocks][12] accumulated s_memtime cycles per phase
+  long long* prof;  // diagnostics only (PROF variant): [blocks][64] accumulated s_memtime cycles per phase
+  int prof_wave;    // which wave's view is recorded (SOCMX_PROF_WAVE, default 0)
 };
 
 // drift b_i(x) -- OU_quadratic.py:51-52, OU_linear.py:43-44, double_well.py:44-48, molecular_dynamics.py:49-53
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       if (producer) NZ[((k + 1) & 1) * 256 + pr * 16 + pi] = draw(k + 1);
       SOCMX_TICK(9)
     }
-    if (PROF && tid == 0 && a.prof)
+    if (PROF && tid == a.prof_wave * 64 && a.prof)
       for (int s = 0; s < 64; ++s) a.prof[(size_t)blockIdx.x * 64 + s] = acc_prof[s];
     if (act) {                                                            // terminal cost (utils.py:101)
       float gval = 0.f;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     __syncthreads();
     SOCMX_TICK(9)
   }
-  if (PROF && tid == 0 && a.prof)
+  if (PROF && tid == a.prof_wave * 64 && a.prof)
     for (int s = 0; s < 64; ++s) a.prof[(size_t)blockIdx.x * 64 + s] = acc_prof[s];
 
   // ---- terminal cost (utils.py:101) --------------------------------------------------------
@@ -686,6 +687,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.states = states; a.noises = noises; a.controls = controls; a.stop_ind = stop_indicators;
   a.frac = fractional_timesteps; a.lpd = lpd; a.lps = lps; a.ltw = ltw;
   a.prof = prof;
+  { const char* e = getenv("SOCMX_PROF_WAVE"); a.prof_wave = (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }
   a.lds_mats = (a.t.floats + 3) & ~3;
   const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * (d + 1) + 6 * 16 * (size_t)d + 48 + 512;
   const size_t lds_bytes = lds_floats * sizeof(float);
