@@ -312,9 +312,15 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
     for (int s = 0; s < PD; ++s) {
       const f32x4 bx_next = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 1, last) * 16);
       mfma_chunk<NB>(acc, r.slot[s], bx);
-      const int nk = min(kc + s + PD, last);
+      // Refill the slot just consumed with chunk kc+s+PD (nothing to fetch past the end of the GEMM).  The scheduling
+      // barriers keep the loads HERE: left alone, the scheduler sinks them towards their use and the ring that
+      // should hold PD chunks in flight ends up ~2 deep (s_waitcnt vmcnt(2..3) in front of the MFMAs).
+      __builtin_amdgcn_sched_barrier(0);
+      if (kc + s + PD <= last) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)nk * 64];
+        for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)(kc + s + PD) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       bx = bx_next;
     }
   }
