@@ -568,7 +568,31 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
   w.part = w0.part; w.parts = w0.parts; w.use_pre = w0.use_pre;
 #pragma unroll
   for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
-  unet_stage<NW>(Wp, lds + t.bias, sd, w, lds, lds + t.scratch, c, [&](int sub) { hook(16 + SI * 8 + sub); }, to_reg);
+  constexpr int NBLK = sd.L1.out_pad >> 4;
+  constexpr WaveWork wref = wave_work_of(sd, NW, 0);
+  // every active wave owns the same number of neuron blocks: instantiate exactly that stage_direct<NB> (the generic
+  // stage keeps all four NB variants alive behind a runtime switch on w.cnt -- three quarters of its code is dead)
+  constexpr bool uniform = !wref.split && ((NBLK >= NW && NBLK % NW == 0 && NBLK / NW <= 4 && NBLK / NW != 3) ||
+                                           (NBLK < NW));
+  if constexpr (uniform) {
+    constexpr int NBc = NBLK >= NW ? NBLK / NW : 1;
+    constexpr int nact = NBLK >= NW ? NW : NBLK;
+    const int lane = threadIdx.x & 63;
+    auto sub = [&](int x) { hook(16 + SI * 8 + x); };
+    sub(5);
+    asm volatile("" : "+v"(c.f[0]), "+v"(c.f[1]), "+v"(c.f[2]), "+v"(c.f[3]));
+    asm volatile("" : "+v"(c.f[4]), "+v"(c.f[5]), "+v"(c.f[6]), "+v"(c.f[7]));
+    sub(6);
+    if (wave < nact)
+      stage_direct<NBc, NW>(Wp, lds + t.bias, sd.L1, lds + sd.x1, sd.s1, sd.has2 != 0, sd.L2, lds + sd.x2, sd.s2,
+                            lds + sd.y, sd.sy, wave, lane, c, w.use_pre != 0, sub);
+    c = prefetch_fragments(Wp, sd.Ln, w, lane);
+    sub(3);
+    __syncthreads();
+    sub(4);
+  } else {
+    unet_stage<NW>(Wp, lds + t.bias, sd, w, lds, lds + t.scratch, c, [&](int sub) { hook(16 + SI * 8 + sub); }, to_reg);
+  }
   hook(SI + 1);
 }
 
