@@ -561,15 +561,14 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
   constexpr UnetDesc u = NET::desc();
   constexpr TileLayout t = NET::layout(NW);
   constexpr StageDesc sd = unet_stage_desc(u, t, SI);
-  const WaveWork w0 = wave_work_of(sd, NW, wave);
-  WaveWorkS w;
-  w.split = w0.split; w.blk0 = w0.blk0; w.cnt = w0.cnt; w.active = w0.active;
-  w.kc0a = w0.kc0a; w.kc1a = w0.kc1a; w.kc0b = w0.kc0b; w.kc1b = w0.kc1b;
-  w.part = w0.part; w.parts = w0.parts; w.use_pre = w0.use_pre;
-#pragma unroll
-  for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
   constexpr int NBLK = sd.L1.out_pad >> 4;
   constexpr WaveWork wref = wave_work_of(sd, NW, 0);
+  // the stage that follows (its GEMM 1 is this stage's Ln): is its work split the uniform direct one as well?
+  constexpr StageDesc sdn = unet_stage_desc(u, t, (SI + 1) % 6);
+  constexpr int NBLKn = sdn.L1.out_pad >> 4, KCn = sdn.L1.in_pad >> 4;
+  constexpr WaveWork wrefn = wave_work_of(sdn, NW, 0);
+  constexpr bool uniform_next = !wrefn.split && ((NBLKn >= NW && NBLKn % NW == 0 && NBLKn / NW <= 4 && NBLKn / NW != 3) ||
+                                                 (NBLKn < NW));
   // every active wave owns the same number of neuron blocks: instantiate exactly that stage_direct<NB> (the generic
   // stage keeps all four NB variants alive behind a runtime switch on w.cnt -- three quarters of its code is dead)
   constexpr bool uniform = !wref.split && ((NBLK >= NW && NBLK % NW == 0 && NBLK / NW <= 4 && NBLK / NW != 3) ||
@@ -585,12 +584,37 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
     sub(6);
     if (wave < nact)
       stage_direct<NBc, NW>(Wp, lds + t.bias, sd.L1, lds + sd.x1, sd.s1, sd.has2 != 0, sd.L2, lds + sd.x2, sd.s2,
-                            lds + sd.y, sd.sy, wave, lane, c, w.use_pre != 0, sub);
-    c = prefetch_fragments(Wp, sd.Ln, w, lane);
+                            lds + sd.y, sd.sy, wave, lane, c, true, sub);
+    if constexpr (uniform_next) {
+      // first ring of the next stage's GEMM 1 for this wave: fragment (block wave + (f % nb) NW, chunk f / nb) -- the
+      // numbering of first_fragment_numbers() with every term but the wave id folded into an immediate
+      constexpr int nbn = NBLKn >= NW ? NBLKn / NW : 1;
+      const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + sdn.L1.w_off) + lane;
+      const int wb = min(wave, NBLKn - 1) * KCn;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int kc = (f / nbn) < KCn ? (f / nbn) : KCn - 1;
+        const int boff = ((f % nbn) * NW) * KCn;
+        c.f[f] = wl[(size_t)(wb + boff + kc) * 64];
+      }
+    } else {
+      const WaveWork w0 = wave_work_of(sd, NW, wave);
+      WaveWorkS w{};
+#pragma unroll
+      for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
+      c = prefetch_fragments(Wp, sd.Ln, w, lane);
+    }
     sub(3);
     __syncthreads();
     sub(4);
   } else {
+    const WaveWork w0 = wave_work_of(sd, NW, wave);
+    WaveWorkS w;
+    w.split = w0.split; w.blk0 = w0.blk0; w.cnt = w0.cnt; w.active = w0.active;
+    w.kc0a = w0.kc0a; w.kc1a = w0.kc1a; w.kc0b = w0.kc0b; w.kc1b = w0.kc1b;
+    w.part = w0.part; w.parts = w0.parts; w.use_pre = w0.use_pre;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
     unet_stage<NW>(Wp, lds + t.bias, sd, w, lds, lds + t.scratch, c, [&](int sub) { hook(16 + SI * 8 + sub); }, to_reg);
   }
   hook(SI + 1);
