@@ -306,11 +306,13 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
   constexpr int PD = Ring<NB>::PD;
   const int last = p.kc1 - 1;
   int kc = p.kc0;
+  // activations (B operand) are read from LDS two chunks ahead of their MFMAs
   f32x4 bx = *reinterpret_cast<const f32x4*>(p.xrow + min(kc, last) * 16);
+  f32x4 bx_next = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + 1, last) * 16);
   for (; kc + PD <= p.kc1; kc += PD) {
 #pragma unroll
     for (int s = 0; s < PD; ++s) {
-      const f32x4 bx_next = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 1, last) * 16);
+      const f32x4 bx_next2 = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 2, last) * 16);
       mfma_chunk<NB>(acc, r.slot[s], bx);
       // Refill the slot just consumed with chunk kc+s+PD (nothing to fetch past the end of the GEMM).  The scheduling
       // barriers keep the loads HERE: left alone, the scheduler sinks them towards their use and the ring that
@@ -322,15 +324,17 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
       }
       __builtin_amdgcn_sched_barrier(0);
       bx = bx_next;
+      bx_next = bx_next2;
     }
   }
   // tail: fewer than PD chunks left; they already sit in slots 0..rem-1
 #pragma unroll
   for (int s = 0; s < PD - 1; ++s) {
     if (kc + s < p.kc1) {
-      const f32x4 bx_next = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 1, last) * 16);
+      const f32x4 bx_next2 = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 2, last) * 16);
       mfma_chunk<NB>(acc, r.slot[s], bx);
       bx = bx_next;
+      bx_next = bx_next2;
     }
   }
 }
