@@ -149,8 +149,16 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     const int grow = tile_row0 + r;
     const bool store = lane_ok && grow < B;
     const size_t rowoff = (size_t)grow * d + i;
+    // sum over the 16 lanes of a row group with DPP moves (quad swaps, half-row mirror, row mirror): every lane ends
+    // with the total, no trip through the LDS crossbar as with ds_bpermute (__shfl_xor)
     auto gsum = [](float v) {
-      v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+      auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+      };
+      v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+      v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+      v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+      v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
       return v;
     };
     float x = lane_ok ? a.x0[(size_t)min(grow, B - 1) * d + i] : 0.f;
