@@ -301,7 +301,10 @@ __device__ __forceinline__ void ring_fill(Ring<NB>& r, const GemmPlan<NB>& p, co
   }
 }
 
-template <int NB>
+// PINNED (the constexpr-specialised stages, fully unrolled): refill loads fenced by scheduling barriers and skipped
+// past the end of the GEMM.  The table-driven stages keep rolled loops with runtime bounds, where the fences and the
+// extra branch cost more than they give (3.78 -> 4.00 ms on cfg3): they re-request the last chunk instead.
+template <int NB, bool PINNED = false>
 __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const GemmPlan<NB>& p) {
   constexpr int PD = Ring<NB>::PD;
   const int last = p.kc1 - 1;
@@ -317,12 +320,18 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
       // Refill the slot just consumed with chunk kc+s+PD (nothing to fetch past the end of the GEMM).  The scheduling
       // barriers keep the loads HERE: left alone, the scheduler sinks them towards their use and the ring that
       // should hold PD chunks in flight ends up ~2 deep (s_waitcnt vmcnt(2..3) in front of the MFMAs).
-      __builtin_amdgcn_sched_barrier(0);
-      if (kc + s + PD <= last) {
+      if constexpr (PINNED) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + s + PD <= last) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)(kc + s + PD) * 64];
+          for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)(kc + s + PD) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        const int nk = min(kc + s + PD, last);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)nk * 64];
       }
-      __builtin_amdgcn_sched_barrier(0);
       bx = bx_next;
       bx_next = bx_next2;
     }
@@ -387,7 +396,7 @@ __device__ __forceinline__ Pre prefetch_fragments(const float* __restrict__ Wp, 
   return pre;
 }
 
-template <int NB, int NW, typename Hook>
+template <int NB, int NW, typename Hook, bool PINNED = false>
 __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const float* bias_lds,
                                              const LayerDesc& L1, const float* X1, int S1, bool has2,
                                              const LayerDesc& L2, const float* X2, int S2, float* Y, int SY,
@@ -404,7 +413,7 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
     acc[j] = *reinterpret_cast<const f32x4*>(bias_lds + L1.b_lds + (blk0 + j * NW) * 16 + 4 * g);
   }
   hook(0);
-  gemm_run<NB>(acc, r1, p1);
+  gemm_run<NB, PINNED>(acc, r1, p1);
   hook(1);
 #pragma unroll
   for (int j = 0; j < NB; ++j)
@@ -415,7 +424,7 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
     for (int j = 0; j < NB; ++j) {
       acc[j] += *reinterpret_cast<const f32x4*>(bias_lds + L2.b_lds + (blk0 + j * NW) * 16 + 4 * g);
     }
-    gemm_run<NB>(acc, r2, p2);
+    gemm_run<NB, PINNED>(acc, r2, p2);
   }
   hook(2);
 #pragma unroll
@@ -595,8 +604,8 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
     asm volatile("" : "+v"(c.f[4]), "+v"(c.f[5]), "+v"(c.f[6]), "+v"(c.f[7]));
     sub(6);
     if (wave < nact)
-      stage_direct<NBc, NW>(Wp, lds + t.bias, sd.L1, lds + sd.x1, sd.s1, sd.has2 != 0, sd.L2, lds + sd.x2, sd.s2,
-                            lds + sd.y, sd.sy, wave, lane, c, true, sub);
+      stage_direct<NBc, NW, decltype(sub), true>(Wp, lds + t.bias, sd.L1, lds + sd.x1, sd.s1, sd.has2 != 0, sd.L2,
+                                                 lds + sd.x2, sd.s2, lds + sd.y, sd.sy, wave, lane, c, true, sub);
     if constexpr (uniform_next) {
       // first ring of the next stage's GEMM 1 for this wave: fragment (block wave + (f % nb) NW, chunk f / nb) -- the
       // numbering of first_fragment_numbers() with every term but the wave id folded into an immediate
