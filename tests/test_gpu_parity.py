@@ -539,3 +539,29 @@ def test_main_trains_on_the_gpu(tmp_path, overrides):
     assert "nan" not in res.stdout.lower(), res.stdout[-3000:]
     folders = [p for p in (tmp_path / "outputs" / "runs").iterdir() if p.is_dir()]
     assert len(folders) == 1 and (folders[0] / "last.pkl").exists()
+
+
+def test_the_integration_stub_in_the_docs_runs(monkeypatch):
+    """the ctypes stub a reference maintainer would paste is executed verbatim (struct layouts,
+    argument order) and must reproduce this package's own rollout for the same Philox key."""
+    import re
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "socmx_rollout_f32" in b][0]
+    monkeypatch.chdir(root)                                  # the stub opens the library by its in-tree relative path
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+    net = sde.nabla_V
+    shim = types.SimpleNamespace(sigma=sde.sigma.contiguous(), kappa=sde.problem.kappa.contiguous(),
+                                 nu=sde.problem.nu.contiguous(), hdims=net.hdims, _calls=7,
+                                 _packed=ns["pack"](net, aux["d"], net.hdims))
+    x0 = aux["x0"].repeat(32, 1).contiguous()
+    ts = aux["ts"].to(DEV).contiguous()
+    torch.manual_seed(123)
+    got = ns["stochastic_trajectories"](shim, x0, ts, aux["lmbd"])
+    from socmx import rollout as R
+    want = R.hip_trajectories(sde, x0, ts, aux["lmbd"], seed=123, offset=7)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
