@@ -465,6 +465,17 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
         "    x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)\n"
         "r = utils.stochastic_trajectories(sde, x0.repeat(40, 1), ts, 1.0, seed=5, offset=2)\n"
         "for i, t in enumerate(r): out[f'ou_linear_d64_{i}'] = t.cpu().numpy()\n"
+        "# molecular_dynamics with the default widths: the specialised kernel's STOPPING variant (Phi = -x_0)\n"
+        "cfg = load_config(['method.setting=molecular_dynamics', 'method.d=2', 'method.num_steps=40', 'method.T=2.0',\n"
+        "                   'method.lmbd=2.0', 'method.use_stopping_time=True'])\n"
+        "cfg.method.device = 'cuda:0'\n"
+        "torch.manual_seed(0)\n"
+        "ts = torch.linspace(0, 2.0, 41).to('cuda:0')\n"
+        "with contextlib.redirect_stdout(io.StringIO()):\n"
+        "    x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)\n"
+        "r = utils.stochastic_trajectories(sde, x0.repeat(48, 1), ts, 2.0, seed=9, offset=3)\n"
+        "assert float(r[2].min()) == 0.0 and float(r[2].max()) == 1.0, 'want both stopped and running rows'\n"
+        "for i, t in enumerate(r): out[f'md_d2_{i}'] = t.cpu().numpy()\n"
         "np.savez(sys.argv[1], **out)\n")
     outs = []
     for tag, env in (("fast", {}), ("generic", {"SOCMX_GENERIC": "1", "SOCMX_NOFAST": "1"})):
