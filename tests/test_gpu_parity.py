@@ -576,3 +576,36 @@ def test_the_integration_stub_in_the_docs_runs(monkeypatch):
     want = R.hip_trajectories(sde, x0, ts, aux["lmbd"], seed=123, offset=7)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("setting,d,extra", [
+    ("OU_quadratic_hard", 20, []), ("OU_quadratic_easy", 33, []), ("double_well", 24, []),
+    ("molecular_dynamics", 17, ["method.use_stopping_time=True", "method.T=2.0", "method.lmbd=2.0"]),
+    ("OU_linear", 16, []),
+])
+def test_rollout_large_d_settings_vs_eager_path(setting, d, extra):
+    """d >= 16 for the settings no reference fixture covers at that size (general SDE step: MFMA products with LDS
+    operands, per-row cost loops): the HIP kernel against the device-agnostic eager path -- itself pinned by the
+    reference fixtures on the CPU -- on the same injected noise."""
+    import contextlib, io
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from socmx import rollout as R
+    K, B = (12 if setting.startswith("OU") else 100), 21       # the cubic drift needs a small step to stay bounded
+    cfg = load_config([f"method.setting={setting}", f"method.d={d}", f"method.num_steps={K}", "arch.hdims=[48,32,16]"]
+                      + extra)
+    cfg.method.device = DEV
+    torch.manual_seed(4)
+    T = float(cfg.method.T)
+    ts = torch.linspace(0, T, K + 1).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)
+    lmbd = float(cfg.method.lmbd)
+    noise = torch.randn(K, B, d, generator=torch.Generator().manual_seed(8)).to(DEV)
+    state0 = x0.repeat(B, 1)
+    got = R.hip_trajectories(sde, state0, ts, lmbd, noise_in=noise)
+    with torch.no_grad():
+        want = R.eager_trajectories(sde, state0, ts, lmbd, noise_in=noise)
+    names = ["states", "noises", "stop_indicators", "fractional_timesteps", "lpd", "lps", "ltw", "controls"]
+    for n, a, b in zip(names, got, want):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-4, atol=2e-4, err_msg=n)
