@@ -221,7 +221,7 @@ int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* 
  * Column sums of a tall row-major (R, C) matrix: out[c] = sum_r x[r][c].  Bias gradients of the nn.Linear layers
  * (models.py:212-228, 253-257) over the (K+1)*B trajectory rows / the Np pair rows; no reference counterpart beyond
  * autograd's reduction.  partial is a caller-owned workspace of socmx_colsum_blocks(R, C) * C floats; the result
- * is deterministic (fixed summation order).
+ * is deterministic (fixed summation order).  out == NULL: leave the partials for socmx_linear_bwd_finish_f32.
  */
 int32_t socmx_colsum_blocks(int64_t R, int32_t C);
 int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* partial, float* out, socmx_stream_t stream);
@@ -230,6 +230,14 @@ int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* partial, float
  * gz = gy * (y > 0) with y the layer's ReLU output, out[c] = sum_r gz[r][c].  gz must not alias gy. */
 int socmx_relu_bwd_colsum_f32(const float* gy, const float* y, int64_t R, int32_t C, float* gz, float* partial,
                               float* out, socmx_stream_t stream);
+
+/*
+ * Finishes the backward of one nn.Linear over many rows in ONE launch: gw (N = out*in) = tail (nullable) + the sum of
+ * the S split-K slabs gw_parts (S, N) of the weight gradient, and gb (C) = the sum of the nblk column-sum partials
+ * that socmx_colsum_f32 / socmx_relu_bwd_colsum_f32 leave in `partial` when called with out == NULL.
+ */
+int socmx_linear_bwd_finish_f32(const float* gw_parts, int32_t S, int64_t N, const float* tail, float* gw,
+                                const float* partial, int32_t nblk, int32_t C, float* gb, socmx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1145,6 +1145,41 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+// One launch finishes a Linear layer's backward: blocks [0, nb1) add the S split-K slabs of the weight gradient
+// (+ the optional tail GEMM's contribution), the remaining blocks add the nblk column-sum partials of the bias
+// gradient (same fixed order as colsum_final_kernel).
+__global__ __launch_bounds__(256) void linear_bwd_finish_kernel(const float* __restrict__ parts, int S, int64_t N,
+                                                                const float* __restrict__ tail, float* __restrict__ gw,
+                                                                const float* __restrict__ partial, int nblk, int C,
+                                                                float* __restrict__ gb, int nb1) {
+  __shared__ float red[256];
+  if ((int)blockIdx.x < nb1) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N) return;
+    float s = tail ? tail[idx] : 0.f;
+    for (int p = 0; p < S; ++p) s += parts[(size_t)p * N + idx];
+    gw[idx] = s;
+    return;
+  }
+  const int c = ((int)blockIdx.x - nb1) * 16 + (threadIdx.x & 15), bl = threadIdx.x >> 4;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int b = bl;
+    for (; b + 16 < nblk; b += 32) {
+      a0 += partial[(size_t)b * C + c];
+      a1 += partial[(size_t)(b + 16) * C + c];
+    }
+    if (b < nblk) a0 += partial[(size_t)b * C + c];
+  }
+  red[threadIdx.x] = a0 + a1;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    float s = red[threadIdx.x];
+    for (int k = 1; k < 16; ++k) s += red[k * 16 + threadIdx.x];
+    gb[c] = s;
+  }
+}
+
 }  // namespace socmx
 
 // =================================================================================================
@@ -1348,7 +1383,7 @@ extern "C" int32_t socmx_colsum_blocks(int64_t R, int32_t C) {
 
 extern "C" int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* partial, float* out,
                                 socmx_stream_t stream) {
-  if (!x || !partial || !out) return SOCMX_E_NULL;
+  if (!x || !partial) return SOCMX_E_NULL;
   if (R < 1 || C < 1) return SOCMX_E_DIM;
   const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
   const int nblk = socmx_colsum_blocks(R, C);
@@ -1356,6 +1391,7 @@ extern "C" int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* par
                      R, (int)C, cw, partial);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
+  if (!out) return 0;                     // partials only: socmx_linear_bwd_finish_f32 adds them up
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                      (int)C, out);
   return (int)hipGetLastError();
@@ -1363,7 +1399,7 @@ extern "C" int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* par
 
 extern "C" int socmx_relu_bwd_colsum_f32(const float* gy, const float* y, int64_t R, int32_t C, float* gz,
                                          float* partial, float* out, socmx_stream_t stream) {
-  if (!gy || !y || !gz || !partial || !out) return SOCMX_E_NULL;
+  if (!gy || !y || !gz || !partial) return SOCMX_E_NULL;
   if (R < 1 || C < 1) return SOCMX_E_DIM;
   const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
   const int nblk = socmx_colsum_blocks(R, C);
@@ -1371,7 +1407,19 @@ extern "C" int socmx_relu_bwd_colsum_f32(const float* gy, const float* y, int64_
                      cw, partial);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return (int)err;
+  if (!out) return 0;
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                      (int)C, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int socmx_linear_bwd_finish_f32(const float* gw_parts, int32_t S, int64_t N, const float* tail, float* gw,
+                                           const float* partial, int32_t nblk, int32_t C, float* gb,
+                                           socmx_stream_t stream) {
+  if (!gw_parts || !gw || !partial || !gb) return SOCMX_E_NULL;
+  if (S < 1 || N < 1 || nblk < 1 || C < 1) return SOCMX_E_DIM;
+  const int nb1 = (int)((N + 255) / 256);
+  hipLaunchKernelGGL(linear_bwd_finish_kernel, dim3(nb1 + (C + 15) / 16), dim3(256), 0, (hipStream_t)stream, gw_parts,
+                     (int)S, N, tail, gw, partial, (int)nblk, (int)C, gb, nb1);
   return (int)hipGetLastError();
 }

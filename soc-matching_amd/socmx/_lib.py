@@ -59,6 +59,7 @@ PROTOTYPES = {
                                             _fp]),
     "socmx_colsum_blocks": (C.c_int32, [C.c_int64, C.c_int32]),
     "socmx_colsum_f32": (C.c_int, [_fp, C.c_int64, C.c_int32, _fp, _fp, _fp]),
+    "socmx_linear_bwd_finish_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_int32, C.c_int32, _fp, _fp]),
     "socmx_relu_bwd_colsum_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp]),
     "socmx_socm_target_fwd_net_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp,
                                                 _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp]),

@@ -48,6 +48,9 @@ class _LinearSplitK(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gy @ weight if ctx.needs_input_grad[0] else None
+        if gy.is_cuda and gy.dtype == torch.float32 and gy.shape[0] >= 4096 and x.is_contiguous():
+            _, gw, gb = _wgrad_bias_fused(gy, x)
+            return gx, gw, gb
         gb = _colsum(gy) if ctx.needs_input_grad[2] else None
         return gx, _wgrad_splitk(gy, x), gb
 
@@ -65,16 +68,9 @@ class _LinearReluSplitK(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        L = _lib.lib()
-        gy = gy.contiguous()
-        R, C = gy.shape
-        gz = torch.empty_like(gy)
-        partial = torch.empty(L.socmx_colsum_blocks(R, C) * C, dtype=torch.float32, device=gy.device)
-        gb = torch.empty(C, dtype=torch.float32, device=gy.device)
-        _lib.check(L.socmx_relu_bwd_colsum_f32(_lib.ptr(gy), _lib.ptr(y), R, C, _lib.ptr(gz), _lib.ptr(partial),
-                                               _lib.ptr(gb), _lib.stream_ptr(gy.device)), "socmx_relu_bwd_colsum_f32")
+        gz, gw, gb = _wgrad_bias_fused(gy.contiguous(), x, y=y)
         gx = gz @ weight if ctx.needs_input_grad[0] else None
-        return gx, _wgrad_splitk(gz, x), gb
+        return gx, gw, gb
 
 
 def _colsum(gy):
@@ -102,6 +98,33 @@ def _wgrad_splitk(gy, x, S=16):
     if main < R:
         gw = gw + gy[main:].t() @ x[main:]
     return gw
+
+
+def _wgrad_bias_fused(gz, x, y=None, S=16):
+    """(gz' , dW, db) of a Linear(+ReLU) layer over many GPU rows: column-sum partials (with the ReLU mask when `y` is
+    given), the split-K bmm, then ONE launch that adds the S weight-gradient slabs and the bias partials."""
+    L = _lib.lib()
+    R, C = gz.shape
+    dev = gz.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    nblk = L.socmx_colsum_blocks(R, C)
+    partial = torch.empty(nblk * C, **f32)
+    if y is not None:
+        gy, gz = gz, torch.empty_like(gz)
+        _lib.check(L.socmx_relu_bwd_colsum_f32(_lib.ptr(gy), _lib.ptr(y), R, C, _lib.ptr(gz), _lib.ptr(partial), None,
+                                               _lib.stream_ptr(dev)), "socmx_relu_bwd_colsum_f32")
+    else:
+        _lib.check(L.socmx_colsum_f32(_lib.ptr(gz), R, C, _lib.ptr(partial), None, _lib.stream_ptr(dev)),
+                   "socmx_colsum_f32")
+    main = (R // S) * S
+    parts = torch.bmm(gz[:main].view(S, main // S, -1).transpose(1, 2), x[:main].view(S, main // S, -1))
+    tail = (gz[main:].t() @ x[main:]).contiguous() if main < R else None
+    gw = torch.empty(C, x.shape[1], **f32)
+    gb = torch.empty(C, **f32)
+    _lib.check(L.socmx_linear_bwd_finish_f32(_lib.ptr(parts), S, gw.numel(), _lib.ptr(tail), _lib.ptr(gw),
+                                             _lib.ptr(partial), nblk, C, _lib.ptr(gb), _lib.stream_ptr(dev)),
+               "socmx_linear_bwd_finish_f32")
+    return gz, gw, gb
 
 
 def _linear(seq, x, splitk):
