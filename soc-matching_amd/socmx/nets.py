@@ -155,7 +155,6 @@ class FullyConnectedUNet(nn.Module):
         for name, _, _ in _UNET_SPEC:
             _scale_(getattr(self, name), scaling_factor)
         self._packed = None
-        self._packed_version = None
 
     def forward(self, x):
         # many rows on the GPU with gradients on: same math, split-K weight gradients (see _LinearSplitK)
@@ -168,9 +167,6 @@ class FullyConnectedUNet(nn.Module):
         return _linear(self.up_0, o1, sk) + _linear(self.res_0, x, sk)
 
     # ---- HIP side ---------------------------------------------------------------
-    def _version(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
-
     def c_struct(self):
         s = _lib.Unet(d=self.dim, hdims=_lib.i3(self.hdims))
         keep = []
@@ -184,23 +180,21 @@ class FullyConnectedUNet(nn.Module):
         return s, keep
 
     def packed(self):
-        """Fragment-ordered image of the current weights (re-packed when any parameter changed)."""
+        """Fragment-ordered image of the CURRENT weights.  Re-packed on every call (one ~3 us kernel per rollout): an
+        in-place update cannot be detected reliably -- torch's fused multi-tensor Adam does not bump the parameters'
+        `_version`, and a cached image silently kept the rollout on the initial weights."""
         L = _lib.lib()
-        ver = self._version()
-        if self._packed is None or self._packed_version != ver:
-            dev = next(self.parameters()).device
-            n = L.socmx_unet_packed_floats(self.dim, _lib.i3(self.hdims))
-            if self._packed is None or self._packed.numel() != n or self._packed.device != dev:
-                self._packed = torch.empty(n, dtype=torch.float32, device=dev)
-            s, keep = self.c_struct()
-            _lib.check(L.socmx_unet_pack_f32(s, _lib.ptr(self._packed), _lib.stream_ptr(dev)), "socmx_unet_pack_f32")
-            self._packed_version = ver
+        dev = next(self.parameters()).device
+        n = L.socmx_unet_packed_floats(self.dim, _lib.i3(self.hdims))
+        if self._packed is None or self._packed.numel() != n or self._packed.device != dev:
+            self._packed = torch.empty(n, dtype=torch.float32, device=dev)
+        s, keep = self.c_struct()
+        _lib.check(L.socmx_unet_pack_f32(s, _lib.ptr(self._packed), _lib.stream_ptr(dev)), "socmx_unet_pack_f32")
         return self._packed
 
     def __getstate__(self):  # keep the solver picklable (reference main.py:466 pickles the module)
         st = self.__dict__.copy()
         st["_packed"] = None
-        st["_packed_version"] = None
         return st
 
 

@@ -609,3 +609,30 @@ def test_rollout_large_d_settings_vs_eager_path(setting, d, extra):
     names = ["states", "noises", "stop_indicators", "fractional_timesteps", "lpd", "lps", "ltw", "controls"]
     for n, a, b in zip(names, got, want):
         np.testing.assert_allclose(_np(a), _np(b), rtol=2e-4, atol=2e-4, err_msg=n)
+
+
+def test_rollout_follows_the_optimizer(tmp_path):
+    """After optimizer steps (fused multi-tensor Adam updates the parameters without bumping their `_version`) the
+    rollout must integrate with the CURRENT weights: controls = -sigma^T nabla_V(t_k, X_k) of the updated module, and
+    the fragment image differs from the initial one.  (Regression: a cached image kept the initial weights.)"""
+    from SOC_matching.method import SOC_Solver
+    from SOC_matching import utils
+    from socmx.train import Trainer, make_optimizer
+    sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+    K, d, B = aux["K"], aux["d"], 32
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=K, lmbd=aux["lmbd"], d=d, sigma=sde.sigma)
+    opt = make_optimizer(solver, nabla_V_lr=1e-2, M_lr=1e-3)       # a large step: the change must be visible
+    tr = Trainer(solver, opt, B, sync_timing=False)
+    before = sde.nabla_V.packed().clone()
+    w_before = sde.nabla_V.down_1[0].weight.detach().clone()
+    for _ in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    assert float((sde.nabla_V.down_1[0].weight - w_before).abs().max()) > 1e-3
+    assert float((sde.nabla_V.packed() - before).abs().max()) > 1e-3
+    states, noises, _, _, _, _, _, controls = utils.stochastic_trajectories(
+        sde, aux["x0"].repeat(B, 1), aux["ts"], aux["lmbd"], seed=5, offset=0)
+    tx = torch.cat([aux["ts"].to(DEV)[:-1].reshape(-1, 1, 1).expand(K, B, 1), states[:-1]], -1).reshape(-1, d + 1)
+    with torch.no_grad():
+        u_ref = -(sde.nabla_V(tx).reshape(K, B, d) @ sde.sigma)
+    np.testing.assert_allclose(_np(controls), _np(u_ref), rtol=1e-4, atol=1e-4)
