@@ -12,7 +12,8 @@
  *                                 + experiment_settings/{OU_quadratic,OU_linear,double_well,
  *                                   molecular_dynamics}.py  b(), f(), g(), Phi()
  *   socmx_unet_pack_f32          (no counterpart: re-lays nn.Linear weights, models.py:212-228,
- *                                 into MFMA fragment order once per optimizer step)
+ *                                 into MFMA fragment order; needed whenever the weights changed -- the host package
+ *                                 re-packs before every rollout, ~3 us)
  *   socmx_unet_forward_f32       SOC_matching/method.py:272-278 (nabla_V on the trajectory rows)
  *   socmx_weights_stats_f32      SOC_matching/method.py:258-262, 903-904 (w, mean(w), std(w))
  *   socmx_socm_prep_f32          SOC_matching/method.py:591-646 operand preparation
