@@ -667,3 +667,13 @@ def test_training_improves_the_control_objective():
     m1, s1 = objective()
     assert m1 < m0 - 20 * (s0 + s1), (m0, m1)
     assert m1 > 0.55                     # cannot beat the optimal control
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("name", ["train_ou_quadratic_easy_d2", "train_double_well_d10"])
+def test_training_iterations_match_reference_on_gpu(name, overlap):
+    """The reference's training loop (fixtures from tests/golden/make_golden_train.py) replayed on the HIP path:
+    iteration n+1 must integrate with the weights iteration n produced -- losses, normaliser and final parameters."""
+    from test_host_cpu import run_training_fixture, check_training_fixture
+    sde, z, rec = run_training_fixture(name, DEV, overlap_M_backward=overlap, gemm_select=False)
+    check_training_fixture(sde, z, rec, rtol=1e-3)

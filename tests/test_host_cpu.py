@@ -11,7 +11,7 @@ from oracle import socm_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-             if not os.path.basename(p).startswith("dw_pde"))
+             if not os.path.basename(p).startswith(("dw_pde", "train_")))
 TINY = [n for n in ALL if n.startswith("tiny_")]
 LOSS = [n for n in TINY if not n.endswith("_stopping")]
 
@@ -26,7 +26,7 @@ def build_sde(name, device="cpu"):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     setting = str(z["meta_setting"])
     d, K, B, seed, stopping = [int(v) for v in z["meta"]]
-    T, lmbd, gamma, sfV, sfM = [float(v) for v in z["meta_f"]]
+    T, lmbd, gamma, sfV, sfM = [float(v) for v in z["meta_f"][:5]]
     c = lambda k: torch.from_numpy(z["const_" + k].copy()).to(device)
     common = dict(device=device, dim=d, hdims=[int(h) for h in z["hdims"]], hdims_M=[int(h) for h in z["hdims_M"]],
                   lmbd=lmbd, sigma=c("sigma"), gamma=gamma, scaling_factor_nabla_V=sfV, scaling_factor_M=sfM)
@@ -214,3 +214,51 @@ def test_trainer_gradient_telemetry_follows_the_reference_bookkeeping():
         np.testing.assert_allclose(step["grad_norm_sqd"].item(), gns.item(), rtol=1e-5)
         np.testing.assert_allclose(step["EMA_grad_norm_sqd"].item(), ema_norm.item(), rtol=1e-5)
         np.testing.assert_allclose(step["sqd_norm_EMA_grad"].item(), sum(torch.norm(e) ** 2 for e in ema_grad).item(), rtol=1e-5)
+
+
+TRAIN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "train_*.npz")))
+
+
+def run_training_fixture(name, device, **trainer_kw):
+    """Replays a reference-generated training fixture (tests/golden/make_golden_train.py) through Trainer.step."""
+    from SOC_matching.method import SOC_Solver
+    from socmx.train import Trainer, make_optimizer
+    sde, aux = build_sde(name, device)
+    z = aux["z"]
+    lr_V, lr_M, eps, norm0 = [float(v) for v in z["meta_f"][5:9]]
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                        sigma=sde.sigma)
+    opt = make_optimizer(solver, nabla_V_lr=lr_V, M_lr=lr_M, adam_eps=eps)
+    tr = Trainer(solver, opt, aux["B"], normalization_const=norm0, sync_timing=False, **trainer_kw)
+    rec = dict(loss=[], weight_mean=[], norm=[])
+    for it in range(int(z["train_iters"])):
+        solver.noise_in = aux["noise"][it]
+        out = tr.step()
+        rec["loss"].append(float(out["loss"]))
+        rec["weight_mean"].append(float(out["weight_mean"]))
+        rec["norm"].append(float(tr.normalization_const))
+    tr.join()
+    return sde, z, rec
+
+
+def check_training_fixture(sde, z, rec, rtol):
+    np.testing.assert_allclose(rec["loss"], z["train_loss"], rtol=rtol)
+    np.testing.assert_allclose(rec["weight_mean"], z["train_weight_mean"], rtol=rtol)
+    np.testing.assert_allclose(rec["norm"], z["train_norm_const"], rtol=rtol)
+    num = den = 0.0
+    for prefix, mod in (("final_nablaV.", sde.nabla_V), ("final_M.", sde.M)):
+        for k, v in mod.state_dict().items():
+            w = z[prefix + k]
+            num += float(((v.detach().cpu().numpy() - w) ** 2).sum())
+            den += float((w ** 2).sum())
+    assert (num / den) ** 0.5 < 10 * rtol, (num / den) ** 0.5
+    np.testing.assert_allclose(sde.gamma.detach().cpu().numpy(), z["final_gamma"], rtol=10 * rtol)
+
+
+@pytest.mark.parametrize("name", TRAIN)
+def test_training_iterations_match_reference_on_cpu(name):
+    """main.py:280-359 replayed: the same losses, importance-weight means, normaliser recursion and final
+    parameters as the reference's own loop (SOC_Solver.loss -> /normaliser -> backward -> Adam groups -> EMA)."""
+    torch.set_num_threads(1)
+    sde, z, rec = run_training_fixture(name, "cpu")
+    check_training_fixture(sde, z, rec, rtol=2e-4)
