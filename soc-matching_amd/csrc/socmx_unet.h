@@ -228,6 +228,29 @@ inline void fill_wave_work(UnetProgram& p, int NW) {
 
 __device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.f ? 0.f : x; }
 
+// the same for an accumulator quad: four compares into four SGPR pairs, then four selects.  The compiler's form goes
+// through VCC (v_cmp / s_nop / v_cndmask per element: a wait state after every compare), and this sits on the serial
+// path between a stage's last MFMA and its ds_write.  NaN stays NaN (not (x < 0) selects x).
+__device__ __forceinline__ void relu4_keep_nan(f32x4& v) {
+  unsigned long long m0, m1, m2, m3;
+  float a = v[0], b = v[1], c = v[2], d = v[3];
+  // (the compiler does not look inside inline asm when it inserts the wait states an MFMA result needs before a
+  //  VALU instruction may read it -- 11 for the 8-pass 16x16x4 -- so they are spelled out here)
+  asm volatile(
+      "s_nop 7\n\t"
+      "s_nop 2\n\t"
+      "v_cmp_ngt_f32_e64 %4, 0, %0\n\t"
+      "v_cmp_ngt_f32_e64 %5, 0, %1\n\t"
+      "v_cmp_ngt_f32_e64 %6, 0, %2\n\t"
+      "v_cmp_ngt_f32_e64 %7, 0, %3\n\t"
+      "v_cndmask_b32_e64 %0, 0, %0, %4\n\t"
+      "v_cndmask_b32_e64 %1, 0, %1, %5\n\t"
+      "v_cndmask_b32_e64 %2, 0, %2, %6\n\t"
+      "v_cndmask_b32_e64 %3, 0, %3, %7"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3));
+  v = f32x4{a, b, c, d};
+}
+
 // all threads: copy the padded biases of the nine layers from the packed image into LDS (once per kernel)
 __device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, const UnetDesc& u, const TileLayout& t,
                                                  float* lds, int tid, int nthr) {
@@ -418,7 +441,7 @@ __device__ __forceinline__ void stage_direct(const float* __restrict__ Wp, const
 #pragma unroll
   for (int j = 0; j < NB; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[j][r] = relu_keep_nan(acc[j][r]);
+    for (int r = 0; r < 4; ++r) { if (r == 0) relu4_keep_nan(acc[j]); }
   if (has2) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
