@@ -47,6 +47,19 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, u
   return (dim & 1) ? r * s : r * c;
 }
 
+// sum over the 16 lanes of a row group with DPP moves (quad swaps, half-row mirror, row mirror): every lane ends with
+// the total, no trip through the LDS crossbar as with ds_bpermute (__shfl_xor)
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
+}
+
 struct RolloutArgs {
   UnetDesc u;
   TileLayout t;
@@ -149,18 +162,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     const int grow = tile_row0 + r;
     const bool store = lane_ok && grow < B;
     const size_t rowoff = (size_t)grow * d + i;
-    // sum over the 16 lanes of a row group with DPP moves (quad swaps, half-row mirror, row mirror): every lane ends
-    // with the total, no trip through the LDS crossbar as with ds_bpermute (__shfl_xor)
-    auto gsum = [](float v) {
-      auto dpp = [](float x, auto ctrl) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
-      };
-      v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-      v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-      v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-      v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
-      return v;
-    };
+    auto gsum = [](float v) { return row16_sum(v); };
     float x = lane_ok ? a.x0[(size_t)min(grow, B - 1) * d + i] : 0.f;
     const float kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
     float stop = 1.f, lpd = 0.f, lps = 0.f;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     ST[tid] = 1.f;
     if (tile_row0 + tid < B) a.stop_ind[tile_row0 + tid] = 1.f;  // stop_indicators[0] = ones (utils.py:28)
   }
-  float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in threads 0..15
+  float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in lane 0 of each 16-lane row group (threads 0, 16, ..., 240)
   const bool mm = d >= 16;                                  // matrix products of the SDE step on the MFMA
   const int mwave = __builtin_amdgcn_readfirstlane(tid >> 6), mc16 = tid & 15, mg4 = (tid & 63) >> 4;
   const int mblocks = (d + 15) >> 4;
@@ -444,34 +446,42 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     }
 
     // ---- running cost / log path weights (utils.py:82-99), f at the NEW state, OLD time ----
-    if (tid < 16) {
-      const int r = tid;
+    // 16 lanes per row (threads 0..255): each lane takes components l, l+16, ...; row totals by DPP; lane 0 of the
+    // row group owns the row's accumulators.  (One thread per row walked d -- and d*d for x'Px -- serially.)
+    if (tid < 256) {
+      const int r = tid >> 4, l = tid & 15;
       const float* x = XE + r * d;
       float f = 0.f;
       if (kind == SOCMX_OU_QUADRATIC) {  // OU_quadratic.py:66-69
-        for (int i = 0; i < d; ++i) {
+        float part = 0.f;
+        for (int i = l; i < d; i += 16) {
           float px = 0.f;
           for (int j = 0; j < d; ++j) px += P_l[i * ds + j] * x[j];
-          f += x[i] * px;
+          part += x[i] * px;
         }
+        f = row16_sum(part);
       } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
         f = 1.f;                         // molecular_dynamics.py:87
       }
       float uu = 0.f, ue = 0.f;
-      for (int i = 0; i < d; ++i) {
+      for (int i = l; i < d; i += 16) {
         uu += U[r * d + i] * U[r * d + i];
         ue += U[r * d + i] * E[r * d + i];
       }
-      const float step = STOPPING ? FD[r] : dt;
-      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
-      lps = lps + sqrtf(step / a.lmbd) * (-ue);
-      const int grow = tile_row0 + r;
-      if (grow < B) {
-        a.frac[(size_t)k * B + grow] = step;
-        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
+      uu = row16_sum(uu);
+      ue = row16_sum(ue);
+      if (l == 0) {
+        const float step = STOPPING ? FD[r] : dt;
+        lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
+        lps = lps + sqrtf(step / a.lmbd) * (-ue);
+        const int grow = tile_row0 + r;
+        if (grow < B) {
+          a.frac[(size_t)k * B + grow] = step;
+          a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
+        }
       }
-      if (STOPPING) ST[r] = SN[r];
     }
+    if (STOPPING && tid < 16) ST[tid] = SN[tid];   // (nobody reads ST in this phase; its readers sit behind barriers)
     for (int e = tid; e < 16 * d; e += nthr) {
       const int r = SOCMX_DIV_D(e), i = e - r * d;
       const float x = XE[e];
@@ -484,27 +494,31 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   if (PROF && tid == a.prof_wave * 64 && a.prof)
     for (int s = 0; s < 64; ++s) a.prof[(size_t)blockIdx.x * 64 + s] = acc_prof[s];
 
-  // ---- terminal cost (utils.py:101) --------------------------------------------------------
-  if (tid < 16 && tile_row0 + tid < B) {
-    const float* x = XS + tid * d;
-    float gval = 0.f;
+  // ---- terminal cost (utils.py:101): same 16-lanes-per-row mapping -----------------------------
+  if (tid < 256) {
+    const int r = tid >> 4, l = tid & 15;
+    const float* x = XS + r * d;
+    float part = 0.f;
     if (kind == SOCMX_OU_QUADRATIC) {          // OU_quadratic.py:76-79
-      for (int i = 0; i < d; ++i) {
+      for (int i = l; i < d; i += 16) {
         float qx = 0.f;
         for (int j = 0; j < d; ++j) qx += a.Q[i * d + j] * x[j];
-        gval += x[i] * qx;
+        part += x[i] * qx;
       }
     } else if (kind == SOCMX_OU_LINEAR) {      // OU_linear.py:83-84
-      for (int i = 0; i < d; ++i) gval += a.omega[i] * x[i];
+      for (int i = l; i < d; i += 16) part += a.omega[i] * x[i];
     } else if (kind == SOCMX_DOUBLE_WELL) {    // double_well.py:75-84
-      for (int i = 0; i < d; ++i) {
+      for (int i = l; i < d; i += 16) {
         const float q = x[i] * x[i] - 1.f;
-        gval += a.nu[i] * (q * q);
+        part += a.nu[i] * (q * q);
       }
     }
-    a.lpd[tile_row0 + tid] = lpd;
-    a.lps[tile_row0 + tid] = lps;
-    a.ltw[tile_row0 + tid] = -gval / a.lmbd;
+    const float gval = row16_sum(part);
+    if (l == 0 && tile_row0 + r < B) {
+      a.lpd[tile_row0 + r] = lpd;
+      a.lps[tile_row0 + r] = lps;
+      a.ltw[tile_row0 + r] = -gval / a.lmbd;
+    }
   }
 }
 
