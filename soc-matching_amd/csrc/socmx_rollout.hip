@@ -128,13 +128,15 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   float* sig = lds + a.lds_mats;          // (d,ds)
   float* A_l = sig + d * ds;              // (d,ds)  OU only
   float* P_l = A_l + d * ds;              // (d,ds)  OU_quadratic only
-  float* XS = P_l + d * ds;               // (16,d) current state
-  float* XN = XS + 16 * d;                // (16,d) proposed state
-  float* XF = XN + 16 * d;                // (16,d) state after the stopping re-interpolation
-  float* U = XF + 16 * d;                 // (16,d) control
-  float* E = U + 16 * d;                  // (16,d) noise
-  float* UP = E + 16 * d;                 // (16,d) update
-  float* ST = UP + 16 * d;                // (16,)  stop_inds (1 = still running)
+  // six (16, d) tiles with row stride ds = d + 1: the MFMA products of the general SDE step read them with the 16
+  // rows across the lanes, and a stride of d = 64 floats put all 16 rows on one bank (16-way conflicts)
+  float* XS = P_l + d * ds;               // current state
+  float* XN = XS + 16 * ds;               // proposed state
+  float* XF = XN + 16 * ds;               // state after the stopping re-interpolation
+  float* U = XF + 16 * ds;                // control
+  float* E = U + 16 * ds;                 // noise
+  float* UP = E + 16 * ds;                // update
+  float* ST = UP + 16 * ds;               // (16,)  stop_inds (1 = still running)
   float* SN = ST + 16;                    // (16,)  next stop_inds
   float* FD = SN + 16;                    // (16,)  fractional time step
   float* NZ = FD + 16;                    // (2,16,16) FAST path: double-buffered noise of steps k, k+1
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     const int r = SOCMX_DIV_D(e), i = e - r * d;
     const int grow = min(tile_row0 + r, B - 1);  // ragged tail: replicate the last row, never stored
     const float x = a.x0[(size_t)grow * d + i];
-    XS[e] = x;
+    XS[r * ds + i] = x;
     if (tile_row0 + r < B) a.states[(size_t)(tile_row0 + r) * d + i] = x;  // states[0]
   }
   if (tid < 16) {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     // ---- network input [t, x, 0...]  (method.py:65-67) --------------------------------
     for (int e = tid; e < 16 * ud.in0p; e += nthr) {
       const int r = (int)(((float)e + 0.5f) * inv_in0p), c = e - r * ud.in0p;
-      X0[r * tl.s0 + c] = (c == 0) ? t0 : (c <= d ? XS[r * d + c - 1] : 0.f);
+      X0[r * tl.s0 + c] = (c == 0) ? t0 : (c <= d ? XS[r * ds + c - 1] : 0.f);
     }
     __syncthreads();
     SOCMX_TICK(0)
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         float eps;
         if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
         else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
-        E[e] = eps;
+        E[r * ds + i] = eps;
         if (grow < B) a.noises[((size_t)k * B + grow) * d + i] = eps;
       }
       for (int ib = mwave; ib < mblocks; ib += NW) {
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           const int io = ib * 16 + 4 * mg4 + rr;
           if (io < d) {
             const float u = -acc[rr];
-            U[mc16 * d + io] = u;
+            U[mc16 * ds + io] = u;
             if (grow < B) a.controls[((size_t)k * B + grow) * d + io] = u;
           }
         }
@@ -368,8 +370,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         float eps;
         if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
         else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
-        U[e] = u;
-        E[e] = eps;
+        U[r * ds + i] = u;
+        E[r * ds + i] = eps;
         if (grow < B) {
           a.controls[((size_t)k * B + grow) * d + i] = u;
           a.noises[((size_t)k * B + grow) * d + i] = eps;
@@ -388,10 +390,10 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           const int j = j0 + mg4, jc = min(j, d - 1);
           const bool ok = j < d && i < d;
           const float sv = ok ? sig[ic * ds + jc] : 0.f;
-          const float bu = U[mc16 * d + jc], be = E[mc16 * d + jc];
+          const float bu = U[mc16 * ds + jc], be = E[mc16 * ds + jc];
           if (is_ou) {
             const float aa = ok ? A_l[ic * ds + jc] : 0.f;
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, XS[mc16 * d + jc], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, XS[mc16 * ds + jc], acc1, 0, 0, 0);
           }
           acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, be, acc2, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, bu, acc1, 0, 0, 0);
@@ -400,8 +402,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         for (int rr = 0; rr < 4; ++rr) {
           const int io = ib * 16 + 4 * mg4 + rr;
           if (io < d) {
-            const int e = mc16 * d + io;
-            const float bi = is_ou ? 0.f : drift_i(kind, d, io, XS + mc16 * d, A_l, a.kappa);
+            const int e = mc16 * ds + io;
+            const float bi = is_ou ? 0.f : drift_i(kind, d, io, XS + mc16 * ds, A_l, a.kappa);
             const float upd = (bi + acc1[rr]) * dt + sq_ldt * acc2[rr];
             UP[e] = upd;
             XN[e] = XS[e] + ST[mc16] * upd;
@@ -411,15 +413,15 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     } else {
       for (int e = tid; e < 16 * d; e += nthr) {
         const int r = SOCMX_DIV_D(e), i = e - r * d;
-        const float bi = drift_i(kind, d, i, XS + r * d, A_l, a.kappa);
+        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, a.kappa);
         float su = 0.f, se = 0.f;
         for (int j = 0; j < d; ++j) {
-          su += sig[i * ds + j] * U[r * d + j];
-          se += sig[i * ds + j] * E[r * d + j];
+          su += sig[i * ds + j] * U[r * ds + j];
+          se += sig[i * ds + j] * E[r * ds + j];
         }
         const float upd = (bi + su) * dt + sq_ldt * se;
-        UP[e] = upd;
-        XN[e] = XS[e] + ST[r] * upd;
+        UP[r * ds + i] = upd;
+        XN[r * ds + i] = XS[r * ds + i] + ST[r] * upd;
       }
     }
     __syncthreads();
@@ -430,12 +432,12 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       // utils.py:42-44, 49-75 with Phi(x) = -x_0 (molecular_dynamics.py:94-99)
       for (int e = tid; e < 16 * d; e += nthr) {
         const int r = SOCMX_DIV_D(e), i = e - r * d;
-        const float phi_b = -XS[r * d], phi_a = -XN[r * d];
+        const float phi_b = -XS[r * ds], phi_a = -XN[r * ds];
         const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
         const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
         const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
-        const float xi = js * (XS[e] + fr * ST[r] * UP[e]) + (1.f - js) * XN[e];
-        XF[e] = xi;
+        const float xi = js * (XS[r * ds + i] + fr * ST[r] * UP[r * ds + i]) + (1.f - js) * XN[r * ds + i];
+        XF[r * ds + i] = xi;
         if (i == 0) {
           FD[r] = js * (fr * fr) * dt + ns * dt;   // utils.py:70-72 (step_fraction squared)
           SN[r] = (-xi > 0.f) ? 1.f : 0.f;         // utils.py:74
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     // row group owns the row's accumulators.  (One thread per row walked d -- and d*d for x'Px -- serially.)
     if (tid < 256) {
       const int r = tid >> 4, l = tid & 15;
-      const float* x = XE + r * d;
+      const float* x = XE + r * ds;
       float f = 0.f;
       if (kind == SOCMX_OU_QUADRATIC) {  // OU_quadratic.py:66-69
         float part = 0.f;
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       }
       float uu = 0.f, ue = 0.f;
       for (int i = l; i < d; i += 16) {
-        uu += U[r * d + i] * U[r * d + i];
-        ue += U[r * d + i] * E[r * d + i];
+        uu += U[r * ds + i] * U[r * ds + i];
+        ue += U[r * ds + i] * E[r * ds + i];
       }
       uu = row16_sum(uu);
       ue = row16_sum(ue);
@@ -484,8 +486,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if (STOPPING && tid < 16) ST[tid] = SN[tid];   // (nobody reads ST in this phase; its readers sit behind barriers)
     for (int e = tid; e < 16 * d; e += nthr) {
       const int r = SOCMX_DIV_D(e), i = e - r * d;
-      const float x = XE[e];
-      XS[e] = x;
+      const float x = XE[r * ds + i];
+      XS[r * ds + i] = x;
       if (tile_row0 + r < B) a.states[((size_t)(k + 1) * B + tile_row0 + r) * d + i] = x;
     }
     __syncthreads();
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   // ---- terminal cost (utils.py:101): same 16-lanes-per-row mapping -----------------------------
   if (tid < 256) {
     const int r = tid >> 4, l = tid & 15;
-    const float* x = XS + r * d;
+    const float* x = XS + r * ds;
     float part = 0.f;
     if (kind == SOCMX_OU_QUADRATIC) {          // OU_quadratic.py:76-79
       for (int i = l; i < d; i += 16) {
@@ -711,7 +713,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.prof = prof;
   { const char* e = getenv("SOCMX_PROF_WAVE"); a.prof_wave = (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }
   a.lds_mats = (a.t.floats + 3) & ~3;
-  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * (d + 1) + 6 * 16 * (size_t)d + 48 + 512;
+  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * (d + 1) + 6 * 16 * (size_t)(d + 1) + 48 + 512;
   const size_t lds_bytes = lds_floats * sizeof(float);
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
   const int blocks = (B + 15) / 16;
