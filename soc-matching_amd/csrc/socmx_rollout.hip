@@ -303,17 +303,18 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   long long last_sub = 0;
   long long last_tick = PROF ? clock64() : 0;
 
+  // ---- network input [t, x, 0...]  (method.py:65-67): built once; afterwards the end of every step writes the new
+  //      state and time straight into it (the padding columns stay zero) ------------------------------------------
+  for (int e = tid; e < 16 * ud.in0p; e += nthr) {
+    const int r = (int)(((float)e + 0.5f) * inv_in0p), c = e - r * ud.in0p;
+    X0[r * tl.s0 + c] = (c == 0) ? a.ts[0] : (c <= d ? XS[r * ds + c - 1] : 0.f);
+  }
+  __syncthreads();
+
   for (int k = 0; k < K; ++k) {
     const float t0 = a.ts[k];
     const float dt = a.ts[k + 1] - t0;        // utils.py:38
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
-
-    // ---- network input [t, x, 0...]  (method.py:65-67) --------------------------------
-    for (int e = tid; e < 16 * ud.in0p; e += nthr) {
-      const int r = (int)(((float)e + 0.5f) * inv_in0p), c = e - r * ud.in0p;
-      X0[r * tl.s0 + c] = (c == 0) ? t0 : (c <= d ? XS[r * ds + c - 1] : 0.f);
-    }
-    __syncthreads();
     SOCMX_TICK(0)
     last_sub = last_tick;
     auto hook = [&](int slot) {
@@ -488,8 +489,10 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       const int r = SOCMX_DIV_D(e), i = e - r * d;
       const float x = XE[r * ds + i];
       XS[r * ds + i] = x;
+      X0[r * tl.s0 + 1 + i] = x;                      // next step's network input (the last stage is done with X0)
       if (tile_row0 + r < B) a.states[((size_t)(k + 1) * B + tile_row0 + r) * d + i] = x;
     }
+    if (tid < 16) X0[tid * tl.s0] = a.ts[k + 1];
     __syncthreads();
     SOCMX_TICK(9)
   }
