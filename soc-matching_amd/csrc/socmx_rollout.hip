@@ -343,12 +343,17 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       for (int ib = mwave; ib < mblocks; ib += NW) {
         const int i = ib * 16 + mc16;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int j0 = 0; j0 < d; j0 += 4) {
-          const int j = j0 + mg4;
-          const bool okj = j < d;
-          const float av = (okj && i < d) ? sig[min(j, d - 1) * ds + min(i, d - 1)] : 0.f;   // (sigma^T)[i][j]
-          const float bv = okj ? GV[mc16 * tl.sg + min(j, d - 1)] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        for (int j0 = 0; j0 < d; j0 += 16) {         // four k-steps per trip: eight LDS reads in flight, then four MFMAs
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u + mg4;
+            const bool okj = j < d;
+            av[u] = (okj && i < d) ? sig[min(j, d - 1) * ds + min(i, d - 1)] : 0.f;   // (sigma^T)[i][j]
+            bv[u] = okj ? GV[mc16 * tl.sg + min(j, d - 1)] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
         }
         const int grow = tile_row0 + mc16;            // D: lane holds rows i = ib*16 + 4*g4 + rr of batch column c16
 #pragma unroll
@@ -387,17 +392,24 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       for (int ib = mwave; ib < mblocks; ib += NW) {
         const int i = ib * 16 + mc16, ic = min(i, d - 1);
         f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // A x + sigma u ; sigma eps
-        for (int j0 = 0; j0 < d; j0 += 4) {
-          const int j = j0 + mg4, jc = min(j, d - 1);
-          const bool ok = j < d && i < d;
-          const float sv = ok ? sig[ic * ds + jc] : 0.f;
-          const float bu = U[mc16 * ds + jc], be = E[mc16 * ds + jc];
-          if (is_ou) {
-            const float aa = ok ? A_l[ic * ds + jc] : 0.f;
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, XS[mc16 * ds + jc], acc1, 0, 0, 0);
+        for (int j0 = 0; j0 < d; j0 += 16) {         // four k-steps per trip (LDS reads first, MFMAs after)
+          float sv[4], aa[4], bu[4], be[4], bx[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u + mg4, jc = min(j, d - 1);
+            const bool okj = j < d, ok = okj && i < d;
+            sv[u] = ok ? sig[ic * ds + jc] : 0.f;
+            aa[u] = (ok && is_ou) ? A_l[ic * ds + jc] : 0.f;
+            bu[u] = okj ? U[mc16 * ds + jc] : 0.f;
+            be[u] = okj ? E[mc16 * ds + jc] : 0.f;
+            bx[u] = (okj && is_ou) ? XS[mc16 * ds + jc] : 0.f;
           }
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, be, acc2, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, bu, acc1, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (is_ou) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[u], bx[u], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], be[u], acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], bu[u], acc1, 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
