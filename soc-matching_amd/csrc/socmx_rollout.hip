@@ -97,6 +97,25 @@ __device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x,
     last_tick = now_;                                      \
   }
 
+// the four draws of one Philox block (dims 4b .. 4b+3 of a row): same values as four philox_normal calls, a quarter of
+// the generator work
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t offset, uint32_t grow, uint32_t step, int block) {
+  uint32_t w[4];
+  philox4x32_10(grow, step, (uint32_t)block, (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  f32x4 out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float ua = ((float)w[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+    const float ub = ((float)w[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+    const float r = sqrtf(-2.0f * logf(ua));
+    float sn, cs;
+    sincospif(2.0f * ub, &sn, &cs);
+    out[2 * h] = r * cs;
+    out[2 * h + 1] = r * sn;
+  }
+  return out;
+}
+
 struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
 typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
 typedef StaticNet<80, 256, 128, 64, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
@@ -331,14 +350,30 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if (mm) {
       // d >= 16: the (16 rows x d) . (d x d) products run on the MFMA with both operands read from LDS
       // (one ds_read_b32 pair per MFMA instead of two LDS reads per multiply-add)
-      for (int e = tid; e < 16 * d; e += nthr) {
-        const int r = SOCMX_DIV_D(e), i = e - r * d;
-        const int grow = tile_row0 + r;
-        float eps;
-        if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
-        else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
-        E[r * ds + i] = eps;
-        if (grow < B) a.noises[((size_t)k * B + grow) * d + i] = eps;
+      if (a.noise_in) {
+        for (int e = tid; e < 16 * d; e += nthr) {
+          const int r = SOCMX_DIV_D(e), i = e - r * d;
+          const int grow = tile_row0 + r;
+          const float eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
+          E[r * ds + i] = eps;
+          if (grow < B) a.noises[((size_t)k * B + grow) * d + i] = eps;
+        }
+      } else {                                        // one Philox block = four consecutive components of a row
+        const int nq = (d + 3) >> 2;
+        const float inv_nq = __builtin_amdgcn_rcpf((float)nq);
+        for (int q = tid; q < 16 * nq; q += nthr) {
+          const int r = (int)(((float)q + 0.5f) * inv_nq), b = q - r * nq;
+          const int grow = tile_row0 + r;
+          const f32x4 z = philox_normal4(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, b);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * b + c;
+            if (i < d) {
+              E[r * ds + i] = z[c];
+              if (grow < B) a.noises[((size_t)k * B + grow) * d + i] = z[c];
+            }
+          }
+        }
       }
       for (int ib = mwave; ib < mblocks; ib += NW) {
         const int i = ib * 16 + mc16;

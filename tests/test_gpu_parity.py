@@ -124,6 +124,22 @@ def test_philox_noise_contract_and_moments():
     np.testing.assert_allclose(_np(r[0]), want[0].numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["tiny_ou_linear_d20", "tiny_ou_linear_d64", "tiny_ou_linear_d6"])
+def test_philox_contract_on_the_general_sde_path(name):
+    """Dense sigma (and d >= 16: one Philox block feeds four components): the documented draw
+    noise[k, row, i] = N(seed, offset, global row, step k, component i) holds there too, and shards agree."""
+    from SOC_matching import utils
+    sde, aux = build_sde(name, DEV)
+    B, d, K = 21, aux["d"], aux["K"]
+    r = utils.stochastic_trajectories(sde, aux["x0"].repeat(B, 1), aux["ts"], aux["lmbd"], seed=77, offset=3, row0=40)
+    noises = _np(r[1])
+    for (k, m) in [(0, 0), (1, 17), (K - 1, 20)]:
+        want = O.philox_normals(77, 3, 40 + m, k, d)
+        np.testing.assert_allclose(noises[k, m], want, rtol=2e-4, atol=2e-5)
+    r2 = utils.stochastic_trajectories(sde, aux["x0"].repeat(5, 1), aux["ts"], aux["lmbd"], seed=77, offset=3, row0=56)
+    assert np.array_equal(_np(r2[1]), noises[:, 16:])
+
+
 def test_weights_stats_kernel():
     from socmx import loss as L
     for B in (1 + 1, 128, 1000):
