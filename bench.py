@@ -273,7 +273,7 @@ def main():
         }
         if burst is not None:
             line["roofline_full_chip"] = burst
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 figure
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
