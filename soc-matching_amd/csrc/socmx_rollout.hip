@@ -119,6 +119,7 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t offset, 
 struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
 typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
 typedef StaticNet<80, 256, 128, 64, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
+typedef StaticNet<32, 256, 128, 64, 32> Wide32Net;   // ... and at 16 <= d <= 31 (soc.yaml's default d = 20)
 
 template <int NW, bool STOPPING, bool PROF, class NET, bool FAST>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
@@ -789,8 +790,11 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   } while (0)
   const bool is_wide64 = !force_generic && nw == 8 && a.u.in0p == 80 && a.u.hp[0] == 256 && a.u.hp[1] == 128 &&
                          a.u.hp[2] == 64 && a.u.outp == 64;
+  const bool is_wide32 = !force_generic && nw == 8 && a.u.in0p == 32 && a.u.hp[0] == 256 && a.u.hp[1] == 128 &&
+                         a.u.hp[2] == 64 && a.u.outp == 32;
   if (is_default) SOCMX_PICK(8, DefaultNet);
   else if (is_wide64) SOCMX_PICK(8, Wide64Net);
+  else if (is_wide32) SOCMX_PICK(8, Wide32Net);
   else if (nw == 4) SOCMX_PICK(4, DynamicNet);
   else SOCMX_PICK(8, DynamicNet);
 #undef SOCMX_PICK

@@ -481,6 +481,15 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
         "    x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)\n"
         "r = utils.stochastic_trajectories(sde, x0.repeat(40, 1), ts, 1.0, seed=5, offset=2)\n"
         "for i, t in enumerate(r): out[f'ou_linear_d64_{i}'] = t.cpu().numpy()\n"
+        "# d = 20 (soc.yaml's default) and d = 31: the 16 <= d <= 31 instantiation\n"
+        "for dd, setting in ((20, 'OU_quadratic_easy'), (31, 'OU_linear')):\n"
+        "    cfg = load_config([f'method.setting={setting}', f'method.d={dd}', 'method.num_steps=12'])\n"
+        "    cfg.method.device = 'cuda:0'\n"
+        "    torch.manual_seed(0)\n"
+        "    with contextlib.redirect_stdout(io.StringIO()):\n"
+        "        x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)\n"
+        "    r = utils.stochastic_trajectories(sde, x0.repeat(40, 1), ts, 1.0, seed=6, offset=4)\n"
+        "    for i, t in enumerate(r): out[f'{setting}_d{dd}_{i}'] = t.cpu().numpy()\n"
         "# molecular_dynamics with the default widths: the specialised kernel's STOPPING variant (Phi = -x_0)\n"
         "cfg = load_config(['method.setting=molecular_dynamics', 'method.d=2', 'method.num_steps=40', 'method.T=2.0',\n"
         "                   'method.lmbd=2.0', 'method.use_stopping_time=True'])\n"

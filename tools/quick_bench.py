@@ -16,6 +16,8 @@ CONFIGS = {
     "cfg3": ("double_well", 10, 200, 128, 6.0),
     "cfg4r": ("double_well", 10, 200, 1024, 6.0),
     "cfg5r": ("OU_linear", 64, 400, 512, 2.0),
+    "ouq20": ("OU_quadratic_easy", 20, 50, 128, 2.0),            # soc.yaml defaults (d = 20)
+    "ouq20b": ("OU_quadratic_hard", 20, 50, 2048, 2.0),
     "burst": ("double_well", 10, 200, 65536, 6.0),
 }
 which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg3"]
