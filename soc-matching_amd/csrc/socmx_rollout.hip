@@ -116,6 +116,29 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t offset, 
   return out;
 }
 
+// one Box-Muller pair of that block (draws 2h, 2h+1): lets two threads share a block's latency instead of one thread
+// walking both pairs (the generator is instruction-bound for a lone wave; the redundant block costs idle VALU slots)
+__device__ __forceinline__ void philox_normal2(uint64_t seed, uint64_t offset, uint32_t grow, uint32_t step, int block,
+                                               int h, float& z0, float& z1) {
+  uint32_t w[4];
+  philox4x32_10(grow, step, (uint32_t)block, (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const uint32_t wa = h ? w[2] : w[0], wb = h ? w[3] : w[1];
+  const float ua = ((float)wa + 0.5f) * 2.3283064365386963e-10f;
+  const float ub = ((float)wb + 0.5f) * 2.3283064365386963e-10f;
+  const float r = sqrtf(-2.0f * logf(ua));
+  float sn, cs;
+  sincospif(2.0f * ub, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
+// LDS operand of a masked MFMA step: the load is unconditional (the address is clamped in range by the caller) and the
+// mask is a select -- written as `c ? p[..] : 0` the compiler branches around every load and waits for each in turn
+__device__ __forceinline__ float lds_sel(const float* p, bool c) {
+  const float t = *p;
+  return c ? t : 0.f;
+}
+
 struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
 typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
 typedef StaticNet<80, 256, 128, 64, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
@@ -145,29 +168,37 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   float* GV = lds + tl.gv;
   // small per-tile state (behind the network tiles)
   const int ds = d + 1;                   // padded row stride of the LDS matrix copies (bank spread)
+  // which constant matrices and tiles exist depends on the setting (d = 64 with all of them would not fit 160 KiB):
+  // the launcher sizes the allocation with the same rule (rollout_sde_floats)
+  const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
+  const bool is_quad = kind == SOCMX_OU_QUADRATIC;
   float* sig = lds + a.lds_mats;          // (d,ds)
   float* A_l = sig + d * ds;              // (d,ds)  OU only
-  float* P_l = A_l + d * ds;              // (d,ds)  OU_quadratic only
-  // six (16, d) tiles with row stride ds = d + 1: the MFMA products of the general SDE step read them with the 16
+  float* KAP = A_l;                       // (d,)    the other settings: kappa (a global load per step would queue
+                                          //         behind the step's stores)
+  float* P_l = A_l + (is_ou ? d * ds : d);    // (d,ds)  OU_quadratic only
+  // (16, d) tiles with row stride ds = d + 1: the MFMA products of the general SDE step read them with the 16
   // rows across the lanes, and a stride of d = 64 floats put all 16 rows on one bank (16-way conflicts)
-  float* XS = P_l + d * ds;               // current state
+  float* XS = P_l + (is_quad ? d * ds : 0);   // current state
   float* XN = XS + 16 * ds;               // proposed state
-  float* XF = XN + 16 * ds;               // state after the stopping re-interpolation
-  float* U = XF + 16 * ds;                // control
-  float* E = U + 16 * ds;                 // noise
-  float* UP = E + 16 * ds;                // update
-  float* ST = UP + 16 * ds;               // (16,)  stop_inds (1 = still running)
+  float* U = XN + 16 * ds;                // control
+  float* E0 = U + 16 * ds;                // noise of the even steps ...
+  float* E1 = E0 + 16 * ds;               // ... and of the odd ones (general path: drawn one step ahead)
+  float* XF = E1 + 16 * ds;               // stopping time only: state after the re-interpolation
+  float* UP = XF + (STOPPING ? 16 * ds : 0);  // stopping time only: the update
+  float* ST = UP + (STOPPING ? 16 * ds : 0);  // (16,)  stop_inds (1 = still running)
   float* SN = ST + 16;                    // (16,)  next stop_inds
   float* FD = SN + 16;                    // (16,)  fractional time step
   float* NZ = FD + 16;                    // (2,16,16) FAST path: double-buffered noise of steps k, k+1
+  float* FQ = NZ;                         // general path: (d/16 blocks, 4, 16) partial sums of x'Px
 
-  const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
   for (int e = tid; e < d * d; e += nthr) {
     const int r = e / d, c = e - r * d;
     sig[r * ds + c] = a.sigma[e];
-    A_l[r * ds + c] = is_ou ? a.A[e] : 0.f;
-    P_l[r * ds + c] = (kind == SOCMX_OU_QUADRATIC) ? a.P[e] : 0.f;
+    if (is_ou) A_l[r * ds + c] = a.A[e];
+    if (is_quad) P_l[r * ds + c] = a.P[e];
   }
+  if (!is_ou) for (int e = tid; e < d; e += nthr) KAP[e] = a.kappa[e];
   unet_load_biases(a.packed, ud, tl, lds, tid, nthr);
   Pre carry;
   if constexpr (kStatic) carry = unet_carry_init_static<NW, NET>(a.packed);
@@ -315,6 +346,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   }
   float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in lane 0 of each 16-lane row group (threads 0, 16, ..., 240)
   const bool mm = d >= 16;                                  // matrix products of the SDE step on the MFMA
+  const bool sid = a.sigma_identity != 0;                   // sigma = I: the products with sigma drop out (mm path)
   const int mwave = __builtin_amdgcn_readfirstlane(tid >> 6), mc16 = tid & 15, mg4 = (tid & 63) >> 4;
   const int mblocks = (d + 15) >> 4;
   __syncthreads();
@@ -329,11 +361,41 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     const int r = (int)(((float)e + 0.5f) * inv_in0p), c = e - r * ud.in0p;
     X0[r * tl.s0 + c] = (c == 0) ? a.ts[0] : (c <= d ? XS[r * ds + c - 1] : 0.f);
   }
+  // noise of step kk into tile Eb (and the noises output), by threads t_ = 0 .. nt_-1: injected, or Philox with one
+  // Box-Muller pair (two consecutive components) per thread
+  auto draw_noise = [&](int kk, float* Eb, int t_, int nt_) {
+    if (a.noise_in) {
+      for (int e = t_; e < 16 * d; e += nt_) {
+        const int r = SOCMX_DIV_D(e), i = e - r * d;
+        const int grow = tile_row0 + r;
+        const float eps = a.noise_in[((size_t)kk * B + min(grow, B - 1)) * d + i];
+        Eb[r * ds + i] = eps;
+        if (grow < B) a.noises[((size_t)kk * B + grow) * d + i] = eps;
+      }
+    } else {
+      const int np = (d + 1) >> 1;
+      const float inv_np = __builtin_amdgcn_rcpf((float)np);
+      for (int q = t_; q < 16 * np; q += nt_) {
+        const int r = (int)(((float)q + 0.5f) * inv_np), pr = q - r * np;
+        const int grow = tile_row0 + r;
+        float z0, z1;
+        philox_normal2(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)kk, pr >> 1, pr & 1, z0, z1);
+        const int i = 2 * pr;
+        Eb[r * ds + i] = z0;
+        if (grow < B) a.noises[((size_t)kk * B + grow) * d + i] = z0;
+        if (i + 1 < d) {
+          Eb[r * ds + i + 1] = z1;
+          if (grow < B) a.noises[((size_t)kk * B + grow) * d + i + 1] = z1;
+        }
+      }
+    }
+  };
+  draw_noise(0, E0, tid, nthr);
   __syncthreads();
 
   for (int k = 0; k < K; ++k) {
-    const float t0 = a.ts[k];
-    const float dt = a.ts[k + 1] - t0;        // utils.py:38
+    const float t0 = a.ts[k], t1 = a.ts[k + 1];
+    const float dt = t1 - t0;                 // utils.py:38
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
     SOCMX_TICK(0)
     last_sub = last_tick;
@@ -347,35 +409,20 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, hook);   // GV = nabla_V(t, x)
     else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);  // GV = nabla_V(t,x)
 
-    // ---- control u = -sigma^T nabla_V (method.py:68-72) and the step's noise (utils.py:39) ---
+    // ---- control u = -sigma^T nabla_V (method.py:68-72); the step's noise (utils.py:39) is already in E ---
+    float* E = (k & 1) ? E1 : E0;
+    float* En = (k & 1) ? E0 : E1;
     if (mm) {
       // d >= 16: the (16 rows x d) . (d x d) products run on the MFMA with both operands read from LDS
       // (one ds_read_b32 pair per MFMA instead of two LDS reads per multiply-add)
-      if (a.noise_in) {
+      if (sid) {                                      // sigma = I: u = -nabla_V, no product
         for (int e = tid; e < 16 * d; e += nthr) {
           const int r = SOCMX_DIV_D(e), i = e - r * d;
-          const int grow = tile_row0 + r;
-          const float eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
-          E[r * ds + i] = eps;
-          if (grow < B) a.noises[((size_t)k * B + grow) * d + i] = eps;
+          const float u = -GV[r * tl.sg + i];
+          U[r * ds + i] = u;
+          if (tile_row0 + r < B) a.controls[((size_t)k * B + tile_row0 + r) * d + i] = u;
         }
-      } else {                                        // one Philox block = four consecutive components of a row
-        const int nq = (d + 3) >> 2;
-        const float inv_nq = __builtin_amdgcn_rcpf((float)nq);
-        for (int q = tid; q < 16 * nq; q += nthr) {
-          const int r = (int)(((float)q + 0.5f) * inv_nq), b = q - r * nq;
-          const int grow = tile_row0 + r;
-          const f32x4 z = philox_normal4(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, b);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int i = 4 * b + c;
-            if (i < d) {
-              E[r * ds + i] = z[c];
-              if (grow < B) a.noises[((size_t)k * B + grow) * d + i] = z[c];
-            }
-          }
-        }
-      }
+      } else
       for (int ib = mwave; ib < mblocks; ib += NW) {
         const int i = ib * 16 + mc16;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -385,8 +432,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           for (int u = 0; u < 4; ++u) {
             const int j = j0 + 4 * u + mg4;
             const bool okj = j < d;
-            av[u] = (okj && i < d) ? sig[min(j, d - 1) * ds + min(i, d - 1)] : 0.f;   // (sigma^T)[i][j]
-            bv[u] = okj ? GV[mc16 * tl.sg + min(j, d - 1)] : 0.f;
+            av[u] = lds_sel(sig + min(j, d - 1) * ds + min(i, d - 1), okj && i < d);   // (sigma^T)[i][j]
+            bv[u] = lds_sel(GV + mc16 * tl.sg + min(j, d - 1), okj);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
@@ -409,67 +456,98 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         for (int j = 0; j < d; ++j) s += sig[j * ds + i] * GV[r * tl.sg + j];
         const float u = -s;
         const int grow = tile_row0 + r;
-        float eps;
-        if (a.noise_in) eps = a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i];
-        else eps = philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i);
         U[r * ds + i] = u;
-        E[r * ds + i] = eps;
-        if (grow < B) {
-          a.controls[((size_t)k * B + grow) * d + i] = u;
-          a.noises[((size_t)k * B + grow) * d + i] = eps;
-        }
+        if (grow < B) a.controls[((size_t)k * B + grow) * d + i] = u;
       }
     }
     __syncthreads();
     SOCMX_TICK(7)
 
     // ---- Euler-Maruyama update (utils.py:45-48) ------------------------------------------
-    if (mm) {
-      for (int ib = mwave; ib < mblocks; ib += NW) {
-        const int i = ib * 16 + mc16, ic = min(i, d - 1);
-        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // A x + sigma u ; sigma eps
-        for (int j0 = 0; j0 < d; j0 += 16) {         // four k-steps per trip (LDS reads first, MFMAs after)
-          float sv[4], aa[4], bu[4], be[4], bx[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 4 * u + mg4, jc = min(j, d - 1);
-            const bool okj = j < d, ok = okj && i < d;
-            sv[u] = ok ? sig[ic * ds + jc] : 0.f;
-            aa[u] = (ok && is_ou) ? A_l[ic * ds + jc] : 0.f;
-            bu[u] = okj ? U[mc16 * ds + jc] : 0.f;
-            be[u] = okj ? E[mc16 * ds + jc] : 0.f;
-            bx[u] = (okj && is_ou) ? XS[mc16 * ds + jc] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (is_ou) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[u], bx[u], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], be[u], acc2, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], bu[u], acc1, 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int io = ib * 16 + 4 * mg4 + rr;
-          if (io < d) {
-            const int e = mc16 * ds + io;
-            const float bi = is_ou ? 0.f : drift_i(kind, d, io, XS + mc16 * ds, A_l, a.kappa);
-            const float upd = (bi + acc1[rr]) * dt + sq_ldt * acc2[rr];
-            UP[e] = upd;
-            XN[e] = XS[e] + ST[mc16] * upd;
-          }
-        }
+    // the noise of step k + 1 is drawn here, by the upper four waves when there are eight: up to d = 64 they have no
+    // part in the MFMA products below, so the generator's latency (instruction-bound, ~2k cycles) hides behind them
+    if (k + 1 < K) {
+      if (nthr >= 512) { if (tid >= 256) draw_noise(k + 1, En, tid - 256, nthr - 256); }
+      else draw_noise(k + 1, En, tid, nthr);
+    }
+    if (mm && sid && !is_ou) {
+      // sigma = I and an elementwise drift (double_well, molecular_dynamics): nothing to multiply
+      for (int e = tid; e < 16 * d; e += nthr) {
+        const int r = SOCMX_DIV_D(e), i = e - r * d;
+        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP);
+        const float upd = (bi + U[r * ds + i]) * dt + sq_ldt * E[r * ds + i];
+        if (STOPPING) UP[r * ds + i] = upd;
+        XN[r * ds + i] = XS[r * ds + i] + ST[r] * upd;
       }
+    } else if (mm) {
+      // (the two uniform flags are compile-time inside the loop: a run-time test per operand splits the loads into
+      //  basic blocks that each wait for their own LDS round trip)
+      auto em_mfma = [&](auto sid_c, auto ou_c) {
+        constexpr bool SID = decltype(sid_c)::value, OU = decltype(ou_c)::value;
+        for (int ib = mwave; ib < mblocks; ib += NW) {
+          const int i = ib * 16 + mc16, ic = min(i, d - 1);
+          f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // A x + sigma u ; sigma eps
+          for (int j0 = 0; j0 < d; j0 += 16) {         // four k-steps per trip (LDS reads first, MFMAs after)
+            float sv[4], aa[4], bu[4], be[4], bx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 + 4 * u + mg4, jc = min(j, d - 1);
+              const bool okj = j < d, ok = okj && i < d;
+              if constexpr (!SID) {
+                sv[u] = lds_sel(sig + ic * ds + jc, ok);
+                bu[u] = lds_sel(U + mc16 * ds + jc, okj);
+                be[u] = lds_sel(E + mc16 * ds + jc, okj);
+              }
+              if constexpr (OU) {
+                aa[u] = lds_sel(A_l + ic * ds + jc, ok);
+                bx[u] = lds_sel(XS + mc16 * ds + jc, okj);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if constexpr (OU) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[u], bx[u], acc1, 0, 0, 0);
+              if constexpr (!SID) {                      // sigma = I: sigma u = u and sigma eps = eps, added below
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], be[u], acc2, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[u], bu[u], acc1, 0, 0, 0);
+              }
+            }
+          }
+          SOCMX_TICK(10)
+          const float st = ST[mc16];
+          float xs[4], uo[4], eo[4], bi[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {               // every read first, unconditionally (clamped), then the stores
+            const int ioc = min(ib * 16 + 4 * mg4 + rr, d - 1), e = mc16 * ds + ioc;
+            xs[rr] = XS[e];
+            if constexpr (SID) { uo[rr] = U[e]; eo[rr] = E[e]; }
+            bi[rr] = OU ? 0.f : drift_i(kind, d, ioc, XS + mc16 * ds, A_l, KAP);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int io = ib * 16 + 4 * mg4 + rr;
+            const float a1 = SID ? acc1[rr] + uo[rr] : acc1[rr], a2 = SID ? eo[rr] : acc2[rr];
+            const float upd = (bi[rr] + a1) * dt + sq_ldt * a2;
+            if (io < d) {
+              if (STOPPING) UP[mc16 * ds + io] = upd;
+              XN[mc16 * ds + io] = xs[rr] + st * upd;
+            }
+          }
+        }
+      };
+      if (sid) em_mfma(std::true_type{}, std::true_type{});          // (sigma = I without A x took the branch above)
+      else if (is_ou) em_mfma(std::false_type{}, std::true_type{});
+      else em_mfma(std::false_type{}, std::false_type{});
     } else {
       for (int e = tid; e < 16 * d; e += nthr) {
         const int r = SOCMX_DIV_D(e), i = e - r * d;
-        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, a.kappa);
+        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP);
         float su = 0.f, se = 0.f;
         for (int j = 0; j < d; ++j) {
           su += sig[i * ds + j] * U[r * ds + j];
           se += sig[i * ds + j] * E[r * ds + j];
         }
         const float upd = (bi + su) * dt + sq_ldt * se;
-        UP[r * ds + i] = upd;
+        if (STOPPING) UP[r * ds + i] = upd;
         XN[r * ds + i] = XS[r * ds + i] + ST[r] * upd;
       }
     }
@@ -497,41 +575,59 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     }
 
     // ---- running cost / log path weights (utils.py:82-99), f at the NEW state, OLD time ----
-    // 16 lanes per row (threads 0..255): each lane takes components l, l+16, ...; row totals by DPP; lane 0 of the
-    // row group owns the row's accumulators.  (One thread per row walked d -- and d*d for x'Px -- serially.)
+    // u'u and u'eps: 16 lanes per row (threads 0..255), each lane takes components l, l+16, ...; row totals by DPP;
+    // lane 0 of the row group owns the row's accumulators.
+    // x'Px (OU_quadratic.py:66-69): P x on the MFMA like the products above, block ib of P's rows on wave NW-1-ib
+    // (the upper waves have nothing else here); each lane folds its four (P x)_i x_i into one partial in FQ and the
+    // owners add the 4 d/16 partials of their row after the barrier that ends the step.
+    const bool quad = kind == SOCMX_OU_QUADRATIC;
+    if (quad) {
+      for (int ib = NW - 1 - mwave; ib < mblocks; ib += NW) {
+        const int i = ib * 16 + mc16, ic = min(i, d - 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < d; j0 += 16) {
+          float pv[4], xv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u + mg4, jc = min(j, d - 1);
+            pv[u] = lds_sel(P_l + ic * ds + jc, j < d && i < d);
+            xv[u] = lds_sel(XE + mc16 * ds + jc, j < d);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[u], xv[u], acc, 0, 0, 0);
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int io = ib * 16 + 4 * mg4 + rr;
+          part += lds_sel(XE + mc16 * ds + min(io, d - 1), io < d) * acc[rr];
+        }
+        FQ[(ib * 4 + mg4) * 16 + mc16] = part;
+      }
+    }
+    SOCMX_TICK(11)
+    float uu = 0.f, ue = 0.f;
+    auto owner_update = [&](int r, float f) {          // lane 0 of row r's 16-lane group
+      const float step = STOPPING ? FD[r] : dt;
+      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
+      lps = lps + sqrtf(step / a.lmbd) * (-ue);
+      const int grow = tile_row0 + r;
+      if (grow < B) {
+        a.frac[(size_t)k * B + grow] = step;
+        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
+      }
+    };
     if (tid < 256) {
       const int r = tid >> 4, l = tid & 15;
-      const float* x = XE + r * ds;
-      float f = 0.f;
-      if (kind == SOCMX_OU_QUADRATIC) {  // OU_quadratic.py:66-69
-        float part = 0.f;
-        for (int i = l; i < d; i += 16) {
-          float px = 0.f;
-          for (int j = 0; j < d; ++j) px += P_l[i * ds + j] * x[j];
-          part += x[i] * px;
-        }
-        f = row16_sum(part);
-      } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
-        f = 1.f;                         // molecular_dynamics.py:87
-      }
-      float uu = 0.f, ue = 0.f;
       for (int i = l; i < d; i += 16) {
         uu += U[r * ds + i] * U[r * ds + i];
         ue += U[r * ds + i] * E[r * ds + i];
       }
       uu = row16_sum(uu);
       ue = row16_sum(ue);
-      if (l == 0) {
-        const float step = STOPPING ? FD[r] : dt;
-        lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
-        lps = lps + sqrtf(step / a.lmbd) * (-ue);
-        const int grow = tile_row0 + r;
-        if (grow < B) {
-          a.frac[(size_t)k * B + grow] = step;
-          a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
-        }
-      }
+      if (l == 0 && !quad) owner_update(r, kind == SOCMX_MOLECULAR_DYNAMICS ? 1.f : 0.f);   // molecular_dynamics.py:87
     }
+    SOCMX_TICK(12)
     if (STOPPING && tid < 16) ST[tid] = SN[tid];   // (nobody reads ST in this phase; its readers sit behind barriers)
     for (int e = tid; e < 16 * d; e += nthr) {
       const int r = SOCMX_DIV_D(e), i = e - r * d;
@@ -540,8 +636,15 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       X0[r * tl.s0 + 1 + i] = x;                      // next step's network input (the last stage is done with X0)
       if (tile_row0 + r < B) a.states[((size_t)(k + 1) * B + tile_row0 + r) * d + i] = x;
     }
-    if (tid < 16) X0[tid * tl.s0] = a.ts[k + 1];
+    if (tid < 16) X0[tid * tl.s0] = t1;       // (a fresh load here would queue behind this step's stores)
+    SOCMX_TICK(14)
     __syncthreads();
+    if (quad && tid < 256 && (tid & 15) == 0) {
+      const int r = tid >> 4;
+      float f = 0.f;
+      for (int q = 0; q < 4 * mblocks; ++q) f += FQ[q * 16 + r];
+      owner_update(r, f);                   // (FD, SN, FQ are next written behind the barriers of the next step)
+    }
     SOCMX_TICK(9)
   }
   if (PROF && tid == a.prof_wave * 64 && a.prof)
@@ -764,7 +867,12 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.prof = prof;
   { const char* e = getenv("SOCMX_PROF_WAVE"); a.prof_wave = (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }
   a.lds_mats = (a.t.floats + 3) & ~3;
-  const size_t lds_floats = (size_t)a.lds_mats + 3 * (size_t)d * (d + 1) + 6 * 16 * (size_t)(d + 1) + 48 + 512;
+  // sigma (+ A for the OU settings, kappa for the others, + P for OU_quadratic); five (16, d+1) tiles (+ two with a stopping time);
+  // ST/SN/FD; the 512-float noise / partial-sum scratch -- the rule of the kernel's pointer layout
+  const bool ou = pb->kind == SOCMX_OU_QUADRATIC || pb->kind == SOCMX_OU_LINEAR;
+  const int n_mats = 1 + (ou ? 1 : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? 1 : 0);
+  const int n_tiles = 5 + (pb->kind == SOCMX_MOLECULAR_DYNAMICS ? 2 : 0);
+  const size_t lds_floats = (size_t)a.lds_mats + n_mats * (size_t)d * (d + 1) + (ou ? 0 : d) + n_tiles * 16 * (size_t)(d + 1) + 48 + 512;
   const size_t lds_bytes = lds_floats * sizeof(float);
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
   const int blocks = (B + 15) / 16;

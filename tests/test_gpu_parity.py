@@ -636,6 +636,34 @@ def test_rollout_large_d_settings_vs_eager_path(setting, d, extra):
         np.testing.assert_allclose(_np(a), _np(b), rtol=2e-4, atol=2e-4, err_msg=n)
 
 
+@pytest.mark.parametrize("d,dense_sigma", [(7, False), (12, True), (20, False), (20, True), (37, False)])
+def test_rollout_ou_quadratic_dense_matrices_vs_eager_path(d, dense_sigma):
+    """OU_quadratic with DENSE, non-symmetric A, P, Q (the reference's settings only ever pass multiples of the
+    identity, settings.py:226-246, which would hide an index mix-up in x'Px or A x): every SDE-step variant --
+    16-lane fused (d <= 15, sigma = I), scalar loops (d <= 15, dense sigma), MFMA products with and without the
+    sigma = I shortcut (d >= 16) -- against the eager path on the same injected noise."""
+    from SOC_matching.experiment_settings.OU_quadratic import OU_Quadratic
+    from socmx import rollout as R
+    K, B, lmbd = 10, 37, 1.3
+    g = torch.Generator().manual_seed(100 + d)
+    def rnd(scale): return (scale * torch.randn(d, d, generator=g) / d ** 0.5).to(DEV)
+    A, P, Q = rnd(0.5) - 0.3 * torch.eye(d, device=DEV), rnd(1.0), rnd(1.0)
+    sigma = torch.eye(d, device=DEV) + (rnd(0.3) if dense_sigma else 0.0)
+    torch.manual_seed(5)
+    sde = OU_Quadratic(device=DEV, dim=d, lmbd=lmbd, A=A, P=P, Q=Q, sigma=sigma, T=1.0)
+    sde.initialize_models()
+    sde.to(DEV)
+    ts = torch.linspace(0, 1.0, K + 1).to(DEV)
+    state0 = (0.5 * torch.randn(B, d, generator=g)).to(DEV)
+    noise = torch.randn(K, B, d, generator=g).to(DEV)
+    got = R.hip_trajectories(sde, state0, ts, lmbd, noise_in=noise)
+    with torch.no_grad():
+        want = R.eager_trajectories(sde, state0, ts, lmbd, noise_in=noise)
+    names = ["states", "noises", "stop_indicators", "fractional_timesteps", "lpd", "lps", "ltw", "controls"]
+    for n, a, b in zip(names, got, want):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-4, atol=2e-4, err_msg=n)
+
+
 def test_rollout_follows_the_optimizer(tmp_path):
     """After optimizer steps (fused multi-tensor Adam updates the parameters without bumping their `_version`) the
     rollout must integrate with the CURRENT weights: controls = -sigma^T nabla_V(t_k, X_k) of the updated module, and
