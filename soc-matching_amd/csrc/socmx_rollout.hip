@@ -80,10 +80,10 @@ struct RolloutArgs {
 
 // drift b_i(x) -- OU_quadratic.py:51-52, OU_linear.py:43-44, double_well.py:44-48, molecular_dynamics.py:49-53
 __device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x, const float* A_l,
-                                         const float* __restrict__ kappa) {
+                                         const float* __restrict__ kappa, int ds) {
   if (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR) {
     float s = 0.f;
-    for (int j = 0; j < d; ++j) s += A_l[i * (d + 1) + j] * x[j];
+    for (int j = 0; j < d; ++j) s += A_l[i * ds + j] * x[j];
     return s;
   }
   const float xi = x[i];
@@ -139,6 +139,8 @@ __device__ __forceinline__ float lds_sel(const float* p, bool c) {
   return c ? t : 0.f;
 }
 
+__host__ __device__ constexpr int socmx_sde_stride(int d) { return ((d + 15) & ~15) + 1; }
+
 struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
 typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
 typedef StaticNet<80, 256, 128, 64, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
@@ -167,7 +169,10 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   float* X0 = lds + tl.x0;
   float* GV = lds + tl.gv;
   // small per-tile state (behind the network tiles)
-  const int ds = d + 1;                   // padded row stride of the LDS matrix copies (bank spread)
+  // row stride of the LDS matrix copies and (16, d) tiles: d rounded up to the MFMA's k-block, plus one for the bank
+  // spread.  The padding columns are zeroed once and never written, so the MFMA products read whole 16-wide k-blocks
+  // with no per-element clamp or mask.
+  const int ds = socmx_sde_stride(d);
   // which constant matrices and tiles exist depends on the setting (d = 64 with all of them would not fit 160 KiB):
   // the launcher sizes the allocation with the same rule (rollout_sde_floats)
   const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
@@ -192,6 +197,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   float* NZ = FD + 16;                    // (2,16,16) FAST path: double-buffered noise of steps k, k+1
   float* FQ = NZ;                         // general path: (d/16 blocks, 4, 16) partial sums of x'Px
 
+  for (float* z = sig + tid; z < NZ + 512; z += nthr) *z = 0.f;   // (the padding columns stay zero for good)
+  __syncthreads();
   for (int e = tid; e < d * d; e += nthr) {
     const int r = e / d, c = e - r * d;
     sig[r * ds + c] = a.sigma[e];
@@ -432,8 +439,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           for (int u = 0; u < 4; ++u) {
             const int j = j0 + 4 * u + mg4;
             const bool okj = j < d;
-            av[u] = lds_sel(sig + min(j, d - 1) * ds + min(i, d - 1), okj && i < d);   // (sigma^T)[i][j]
-            bv[u] = lds_sel(GV + mc16 * tl.sg + min(j, d - 1), okj);
+            av[u] = lds_sel(sig + min(j, d - 1) * ds + min(i, d - 1), okj);   // (sigma^T)[i][j]; rows j >= d: none
+            bv[u] = GV[mc16 * tl.sg + j];               // the network's padded outputs are exact zeros
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       // sigma = I and an elementwise drift (double_well, molecular_dynamics): nothing to multiply
       for (int e = tid; e < 16 * d; e += nthr) {
         const int r = SOCMX_DIV_D(e), i = e - r * d;
-        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP);
+        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP, ds);
         const float upd = (bi + U[r * ds + i]) * dt + sq_ldt * E[r * ds + i];
         if (STOPPING) UP[r * ds + i] = upd;
         XN[r * ds + i] = XS[r * ds + i] + ST[r] * upd;
@@ -491,16 +498,15 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
             float sv[4], aa[4], bu[4], be[4], bx[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const int j = j0 + 4 * u + mg4, jc = min(j, d - 1);
-              const bool okj = j < d, ok = okj && i < d;
-              if constexpr (!SID) {
-                sv[u] = lds_sel(sig + ic * ds + jc, ok);
-                bu[u] = lds_sel(U + mc16 * ds + jc, okj);
-                be[u] = lds_sel(E + mc16 * ds + jc, okj);
+              const int j = j0 + 4 * u + mg4;            // < stride - 1: zero columns past d (rows i >= d of the
+              if constexpr (!SID) {                      //  result repeat row d-1 and are not stored)
+                sv[u] = sig[ic * ds + j];
+                bu[u] = U[mc16 * ds + j];
+                be[u] = E[mc16 * ds + j];
               }
               if constexpr (OU) {
-                aa[u] = lds_sel(A_l + ic * ds + jc, ok);
-                bx[u] = lds_sel(XS + mc16 * ds + jc, okj);
+                aa[u] = A_l[ic * ds + j];
+                bx[u] = XS[mc16 * ds + j];
               }
             }
 #pragma unroll
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
             const int ioc = min(ib * 16 + 4 * mg4 + rr, d - 1), e = mc16 * ds + ioc;
             xs[rr] = XS[e];
             if constexpr (SID) { uo[rr] = U[e]; eo[rr] = E[e]; }
-            bi[rr] = OU ? 0.f : drift_i(kind, d, ioc, XS + mc16 * ds, A_l, KAP);
+            bi[rr] = OU ? 0.f : drift_i(kind, d, ioc, XS + mc16 * ds, A_l, KAP, ds);
           }
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     } else {
       for (int e = tid; e < 16 * d; e += nthr) {
         const int r = SOCMX_DIV_D(e), i = e - r * d;
-        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP);
+        const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP, ds);
         float su = 0.f, se = 0.f;
         for (int j = 0; j < d; ++j) {
           su += sig[i * ds + j] * U[r * ds + j];
@@ -589,9 +595,9 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           float pv[4], xv[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 4 * u + mg4, jc = min(j, d - 1);
-            pv[u] = lds_sel(P_l + ic * ds + jc, j < d && i < d);
-            xv[u] = lds_sel(XE + mc16 * ds + jc, j < d);
+            const int j = j0 + 4 * u + mg4;
+            pv[u] = P_l[ic * ds + j];
+            xv[u] = XE[mc16 * ds + j];
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[u], xv[u], acc, 0, 0, 0);
@@ -867,12 +873,13 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.prof = prof;
   { const char* e = getenv("SOCMX_PROF_WAVE"); a.prof_wave = (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }
   a.lds_mats = (a.t.floats + 3) & ~3;
-  // sigma (+ A for the OU settings, kappa for the others, + P for OU_quadratic); five (16, d+1) tiles (+ two with a stopping time);
+  // sigma (+ A for the OU settings, kappa for the others, + P for OU_quadratic); five (16, stride) tiles (+ two with a stopping time);
   // ST/SN/FD; the 512-float noise / partial-sum scratch -- the rule of the kernel's pointer layout
   const bool ou = pb->kind == SOCMX_OU_QUADRATIC || pb->kind == SOCMX_OU_LINEAR;
   const int n_mats = 1 + (ou ? 1 : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? 1 : 0);
   const int n_tiles = 5 + (pb->kind == SOCMX_MOLECULAR_DYNAMICS ? 2 : 0);
-  const size_t lds_floats = (size_t)a.lds_mats + n_mats * (size_t)d * (d + 1) + (ou ? 0 : d) + n_tiles * 16 * (size_t)(d + 1) + 48 + 512;
+  const size_t sds = (size_t)socmx_sde_stride(d);
+  const size_t lds_floats = (size_t)a.lds_mats + n_mats * (size_t)d * sds + (ou ? 0 : d) + n_tiles * 16 * sds + 48 + 512;
   const size_t lds_bytes = lds_floats * sizeof(float);
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
   const int blocks = (B + 15) / 16;
