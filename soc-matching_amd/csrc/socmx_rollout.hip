@@ -141,6 +141,24 @@ __device__ __forceinline__ float lds_sel(const float* p, bool c) {
 
 __host__ __device__ constexpr int socmx_sde_stride(int d) { return ((d + 15) & ~15) + 1; }
 
+// the two halves of philox_normal2, for callers that spread them over two phases of a step
+__device__ __forceinline__ void philox_pair_words(uint64_t seed, uint64_t offset, uint32_t grow, uint32_t step,
+                                                  int block, int h, uint32_t& wa, uint32_t& wb) {
+  uint32_t w[4];
+  philox4x32_10(grow, step, (uint32_t)block, (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  wa = h ? w[2] : w[0];
+  wb = h ? w[3] : w[1];
+}
+__device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, float& z0, float& z1) {
+  const float ua = ((float)wa + 0.5f) * 2.3283064365386963e-10f;
+  const float ub = ((float)wb + 0.5f) * 2.3283064365386963e-10f;
+  const float r = sqrtf(-2.0f * logf(ua));
+  float sn, cs;
+  sincospif(2.0f * ub, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
 struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
 typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
 typedef StaticNet<80, 256, 128, 64, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
@@ -397,6 +415,81 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       }
     }
   };
+  // Philox in two halves: the counter-mode block during the Euler-Maruyama phase of step kk - 1, Box-Muller and the
+  // stores during its cost phase (the words wait in registers across the barrier between them).  Each half is about
+  // as long as what the other waves do in that phase; in one piece the generator was the Euler-Maruyama phase's
+  // critical path.  (Tiles too wide for the rule below take the one-piece draw_noise.)
+  const int nz_t = (nthr >= 512) ? tid - 256 : tid;          // noise duty: the upper four waves when there are eight
+  const int nz_n = (nthr >= 512) ? nthr - 256 : nthr;
+  // Unit of work: one Box-Muller pair per thread when that covers the tile in one pass (d <= 32 on 256 threads: two
+  // threads share a block's latency), otherwise whole blocks (four components), up to two per thread.
+  const int nz_pairs = 16 * ((d + 1) >> 1), nz_quads = 16 * ((d + 3) >> 2);
+  const bool nz_by_pair = nz_pairs <= nz_n;
+  const bool nz_split = !a.noise_in && (nz_by_pair || nz_quads <= 2 * nz_n);
+  uint32_t pw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  auto noise_words = [&](int kk) {
+    if (nz_by_pair) {
+      const int np = (d + 1) >> 1;
+      if (nz_t < nz_pairs) {
+        const int r = (int)(((float)nz_t + 0.5f) * __builtin_amdgcn_rcpf((float)np)), pr = nz_t - r * np;
+        philox_pair_words(a.seed, a.offset, (uint32_t)(a.row0 + tile_row0 + r), (uint32_t)kk, pr >> 1, pr & 1,
+                          pw[0][0], pw[0][1]);
+      }
+    } else {
+      const int nq = (d + 3) >> 2;
+      const float inv_nq = __builtin_amdgcn_rcpf((float)nq);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int q = nz_t + it * nz_n;
+        if (q < nz_quads) {
+          const int r = (int)(((float)q + 0.5f) * inv_nq), b = q - r * nq;
+          philox4x32_10((uint32_t)(a.row0 + tile_row0 + r), (uint32_t)kk, (uint32_t)b, (uint32_t)a.offset,
+                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32), pw[it]);
+        }
+      }
+    }
+  };
+  auto noise_put = [&](int kk, float* Eb, int r, int i, float z) {
+    if (i < d) {
+      Eb[r * ds + i] = z;
+      if (tile_row0 + r < B) a.noises[((size_t)kk * B + tile_row0 + r) * d + i] = z;
+    }
+  };
+  // which: 0 = the first Box-Muller pair of each block, 1 = the second, 2 = both (by-pair mode: all in call 0 or 2)
+  auto noise_finish = [&](int kk, float* Eb, int which) {
+    if (nz_by_pair) {
+      if (which == 1) return;
+      const int np = (d + 1) >> 1;
+      if (nz_t < nz_pairs) {
+        const int r = (int)(((float)nz_t + 0.5f) * __builtin_amdgcn_rcpf((float)np)), pr = nz_t - r * np;
+        float z0, z1;
+        box_muller_pair(pw[0][0], pw[0][1], z0, z1);
+        noise_put(kk, Eb, r, 2 * pr, z0);
+        noise_put(kk, Eb, r, 2 * pr + 1, z1);
+      }
+    } else {
+      const int nq = (d + 3) >> 2;
+      const float inv_nq = __builtin_amdgcn_rcpf((float)nq);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int q = nz_t + it * nz_n;
+        if (q < nz_quads) {
+          const int r = (int)(((float)q + 0.5f) * inv_nq), b = q - r * nq;
+          float z0, z1;
+          if (which != 1) {
+            box_muller_pair(pw[it][0], pw[it][1], z0, z1);
+            noise_put(kk, Eb, r, 4 * b, z0);
+            noise_put(kk, Eb, r, 4 * b + 1, z1);
+          }
+          if (which != 0) {
+            box_muller_pair(pw[it][2], pw[it][3], z0, z1);
+            noise_put(kk, Eb, r, 4 * b + 2, z0);
+            noise_put(kk, Eb, r, 4 * b + 3, z1);
+          }
+        }
+      }
+    }
+  };
   draw_noise(0, E0, tid, nthr);
   __syncthreads();
 
@@ -419,17 +512,12 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     // ---- control u = -sigma^T nabla_V (method.py:68-72); the step's noise (utils.py:39) is already in E ---
     float* E = (k & 1) ? E1 : E0;
     float* En = (k & 1) ? E0 : E1;
-    if (mm) {
+    const bool ctrl_in_em = mm && sid;               // sigma = I: u = -nabla_V is formed where the update needs it
+    if (ctrl_in_em) {
+    } else if (mm) {
+      if (k > 0 && nz_split && nz_t >= 0) noise_finish(k, E, 1);     // second half of this step's noise (see below)
       // d >= 16: the (16 rows x d) . (d x d) products run on the MFMA with both operands read from LDS
       // (one ds_read_b32 pair per MFMA instead of two LDS reads per multiply-add)
-      if (sid) {                                      // sigma = I: u = -nabla_V, no product
-        for (int e = tid; e < 16 * d; e += nthr) {
-          const int r = SOCMX_DIV_D(e), i = e - r * d;
-          const float u = -GV[r * tl.sg + i];
-          U[r * ds + i] = u;
-          if (tile_row0 + r < B) a.controls[((size_t)k * B + tile_row0 + r) * d + i] = u;
-        }
-      } else
       for (int ib = mwave; ib < mblocks; ib += NW) {
         const int i = ib * 16 + mc16;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -467,22 +555,25 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         if (grow < B) a.controls[((size_t)k * B + grow) * d + i] = u;
       }
     }
-    __syncthreads();
+    if (!ctrl_in_em) __syncthreads();
     SOCMX_TICK(7)
 
     // ---- Euler-Maruyama update (utils.py:45-48) ------------------------------------------
-    // the noise of step k + 1 is drawn here, by the upper four waves when there are eight: up to d = 64 they have no
-    // part in the MFMA products below, so the generator's latency (instruction-bound, ~2k cycles) hides behind them
-    if (k + 1 < K) {
-      if (nthr >= 512) { if (tid >= 256) draw_noise(k + 1, En, tid - 256, nthr - 256); }
-      else draw_noise(k + 1, En, tid, nthr);
+    // the noise of step k + 1 is started here, by the upper four waves when there are eight: up to d = 64 they have
+    // no part in the MFMA products below
+    if (k + 1 < K && nz_t >= 0) {
+      if (nz_split) noise_words(k + 1);
+      else draw_noise(k + 1, En, nz_t, nz_n);
     }
     if (mm && sid && !is_ou) {
       // sigma = I and an elementwise drift (double_well, molecular_dynamics): nothing to multiply
       for (int e = tid; e < 16 * d; e += nthr) {
         const int r = SOCMX_DIV_D(e), i = e - r * d;
         const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP, ds);
-        const float upd = (bi + U[r * ds + i]) * dt + sq_ldt * E[r * ds + i];
+        const float u = -GV[r * tl.sg + i];
+        U[r * ds + i] = u;
+        if (tile_row0 + r < B) a.controls[((size_t)k * B + tile_row0 + r) * d + i] = u;
+        const float upd = (bi + u) * dt + sq_ldt * E[r * ds + i];
         if (STOPPING) UP[r * ds + i] = upd;
         XN[r * ds + i] = XS[r * ds + i] + ST[r] * upd;
       }
@@ -525,7 +616,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           for (int rr = 0; rr < 4; ++rr) {               // every read first, unconditionally (clamped), then the stores
             const int ioc = min(ib * 16 + 4 * mg4 + rr, d - 1), e = mc16 * ds + ioc;
             xs[rr] = XS[e];
-            if constexpr (SID) { uo[rr] = U[e]; eo[rr] = E[e]; }
+            if constexpr (SID) { uo[rr] = -GV[mc16 * tl.sg + ioc]; eo[rr] = E[e]; }
             bi[rr] = OU ? 0.f : drift_i(kind, d, ioc, XS + mc16 * ds, A_l, KAP, ds);
           }
 #pragma unroll
@@ -536,6 +627,10 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
             if (io < d) {
               if (STOPPING) UP[mc16 * ds + io] = upd;
               XN[mc16 * ds + io] = xs[rr] + st * upd;
+              if constexpr (SID) {
+                U[mc16 * ds + io] = uo[rr];
+                if (tile_row0 + mc16 < B) a.controls[((size_t)k * B + tile_row0 + mc16) * d + io] = uo[rr];
+              }
             }
           }
         }
@@ -586,6 +681,9 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     // x'Px (OU_quadratic.py:66-69): P x on the MFMA like the products above, block ib of P's rows on wave NW-1-ib
     // (the upper waves have nothing else here); each lane folds its four (P x)_i x_i into one partial in FQ and the
     // owners add the 4 d/16 partials of their row after the barrier that ends the step.
+    // (with a separate control phase -- dense sigma -- the second pair of each block waits for it: the upper waves
+    //  idle there as well, and two Box-Muller evaluations in a row made them the last to reach this phase's barrier)
+    if (k + 1 < K && nz_split && nz_t >= 0) noise_finish(k + 1, En, (mm && !sid) ? 0 : 2);
     const bool quad = kind == SOCMX_OU_QUADRATIC;
     if (quad) {
       for (int ib = NW - 1 - mwave; ib < mblocks; ib += NW) {
@@ -612,26 +710,28 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       }
     }
     SOCMX_TICK(11)
-    float uu = 0.f, ue = 0.f;
-    auto owner_update = [&](int r, float f) {          // lane 0 of row r's 16-lane group
-      const float step = STOPPING ? FD[r] : dt;
-      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
-      lps = lps + sqrtf(step / a.lmbd) * (-ue);
-      const int grow = tile_row0 + r;
-      if (grow < B) {
-        a.frac[(size_t)k * B + grow] = step;
-        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
-      }
-    };
+    float step_over_lmbd = 0.f;                        // owners: kept for the x'Px term added behind the barrier
     if (tid < 256) {
       const int r = tid >> 4, l = tid & 15;
+      float uu = 0.f, ue = 0.f;
       for (int i = l; i < d; i += 16) {
         uu += U[r * ds + i] * U[r * ds + i];
         ue += U[r * ds + i] * E[r * ds + i];
       }
       uu = row16_sum(uu);
       ue = row16_sum(ue);
-      if (l == 0 && !quad) owner_update(r, kind == SOCMX_MOLECULAR_DYNAMICS ? 1.f : 0.f);   // molecular_dynamics.py:87
+      if (l == 0) {
+        const float step = STOPPING ? FD[r] : dt;
+        const float f = kind == SOCMX_MOLECULAR_DYNAMICS ? 1.f : 0.f;      // molecular_dynamics.py:87; x'Px: below
+        step_over_lmbd = step / a.lmbd;
+        lpd = lpd + step_over_lmbd * (-f - 0.5f * uu);
+        lps = lps + sqrtf(step_over_lmbd) * (-ue);
+        const int grow = tile_row0 + r;
+        if (grow < B) {
+          a.frac[(size_t)k * B + grow] = step;
+          a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
+        }
+      }
     }
     SOCMX_TICK(12)
     if (STOPPING && tid < 16) ST[tid] = SN[tid];   // (nobody reads ST in this phase; its readers sit behind barriers)
@@ -648,8 +748,11 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if (quad && tid < 256 && (tid & 15) == 0) {
       const int r = tid >> 4;
       float f = 0.f;
-      for (int q = 0; q < 4 * mblocks; ++q) f += FQ[q * 16 + r];
-      owner_update(r, f);                   // (FD, SN, FQ are next written behind the barriers of the next step)
+      for (int q = 0; q < 4 * mblocks; q += 4) {      // (FQ is next written behind the barriers of the next step)
+        const float f0 = FQ[q * 16 + r], f1 = FQ[(q + 1) * 16 + r], f2 = FQ[(q + 2) * 16 + r], f3 = FQ[(q + 3) * 16 + r];
+        f += (f0 + f1) + (f2 + f3);
+      }
+      lpd = lpd - step_over_lmbd * f;
     }
     SOCMX_TICK(9)
   }
