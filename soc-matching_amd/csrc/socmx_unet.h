@@ -609,10 +609,14 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
   // the wave's whole share of GEMM 1 (and GEMM 2's few chunks) arrives through the prefetch, the stage itself issues
   // no load and has no runtime loop bounds
   constexpr int KC1 = sd.L1.in_pad >> 4, KC2 = sd.L2.in_pad >> 4;
-  constexpr bool slim_split = wref.split && NBLK == 1 && KC1 % NW == 0 && (KC1 / NW) + 1 <= 8 && (!sd.has2 || KC2 <= NW);
+  // (one or two blocks: wave w takes block w % NBLK and part w / NBLK of the K range, NW / NBLK parts per block)
+  constexpr int PARTS = (NBLK <= 2 && NW % NBLK == 0) ? NW / NBLK : 1;
+  constexpr bool slim_split = wref.split && NBLK <= 2 && NW % NBLK == 0 && KC1 % PARTS == 0 && (KC1 / PARTS) + 1 <= 8 &&
+                              (!sd.has2 || KC2 <= PARTS);
   constexpr int KC2n = sdn.L2.in_pad >> 4;
-  constexpr bool slim_split_next = wrefn.split && NBLKn == 1 && KCn % NW == 0 && (KCn / NW) + 1 <= 8 &&
-                                   (!sdn.has2 || KC2n <= NW);
+  constexpr int PARTSn = (NBLKn <= 2 && NW % NBLKn == 0) ? NW / NBLKn : 1;
+  constexpr bool slim_split_next = wrefn.split && NBLKn <= 2 && NW % NBLKn == 0 && KCn % PARTSn == 0 &&
+                                   (KCn / PARTSn) + 1 <= 8 && (!sdn.has2 || KC2n <= PARTSn);
   // every active wave owns the same number of neuron blocks: instantiate exactly that stage_direct<NB> (the generic
   // stage keeps all four NB variants alive behind a runtime switch on w.cnt -- three quarters of its code is dead)
   constexpr bool uniform = !wref.split && ((NBLK >= NW && NBLK % NW == 0 && NBLK / NW <= 4 && NBLK / NW != 3) ||
@@ -642,12 +646,15 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
         c.f[f] = wl[(size_t)(wb + boff + kc) * 64];
       }
     } else if constexpr (slim_split_next) {
-      // wave w of the next stage multiplies chunks [w CPW, (w+1) CPW) of GEMM 1 and chunk w of GEMM 2 (if it has one)
-      constexpr int CPWn = KCn / NW;
+      // wave w of the next stage (block b = w % NBLKn, part p = w / NBLKn) multiplies chunks [p CPW, (p+1) CPW) of
+      // GEMM 1 and chunk p of GEMM 2 (if it has one); fragment (block, chunk) sits at index block KC + chunk
+      constexpr int CPWn = KCn / PARTSn;
+      const int bn = wave % NBLKn, pn = wave / NBLKn;
       const f32x4* w1 = reinterpret_cast<const f32x4*>(Wp + sdn.L1.w_off) + lane;
 #pragma unroll
-      for (int f = 0; f < CPWn; ++f) c.f[f] = w1[(size_t)(wave * CPWn + f) * 64];
-      if (sdn.has2 && wave < KC2n) c.f[CPWn] = (reinterpret_cast<const f32x4*>(Wp + sdn.L2.w_off) + lane)[(size_t)wave * 64];
+      for (int f = 0; f < CPWn; ++f) c.f[f] = w1[(size_t)(bn * KCn + pn * CPWn + f) * 64];
+      if (sdn.has2 && pn < KC2n)
+        c.f[CPWn] = (reinterpret_cast<const f32x4*>(Wp + sdn.L2.w_off) + lane)[(size_t)(bn * KC2n + pn) * 64];
     } else {
       const WaveWork w0 = wave_work_of(sd, NW, wave);
       WaveWorkS w{};
@@ -659,28 +666,30 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
     __syncthreads();
     sub(4);
   } else if constexpr (slim_split) {
-    constexpr int CPW = KC1 / NW;
+    constexpr int CPW = KC1 / PARTS;
+    static_assert(NBLK * 256 <= NW * 64, "the combine needs one thread per output element");
     const int lane = threadIdx.x & 63, row = lane & 15, g = lane >> 4;
-    float* P1 = lds + t.scratch;                       // [NW][16 rows][16]
-    float* P2 = P1 + NW * 256;                         // [KC2][16 rows][16]
+    const int blk = wave % NBLK, part = wave / NBLK;
+    float* P1 = lds + t.scratch;                       // [NBLK][PARTS][16 rows][16]  (NBLK PARTS = NW)
+    float* P2 = P1 + NW * 256;                         // [NBLK][KC2][16 rows][16]
     asm volatile("" : "+v"(c.f[0]), "+v"(c.f[1]), "+v"(c.f[2]), "+v"(c.f[3]));
     asm volatile("" : "+v"(c.f[4]), "+v"(c.f[5]), "+v"(c.f[6]), "+v"(c.f[7]));
     {
-      const float* xrow = lds + sd.x1 + row * sd.s1 + 4 * g + wave * (CPW * 16);
+      const float* xrow = lds + sd.x1 + row * sd.s1 + 4 * g + part * (CPW * 16);
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int f = 0; f < CPW; ++f) {
         const f32x4 a1[1] = {c.f[f]};
         mfma_chunk<1>(acc, a1, *reinterpret_cast<const f32x4*>(xrow + f * 16));
       }
-      *reinterpret_cast<f32x4*>(P1 + (wave * 16 + row) * 16 + 4 * g) = acc[0];
+      *reinterpret_cast<f32x4*>(P1 + ((blk * PARTS + part) * 16 + row) * 16 + 4 * g) = acc[0];
     }
-    if (sd.has2 && wave < KC2) {
-      const float* xrow = lds + sd.x2 + row * sd.s2 + 4 * g + wave * 16;
+    if (sd.has2 && part < KC2) {
+      const float* xrow = lds + sd.x2 + row * sd.s2 + 4 * g + part * 16;
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       const f32x4 a2[1] = {c.f[CPW]};
       mfma_chunk<1>(acc, a2, *reinterpret_cast<const f32x4*>(xrow));
-      *reinterpret_cast<f32x4*>(P2 + (wave * 16 + row) * 16 + 4 * g) = acc[0];
+      *reinterpret_cast<f32x4*>(P2 + ((blk * KC2 + part) * 16 + row) * 16 + 4 * g) = acc[0];
     }
     // prefetch for the stage that follows (stage 0 of the next time step)
     if constexpr (uniform_next) {
@@ -702,25 +711,25 @@ __device__ __forceinline__ void unet_stage_static(const float* __restrict__ Wp, 
     }
     __syncthreads();
     const float* bias_lds = lds + t.bias;
-    const int e = threadIdx.x;
+    const int e = threadIdx.x & 255, eb = threadIdx.x >> 8;   // element (r, n) = (e >> 4, e & 15) of block eb
     float v = 0.f;
-    if (e < 256) {                                     // element (r, n) = (e >> 4, e & 15): bias, ReLU, residual
-      const int n = e & 15;
+    if (eb < NBLK) {                                   // bias, ReLU, residual
+      const int n = eb * 16 + (e & 15);
       v = bias_lds[sd.L1.b_lds + n];
 #pragma unroll
-      for (int p = 0; p < NW; ++p) v += P1[p * 256 + e];
+      for (int p = 0; p < PARTS; ++p) v += P1[(eb * PARTS + p) * 256 + e];
       v = relu_keep_nan(v);
       if (sd.has2) {
         float v2 = bias_lds[sd.L2.b_lds + n];
 #pragma unroll
-        for (int p = 0; p < KC2; ++p) v2 += P2[p * 256 + e];
+        for (int p = 0; p < KC2; ++p) v2 += P2[(eb * KC2 + p) * 256 + e];
         v += v2;
       }
     }
-    if (to_reg) {
+    if (to_reg) {                                      // (16-wide outputs only: thread tid < 256 holds element tid)
       *to_reg = v;                                     // the caller synchronises before LDS is reused (see unet_stage)
     } else {
-      if (e < 256) (lds + sd.y)[(e >> 4) * sd.sy + (e & 15)] = v;
+      if (eb < NBLK) (lds + sd.y)[(e >> 4) * sd.sy + eb * 16 + (e & 15)] = v;
       __syncthreads();
     }
   } else {
