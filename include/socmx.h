@@ -53,7 +53,8 @@ extern "C" {
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
 #define SOCMX_E_KIND (-3)      /* unknown problem kind                 */
 #define SOCMX_E_WORKSPACE (-4) /* workspace too small                  */
-#define SOCMX_E_LDS (-5)       /* configuration does not fit in 160 KiB of LDS */
+#define SOCMX_E_LDS (-5)       /* configuration does not fit in 160 KiB of LDS (rollout, hidden widths 256/128/64:
+                                  d <= 64 OU_quadratic, 74 OU_linear, 96 double_well, 80 molecular_dynamics) */
 
 typedef void* socmx_stream_t; /* hipStream_t */
 

@@ -101,9 +101,13 @@ def lib():
     return _lib
 
 
+_STATUS_TEXT = {-1: "null pointer", -2: "bad dimension", -3: "unknown problem kind", -4: "workspace too small",
+                -5: "does not fit in 160 KiB of LDS (d too large for this setting / these hidden widths)"}
+
+
 def check(status, what):
     if status != 0:
-        kind = "invalid argument" if status < 0 else "hipError_t"
+        kind = _STATUS_TEXT.get(status, "invalid argument") if status < 0 else "hipError_t"
         raise SocmxError(f"{what} failed with status {status} ({kind})")
 
 

@@ -668,6 +668,22 @@ def test_rollout_ou_quadratic_dense_matrices_vs_eager_path(d, dense_sigma):
         np.testing.assert_allclose(_np(a), _np(b), rtol=2e-4, atol=2e-4, err_msg=n)
 
 
+def test_rollout_that_does_not_fit_lds_raises():
+    """OU_quadratic at d = 100 needs three 100 x 113 matrices beside the network tiles: more than 160 KiB of LDS.  The C
+    ABI answers SOCMX_E_LDS and the Python layer raises -- there is no slower path to fall back to."""
+    from SOC_matching.experiment_settings.OU_quadratic import OU_Quadratic
+    from socmx import rollout as R, _lib
+    d, K, B = 100, 4, 16
+    eye = torch.eye(d, device=DEV)
+    torch.manual_seed(0)
+    sde = OU_Quadratic(device=DEV, dim=d, lmbd=1.0, A=-eye, P=eye, Q=eye, sigma=eye, T=1.0)
+    sde.initialize_models()
+    sde.to(DEV)
+    ts = torch.linspace(0, 1.0, K + 1).to(DEV)
+    with pytest.raises(_lib.SocmxError, match="-5"):
+        R.hip_trajectories(sde, torch.zeros(B, d, device=DEV), ts, 1.0, seed=0, offset=0)
+
+
 def test_rollout_follows_the_optimizer(tmp_path):
     """After optimizer steps (fused multi-tensor Adam updates the parameters without bumping their `_version`) the
     rollout must integrate with the CURRENT weights: controls = -sigma^T nabla_V(t_k, X_k) of the updated module, and
