@@ -140,6 +140,35 @@ def test_philox_contract_on_the_general_sde_path(name):
     assert np.array_equal(_np(r2[1]), noises[:, 16:])
 
 
+@pytest.mark.parametrize("setting,d", [("double_well", 40), ("OU_quadratic_easy", 20), ("OU_quadratic_easy", 48)])
+def test_philox_contract_with_identity_sigma_at_large_d(setting, d):
+    """sigma = I at d >= 16 (no control phase: both Box-Muller halves of a block run in the cost phase; d <= 32: one
+    pair per thread): the same documented draw, on a ragged tile, and independent of the sharding."""
+    import contextlib, io
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from SOC_matching import utils
+    K, B = 6, 21
+    cfg = load_config([f"method.setting={setting}", f"method.d={d}", f"method.num_steps={K}"])
+    cfg.method.device = DEV
+    torch.manual_seed(0)
+    ts = torch.linspace(0, 0.05, K + 1).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)
+    r = utils.stochastic_trajectories(sde, x0.repeat(B, 1), ts, 1.0, seed=91, offset=5, row0=8)
+    noises = _np(r[1])
+    for (k, m) in [(0, 0), (1, 17), (2, 3), (K - 1, 20)]:
+        want = O.philox_normals(91, 5, 8 + m, k, d)
+        np.testing.assert_allclose(noises[k, m], want, rtol=2e-4, atol=2e-5)
+    r2 = utils.stochastic_trajectories(sde, x0.repeat(5, 1), ts, 1.0, seed=91, offset=5, row0=24)
+    assert np.array_equal(_np(r2[1]), noises[:, 16:])
+    # and the trajectory is the one that noise drives (eager path, same noise)
+    from socmx import rollout as R
+    with torch.no_grad():
+        want = R.eager_trajectories(sde, x0.repeat(B, 1), ts, 1.0, noise_in=r[1])
+    np.testing.assert_allclose(_np(r[0]), _np(want[0]), rtol=2e-4, atol=2e-4)
+
+
 def test_weights_stats_kernel():
     from socmx import loss as L
     for B in (1 + 1, 128, 1000):
