@@ -745,6 +745,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if (tid < 16) X0[tid * tl.s0] = t1;       // (a fresh load here would queue behind this step's stores)
     SOCMX_TICK(14)
     __syncthreads();
+    SOCMX_TICK(15)
     if (quad && tid < 256 && (tid & 15) == 0) {
       const int r = tid >> 4;
       float f = 0.f;

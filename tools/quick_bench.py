@@ -61,8 +61,8 @@ for name in which:
         # general SDE step only (wave 0's view): 10 = MFMA products of the Euler-Maruyama phase (8 = its epilogue +
         # barrier), 11 = x'Px partials / noise finish, 12 = u'u, u'eps and the owners' update, 14 = write-back
         # (9 = the barrier that ends the step + the owners' x'Px sum)
-        print("   SDE-step slots 10 (EM products) 11 (x'Px, noise) 12 (u'u, u'eps) 14 (write-back):",
-              " ".join(f"{c[i]:.0f}" for i in (10, 11, 12, 14)))
+        print("   SDE-step slots 10 (EM products) 11 (x'Px, noise) 12 (u'u, u'eps) 14 (write-back) 15 (last barrier):",
+              " ".join(f"{c[i]:.0f}" for i in (10, 11, 12, 14, 15)))
         for si in range(6):
             sub = c[16 + si * 8: 16 + si * 8 + 7]
             print(f"   stage {si+1} ({names[si+1]}): desc={sub[5]:.0f} prewait={sub[6]:.0f} issue={sub[0]:.0f} gemm1={sub[1]:.0f} gemm2={sub[2]:.0f} store+prefetch={sub[3]:.0f} barrier={sub[4]:.0f}")
