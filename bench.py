@@ -52,13 +52,13 @@ def bytes_per_traj_step(d):
     return 3 * d * 4 + 8                        # state + noise + control + stop/frac
 
 
-def build(device):
+def build(device, setting=SETTING, d=D, num_steps=NUM_STEPS, gamma=GAMMA, batch=BATCH_PER_GPU):
     from socmx.config import load_config
     from socmx.settings import define_variables
     from SOC_matching.method import SOC_Solver
-    cfg = load_config([f"method.setting={SETTING}", f"method.d={D}", f"method.num_steps={NUM_STEPS}",
-                       f"method.gamma={GAMMA}", "method.scaling_factor_M=0.1", "optim.M_lr=1e-3",
-                       f"optim.batch_size={BATCH_PER_GPU}", "method.lmbd=1.0", "method.seed=0"])
+    cfg = load_config([f"method.setting={setting}", f"method.d={d}", f"method.num_steps={num_steps}",
+                       f"method.gamma={gamma}", "method.scaling_factor_M=0.1", "optim.M_lr=1e-3",
+                       f"optim.batch_size={batch}", "method.lmbd=1.0", "method.seed=0"])
     cfg.method.device = str(device)
     torch.manual_seed(cfg.method.seed)
     ts = torch.linspace(0, cfg.method.T, cfg.method.num_steps + 1).to(device)
@@ -68,6 +68,48 @@ def build(device):
     solver = SOC_Solver(sde, x0, None, T=cfg.method.T, num_steps=cfg.method.num_steps, lmbd=cfg.method.lmbd,
                         d=cfg.method.d, sigma=sigma)
     return cfg, ts, x0, sde, solver
+
+
+def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_dist, row0):
+    """Rollout and full-iteration timings of another BASELINE configuration (driver-timed secondary entries: the
+    headline `value` stays configs[2])."""
+    from socmx import rollout
+    from socmx.train import Trainer, make_optimizer
+    cfg, ts, x0, sde, solver = build(device, setting, d, K, gamma, B)
+    state0 = x0.repeat(B, 1)
+    for i in range(warmup):
+        rollout.stochastic_trajectories(sde, state0, ts, 1.0, seed=0, offset=i, row0=row0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record()
+    for i in range(steps):
+        rollout.stochastic_trajectories(sde, state0, ts, 1.0, seed=0, offset=warmup + i, row0=row0)
+    e1.record()
+    torch.cuda.synchronize(device)
+    roll_ms = e0.elapsed_time(e1) / steps
+    if use_dist:
+        from socmx import dist as sdist
+        solver.shard = sdist.Shard()
+    world = dist.get_world_size() if use_dist else 1
+    opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
+    trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True)
+    for _ in range(max(2, warmup)):
+        trainer.step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        info = trainer.step()
+    torch.cuda.synchronize(device)
+    it_ms = 1e3 * (time.perf_counter() - t0) / steps
+    fl = flops_per_traj_step(d, HDIMS) * B * K
+    out = {"workload": label, "rollout_ms": roll_ms, "trajectory_steps_per_s": B * K / (roll_ms * 1e-3),
+           "socm_ms_per_iter": it_ms, "socm_iters_per_sec": 1e3 / it_ms, "last_loss": float(info["loss"]),
+           "rollout_roofline": {"bound": "mfma", "achieved": fl / (roll_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
+                                "unit": "TFLOP/s", "frac": fl / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                                "active_workgroups": (B + 15) // 16}}
+    del trainer, opt, solver, sde
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(budget_s=12.0):
@@ -134,6 +176,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-burst", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4]-slice entries")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and take the sharded code path even at world_size 1")
     args = ap.parse_args()
 
@@ -194,7 +237,7 @@ def main():
     if use_dist:
         solver.shard = sdist.Shard()
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
-    trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False)
+    trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True)
     it_steps, it_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
     for _ in range(it_warm):
         trainer.step()
@@ -235,6 +278,16 @@ def main():
         del big
         torch.cuda.empty_cache()
 
+    # ---- the other BASELINE configurations, per GPU (every rank runs them: the sharded iteration has collectives) ----
+    secondary = []
+    if not args.no_secondary:
+        n2 = max(3, args.steps // 5)
+        secondary.append(secondary_config(device, "OU_quadratic_easy d=2 num_steps=50 batch=128 SOCM (BASELINE configs[1])",
+                                          "OU_quadratic_easy", 2, 50, 128, 2.0, 4 * n2, 3, use_dist, rank * 128))
+        secondary.append(secondary_config(device, "OU_linear d=64 num_steps=400 batch=512/GPU SOCM (one GPU's slice of "
+                                          "BASELINE configs[4])", "OU_linear", 64, 400, 512, 2.0, n2, 2, use_dist,
+                                          rank * 512))
+
     if rank == 0:
         flops = flops_per_traj_step(d, HDIMS) * B * K
         byts = bytes_per_traj_step(d) * B * K
@@ -242,14 +295,19 @@ def main():
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/):
         # WRITE_SIZE + 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-byte-per-lane reads), in bytes
         traffic, traffic_src = None, None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")))
-            for kname, v in pm.items():
-                if "rollout_kernel" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                    traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
-                    traffic_src = "profiles/r1/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
+            try:
+                pm = json.load(open(path))
+                for kname, v in pm.items():
+                    if "rollout_kernel" in kname and "StaticNet<16" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                        traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
+                        traffic_src = (os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                       "passes of this command; FETCH_SIZE doubled per the gfx950 note)")
+            except Exception:
+                pass
+            if traffic is not None:
+                break
         line = {
             "metric": "trajectory-steps/sec", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -273,6 +331,8 @@ def main():
         }
         if burst is not None:
             line["roofline_full_chip"] = burst
+        if secondary:
+            line["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 figure
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

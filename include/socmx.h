@@ -27,13 +27,18 @@
  *                                 253-257 on the trajectory / pair rows: bias gradient, ReLU backward
  *
  * Conventions
- *   - every function returns int: 0 = ok, < 0 = invalid argument (SOCMX_E_*), > 0 = hipError_t;
+ *   - every function returns int: 0 = ok, < 0 = invalid argument (SOCMX_E_*), > 0 = hipError_t of THIS call's launch
+ *     (hipLaunchKernel's own status: an error left pending by unrelated work is not picked up);
+ *   - the device that owns the buffers must be the current HIP device of the calling thread (kernels launch on the
+ *     current device; the Python binding wraps every call in a device guard);
  *   - never throws, never allocates, never synchronises; all work is enqueued on `stream`
  *     (a hipStream_t passed as void*); safe to capture in a hipGraph;
  *   - every pointer marked "device" is caller-owned device memory (e.g. torch tensor storage),
  *     fp32, contiguous, row-major in the shape given; structs themselves live on the host;
- *   - re-entrant: no global mutable state (a few getenv() switches for A/B runs are read once per process:
- *     SOCMX_GENERIC, SOCMX_NOFAST, SOCMX_WAVES, SOCMX_TARGET_WIDE_REGS, SOCMX_TARGET_BWD_REGS).
+ *   - re-entrant: the only mutable state is a mutex-protected per-process cache of which kernels already had their
+ *     dynamic-LDS limit raised (hipFuncSetAttribute once per kernel and device, not per call); a few getenv()
+ *     switches for A/B runs are read once per process: SOCMX_GENERIC, SOCMX_NOFAST, SOCMX_WAVES, SOCMX_PROF_WAVE,
+ *     SOCMX_TARGET_WIDE_REGS, SOCMX_TARGET_BWD_REGS.
  *
  * Reference-side binding: see INTEGRATION.md (ctypes stub).
  */
@@ -47,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 100 /* 0.1.0 */
+#define SOCMX_VERSION 110 /* 0.1.1 */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -130,6 +135,9 @@ int socmx_unet_forward_f32(const float* packed, int32_t d, const int32_t hdims[3
  *     stop_indicators (K+1,B)  fractional_timesteps (K,B)  lpd, lps, ltw (B,)
  *   The stopping-time branch (utils.py:42-44, 49-75) is taken iff kind == MOLECULAR_DYNAMICS,
  *   mirroring `hasattr(sde, "Phi")` (utils.py:33).
+ *   Costs-only launch: states, noises, controls, stop_indicators and fractional_timesteps may ALL be NULL; then only
+ *   lpd / lps / ltw are written (what the evaluation bursts utils.py:131-231 and method.py:185-221 consume; at
+ *   d = 64, K = 400 the trajectory of 65,536 rows would be 20 GB).  Any other mix of NULLs is SOCMX_E_NULL.
  */
 int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
                       const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
@@ -137,6 +145,21 @@ int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, co
                       float* states, float* noises, float* controls, float* stop_indicators,
                       float* fractional_timesteps, float* lpd, float* lps, float* ltw,
                       socmx_stream_t stream);
+
+/*
+ * The same rollout with the Philox key in DEVICE memory: key[0] = seed, key[1] = offset (uint64 each), read by the
+ * kernel when it starts.  A launch captured in a hipGraph therefore draws fresh noise on every replay once
+ * socmx_philox_advance (key[1] += inc, a one-thread node enqueued on the same stream) follows it -- the by-value
+ * seed/offset of socmx_rollout_f32 are frozen into a captured node.  Replaces the same reference lines as
+ * socmx_rollout_f32 (the reference advances torch's global generator: utils.py:39).
+ */
+int socmx_rollout_keyed_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
+                            const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
+                            const uint64_t* key, int64_t row0, const float* noise_in,
+                            float* states, float* noises, float* controls, float* stop_indicators,
+                            float* fractional_timesteps, float* lpd, float* lps, float* ltw,
+                            socmx_stream_t stream);
+int socmx_philox_advance(uint64_t* key, uint64_t inc, socmx_stream_t stream);
 
 /* Diagnostics: the same rollout instrumented with s_memtime; cycles ((B+15)/16, 64) int64 device receives, per
  * workgroup, shader cycles summed over the K steps for: [0] input tile build, [1..6] the six network stages

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/socmx.h"
+#include "socmx_launch.h"
 
 namespace socmx {
 
@@ -1191,8 +1192,7 @@ extern "C" int socmx_weights_stats_f32(const float* lpd, const float* lps, const
                                        float* stats, socmx_stream_t stream) {
   if (!lpd || !lps || !ltw || !w || !stats) return SOCMX_E_NULL;
   if (B < 1) return SOCMX_E_DIM;
-  hipLaunchKernelGGL(weights_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lpd, lps, ltw, B, w, stats);
-  return (int)hipGetLastError();
+  return launch(weights_stats_kernel, dim3(1), dim3(256), 0, stream, lpd, lps, ltw, (int)B, w, stats);
 }
 
 extern "C" int64_t socmx_num_pairs(int32_t K) { return K < 0 ? 0 : (int64_t)(K + 1) * (K + 2) / 2; }
@@ -1218,19 +1218,14 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
   a.v = v; a.q = q; a.gT = gT; a.vT = vT; a.qT = qT; a.gTT = gTT;
   const size_t tile_lds = (size_t)4 * 64 * (pb->d + 1) * sizeof(float);
   if (pb->d <= 128 && tile_lds <= 160 * 1024) {
-    auto kern = socm_prep_tiled_kernel;
-    hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds);
-    if (err != hipSuccess) return (int)err;
+    if (const int err = ensure_max_lds(socm_prep_tiled_kernel)) return err;
     const int64_t rows = (int64_t)K * B;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 63) / 64)), dim3(256), tile_lds, (hipStream_t)stream, a);
-    err = hipGetLastError();
-    if (err != hipSuccess) return (int)err;
-    hipLaunchKernelGGL(socm_prep_terminal_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+    if (const int err = launch(socm_prep_tiled_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), tile_lds, stream, a))
+      return err;
+    return launch(socm_prep_terminal_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
   }
   const int64_t n = (int64_t)(K + 1) * B;
-  hipLaunchKernelGGL(socm_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return launch(socm_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
 }
 
 static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all, const float* dM_all,
@@ -1246,8 +1241,9 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.q = q; a.v = v; a.gT = gT;
   a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective;
   a.delta = delta; a.gamma = gamma;
-  const hipStream_t st0 = (hipStream_t)stream;
+  void* const st0 = stream;
   bool launched = false;
+  int lerr = 0;
   if (d > 16 && d <= 64 && B >= 256) {                 // wide form: all k-blocks and 8 x 2 batch tiles per workgroup
     dim3 wgrid((K + 2) / 2, (B + 16 * 2 * kTargetWaves - 1) / (16 * 2 * kTargetWaves));
     const dim3 wblk(64 * kTargetWaves);
@@ -1255,27 +1251,26 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
     if (!use_regs) {
       wgrid.x = K + 1;
       if (delta) {
-        if (d <= 32) hipLaunchKernelGGL((socm_target_lds_kernel<true, 2>), wgrid, wblk, 0, st0, a);
-        else         hipLaunchKernelGGL((socm_target_lds_kernel<true, 4>), wgrid, wblk, 0, st0, a);
+        if (d <= 32) lerr = launch(socm_target_lds_kernel<true, 2>, wgrid, wblk, 0, st0, a);
+        else         lerr = launch(socm_target_lds_kernel<true, 4>, wgrid, wblk, 0, st0, a);
       } else {
-        if (d <= 32) hipLaunchKernelGGL((socm_target_lds_kernel<false, 2>), wgrid, wblk, 0, st0, a);
-        else         hipLaunchKernelGGL((socm_target_lds_kernel<false, 4>), wgrid, wblk, 0, st0, a);
+        if (d <= 32) lerr = launch(socm_target_lds_kernel<false, 2>, wgrid, wblk, 0, st0, a);
+        else         lerr = launch(socm_target_lds_kernel<false, 4>, wgrid, wblk, 0, st0, a);
       }
     } else if (delta) {
-      if (d <= 32) hipLaunchKernelGGL((socm_target_wide_kernel<true, 2, 2>), wgrid, wblk, 0, st0, a);
-      else         hipLaunchKernelGGL((socm_target_wide_kernel<true, 4, 2>), wgrid, wblk, 0, st0, a);
+      if (d <= 32) lerr = launch(socm_target_wide_kernel<true, 2, 2>, wgrid, wblk, 0, st0, a);
+      else         lerr = launch(socm_target_wide_kernel<true, 4, 2>, wgrid, wblk, 0, st0, a);
     } else {
-      if (d <= 32) hipLaunchKernelGGL((socm_target_wide_kernel<false, 2, 2>), wgrid, wblk, 0, st0, a);
-      else         hipLaunchKernelGGL((socm_target_wide_kernel<false, 4, 2>), wgrid, wblk, 0, st0, a);
+      if (d <= 32) lerr = launch(socm_target_wide_kernel<false, 2, 2>, wgrid, wblk, 0, st0, a);
+      else         lerr = launch(socm_target_wide_kernel<false, 4, 2>, wgrid, wblk, 0, st0, a);
     }
     launched = true;
   }
   const int ct = B > 32 ? 4 : (B > 16 ? 2 : 1);        // 16-column batch tiles per wave
   dim3 grid((K + 2) / 2, (B + 16 * ct - 1) / (16 * ct), (d + 15) / 16);
   const dim3 blk(64 * kTargetWaves);
-  const hipStream_t st = (hipStream_t)stream;
 #define SOCMX_TARGET_LAUNCH(NETV, CTV, N1V) \
-  hipLaunchKernelGGL((socm_target_mfma_kernel<NETV, CTV, N1V>), grid, blk, 0, st, a)
+  lerr = launch(socm_target_mfma_kernel<NETV, CTV, N1V>, grid, blk, 0, stream, a)
   const bool nlb1 = d <= 16;
   if (launched) {
   } else if (delta) {
@@ -1288,15 +1283,11 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
     else              { if (nlb1) SOCMX_TARGET_LAUNCH(false, 1, true); else SOCMX_TARGET_LAUNCH(false, 1, false); }
   }
 #undef SOCMX_TARGET_LAUNCH
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return (int)err;
+  if (lerr) return lerr;
   const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
   if (lds > 160 * 1024) return SOCMX_E_LDS;
-  auto kern = socm_residual_kernel;
-  err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (err != hipSuccess) return (int)err;
-  hipLaunchKernelGGL(kern, dim3(K + 1, (B + 63) / 64), dim3(64), lds, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  if (const int err = ensure_max_lds(socm_residual_kernel)) return err;
+  return launch(socm_residual_kernel, dim3(K + 1, (B + 63) / 64), dim3(64), lds, stream, a);
 }
 
 extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all,
@@ -1331,30 +1322,21 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
   if (d > 16 && d <= 64 && d % 4 == 0 && !bwd_regs) {
     // (reads of whole 16-byte pieces stay inside the rows because d % 4 == 0)
     dim3 lgrid((unsigned)np);
-    if (net) hipLaunchKernelGGL(socm_target_bwd_lds_kernel<true>, lgrid, dim3(256), 0, (hipStream_t)stream, a);
-    else     hipLaunchKernelGGL(socm_target_bwd_lds_kernel<false>, lgrid, dim3(256), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+    return net ? launch(socm_target_bwd_lds_kernel<true>, lgrid, dim3(256), 0, stream, a)
+               : launch(socm_target_bwd_lds_kernel<false>, lgrid, dim3(256), 0, stream, a);
   }
   if (d > 16) {
     const int nblk = (d + 15) / 16;
     const int lbw = nblk >= 4 ? 4 : 2;                               // l-blocks per wave
     dim3 wgrid((unsigned)np, (nblk + 3) / 4, (nblk + lbw - 1) / lbw);
-    const hipStream_t st = (hipStream_t)stream;
-    if (net) {
-      if (lbw == 4) hipLaunchKernelGGL((socm_target_bwd_wide_kernel<true, 4>), wgrid, dim3(256), 0, st, a);
-      else          hipLaunchKernelGGL((socm_target_bwd_wide_kernel<true, 2>), wgrid, dim3(256), 0, st, a);
-    } else {
-      if (lbw == 4) hipLaunchKernelGGL((socm_target_bwd_wide_kernel<false, 4>), wgrid, dim3(256), 0, st, a);
-      else          hipLaunchKernelGGL((socm_target_bwd_wide_kernel<false, 2>), wgrid, dim3(256), 0, st, a);
-    }
-    return (int)hipGetLastError();
+    if (net) return lbw == 4 ? launch(socm_target_bwd_wide_kernel<true, 4>, wgrid, dim3(256), 0, stream, a)
+                             : launch(socm_target_bwd_wide_kernel<true, 2>, wgrid, dim3(256), 0, stream, a);
+    return lbw == 4 ? launch(socm_target_bwd_wide_kernel<false, 4>, wgrid, dim3(256), 0, stream, a)
+                    : launch(socm_target_bwd_wide_kernel<false, 2>, wgrid, dim3(256), 0, stream, a);
   }
   dim3 grid((unsigned)((np + 3) / 4), (d + 15) / 16, (d + 15) / 16);
-  if (net)
-    hipLaunchKernelGGL(socm_target_bwd_mfma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(socm_target_bwd_mfma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return net ? launch(socm_target_bwd_mfma_kernel<true>, grid, dim3(256), 0, stream, a)
+             : launch(socm_target_bwd_mfma_kernel<false>, grid, dim3(256), 0, stream, a);
 }
 
 extern "C" int socmx_socm_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* G, const float* q,
@@ -1387,14 +1369,11 @@ extern "C" int socmx_colsum_f32(const float* x, int64_t R, int32_t C, float* par
   if (R < 1 || C < 1) return SOCMX_E_DIM;
   const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
   const int nblk = socmx_colsum_blocks(R, C);
-  hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr,
-                     R, (int)C, cw, partial);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return (int)err;
+  if (const int err = launch(colsum_partial_kernel<false>, dim3(nblk), dim3(256), 0, stream, x, nullptr, nullptr, R,
+                             (int)C, cw, partial))
+    return err;
   if (!out) return 0;                     // partials only: socmx_linear_bwd_finish_f32 adds them up
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk,
-                     (int)C, out);
-  return (int)hipGetLastError();
+  return launch(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, partial, nblk, (int)C, out);
 }
 
 extern "C" int socmx_relu_bwd_colsum_f32(const float* gy, const float* y, int64_t R, int32_t C, float* gz,
@@ -1403,14 +1382,11 @@ extern "C" int socmx_relu_bwd_colsum_f32(const float* gy, const float* y, int64_
   if (R < 1 || C < 1) return SOCMX_E_DIM;
   const int cw = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : (C > 16 ? 32 : 16))));
   const int nblk = socmx_colsum_blocks(R, C);
-  hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, gy, y, gz, R, (int)C,
-                     cw, partial);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return (int)err;
+  if (const int err = launch(colsum_partial_kernel<true>, dim3(nblk), dim3(256), 0, stream, gy, y, gz, R, (int)C, cw,
+                             partial))
+    return err;
   if (!out) return 0;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk,
-                     (int)C, out);
-  return (int)hipGetLastError();
+  return launch(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, partial, nblk, (int)C, out);
 }
 
 extern "C" int socmx_linear_bwd_finish_f32(const float* gw_parts, int32_t S, int64_t N, const float* tail, float* gw,
@@ -1419,7 +1395,6 @@ extern "C" int socmx_linear_bwd_finish_f32(const float* gw_parts, int32_t S, int
   if (!gw_parts || !gw || !partial || !gb) return SOCMX_E_NULL;
   if (S < 1 || N < 1 || nblk < 1 || C < 1) return SOCMX_E_DIM;
   const int nb1 = (int)((N + 255) / 256);
-  hipLaunchKernelGGL(linear_bwd_finish_kernel, dim3(nb1 + (C + 15) / 16), dim3(256), 0, (hipStream_t)stream, gw_parts,
-                     (int)S, N, tail, gw, partial, (int)nblk, (int)C, gb, nb1);
-  return (int)hipGetLastError();
+  return launch(linear_bwd_finish_kernel, dim3(nb1 + (C + 15) / 16), dim3(256), 0, stream, gw_parts, (int)S, N, tail,
+                gw, partial, (int)nblk, (int)C, gb, nb1);
 }

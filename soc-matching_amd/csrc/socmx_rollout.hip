@@ -16,6 +16,7 @@
 
 #include "../../include/socmx.h"
 #include "socmx_unet.h"
+#include "socmx_launch.h"
 
 namespace socmx {
 
@@ -67,6 +68,7 @@ struct RolloutArgs {
   int kind, d, B, K;
   float lmbd;
   uint64_t seed, offset;
+  const uint64_t* key_dev;   // device {seed, offset} (socmx_rollout_keyed_f32: a replayed hipGraph draws fresh noise) or NULL
   int64_t row0;
   const float* packed;
   const float *sigma, *A, *P, *Q, *omega, *kappa, *nu;
@@ -167,6 +169,8 @@ typedef StaticNet<32, 256, 128, 64, 32> Wide32Net;   // ... and at 16 <= d <= 31
 template <int NW, bool STOPPING, bool PROF, class NET, bool FAST>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // Philox key: by value, or read from device memory (uniform scalar loads, once per workgroup)
+  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
   constexpr bool kStatic = !std::is_same<NET, DynamicNet>::value;
   TileLayout tl;
   UnetDesc ud;
@@ -238,14 +242,16 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     const int ic = min(i, d - 1);
     const bool lane_ok = act && i < d;
     const int grow = tile_row0 + r;
-    const bool store = lane_ok && grow < B;
+    const bool traj = a.states != nullptr;        // costs-only launches (evaluation bursts) pass no trajectory buffers
+    const bool store = lane_ok && grow < B && traj;
+    const bool store0 = act && i == 0 && grow < B && traj;
     const size_t rowoff = (size_t)grow * d + i;
     auto gsum = [](float v) { return row16_sum(v); };
     float x = lane_ok ? a.x0[(size_t)min(grow, B - 1) * d + i] : 0.f;
     const float kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
     float stop = 1.f, lpd = 0.f, lps = 0.f;
     if (store) a.states[rowoff] = x;
-    if (act && i == 0 && grow < B) a.stop_ind[grow] = 1.f;
+    if (store0) a.stop_ind[grow] = 1.f;
     if (act) {
       if (i < 15) X0[r * tl.s0 + 1 + i] = x;   // columns 1..15; lanes i >= d hold x = 0
       if (i == 0) X0[r * tl.s0] = a.ts[0];
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     auto draw = [&](int k) -> float {
       if (pi >= d || k >= K) return 0.f;
       if (a.noise_in) return a.noise_in[((size_t)k * B + min(pgrow, B - 1)) * d + pi];
-      return philox_normal(a.seed, a.offset, (uint32_t)(a.row0 + pgrow), (uint32_t)k, pi);
+      return philox_normal(key_seed, key_offset, (uint32_t)(a.row0 + pgrow), (uint32_t)k, pi);
     };
     if (producer) NZ[pr * 16 + pi] = draw(0);
     long long acc_prof[64];
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           a.noises[(size_t)k * B * d + rowoff] = eps;
           a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
         }
-        if (i == 0 && grow < B) {
+        if (store0) {
           a.frac[(size_t)k * B + grow] = step;
           a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? stop_new : 1.f;
         }
@@ -358,16 +364,17 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     }
     return;
   }
+  const int Bs = a.states ? B : 0;   // rows whose trajectory is stored: none in a costs-only launch (evaluation bursts)
   for (int e = tid; e < 16 * d; e += nthr) {
     const int r = SOCMX_DIV_D(e), i = e - r * d;
     const int grow = min(tile_row0 + r, B - 1);  // ragged tail: replicate the last row, never stored
     const float x = a.x0[(size_t)grow * d + i];
     XS[r * ds + i] = x;
-    if (tile_row0 + r < B) a.states[(size_t)(tile_row0 + r) * d + i] = x;  // states[0]
+    if (tile_row0 + r < Bs) a.states[(size_t)(tile_row0 + r) * d + i] = x;  // states[0]
   }
   if (tid < 16) {
     ST[tid] = 1.f;
-    if (tile_row0 + tid < B) a.stop_ind[tile_row0 + tid] = 1.f;  // stop_indicators[0] = ones (utils.py:28)
+    if (tile_row0 + tid < Bs) a.stop_ind[tile_row0 + tid] = 1.f;  // stop_indicators[0] = ones (utils.py:28)
   }
   float lpd = 0.f, lps = 0.f;  // per-row accumulators, live in lane 0 of each 16-lane row group (threads 0, 16, ..., 240)
   const bool mm = d >= 16;                                  // matrix products of the SDE step on the MFMA
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         const int grow = tile_row0 + r;
         const float eps = a.noise_in[((size_t)kk * B + min(grow, B - 1)) * d + i];
         Eb[r * ds + i] = eps;
-        if (grow < B) a.noises[((size_t)kk * B + grow) * d + i] = eps;
+        if (grow < Bs) a.noises[((size_t)kk * B + grow) * d + i] = eps;
       }
     } else {
       const int np = (d + 1) >> 1;
@@ -404,13 +411,13 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         const int r = (int)(((float)q + 0.5f) * inv_np), pr = q - r * np;
         const int grow = tile_row0 + r;
         float z0, z1;
-        philox_normal2(a.seed, a.offset, (uint32_t)(a.row0 + grow), (uint32_t)kk, pr >> 1, pr & 1, z0, z1);
+        philox_normal2(key_seed, key_offset, (uint32_t)(a.row0 + grow), (uint32_t)kk, pr >> 1, pr & 1, z0, z1);
         const int i = 2 * pr;
         Eb[r * ds + i] = z0;
-        if (grow < B) a.noises[((size_t)kk * B + grow) * d + i] = z0;
+        if (grow < Bs) a.noises[((size_t)kk * B + grow) * d + i] = z0;
         if (i + 1 < d) {
           Eb[r * ds + i + 1] = z1;
-          if (grow < B) a.noises[((size_t)kk * B + grow) * d + i + 1] = z1;
+          if (grow < Bs) a.noises[((size_t)kk * B + grow) * d + i + 1] = z1;
         }
       }
     }
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       const int np = (d + 1) >> 1;
       if (nz_t < nz_pairs) {
         const int r = (int)(((float)nz_t + 0.5f) * __builtin_amdgcn_rcpf((float)np)), pr = nz_t - r * np;
-        philox_pair_words(a.seed, a.offset, (uint32_t)(a.row0 + tile_row0 + r), (uint32_t)kk, pr >> 1, pr & 1,
+        philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + tile_row0 + r), (uint32_t)kk, pr >> 1, pr & 1,
                           pw[0][0], pw[0][1]);
       }
     } else {
@@ -443,8 +450,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         const int q = nz_t + it * nz_n;
         if (q < nz_quads) {
           const int r = (int)(((float)q + 0.5f) * inv_nq), b = q - r * nq;
-          philox4x32_10((uint32_t)(a.row0 + tile_row0 + r), (uint32_t)kk, (uint32_t)b, (uint32_t)a.offset,
-                        (uint32_t)a.seed, (uint32_t)(a.seed >> 32), pw[it]);
+          philox4x32_10((uint32_t)(a.row0 + tile_row0 + r), (uint32_t)kk, (uint32_t)b, (uint32_t)key_offset,
+                        (uint32_t)key_seed, (uint32_t)(key_seed >> 32), pw[it]);
         }
       }
     }
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   auto noise_put = [&](int kk, float* Eb, int r, int i, float z) {
     if (i < d) {
       Eb[r * ds + i] = z;
-      if (tile_row0 + r < B) a.noises[((size_t)kk * B + tile_row0 + r) * d + i] = z;
+      if (tile_row0 + r < Bs) a.noises[((size_t)kk * B + tile_row0 + r) * d + i] = z;
     }
   };
   // which: 0 = the first Box-Muller pair of each block, 1 = the second, 2 = both (by-pair mode: all in call 0 or 2)
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
           if (io < d) {
             const float u = -acc[rr];
             U[mc16 * ds + io] = u;
-            if (grow < B) a.controls[((size_t)k * B + grow) * d + io] = u;
+            if (grow < Bs) a.controls[((size_t)k * B + grow) * d + io] = u;
           }
         }
       }
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         const float u = -s;
         const int grow = tile_row0 + r;
         U[r * ds + i] = u;
-        if (grow < B) a.controls[((size_t)k * B + grow) * d + i] = u;
+        if (grow < Bs) a.controls[((size_t)k * B + grow) * d + i] = u;
       }
     }
     if (!ctrl_in_em) __syncthreads();
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         const float bi = drift_i(kind, d, i, XS + r * ds, A_l, KAP, ds);
         const float u = -GV[r * tl.sg + i];
         U[r * ds + i] = u;
-        if (tile_row0 + r < B) a.controls[((size_t)k * B + tile_row0 + r) * d + i] = u;
+        if (tile_row0 + r < Bs) a.controls[((size_t)k * B + tile_row0 + r) * d + i] = u;
         const float upd = (bi + u) * dt + sq_ldt * E[r * ds + i];
         if (STOPPING) UP[r * ds + i] = upd;
         XN[r * ds + i] = XS[r * ds + i] + ST[r] * upd;
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
               XN[mc16 * ds + io] = xs[rr] + st * upd;
               if constexpr (SID) {
                 U[mc16 * ds + io] = uo[rr];
-                if (tile_row0 + mc16 < B) a.controls[((size_t)k * B + tile_row0 + mc16) * d + io] = uo[rr];
+                if (tile_row0 + mc16 < Bs) a.controls[((size_t)k * B + tile_row0 + mc16) * d + io] = uo[rr];
               }
             }
           }
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         lpd = lpd + step_over_lmbd * (-f - 0.5f * uu);
         lps = lps + sqrtf(step_over_lmbd) * (-ue);
         const int grow = tile_row0 + r;
-        if (grow < B) {
+        if (grow < Bs) {
           a.frac[(size_t)k * B + grow] = step;
           a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? SN[r] : 1.f;
         }
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
       const float x = XE[r * ds + i];
       XS[r * ds + i] = x;
       X0[r * tl.s0 + 1 + i] = x;                      // next step's network input (the last stage is done with X0)
-      if (tile_row0 + r < B) a.states[((size_t)(k + 1) * B + tile_row0 + r) * d + i] = x;
+      if (tile_row0 + r < Bs) a.states[((size_t)(k + 1) * B + tile_row0 + r) * d + i] = x;
     }
     if (tid < 16) X0[tid * tl.s0] = t1;       // (a fresh load here would queue behind this step's stores)
     SOCMX_TICK(14)
@@ -852,6 +859,12 @@ __global__ void unet_pack_kernel(const PackArgs a) {
   a.packed[idx] = v;
 }
 
+// key[1] += inc: the Philox offset of the next keyed rollout (its own tiny node so that every workgroup of the rollout
+// before it has read the old value: same-stream order)
+__global__ void philox_advance_kernel(uint64_t* key, uint64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) key[1] += inc;
+}
+
 }  // namespace socmx
 
 // =================================================================================================
@@ -903,8 +916,7 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
   }
   a.packed = packed;
   const int threads = 256, blocks = (a.u.total_floats + threads - 1) / threads;
-  hipLaunchKernelGGL(unet_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a);
 }
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)
@@ -935,21 +947,22 @@ extern "C" int socmx_unet_forward_f32(const float* packed, int32_t d, const int3
   const size_t lds_bytes = (size_t)a.t.floats * sizeof(float);
   if (lds_bytes > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
   void (*kern)(const ForwardArgs) = nw == 4 ? unet_forward_kernel<4> : unet_forward_kernel<8>;
-  hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err != hipSuccess) return (int)err;
+  if (const int err = ensure_max_lds(kern)) return err;
   const int64_t blocks = (N + 15) / 16;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(nw * 64), lds_bytes, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return launch(kern, dim3((unsigned)blocks), dim3(nw * 64), lds_bytes, stream, a);
 }
 
 static int rollout_launch(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3], const float* x0,
                           const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed, uint64_t offset,
-                          int64_t row0, const float* noise_in, float* states, float* noises, float* controls,
+                          const uint64_t* key_dev, int64_t row0, const float* noise_in, float* states, float* noises,
+                          float* controls,
                           float* stop_indicators, float* fractional_timesteps, float* lpd, float* lps, float* ltw,
                           long long* prof, socmx_stream_t stream) {
-  if (!pb || !packed_unet || !hdims || !x0 || !ts || !states || !noises || !controls || !stop_indicators ||
-      !fractional_timesteps || !lpd || !lps || !ltw || !pb->sigma)
-    return SOCMX_E_NULL;
+  if (!pb || !packed_unet || !hdims || !x0 || !ts || !lpd || !lps || !ltw || !pb->sigma) return SOCMX_E_NULL;
+  // the five trajectory buffers come together or not at all (costs-only launch: the evaluation bursts of
+  // utils.py:131-231 read nothing but lpd / lps / ltw)
+  const int n_traj = !!states + !!noises + !!controls + !!stop_indicators + !!fractional_timesteps;
+  if (n_traj != 0 && n_traj != 5) return SOCMX_E_NULL;
   const int d = pb->d;
   if (!dims_ok(d, hdims) || B < 1 || K < 1) return SOCMX_E_DIM;
   switch (pb->kind) {
@@ -967,7 +980,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.prog = make_unet_program(a.u, a.t);
   fill_wave_work(a.prog, nw);
   a.kind = pb->kind; a.d = d; a.B = B; a.K = K; a.lmbd = lmbd;
-  a.seed = seed; a.offset = offset; a.row0 = row0;
+  a.seed = seed; a.offset = offset; a.key_dev = key_dev; a.row0 = row0;
   a.sigma_identity = (pb->flags & SOCMX_SIGMA_IDENTITY) ? 1 : 0;
   a.packed = packed_unet;
   a.sigma = pb->sigma; a.A = pb->A; a.P = pb->P; a.Q = pb->Q; a.omega = pb->omega; a.kappa = pb->kappa; a.nu = pb->nu;
@@ -975,7 +988,8 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.states = states; a.noises = noises; a.controls = controls; a.stop_ind = stop_indicators;
   a.frac = fractional_timesteps; a.lpd = lpd; a.lps = lps; a.ltw = ltw;
   a.prof = prof;
-  { const char* e = getenv("SOCMX_PROF_WAVE"); a.prof_wave = (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }
+  static const int prof_wave = [] { const char* e = getenv("SOCMX_PROF_WAVE"); return (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }();
+  a.prof_wave = prof_wave;
   a.lds_mats = (a.t.floats + 3) & ~3;
   // sigma (+ A for the OU settings, kappa for the others, + P for OU_quadratic); five (16, stride) tiles (+ two with a stopping time);
   // ST/SN/FD; the 512-float noise / partial-sum scratch -- the rule of the kernel's pointer layout
@@ -1017,10 +1031,8 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   else if (nw == 4) SOCMX_PICK(4, DynamicNet);
   else SOCMX_PICK(8, DynamicNet);
 #undef SOCMX_PICK
-  hipError_t err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err != hipSuccess) return (int)err;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(nw * 64), lds_bytes, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  if (const int err = ensure_max_lds(kern)) return err;
+  return launch(kern, dim3(blocks), dim3(nw * 64), lds_bytes, stream, a);
 }
 
 extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3],
@@ -1028,8 +1040,24 @@ extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_un
                                  uint64_t offset, int64_t row0, const float* noise_in, float* states, float* noises,
                                  float* controls, float* stop_indicators, float* fractional_timesteps, float* lpd,
                                  float* lps, float* ltw, socmx_stream_t stream) {
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, row0, noise_in, states, noises,
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, row0, noise_in, states, noises,
                         controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
+}
+
+extern "C" int socmx_rollout_keyed_f32(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3],
+                                       const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
+                                       const uint64_t* key, int64_t row0, const float* noise_in, float* states,
+                                       float* noises, float* controls, float* stop_indicators,
+                                       float* fractional_timesteps, float* lpd, float* lps, float* ltw,
+                                       socmx_stream_t stream) {
+  if (!key) return SOCMX_E_NULL;
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, 0, 0, key, row0, noise_in, states, noises, controls,
+                        stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
+}
+
+extern "C" int socmx_philox_advance(uint64_t* key, uint64_t inc, socmx_stream_t stream) {
+  if (!key) return SOCMX_E_NULL;
+  return launch(philox_advance_kernel, dim3(1), dim3(64), 0, stream, key, inc);
 }
 
 extern "C" int socmx_rollout_phase_cycles_f32(const socmx_problem* pb, const float* packed_unet,
@@ -1039,6 +1067,6 @@ extern "C" int socmx_rollout_phase_cycles_f32(const socmx_problem* pb, const flo
                                               float* stop_indicators, float* fractional_timesteps, float* lpd,
                                               float* lps, float* ltw, int64_t* cycles, socmx_stream_t stream) {
   if (!cycles) return SOCMX_E_NULL;
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, row0, noise_in, states, noises,
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, row0, noise_in, states, noises,
                         controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, (long long*)cycles, stream);
 }

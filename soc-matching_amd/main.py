@@ -77,7 +77,10 @@ def run(cfg):
     optimizer = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps,
                                algorithm=algorithm, y0_lr=cfg.optim.y0_lr)
     optimizer.zero_grad()
-    trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm)
+    backend = cfg.get("backend", {}) or {}
+    trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm,
+                      gemm_select=bool(backend.get("gemm_select", True)),
+                      tune_new_shapes=bool(backend.get("tune_new_shapes", False)))
 
     solver.algorithm = algorithm
     info = solver.training_info = {k: [] for k in (

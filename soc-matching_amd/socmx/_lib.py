@@ -46,6 +46,10 @@ PROTOTYPES = {
     "socmx_rollout_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                     C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
                                     _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_rollout_keyed_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
+                                          C.c_int32, C.c_float, _fp, C.c_int64, _fp,
+                                          _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_philox_advance": (C.c_int, [_fp, C.c_uint64, _fp]),
     "socmx_rollout_phase_cycles_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                                  C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
                                                  _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
@@ -117,6 +121,25 @@ def ptr(t):
         return None
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
     return t.data_ptr()
+
+
+class on_device:
+    """Device guard for a native call: kernels launch on the CURRENT HIP device, so the device that owns the buffers is
+    made current for the duration of the call (a no-op when it already is -- the common case costs one comparison)."""
+
+    __slots__ = ("dev", "prev")
+
+    def __init__(self, dev):
+        self.dev = dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.dev:
+            torch.cuda.set_device(self.dev)
+
+    def __exit__(self, *exc):
+        if self.prev != self.dev:
+            torch.cuda.set_device(self.prev)
 
 
 def stream_ptr(device=None):

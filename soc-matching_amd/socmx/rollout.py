@@ -54,8 +54,27 @@ def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noi
 # fused HIP path
 # --------------------------------------------------------------------------------------
 
-def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0, phase_cycles=None):
-    """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 64) -> run the instrumented kernel."""
+class PhiloxKey:
+    """Philox (seed, offset) held in DEVICE memory (2 x int64): the keyed rollout reads it when the kernel starts and
+    `advance()` enqueues key[1] += 1 behind it, so a hipGraph that captured both draws fresh noise on every replay.
+    Eager use is equivalent to passing `seed`, `offset = 0, 1, 2, ...` by value."""
+
+    def __init__(self, device, seed=None, offset=0):
+        seed = torch.initial_seed() if seed is None else int(seed)
+        to_i64 = lambda v: ((int(v) & (2**64 - 1)) ^ (1 << 63)) - (1 << 63)      # same 64 bits, as a signed value
+        self.key = torch.tensor([to_i64(seed), to_i64(offset)], dtype=torch.int64, device=device)
+
+    def advance(self, inc=1):
+        with _lib.on_device(self.key.device):
+            _lib.check(_lib.lib().socmx_philox_advance(self.key.data_ptr(), int(inc), _lib.stream_ptr(self.key.device)),
+                       "socmx_philox_advance")
+
+
+def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0, phase_cycles=None,
+                     costs_only=False, key=None):
+    """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 64) -> run the instrumented kernel.
+    `costs_only`: write lpd / lps / ltw only (the five trajectory entries of the returned tuple are None).
+    `key`: a PhiloxKey -- seed/offset are read from device memory and advanced behind the launch."""
     global _philox_calls
     L = _lib.lib()
     pb = sde.problem
@@ -65,34 +84,68 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
     x0c = x0.detach().to(torch.float32).contiguous()
     tc = t.detach().to(device=dev, dtype=torch.float32).contiguous()
     f32 = dict(dtype=torch.float32, device=dev)
-    states = torch.empty(K + 1, B, d, **f32)
-    noises = torch.empty(K, B, d, **f32)
-    controls = torch.empty(K, B, d, **f32)
-    stop = torch.empty(K + 1, B, **f32)
-    frac = torch.empty(K, B, **f32)
+    if costs_only:
+        states = noises = controls = stop = frac = None
+    else:
+        states = torch.empty(K + 1, B, d, **f32)
+        noises = torch.empty(K, B, d, **f32)
+        controls = torch.empty(K, B, d, **f32)
+        stop = torch.empty(K + 1, B, **f32)
+        frac = torch.empty(K, B, **f32)
     lpd = torch.empty(B, **f32)
     lps = torch.empty(B, **f32)
     ltw = torch.empty(B, **f32)
     if noise_in is not None:
         noise_in = noise_in.detach().to(**f32).contiguous()
         assert noise_in.shape == (K, B, d), noise_in.shape
+    net = sde.nabla_V
+    with _lib.on_device(dev):
+        head = (pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,
+                float(lmbd))
+        tail = (int(row0), _lib.ptr(noise_in), _lib.ptr(states), _lib.ptr(noises), _lib.ptr(controls),
+                _lib.ptr(stop), _lib.ptr(frac), _lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw))
+        if key is not None:
+            assert phase_cycles is None and key.key.device == dev
+            status = L.socmx_rollout_keyed_f32(*head, key.key.data_ptr(), *tail, _lib.stream_ptr(dev))
+        else:
+            if seed is None:
+                seed = torch.initial_seed()
+            if offset is None:
+                offset = _philox_calls
+                _philox_calls += 1
+            mid = (int(seed) & (2**64 - 1), int(offset) & (2**64 - 1))
+            if phase_cycles is not None:
+                assert phase_cycles.dtype == torch.int64 and phase_cycles.is_cuda and phase_cycles.is_contiguous()
+                status = L.socmx_rollout_phase_cycles_f32(*head, *mid, *tail, phase_cycles.data_ptr(),
+                                                          _lib.stream_ptr(dev))
+            else:
+                status = L.socmx_rollout_f32(*head, *mid, *tail, _lib.stream_ptr(dev))
+    _lib.check(status, "socmx_rollout_f32")
+    if key is not None:
+        key.advance()
+    return states, noises, stop, frac, lpd, lps, ltw, controls
+
+
+def burst_log_weights(sde, x0_row, t, lmbd, n, *, noise_in=None, seed=None, offset=None, row0=0, chunk_rows=16384):
+    """(lpd, lps, ltw) of `n` independent trajectories from the point x0_row -- the evaluation bursts of
+    utils.py:131-231 / method.py:185-221 (n_batches rollouts of batch_size rows each) as costs-only launches of at
+    most `chunk_rows` rows: nothing of size (K, n, d) is allocated.  The Philox stream is keyed by the global row
+    (row0 + row), so the result does not depend on the chunking (nor on how `n` is split over ranks)."""
+    global _philox_calls
     if seed is None:
         seed = torch.initial_seed()
     if offset is None:
         offset = _philox_calls
         _philox_calls += 1
-    net = sde.nabla_V
-    args = (pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,
-            float(lmbd), int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), int(row0), _lib.ptr(noise_in),
-            _lib.ptr(states), _lib.ptr(noises), _lib.ptr(controls), _lib.ptr(stop), _lib.ptr(frac),
-            _lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw))
-    if phase_cycles is not None:
-        assert phase_cycles.dtype == torch.int64 and phase_cycles.is_cuda and phase_cycles.is_contiguous()
-        status = L.socmx_rollout_phase_cycles_f32(*args, phase_cycles.data_ptr(), _lib.stream_ptr(dev))
-    else:
-        status = L.socmx_rollout_f32(*args, _lib.stream_ptr(dev))
-    _lib.check(status, "socmx_rollout_f32")
-    return states, noises, stop, frac, lpd, lps, ltw, controls
+    x0_row = x0_row.reshape(1, -1)
+    parts = []
+    for r0 in range(0, n, chunk_rows):
+        r1 = min(n, r0 + chunk_rows)
+        nz = None if noise_in is None else noise_in[:, r0:r1]
+        out = hip_trajectories(sde, x0_row.expand(r1 - r0, -1), t, lmbd, noise_in=nz, seed=seed, offset=offset,
+                               row0=row0 + r0, costs_only=True)
+        parts.append((out[4], out[5], out[6]))
+    return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
 
 # --------------------------------------------------------------------------------------

@@ -79,18 +79,35 @@ class SOC_Solver(nn.Module):
             streams[(device, which)] = torch.cuda.Stream(device)
         return streams[(device, which)]
 
-    def control_objective(self, batch_size, total_n_samples=65536):
+    def control_objective(self, batch_size, total_n_samples=65536, noise_in=None):
         n_batches = int(total_n_samples // batch_size)
-        if R.burst_eligible(self.neural_sde, self.x0.reshape(1, -1)) and self.shard is None:
-            # all n_batches rollouts as ONE launch; `trajectory` is the first batch, as in the reference
+        x0row = self.x0.reshape(1, -1)
+        if R.burst_eligible(self.neural_sde, x0row):
+            # the first batch as an ordinary launch (its states are the returned `trajectory`, as in the reference),
+            # every other row through costs-only launches; rows are split over the ranks of a sharded run
+            from SOC_matching.utils import _mean_and_std_err
             n = n_batches * batch_size
-            out = R.stochastic_trajectories(self.neural_sde, self.x0.reshape(1, -1).expand(n, -1), self.ts, self.lmbd)
-            losses = -self.lmbd * (out[4] + out[6])
-            return torch.mean(losses), torch.std(losses) / np.sqrt(n - 1), out[0][:, :batch_size].contiguous()
+            seed, offset = torch.initial_seed(), R._philox_calls
+            R._philox_calls += 1
+            n_loc, row0 = (n, 0) if self.shard is None else self.shard.local_rows(n)
+            nz = None if noise_in is None else noise_in[:, row0:row0 + n_loc]
+            b0 = min(batch_size, n_loc)
+            first = R.stochastic_trajectories(self.neural_sde, x0row.expand(b0, -1), self.ts, self.lmbd, seed=seed,
+                                              offset=offset, row0=row0, noise_in=None if nz is None else nz[:, :b0])
+            lpd, ltw = [first[4]], [first[6]]
+            if n_loc > b0:
+                rest = R.burst_log_weights(self.neural_sde, x0row, self.ts, self.lmbd, n_loc - b0, seed=seed,
+                                           offset=offset, row0=row0 + b0, noise_in=None if nz is None else nz[:, b0:])
+                lpd.append(rest[0])
+                ltw.append(rest[2])
+            losses = -self.lmbd * (torch.cat(lpd) + torch.cat(ltw))
+            mean, err = _mean_and_std_err(losses, self.shard)
+            return mean, err, first[0]
         losses, trajectory = [], None
         for k in range(n_batches):
             state0 = self.x0.repeat(batch_size, 1)
-            out = R.stochastic_trajectories(self.neural_sde, state0, self.ts.to(state0), self.lmbd)
+            nz = None if noise_in is None else noise_in[:, k * batch_size:(k + 1) * batch_size]
+            out = R.stochastic_trajectories(self.neural_sde, state0, self.ts.to(state0), self.lmbd, noise_in=nz)
             losses.append(-self.lmbd * (out[4] + out[6]))
             if k == 0:
                 trajectory = out[0]
@@ -234,8 +251,10 @@ class SOC_Solver(nn.Module):
         if compute_L2_error:
             target_control = optimal_control(self.ts, states, t_is_tensor=True)
             learned_control = -(nabla_V @ self.sigma)
+            # (a shard holds B_local rows: dividing by the GLOBAL batch makes the sum over ranks the reference's value;
+            #  Trainer adds the shards up inside its flat all-reduce)
             norm_sqd_diff = torch.sum((target_control - learned_control) ** 2 * weight.reshape(1, -1, 1)
-                                      / (target_control.shape[0] * target_control.shape[1]))
+                                      / (target_control.shape[0] * B_global))
         else:
             norm_sqd_diff = None
 

@@ -42,8 +42,8 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
-                 ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=True, overlap_M_backward=True,
-                 grad_telemetry=True):
+                 ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=False, overlap_M_backward=True,
+                 grad_telemetry=True, tune_new_shapes=False):
         self.solver, self.optimizer = solver, optimizer
         self.batch_size = batch_size
         self.normalization_const = normalization_const
@@ -54,9 +54,13 @@ class Trainer:
         self.grad_telemetry = grad_telemetry     # main.py:325-345 bookkeeping (part of the reference's timed iteration)
         self._ema_grad = None
         self._ema_grad_norm_sqd = None
+        # Library-GEMM selection (PyTorch TunableOp) is process-wide state: opt-in (main.py / bench.py pass the
+        # `backend.gemm_select` config key), and by default only the shipped selections are loaded -- timing
+        # candidate solutions for new shapes (`tune_new_shapes`) happens inside the first iterations and may pick
+        # different solutions on different ranks.
         if gemm_select and solver.x0.is_cuda:
             from . import gemm_select as _gs
-            _gs.enable()          # pick the fastest library GEMM per shape (see gemm_select.py)
+            _gs.enable(tune_new_shapes=tune_new_shapes)
         # SOCM on one GPU: the pair-grid network's backward and its Adam groups run on the solver's second stream
         # and overlap with the next iteration's rollout (same arithmetic, same order of updates per parameter)
         self.defer_M = (overlap_M_backward and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None
@@ -158,8 +162,14 @@ class Trainer:
             loss = objective
         loss.backward()                                                  # main.py:323
         if solver.shard is not None:
-            (loss_val,) = solver.shard.allreduce_gradients(
-                [p for g in self.optimizer.param_groups for p in g["params"]], extra=[loss.detach()])
+            # one flat all-reduce: every gradient + the loss value + (when computed) this rank's share of the weighted
+            # L2 error, which solver.loss already divided by the GLOBAL (K+1) B
+            extra = [loss.detach()] + ([out[1].detach()] if out[1] is not None else [])
+            reduced = solver.shard.allreduce_gradients(
+                [p for g in self.optimizer.param_groups for p in g["params"]], extra=extra)
+            loss_val = reduced[0]
+            if out[1] is not None:
+                out = (out[0], reduced[1]) + tuple(out[2:])
         else:
             loss_val = loss.detach()
         pending = solver.__dict__.pop("_pending_M", None)

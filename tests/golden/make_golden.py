@@ -287,6 +287,11 @@ FIXTURES = [
     ("tiny_ou_linear_d20", "OU_linear", 20, 8, 8, TINY, 2.0, 9, dict(with_pairs=False)),
     ("tiny_ou_linear_d64", "OU_linear", 64, 5, 4, dict(hdims=[32, 16, 8], hdims_M=[8, 8]), 2.0, 10,
      dict(with_pairs=False)),
+    # DEFAULT widths at the dimensions that select the other two constexpr rollout instantiations and the LDS-staged
+    # contraction kernels: BASELINE configs[4] (OU_linear d = 64 -> StaticNet<80,256,128,64,64>) and soc.yaml's own
+    # default d = 20 (OU_quadratic_easy -> StaticNet<32,256,128,64,32>)
+    ("cfg5_ou_linear_d64_K20", "OU_linear", 64, 20, 8, DEFAULT, 2.0, 0, dict(with_pairs=False)),
+    ("ouq20_ou_quadratic_easy_d20_K12", "OU_quadratic_easy", 20, 12, 8, DEFAULT, 2.0, 0, dict(with_pairs=False)),
 ]
 
 
