@@ -15,6 +15,7 @@
  *                                 into MFMA fragment order; needed whenever the weights changed -- the host package
  *                                 re-packs before every rollout, ~3 us)
  *   socmx_unet_forward_f32       SOC_matching/method.py:272-278 (nabla_V on the trajectory rows)
+ *   socmx_unet_backward_f32      autograd of the same lines: d objective / d (weights, biases) of models.py:212-242
  *   socmx_weights_stats_f32      SOC_matching/method.py:258-262, 903-904 (w, mean(w), std(w))
  *   socmx_socm_prep_f32          SOC_matching/method.py:591-646 operand preparation
  *                                 (nabla_f, nabla_b . v, nabla_g, sigma^-T noise / control)
@@ -120,6 +121,28 @@ int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_stream_t str
 /* out (N,d) = UNet(tx (N,d+1)).  Same kernel body as the rollout's per-step evaluation. */
 int socmx_unet_forward_f32(const float* packed, int32_t d, const int32_t hdims[3],
                            const float* tx, int64_t N, float* out, socmx_stream_t stream);
+
+/*
+ * Parameter gradients of the U-Net over many rows -- autograd of models.py:233-242 as applied in method.py:272-278
+ * (nabla_V on the (K+1)*B trajectory rows, whose inputs are detached: utils.py:103-115).  Given
+ *     gout (N,d) = d objective / d nabla_V(row)
+ * it writes d objective / d (weight, bias) of the nine layers into `grads`, a flat buffer in SOCMX_L_* order
+ * [weight_0 (out,in) | bias_0 | weight_1 | bias_1 | ...] (torch layouts, socmx_unet_backward_sizes tells its length).
+ * Row r is the network input [ts[r / rows_per_t], x[r,:]]  (x (N,d); for the trajectory tensor `states` (K+1,B,d)
+ * pass ts (K+1,) and rows_per_t = B; rows_per_t = 1 gives every row its own time).
+ * packed / packedT: the fragment-ordered images of the CURRENT weights and of their transposes
+ * (socmx_unet_pack_f32 / socmx_unet_pack_bwd_f32).  workspace: socmx_unet_backward_sizes floats, contents undefined
+ * afterwards.  The forward activations are recomputed tile by tile in LDS (no (N, width) tensors are saved between the
+ * forward and the backward); the summation order over rows is fixed (deterministic, no atomics).
+ * SOCMX_E_LDS: this (d, hdims) does not fit kernel A's LDS tiles -- callers fall back to library autograd.
+ */
+size_t socmx_unet_packed_bwd_floats(int32_t d, const int32_t hdims[3]);
+int socmx_unet_pack_bwd_f32(const socmx_unet* net, float* packedT, socmx_stream_t stream);
+int socmx_unet_backward_sizes(int32_t d, const int32_t hdims[3], int64_t N, int64_t* workspace_floats,
+                              int64_t* grad_floats);
+int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
+                            const float* x, const float* ts, int32_t rows_per_t, int64_t N, const float* gout,
+                            float* workspace, float* grads, socmx_stream_t stream);
 
 /* ---- rollout ------------------------------------------------------------ */
 

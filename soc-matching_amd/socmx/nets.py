@@ -158,7 +158,8 @@ class FullyConnectedUNet(nn.Module):
 
     def forward(self, x):
         # many rows on the GPU with gradients on: same math, split-K weight gradients (see _LinearSplitK)
-        sk = x.is_cuda and x.shape[0] >= 8192 and torch.is_grad_enabled() and x.is_contiguous()
+        sk = (x.is_cuda and x.dtype == torch.float32 and x.shape[0] >= 8192 and torch.is_grad_enabled()
+              and x.is_contiguous())
         r1 = _linear(self.down_0, x, sk)
         r2 = _linear(self.down_1, r1, sk)
         r3 = _linear(self.down_2, r2, sk)
@@ -192,10 +193,67 @@ class FullyConnectedUNet(nn.Module):
         _lib.check(L.socmx_unet_pack_f32(s, _lib.ptr(self._packed), _lib.stream_ptr(dev)), "socmx_unet_pack_f32")
         return self._packed
 
+    def packed_bwd(self):
+        """Fragment-ordered image of the TRANSPOSED weights of the seven layers the backward chain multiplies by
+        (socmx_unet_pack_bwd_f32); rebuilt on every call like `packed()`."""
+        L = _lib.lib()
+        dev = next(self.parameters()).device
+        n = L.socmx_unet_packed_bwd_floats(self.dim, _lib.i3(self.hdims))
+        pt = self.__dict__.get("_packed_bwd")
+        if pt is None or pt.numel() != n or pt.device != dev:
+            pt = self.__dict__["_packed_bwd"] = torch.empty(n, dtype=torch.float32, device=dev)
+        s, keep = self.c_struct()
+        with _lib.on_device(dev):
+            _lib.check(L.socmx_unet_pack_bwd_f32(s, _lib.ptr(pt), _lib.stream_ptr(dev)), "socmx_unet_pack_bwd_f32")
+        return pt
+
     def __getstate__(self):  # keep the solver picklable (reference main.py:466 pickles the module)
         st = self.__dict__.copy()
         st["_packed"] = None
+        st.pop("_packed_bwd", None)
         return st
+
+
+def unet_backward_supported(net, n_rows):
+    """True when socmx_unet_backward_f32 takes this architecture (its 16-row tiles must fit 160 KiB of LDS)."""
+    L = _lib.lib()
+    ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
+    return L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
+
+
+def unet_backward_hip(net, x, ts, rows_per_t, gout):
+    """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
+    x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
+    `net.parameters()` order (views of one flat buffer)."""
+    L = _lib.lib()
+    dev = x.device
+    N, d = x.shape
+    assert d == net.dim and gout.shape == (N, d)
+    x = x.detach().to(torch.float32).contiguous()
+    gout = gout.detach().to(torch.float32).contiguous()
+    ts = ts.detach().to(device=dev, dtype=torch.float32).contiguous()
+    assert ts.numel() * rows_per_t >= N
+    ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
+    _lib.check(L.socmx_unet_backward_sizes(d, _lib.i3(net.hdims), N, _lib.C.byref(ws), _lib.C.byref(ng)),
+               "socmx_unet_backward_sizes")
+    work = torch.empty(ws.value, dtype=torch.float32, device=dev)
+    flat = torch.empty(ng.value, dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(L.socmx_unet_backward_f32(_lib.ptr(net.packed()), _lib.ptr(net.packed_bwd()), d, _lib.i3(net.hdims),
+                                             _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N, _lib.ptr(gout),
+                                             _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
+                   "socmx_unet_backward_f32")
+    # flat is in SOCMX_L_* order (weight, bias per layer); parameters() follows the module construction order = the same
+    grads, off = {}, 0
+    for name in _lib.UNET_LAYERS:
+        lin = getattr(net, name)[0]
+        nw, nb = lin.weight.numel(), lin.bias.numel()
+        grads[name] = (flat[off:off + nw].view_as(lin.weight), flat[off + nw:off + nw + nb])
+        off += nw + nb
+    out = []
+    for name, _, _ in _UNET_SPEC:                  # parameters() order: construction order of the Sequentials
+        out += list(grads[name])
+    return out
 
 
 def unet_forward_hip(net, tx):
