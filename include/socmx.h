@@ -170,18 +170,25 @@ int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, co
                       socmx_stream_t stream);
 
 /*
- * The same rollout with the Philox key in DEVICE memory: key[0] = seed, key[1] = offset (uint64 each), read by the
- * kernel when it starts.  A launch captured in a hipGraph therefore draws fresh noise on every replay once
- * socmx_philox_advance (key[1] += inc, a one-thread node enqueued on the same stream) follows it -- the by-value
- * seed/offset of socmx_rollout_f32 are frozen into a captured node.  Replaces the same reference lines as
- * socmx_rollout_f32 (the reference advances torch's global generator: utils.py:39).
+ * The same rollout with optional extras (any member may be NULL; extra == NULL is socmx_rollout_f32):
+ *   key      device uint64[2] = {seed, offset}: the Philox key is read from DEVICE memory when the kernel starts and the
+ *            by-value seed / offset are ignored.  A launch captured in a hipGraph therefore draws fresh noise on every
+ *            replay once socmx_philox_advance (key[1] += inc, a one-thread node on the same stream) follows it -- by-value
+ *            arguments are frozen into a captured node.  (The reference advances torch's global generator: utils.py:39.)
+ *   nabla_v  device (K+1,B,d): nabla_V(t_k, X_k) for k = 0..K -- the network outputs the integrator computes anyway, plus
+ *            one evaluation at (T, X_K).  These are the forward values of method.py:272-278 (nabla_V on all (K+1) B
+ *            trajectory rows), so the loss needs no second forward pass; needs the trajectory buffers (not costs-only).
  */
-int socmx_rollout_keyed_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
-                            const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
-                            const uint64_t* key, int64_t row0, const float* noise_in,
-                            float* states, float* noises, float* controls, float* stop_indicators,
-                            float* fractional_timesteps, float* lpd, float* lps, float* ltw,
-                            socmx_stream_t stream);
+typedef struct socmx_rollout_extra {
+  const uint64_t* key;
+  float* nabla_v;
+} socmx_rollout_extra;
+int socmx_rollout_ex_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
+                         const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
+                         uint64_t seed, uint64_t offset, int64_t row0, const float* noise_in,
+                         float* states, float* noises, float* controls, float* stop_indicators,
+                         float* fractional_timesteps, float* lpd, float* lps, float* ltw,
+                         const socmx_rollout_extra* extra, socmx_stream_t stream);
 int socmx_philox_advance(uint64_t* key, uint64_t inc, socmx_stream_t stream);
 
 /* Diagnostics: the same rollout instrumented with s_memtime; cycles ((B+15)/16, 64) int64 device receives, per

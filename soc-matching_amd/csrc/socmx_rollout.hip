@@ -68,12 +68,13 @@ struct RolloutArgs {
   int kind, d, B, K;
   float lmbd;
   uint64_t seed, offset;
-  const uint64_t* key_dev;   // device {seed, offset} (socmx_rollout_keyed_f32: a replayed hipGraph draws fresh noise) or NULL
+  const uint64_t* key_dev;   // device {seed, offset} (socmx_rollout_ex_f32: a replayed hipGraph draws fresh noise) or NULL
   int64_t row0;
   const float* packed;
   const float *sigma, *A, *P, *Q, *omega, *kappa, *nu;
   const float *x0, *ts, *noise_in;
   float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
+  float* nabla_v;      // optional (K+1, B, d): the network output at every grid point incl. the terminal one (method.py:272-278)
   int sigma_identity;  // problem->flags & SOCMX_SIGMA_IDENTITY
   int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
   long long* prof;  // diagnostics only (PROF variant): [blocks][64] accumulated s_memtime cycles per phase
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
         else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);
         if (act) gv = GV[r * tl.sg + i];
       }
+      if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
       if (act) {
         const float u = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
         const float eps = NZ[(k & 1) * 256 + r * 16 + i];                 // drawn during the previous step
@@ -344,6 +346,19 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     }
     if (PROF && tid == a.prof_wave * 64 && a.prof)
       for (int s = 0; s < 64; ++s) a.prof[(size_t)blockIdx.x * 64 + s] = acc_prof[s];
+    if (a.nabla_v) {                        // nabla_V(T, X_K): X0 already holds [t_K, x_K] (written at the end of the last step)
+      __syncthreads();
+      auto nohook = [](int) {};
+      float gv = 0.f;
+      if constexpr (kStatic && NET::outp == 16) {
+        unet_tile_forward_static<NW, NET>(a.packed, lds, carry, nohook, &gv);
+      } else {
+        if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, nohook);
+        else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, nohook);
+        if (act) gv = GV[r * tl.sg + i];
+      }
+      if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
+    }
     if (act) {                                                            // terminal cost (utils.py:101)
       float gval = 0.f;
       if (kind == SOCMX_OU_QUADRATIC) {
@@ -516,6 +531,11 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, hook);   // GV = nabla_V(t, x)
     else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, hook);  // GV = nabla_V(t,x)
 
+    if (a.nabla_v)
+      for (int e = tid; e < 16 * d; e += nthr) {
+        const int r = SOCMX_DIV_D(e), i = e - r * d;
+        if (tile_row0 + r < Bs) a.nabla_v[((size_t)k * B + tile_row0 + r) * d + i] = GV[r * tl.sg + i];
+      }
     // ---- control u = -sigma^T nabla_V (method.py:68-72); the step's noise (utils.py:39) is already in E ---
     float* E = (k & 1) ? E1 : E0;
     float* En = (k & 1) ? E0 : E1;
@@ -766,6 +786,15 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   }
   if (PROF && tid == a.prof_wave * 64 && a.prof)
     for (int s = 0; s < 64; ++s) a.prof[(size_t)blockIdx.x * 64 + s] = acc_prof[s];
+  if (a.nabla_v) {                          // nabla_V(T, X_K): X0 holds [t_K, x_K] (the loop ended behind a barrier)
+    auto nohook = [](int) {};
+    if constexpr (kStatic) unet_tile_forward_static<NW, NET>(a.packed, lds, carry, nohook);
+    else unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, nohook);
+    for (int e = tid; e < 16 * d; e += nthr) {
+      const int r = SOCMX_DIV_D(e), i = e - r * d;
+      if (tile_row0 + r < Bs) a.nabla_v[((size_t)K * B + tile_row0 + r) * d + i] = GV[r * tl.sg + i];
+    }
+  }
 
   // ---- terminal cost (utils.py:101): same 16-lanes-per-row mapping -----------------------------
   if (tid < 256) {
@@ -954,8 +983,8 @@ extern "C" int socmx_unet_forward_f32(const float* packed, int32_t d, const int3
 
 static int rollout_launch(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3], const float* x0,
                           const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed, uint64_t offset,
-                          const uint64_t* key_dev, int64_t row0, const float* noise_in, float* states, float* noises,
-                          float* controls,
+                          const uint64_t* key_dev, float* nabla_v, int64_t row0, const float* noise_in, float* states,
+                          float* noises, float* controls,
                           float* stop_indicators, float* fractional_timesteps, float* lpd, float* lps, float* ltw,
                           long long* prof, socmx_stream_t stream) {
   if (!pb || !packed_unet || !hdims || !x0 || !ts || !lpd || !lps || !ltw || !pb->sigma) return SOCMX_E_NULL;
@@ -963,6 +992,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   // utils.py:131-231 read nothing but lpd / lps / ltw)
   const int n_traj = !!states + !!noises + !!controls + !!stop_indicators + !!fractional_timesteps;
   if (n_traj != 0 && n_traj != 5) return SOCMX_E_NULL;
+  if (nabla_v && n_traj == 0) return SOCMX_E_NULL;     // (nabla_v travels with the trajectory buffers)
   const int d = pb->d;
   if (!dims_ok(d, hdims) || B < 1 || K < 1) return SOCMX_E_DIM;
   switch (pb->kind) {
@@ -987,6 +1017,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.x0 = x0; a.ts = ts; a.noise_in = noise_in;
   a.states = states; a.noises = noises; a.controls = controls; a.stop_ind = stop_indicators;
   a.frac = fractional_timesteps; a.lpd = lpd; a.lps = lps; a.ltw = ltw;
+  a.nabla_v = nabla_v;
   a.prof = prof;
   static const int prof_wave = [] { const char* e = getenv("SOCMX_PROF_WAVE"); return (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }();
   a.prof_wave = prof_wave;
@@ -1040,19 +1071,19 @@ extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_un
                                  uint64_t offset, int64_t row0, const float* noise_in, float* states, float* noises,
                                  float* controls, float* stop_indicators, float* fractional_timesteps, float* lpd,
                                  float* lps, float* ltw, socmx_stream_t stream) {
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, row0, noise_in, states, noises,
-                        controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, nullptr, row0, noise_in, states,
+                        noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
 }
 
-extern "C" int socmx_rollout_keyed_f32(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3],
-                                       const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
-                                       const uint64_t* key, int64_t row0, const float* noise_in, float* states,
-                                       float* noises, float* controls, float* stop_indicators,
-                                       float* fractional_timesteps, float* lpd, float* lps, float* ltw,
-                                       socmx_stream_t stream) {
-  if (!key) return SOCMX_E_NULL;
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, 0, 0, key, row0, noise_in, states, noises, controls,
-                        stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
+extern "C" int socmx_rollout_ex_f32(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3],
+                                    const float* x0, const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed,
+                                    uint64_t offset, int64_t row0, const float* noise_in, float* states, float* noises,
+                                    float* controls, float* stop_indicators, float* fractional_timesteps, float* lpd,
+                                    float* lps, float* ltw, const socmx_rollout_extra* extra, socmx_stream_t stream) {
+  const uint64_t* key = extra ? extra->key : nullptr;
+  float* nabla_v = extra ? extra->nabla_v : nullptr;
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, key, nabla_v, row0, noise_in, states,
+                        noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
 }
 
 extern "C" int socmx_philox_advance(uint64_t* key, uint64_t inc, socmx_stream_t stream) {
@@ -1067,6 +1098,6 @@ extern "C" int socmx_rollout_phase_cycles_f32(const socmx_problem* pb, const flo
                                               float* stop_indicators, float* fractional_timesteps, float* lpd,
                                               float* lps, float* ltw, int64_t* cycles, socmx_stream_t stream) {
   if (!cycles) return SOCMX_E_NULL;
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, row0, noise_in, states, noises,
-                        controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, (long long*)cycles, stream);
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, nullptr, row0, noise_in, states,
+                        noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, (long long*)cycles, stream);
 }

@@ -16,6 +16,7 @@
 // Bound: fp32 MFMA (A: forward + activation-gradient GEMMs = 2 x 2 x MACs per row; B: 2 x MACs per row).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/socmx.h"
@@ -196,6 +197,7 @@ struct TileArgs {
   const float* x;         // (N, d) rows
   const float* ts;        // time of row r = ts[r / rows_per_t]
   const float* gout;      // (N, d)  d objective / d nabla_V
+  int dbg;                // developer switch (SOCMX_K2_DBG): bit 0 = no exports
   float* ws;              // workspace: T_N tensors, tensor t at ws + 16 * ntiles * prefix(t), each [tile][width][16]
   int64_t N;
   int rows_per_t;
@@ -208,13 +210,14 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
 // result quad (row r, units n0 .. n0+3) -> [unit][16 rows] slab of its tile: four 4-byte stores, each a 64-byte run over the
 // 16 lanes of a row group
 __device__ __forceinline__ void export4(float* slab, int r, int n0, const f32x4 v) {
+  if (!slab) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i) slab[(size_t)(n0 + i) * 16 + r] = v[i];
 }
 
 struct EpiCtx {
   float* lds;
-  float* ws;               // workspace base
+  float* ws;               // workspace base (nullptr: developer switch SOCMX_K2_DBG=1, no exports -- timing only)
   const float* bias_lds;
   int64_t tile_rows;       // 16 * ntiles
   int tile;
@@ -225,7 +228,7 @@ struct Epi {
   const K2Stage& s;
   const EpiCtx& c;
   __device__ __forceinline__ float* slab(int prefix, int width) const {
-    return c.ws + (size_t)c.tile_rows * prefix + (size_t)c.tile * width * 16;
+    return c.ws ? c.ws + (size_t)c.tile_rows * prefix + (size_t)c.tile * width * 16 : nullptr;
   }
   __device__ __forceinline__ f32x4 init(int n0) const {
     if constexpr (EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_MASK0) return lds4(c.bias_lds + s.sd.L1.b_lds + n0);
@@ -277,7 +280,7 @@ struct Epi {
   }
 };
 
-template <int NB, int NW, class EPI>
+template <int NB, int NW, bool PINNED, class EPI>
 __device__ __forceinline__ void k2_direct(const float* __restrict__ W1, const float* __restrict__ W2, const StageDesc& sd,
                                           float* lds, int blk0, int lane, const Pre& pre, bool use_pre, const EPI& epi,
                                           const UnetDesc& u) {
@@ -291,10 +294,10 @@ __device__ __forceinline__ void k2_direct(const float* __restrict__ W1, const fl
   f32x4 acc[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) acc[j] = epi.init((blk0 + j * NW) * 16 + 4 * g);
-  gemm_run<NB>(acc, r1, p1);
+  gemm_run<NB, PINNED>(acc, r1, p1);
 #pragma unroll
   for (int j = 0; j < NB; ++j) epi.mid(acc[j], row, (blk0 + j * NW) * 16 + 4 * g);
-  if (has2) gemm_run<NB>(acc, r2, p2);
+  if (has2) gemm_run<NB, PINNED>(acc, r2, p2);
 #pragma unroll
   for (int j = 0; j < NB; ++j) epi.fin(acc[j], row, (blk0 + j * NW) * 16 + 4 * g, u);
 }
@@ -302,7 +305,7 @@ __device__ __forceinline__ void k2_direct(const float* __restrict__ W1, const fl
 // One stage on the 16-row tile; same work split as socmx_unet.h's unet_stage (direct: neuron blocks dealt to the waves;
 // fewer than four blocks: the reduction dimension is split over the waves and combined through LDS), generalised
 // epilogue.  Ends with a workgroup barrier.
-template <int NW, class EPI>
+template <int NW, bool PINNED, class EPI>
 __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const float* __restrict__ W2,
                                          const float* __restrict__ Wn, const StageDesc& sd, const WaveWorkS& w, float* lds,
                                          float* scratch, Pre& pre, const EPI& epi, const UnetDesc& u) {
@@ -314,10 +317,10 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
     bool use_pre = w.use_pre != 0;
     int blk0 = w.blk0;
     for (int cnt = w.cnt; cnt > 0; cnt -= 4, blk0 += 4 * NW) {
-      if (cnt >= 4)      k2_direct<4, NW>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
-      else if (cnt == 3) k2_direct<3, NW>(W1, W2, sd, lds, blk0, lane, pre, false, epi, u);
-      else if (cnt == 2) k2_direct<2, NW>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
-      else               k2_direct<1, NW>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
+      if (cnt >= 4)      k2_direct<4, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
+      else if (cnt == 3) k2_direct<3, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, false, epi, u);
+      else if (cnt == 2) k2_direct<2, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
+      else               k2_direct<1, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
       use_pre = false;
     }
     pre = prefetch_fragments(Wn, sd.Ln, w, lane);
@@ -370,11 +373,11 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
     const float* W2 = s.img2 ? a.packedT : a.packed;
     const float* Wn = s.imgn ? a.packedT : a.packed;
     float* scratch = lds + lay.t.scratch;
-    if (s.epi == EPI_RELU)       k2_stage<NW>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RELU>{s, ctx}, u);
-    else if (s.epi == EPI_RES)   k2_stage<NW>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RES>{s, ctx}, u);
-    else if (s.epi == EPI_MASK0) k2_stage<NW>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_MASK0>{s, ctx}, u);
-    else if (s.epi == EPI_DUAL)  k2_stage<NW>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_DUAL>{s, ctx}, u);
-    else                         k2_stage<NW>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_ACTMASK>{s, ctx}, u);
+    if (s.epi == EPI_RELU)       k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RELU>{s, ctx}, u);
+    else if (s.epi == EPI_RES)   k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RES>{s, ctx}, u);
+    else if (s.epi == EPI_MASK0) k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_MASK0>{s, ctx}, u);
+    else if (s.epi == EPI_DUAL)  k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_DUAL>{s, ctx}, u);
+    else                         k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_ACTMASK>{s, ctx}, u);
   };
   if constexpr (kStatic) {
     // every descriptor is a compile-time value: offsets fold into immediates, one NB variant and one epilogue survive
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a
     slabG[e] = v;
   }
   unet_load_biases(a.packed, u, t, lds, tid, nthr);
-  EpiCtx ctx{lds, a.ws, lds + t.bias, tile_rows, tile};
+  EpiCtx ctx{lds, (a.dbg & 1) ? nullptr : a.ws, lds + t.bias, tile_rows, tile};
   // first ring of stage 0 (GEMM 1 = down_0 of the forward image)
   Pre carry;
   {
@@ -730,8 +733,13 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   p.total_bias = off - p.total_cells_floats;
   p.slab_floats = off;
   p.n_items = items;
-  int S = p.ntiles / 8;
-  p.S = S < 1 ? 1 : (S > 64 ? 64 : S);
+  // Slabs of row tiles for kernel B (one wave per (block group, slab)): all waves should be resident at once -- a few
+  // waves past the chip's capacity would run a second round alone and double the kernel's time.  142 VGPRs -> 3 waves
+  // per SIMD = 12 per CU; at least 4 tiles per slab.
+  static const int n_cus = [] { int v = 256, dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256; return v > 0 ? v : 256; }();
+  int S = (int)(0.97 * n_cus * 12) / items;
+  if (S > p.ntiles / 4) S = p.ntiles / 4;
+  p.S = S < 1 ? 1 : (S > 128 ? 128 : S);
   p.part_floats = (int64_t)p.S * p.slab_floats;
   return 0;
 }
@@ -786,6 +794,7 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   for (int si = 0; si < kBwdStages; ++si) ta.prog.st[si] = k2_stage_desc(p.u, p.bd, p.lay, si);
   ta.packed = packed; ta.packedT = packedT; ta.x = x; ta.ts = ts; ta.gout = gout; ta.ws = workspace;
   ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles;
+  { const char* e = getenv("SOCMX_K2_DBG"); ta.dbg = e ? atoi(e) : 0; }
   const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
   static const bool force_generic = getenv("SOCMX_GENERIC") != nullptr;
   const UnetDesc& u = p.u;

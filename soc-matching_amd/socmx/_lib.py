@@ -28,6 +28,10 @@ class Problem(C.Structure):
                 ("A", _fp), ("P", _fp), ("Q", _fp), ("omega", _fp), ("kappa", _fp), ("nu", _fp)]
 
 
+class RolloutExtra(C.Structure):
+    _fields_ = [("key", _fp), ("nabla_v", _fp)]
+
+
 class Unet(C.Structure):
     _fields_ = [("d", C.c_int32), ("hdims", C.c_int32 * 3), ("weight", _fp * 9), ("bias", _fp * 9)]
 
@@ -52,9 +56,9 @@ PROTOTYPES = {
     "socmx_rollout_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                     C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
                                     _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "socmx_rollout_keyed_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
-                                          C.c_int32, C.c_float, _fp, C.c_int64, _fp,
-                                          _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_rollout_ex_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
+                                       _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.POINTER(RolloutExtra), _fp]),
     "socmx_philox_advance": (C.c_int, [_fp, C.c_uint64, _fp]),
     "socmx_rollout_phase_cycles_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                                  C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,

@@ -256,6 +256,29 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout):
     return out
 
 
+class UnetOnTrajectory(torch.autograd.Function):
+    """nabla_V on the trajectory rows (method.py:272-278) as a function of the network parameters, with the VALUES
+    supplied by the rollout kernel (it evaluates the network at every grid point anyway: socmx_rollout_ex_f32's
+    `nabla_v`) and the parameter gradients by socmx_unet_backward_f32.  No forward pass, no saved activations."""
+
+    @staticmethod
+    def forward(ctx, values, states, ts, net, *params):
+        ctx.net = net
+        ctx.save_for_backward(states, ts)
+        return values.view_as(values)
+
+    @staticmethod
+    def backward(ctx, gout):
+        states, ts = ctx.saved_tensors
+        Kp, B, d = states.shape
+        grads = unet_backward_hip(ctx.net, states.reshape(Kp * B, d), ts, B, gout.reshape(Kp * B, d))
+        return (None, None, None, None) + tuple(grads)
+
+
+def unet_on_trajectory(net, values, states, ts):
+    return UnetOnTrajectory.apply(values, states, ts, net, *net.parameters())
+
+
 def unet_forward_hip(net, tx):
     """nabla_V rows through the fused MFMA kernel (no autograd): socmx_unet_forward_f32."""
     L = _lib.lib()

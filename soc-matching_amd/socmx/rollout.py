@@ -44,9 +44,11 @@ def burst_eligible(sde, x0):
 
 
 def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noise_in=None, seed=None,
-                            offset=None, row0=0):
+                            offset=None, row0=0, key=None, want_nabla_v=False):
+    """`want_nabla_v` (HIP path only; ignored -- no ninth entry -- on the eager path): see hip_trajectories."""
     if _eligible_for_hip(sde, x0, detach):
-        return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0)
+        return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0, key=key,
+                                want_nabla_v=want_nabla_v)
     return eager_trajectories(sde, x0, t, lmbd, detach=detach, verbose=verbose, noise_in=noise_in)
 
 
@@ -71,10 +73,11 @@ class PhiloxKey:
 
 
 def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0, phase_cycles=None,
-                     costs_only=False, key=None):
+                     costs_only=False, key=None, want_nabla_v=False):
     """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 64) -> run the instrumented kernel.
     `costs_only`: write lpd / lps / ltw only (the five trajectory entries of the returned tuple are None).
-    `key`: a PhiloxKey -- seed/offset are read from device memory and advanced behind the launch."""
+    `key`: a PhiloxKey -- seed/offset are read from device memory and advanced behind the launch.
+    `want_nabla_v`: also return nabla_V(t_k, X_k), k = 0..K, as a ninth entry (K+1, B, d)."""
     global _philox_calls
     L = _lib.lib()
     pb = sde.problem
@@ -98,32 +101,37 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
     if noise_in is not None:
         noise_in = noise_in.detach().to(**f32).contiguous()
         assert noise_in.shape == (K, B, d), noise_in.shape
+    nabla_v = torch.empty(K + 1, B, d, **f32) if want_nabla_v else None
     net = sde.nabla_V
     with _lib.on_device(dev):
         head = (pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,
                 float(lmbd))
         tail = (int(row0), _lib.ptr(noise_in), _lib.ptr(states), _lib.ptr(noises), _lib.ptr(controls),
                 _lib.ptr(stop), _lib.ptr(frac), _lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw))
-        if key is not None:
-            assert phase_cycles is None and key.key.device == dev
-            status = L.socmx_rollout_keyed_f32(*head, key.key.data_ptr(), *tail, _lib.stream_ptr(dev))
-        else:
+        if key is None:
             if seed is None:
                 seed = torch.initial_seed()
             if offset is None:
                 offset = _philox_calls
                 _philox_calls += 1
             mid = (int(seed) & (2**64 - 1), int(offset) & (2**64 - 1))
-            if phase_cycles is not None:
-                assert phase_cycles.dtype == torch.int64 and phase_cycles.is_cuda and phase_cycles.is_contiguous()
-                status = L.socmx_rollout_phase_cycles_f32(*head, *mid, *tail, phase_cycles.data_ptr(),
-                                                          _lib.stream_ptr(dev))
-            else:
-                status = L.socmx_rollout_f32(*head, *mid, *tail, _lib.stream_ptr(dev))
+        else:
+            assert phase_cycles is None and key.key.device == dev
+            mid = (0, 0)
+        if phase_cycles is not None:
+            assert phase_cycles.dtype == torch.int64 and phase_cycles.is_cuda and phase_cycles.is_contiguous()
+            assert not want_nabla_v
+            status = L.socmx_rollout_phase_cycles_f32(*head, *mid, *tail, phase_cycles.data_ptr(), _lib.stream_ptr(dev))
+        elif key is not None or want_nabla_v:
+            extra = _lib.RolloutExtra(key=None if key is None else key.key.data_ptr(), nabla_v=_lib.ptr(nabla_v))
+            status = L.socmx_rollout_ex_f32(*head, *mid, *tail, extra, _lib.stream_ptr(dev))
+        else:
+            status = L.socmx_rollout_f32(*head, *mid, *tail, _lib.stream_ptr(dev))
     _lib.check(status, "socmx_rollout_f32")
     if key is not None:
         key.advance()
-    return states, noises, stop, frac, lpd, lps, ltw, controls
+    out = (states, noises, stop, frac, lpd, lps, ltw, controls)
+    return out + (nabla_v,) if want_nabla_v else out
 
 
 def burst_log_weights(sde, x0_row, t, lmbd, n, *, noise_in=None, seed=None, offset=None, row0=0, chunk_rows=16384):

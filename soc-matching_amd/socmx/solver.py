@@ -176,8 +176,14 @@ class SOC_Solver(nn.Module):
             t_vec, s_vec, ii, jj, delta = self._pair_grid(ts, K)    # built on this stream the first time: before fork
             fork = torch.cuda.Event()
             fork.record()                       # after the previous optimizer step, before the rollout launch
-        (states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls) = \
-            R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0)
+        # SOCM on the GPU: the rollout kernel hands over nabla_V at all (K+1) B trajectory rows (it evaluates the network
+        # there anyway) and socmx_unet_backward_f32 produces the parameter gradients -- no library forward/backward
+        from . import nets as _nets
+        fused_V = (algorithm == "SOCM" and detach and R.burst_eligible(sde, state0) and getattr(self, "fused_nabla_V", True)
+                   and _nets.unet_backward_supported(sde.nabla_V, Kp * B))
+        rolled = R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0,
+                                           key=getattr(self, "philox_key", None), want_nabla_v=fused_V)
+        (states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls) = rolled[:8]
         if side is not None:
             with torch.cuda.stream(side):
                 side.wait_event(fork)
@@ -204,8 +210,11 @@ class SOC_Solver(nn.Module):
         w_mean, w_std = L.mean_std_from_stats(stats)
 
         # nabla_V on all Kp*B trajectory rows (method.py:272-278): library GEMMs + autograd
-        tx = torch.cat([ts.reshape(-1, 1, 1).expand(Kp, B, 1), states], dim=-1).reshape(-1, d + 1)
-        nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)
+        if fused_V:
+            nabla_V = _nets.unet_on_trajectory(sde.nabla_V, rolled[8], states, ts)
+        else:
+            tx = torch.cat([ts.reshape(-1, 1, 1).expand(Kp, B, 1), states], dim=-1).reshape(-1, d + 1)
+            nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)
 
         frac = fractional_timesteps if use_stopping_time else None
         if algorithm == "SOCM":

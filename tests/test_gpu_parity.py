@@ -926,7 +926,7 @@ def test_costs_only_launch_equals_the_full_launch(name):
 
 
 def test_keyed_rollout_reads_the_device_key_and_advances_it():
-    """socmx_rollout_keyed_f32 / socmx_philox_advance: the key lives in device memory; call n draws the noise of
+    """socmx_rollout_ex_f32 (extra.key) / socmx_philox_advance: the key lives in device memory; call n draws the noise of
     (seed, offset0 + n) exactly as the by-value entry point does."""
     from socmx import rollout as R
     sde, aux = build_sde("tiny_double_well_d10", DEV)
@@ -1040,3 +1040,47 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
     assert (num / den) ** 0.5 < 1e-3
     assert all(np.isfinite(r["losses"])) and len(r["losses"]) == 3
     np.testing.assert_allclose(r["losses"][0], float(z["loss_objective"]), rtol=2e-4)   # normalisation constant 1.0
+
+
+@pytest.mark.parametrize("name", ["tiny_double_well_d10", "tiny_ou_linear_d6", "tiny_ou_linear_d20", "tiny_molecular_dynamics_d2",
+                                  "cfg3_double_well_d10_K200", "ouq20_ou_quadratic_easy_d20_K12", "cfg5_ou_linear_d64_K20"])
+def test_rollout_hands_over_nabla_V_on_all_grid_points(name):
+    """socmx_rollout_ex_f32's `nabla_v` (K+1,B,d): the network outputs of the integrator plus the terminal evaluation =
+    the forward values of method.py:272-278, against the oracle's network on the oracle's trajectory (same noise);
+    every other output is bit-identical to the plain launch."""
+    from socmx import rollout as R
+    sde, aux = build_sde(name, DEV)
+    pb, vp, mp, gamma, oaux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    B, K, d = aux["B"], aux["K"], aux["d"]
+    x0 = aux["x0"].repeat(B, 1)
+    plain = R.hip_trajectories(sde, x0, aux["ts"], aux["lmbd"], noise_in=aux["noise"])
+    ext = R.hip_trajectories(sde, x0, aux["ts"], aux["lmbd"], noise_in=aux["noise"], want_nabla_v=True)
+    for a, b in zip(plain, ext[:8]):
+        assert torch.equal(a, b)
+    states = torch.from_numpy(aux["z"]["roll_states"])
+    tx = torch.cat([oaux["ts"].reshape(-1, 1, 1).expand(K + 1, B, 1), states], -1).reshape(-1, d + 1)
+    with torch.no_grad():
+        want = O.unet_forward(vp, tx).reshape(K + 1, B, d).numpy()
+    same = (_np(ext[2]) == aux["z"]["roll_stop_indicators"]).all(axis=0)
+    assert same.all()
+    np.testing.assert_allclose(_np(ext[8]), want, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(want).max()))
+
+
+def test_loss_with_and_without_the_fused_nabla_V_path_agree():
+    """solver.fused_nabla_V = False takes library autograd through the network (the round-1 path): same objective and
+    gradients as the fused path (rollout-provided values + socmx_unet_backward_f32)."""
+    from SOC_matching.method import SOC_Solver
+    res = []
+    for fused in (True, False):
+        sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+        solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
+                            sigma=sde.sigma)
+        solver.fused_nabla_V = fused
+        solver.noise_in = torch.randn(aux["K"], 64, aux["d"], generator=torch.Generator().manual_seed(8)).to(DEV)
+        out = solver.loss(64, algorithm="SOCM", use_warm_start=False)
+        out[0].backward()
+        res.append((out[0].item(), [p.grad.double().clone() for p in sde.parameters()]))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-5)
+    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(res[0][1], res[1][1]))
+    den = sum(float((b ** 2).sum()) for b in res[1][1])
+    assert (num / den) ** 0.5 < 2e-4
