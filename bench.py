@@ -92,22 +92,32 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
         solver.shard = sdist.Shard()
     world = dist.get_world_size() if use_dist else 1
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
-    trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True)
-    for _ in range(max(2, warmup)):
-        trainer.step()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        info = trainer.step()
-    torch.cuda.synchronize(device)
-    it_ms = 1e3 * (time.perf_counter() - t0) / steps
+    def time_iterations(graph):
+        trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True,
+                          hip_graph=graph)
+        for _ in range(max(3, warmup)):                  # (in hipGraph mode: 2 eager warm-ups + the captured iteration)
+            trainer.step()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            info = trainer.step()
+        torch.cuda.synchronize(device)
+        trainer.join()
+        return 1e3 * (time.perf_counter() - t0) / steps, info
+    it_ms_eager, info = time_iterations(False)
+    it_ms, mode = it_ms_eager, "eager (two HIP streams)"
+    if not use_dist:
+        it_ms_graph, info = time_iterations(True)
+        if it_ms_graph < it_ms:
+            it_ms, mode = it_ms_graph, "hipGraph replay"
     fl = flops_per_traj_step(d, HDIMS) * B * K
     out = {"workload": label, "rollout_ms": roll_ms, "trajectory_steps_per_s": B * K / (roll_ms * 1e-3),
-           "socm_ms_per_iter": it_ms, "socm_iters_per_sec": 1e3 / it_ms, "last_loss": float(info["loss"]),
+           "socm_ms_per_iter": it_ms, "socm_iters_per_sec": 1e3 / it_ms, "iteration_mode": mode,
+           "socm_ms_per_iter_eager": it_ms_eager, "last_loss": float(info["loss"]),
            "rollout_roofline": {"bound": "mfma", "achieved": fl / (roll_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": fl / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                                 "active_workgroups": (B + 15) // 16}}
-    del trainer, opt, solver, sde
+    del opt, solver, sde
     torch.cuda.empty_cache()
     return out
 
@@ -237,21 +247,33 @@ def main():
     if use_dist:
         solver.shard = sdist.Shard()
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
-    trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True)
     it_steps, it_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
-    for _ in range(it_warm):
-        trainer.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(it_steps):
-        info = trainer.step()
-    barrier()
-    it_elapsed = time.perf_counter() - t0
-    t = torch.tensor([it_elapsed], dtype=torch.float64, device=device)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    it_elapsed = float(t.item())
-    last_loss = float(info["loss"])
+
+    def time_iterations(graph):
+        trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True,
+                          hip_graph=graph)
+        for _ in range(it_warm):
+            trainer.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(it_steps):
+            info = trainer.step()
+        barrier()
+        el = time.perf_counter() - t0
+        trainer.join()
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), float(info["loss"])
+
+    # eager schedule (two HIP streams; the only one for sharded runs) and, on one GPU, the whole iteration replayed as ONE
+    # captured hipGraph (Trainer(hip_graph=True)): same arithmetic, no host work between the launches
+    it_elapsed_eager, last_loss = time_iterations(False)
+    it_elapsed, it_mode = it_elapsed_eager, "eager (two HIP streams)"
+    if not use_dist:
+        it_elapsed_graph, last_loss_g = time_iterations(True)
+        if it_elapsed_graph < it_elapsed:
+            it_elapsed, it_mode, last_loss = it_elapsed_graph, "hipGraph replay", last_loss_g
 
     # (after the iteration leg: its 2 GB of buffers and the empty_cache() would otherwise cost the next leg its warm
     #  allocator state)
@@ -317,7 +339,8 @@ def main():
                                    "global batch 128*N)", "step": "one stochastic_trajectories call (full 8-tuple)",
                        "parallelism": f"dp{world} (batch-sharded, no data-path collective in the rollout)"},
             "socm_iters_per_sec": it_steps / it_elapsed, "socm_ms_per_iter": 1e3 * it_elapsed / it_steps,
-            "socm_iters_timed": it_steps, "socm_last_loss": last_loss,
+            "socm_iters_timed": it_steps, "socm_last_loss": last_loss, "socm_iteration_mode": it_mode,
+            "socm_ms_per_iter_eager": 1e3 * it_elapsed_eager / it_steps,
             "roofline": {"bound": "mfma", "kernel": "socmx::rollout_kernel<8,false,false,StaticNet<16,256,128,64,16>,true>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -80,7 +80,8 @@ def run(cfg):
     backend = cfg.get("backend", {}) or {}
     trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm,
                       gemm_select=bool(backend.get("gemm_select", True)),
-                      tune_new_shapes=bool(backend.get("tune_new_shapes", False)))
+                      tune_new_shapes=bool(backend.get("tune_new_shapes", False)),
+                      hip_graph=bool(backend.get("hip_graph", False)))
 
     solver.algorithm = algorithm
     info = solver.training_info = {k: [] for k in (
@@ -103,7 +104,7 @@ def run(cfg):
         vals = dict(time_per_iteration=step["time_per_iteration"], loss=step["loss"], weight_mean=step["weight_mean"],
                     weight_std=step["weight_std"])
         if compute_L2_error:
-            vals["norm_sqd_diff"] = (out[1] / norm_before).detach()
+            vals["norm_sqd_diff"] = (out[1] / step.get("norm_before", norm_before)).detach()
         for k in ("grad_norm_sqd", "EMA_grad_norm_sqd", "sqd_norm_EMA_grad"):      # main.py:408-410
             if k in step:
                 info[k].append(step[k].detach())

@@ -43,7 +43,7 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
                  ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=False, overlap_M_backward=True,
-                 grad_telemetry=True, tune_new_shapes=False):
+                 grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2):
         self.solver, self.optimizer = solver, optimizer
         self.batch_size = batch_size
         self.normalization_const = normalization_const
@@ -61,6 +61,15 @@ class Trainer:
         if gemm_select and solver.x0.is_cuda:
             from . import gemm_select as _gs
             _gs.enable(tune_new_shapes=tune_new_shapes)
+        # hipGraph mode (single GPU, SOCM without stopping times): the whole iteration -- rollout, loss, backward, Adam,
+        # EMA normaliser, gradient telemetry -- is captured once and replayed; see _graph_step
+        self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None
+                              and not getattr(solver.neural_sde, "use_stopping_time", False))
+        self.graph_warmup = int(graph_warmup)
+        self._graphs = {}
+        self._dev = None
+        if self.hip_graph:
+            overlap_M_backward = False     # inside a graph the pair-grid network's backward forks and joins within the iteration
         # SOCM on one GPU: the pair-grid network's backward and its Adam groups run on the solver's second stream
         # and overlap with the next iteration's rollout (same arithmetic, same order of updates per parameter)
         self.defer_M = (overlap_M_backward and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None
@@ -140,7 +149,153 @@ class Trainer:
             self._step_groups(self._groups_side)
         return telemetry
 
+    # ---- hipGraph replay of the iteration -------------------------------------------------------------------------
+    # Everything the iteration needs between launches lives on the device: the Philox key (socmx.rollout.PhiloxKey,
+    # advanced by a one-thread node behind the rollout), the iteration counter and the EMA normaliser (the
+    # reference's host-side compute_EMA, utils.py:389-396, written with torch.where on a device counter), Adam's step
+    # counters (capturable=True).  A replay is then ONE host call; the reference's per-iteration semantics
+    # (main.py:280-359) are unchanged -- test_gpu_graph.py replays reference-generated training fixtures through it.
+    def _graph_state(self):
+        if self._dev is None:
+            from .rollout import PhiloxKey
+            dev = self.solver.x0.device
+            f = lambda v: torch.tensor(float(v), dtype=torch.float32, device=dev)
+            nc = self.normalization_const
+            self._dev = dict(norm=(nc.detach().clone().to(dev, torch.float32).reshape(()) if torch.is_tensor(nc) else f(nc)),
+                             itr=f(self.itr), ema_gn=f(0.0),
+                             ema_grad=[torch.zeros_like(p) for p in self.solver.neural_sde.nabla_V.parameters()])
+            if getattr(self.solver, "philox_key", None) is None:
+                self.solver.philox_key = PhiloxKey(dev)
+            for g in self.optimizer.param_groups:            # device-side step counters: required under capture
+                g["capturable"] = True
+                for p in g["params"]:
+                    st = self.optimizer.state.get(p)
+                    if st and torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
+                        st["step"] = st["step"].to(dev)
+        return self._dev
+
+    @staticmethod
+    def _ema_dev(value, ema, coeff, itr):
+        """compute_EMA with the iteration counter as a device tensor (same arithmetic, branch by torch.where)."""
+        warm = float(int(np.floor(1 / coeff)))
+        running = (value + itr * ema) / (itr + 1)
+        smooth = coeff * value + (1 - coeff) * ema
+        return torch.where(itr == 0, value, torch.where(itr <= warm, running, smooth))
+
+    def _body_dev(self, loss_kwargs):
+        """One iteration expressed on device-resident state only (capturable); returns a (7,) tensor
+        [loss, weight_mean, weight_std, grad_norm_sqd, EMA_grad_norm_sqd, sqd_norm_EMA_grad, normaliser before]."""
+        solver, D = self.solver, self._graph_state()
+        out = solver.loss(self.batch_size, algorithm="SOCM", use_warm_start=False, use_stopping_time=False, **loss_kwargs)
+        norm_before = D["norm"].clone()
+        loss = out[0] / D["norm"]                                        # main.py:313-320
+        loss.backward()                                                  # main.py:323
+        zero = torch.zeros((), device=D["norm"].device)
+        gn = ema_gn = gne = zero
+        if self.grad_telemetry:                                          # main.py:325-345
+            with torch.no_grad():
+                grads = [p.grad for p in solver.neural_sde.nabla_V.parameters()]
+                sq = lambda ts: torch.stack(torch._foreach_norm(ts)).square().sum()
+                gn = sq(grads)
+                itr, c = D["itr"], 0.01
+                warm = float(int(np.floor(1 / c)))
+                a = torch.where(itr == 0, zero, torch.where(itr <= warm, itr / (itr + 1), zero + (1 - c)))
+                b = torch.where(itr == 0, zero + 1, torch.where(itr <= warm, 1 / (itr + 1), zero + c))
+                torch._foreach_mul_(D["ema_grad"], a)
+                torch._foreach_add_(D["ema_grad"], torch._foreach_mul(grads, b))
+                D["ema_gn"].copy_(self._ema_dev(gn, D["ema_gn"], c, itr))
+                ema_gn, gne = D["ema_gn"], sq(D["ema_grad"])
+        with torch.no_grad():
+            self.optimizer.step()                                        # main.py:347-349
+            self.optimizer.zero_grad(set_to_none=True)
+            D["norm"].copy_(self._ema_dev(out[5].detach(), D["norm"], self.coeff, D["itr"]))     # main.py:354-359
+            D["itr"] += 1
+            extra = [out[1].detach().reshape(())] if out[1] is not None else []
+            return torch.stack([loss.detach().reshape(()), out[5].detach().reshape(()), out[6].detach().reshape(()),
+                                gn.reshape(()), ema_gn.reshape(()), gne.reshape(()), norm_before] + extra)
+
+    def _graph_step(self, loss_kwargs):
+        solver = self.solver
+        dev = solver.x0.device
+        key = tuple(sorted((k, id(v) if callable(v) else v) for k, v in loss_kwargs.items()))
+        if self.sync_timing:
+            torch.cuda.synchronize(dev)
+        start = time.time()
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graph_state()
+            self.join()
+            # first calls with this signature: `graph_warmup` iterations run eagerly on a side stream (they are real
+            # training iterations), the next one is captured while it runs
+            n = self._graphs.setdefault(("warm",) + key, 0)
+            if n < self.graph_warmup:
+                self._graphs[("warm",) + key] = n + 1
+                side = torch.cuda.Stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    vals = self._body_dev(loss_kwargs)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                vals.record_stream(torch.cuda.current_stream(dev))
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    static_vals = self._body_dev(loss_kwargs)
+                self._graphs[key] = entry = (g, static_vals)
+                g.replay()                                   # capture does not execute: this replay IS the iteration
+                vals = static_vals.clone()
+        else:
+            entry[0].replay()
+            vals = entry[1].clone()
+        if self.sync_timing:
+            torch.cuda.synchronize(dev)
+        time_per_iteration = time.time() - start
+        self.itr += 1
+        self.normalization_const = self._dev["norm"]         # (a live view of the device-side normaliser)
+        info = dict(loss=vals[0], time_per_iteration=time_per_iteration, weight_mean=vals[1], weight_std=vals[2],
+                    norm_before=vals[6], out=(None, vals[7] if vals.numel() > 7 else None, None, None, None, vals[1],
+                                              vals[2], None))
+        if self.grad_telemetry:
+            info.update(grad_norm_sqd=vals[3], EMA_grad_norm_sqd=vals[4], sqd_norm_EMA_grad=vals[5])
+        return info
+
+    def _graph_eligible(self, loss_kwargs):
+        return (self.hip_graph and not loss_kwargs.get("compute_control_objective", False)
+                and not loss_kwargs.get("verbose", False))
+
+    def _sync_from_device_state(self):
+        """An eager iteration in hipGraph mode (checkpoint iterations: control-objective bursts, verbose prints) works
+        on the host-side mirrors of the device state, and writes them back afterwards."""
+        D = self._dev
+        if D is not None:
+            self.normalization_const = D["norm"].clone()
+
+    def _sync_to_device_state(self):
+        D = self._dev
+        if D is not None:
+            nc = self.normalization_const
+            D["norm"].copy_(nc.detach().reshape(()) if torch.is_tensor(nc) else torch.tensor(float(nc)))
+            D["itr"].fill_(float(self.itr))
+            if self._ema_grad is not None and self._ema_grad is not D["ema_grad"]:
+                torch._foreach_copy_(D["ema_grad"], self._ema_grad)
+            if self._ema_grad_norm_sqd is not None:
+                D["ema_gn"].copy_(self._ema_grad_norm_sqd.detach().reshape(()))
+
     def step(self, **loss_kwargs):
+        if self._graph_eligible(loss_kwargs):
+            return self._graph_step(loss_kwargs)
+        if self.hip_graph:
+            self._graph_state()
+            self._sync_from_device_state()
+            if self._dev is not None and self.itr > 0:
+                self._ema_grad = [g.clone() for g in self._dev["ema_grad"]]
+                self._ema_grad_norm_sqd = self._dev["ema_gn"].clone()
+            try:
+                return self._eager_step(**loss_kwargs)
+            finally:
+                self._sync_to_device_state()
+        return self._eager_step(**loss_kwargs)
+
+    def _eager_step(self, **loss_kwargs):
         solver = self.solver
         dev = solver.x0.device
         if self.sync_timing and dev.type == "cuda":

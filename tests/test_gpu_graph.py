@@ -1,0 +1,73 @@
+"""The SOCM iteration as one replayed hipGraph (Trainer(hip_graph=True)): device-resident Philox key, iteration counter,
+EMA normaliser and Adam step counters.  Checked against the eager Trainer on the same Philox stream, and against the
+reference-generated training fixtures (injected noise through a static buffer)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_host_cpu import build_sde, GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().to("cpu", torch.float32).numpy()
+
+
+def _run(name, graph, steps, B, seed=77):
+    from SOC_matching.method import SOC_Solver
+    from socmx.rollout import PhiloxKey
+    from socmx.train import Trainer, make_optimizer
+    sde, aux = build_sde(name, DEV)
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
+    solver.philox_key = PhiloxKey(torch.device(DEV), seed=seed, offset=5)
+    opt = make_optimizer(solver, M_lr=1e-3)
+    tr = Trainer(solver, opt, B, normalization_const=0.7, sync_timing=False, hip_graph=graph, graph_warmup=2,
+                 overlap_M_backward=False)
+    rec = []
+    for _ in range(steps):
+        info = tr.step()
+        rec.append([float(info[k]) for k in ("loss", "weight_mean", "weight_std", "grad_norm_sqd", "EMA_grad_norm_sqd",
+                                             "sqd_norm_EMA_grad")] + [float(tr.normalization_const)])
+    torch.cuda.synchronize()
+    return np.array(rec), {k: _np(v) for k, v in sde.state_dict().items()}, tr, solver
+
+
+@pytest.mark.parametrize("name,B", [("cfg1_ou_quadratic_easy_d2_K50", 128), ("cfg3_double_well_d10_K200", 64),
+                                    ("ouq20_ou_quadratic_easy_d20_K12", 40)])
+def test_graph_replay_equals_the_eager_iteration(name, B):
+    """7 iterations = 2 eager warm-up + the captured one + 4 replays, fresh Philox noise in every one; the eager Trainer on
+    the same device key is the reference: losses, weight statistics, gradient telemetry, normaliser and the final
+    parameters."""
+    rec_e, par_e, _, _ = _run(name, False, 7, B)
+    rec_g, par_g, tr, solver = _run(name, True, 7, B)
+    assert tr.hip_graph and len([k for k in tr._graphs if not (isinstance(k, tuple) and k and k[0] == "warm")]) == 1
+    np.testing.assert_allclose(rec_g, rec_e, rtol=2e-5, atol=1e-7)
+    assert len(set(np.round(rec_g[:, 0], 9))) == 7                    # every replay drew fresh noise
+    assert solver.philox_key.key.cpu().tolist()[1] == 5 + 7
+    for k in par_e:
+        np.testing.assert_allclose(par_g[k], par_e[k], rtol=2e-5, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["train_ou_quadratic_easy_d2", "train_double_well_d10"])
+def test_graph_mode_replays_the_reference_training_fixture(name):
+    """Reference-generated TRAINING fixture (main.py:280-359 replayed by the reference itself): the noise of iteration n is
+    copied into a static buffer before step n -- the captured graph reads that buffer -- and the losses, normaliser
+    values and final parameters must be the reference's."""
+    from test_host_cpu import run_training_fixture, check_training_fixture
+    sde, z, rec = run_training_fixture(name, DEV, hip_graph=True, graph_warmup=1)
+    check_training_fixture(sde, z, rec, rtol=1e-3)
+
+
+def test_graph_mode_falls_back_to_eager_for_checkpoint_iterations():
+    """compute_control_objective=True (a burst with host-side statistics) runs eagerly and keeps the device-side state
+    (normaliser, iteration counter, telemetry EMAs) in step."""
+    rec, par, tr, solver = _run("tiny_double_well_d10", True, 4, 16)
+    out = tr.step(compute_control_objective=True, total_n_samples=64)
+    assert out["out"][2] is not None and torch.isfinite(out["out"][2])
+    after = tr.step()
+    assert torch.isfinite(after["loss"]) and tr.itr == 6
+    assert float(tr._dev["itr"]) == 6.0

@@ -231,8 +231,11 @@ def run_training_fixture(name, device, **trainer_kw):
     opt = make_optimizer(solver, nabla_V_lr=lr_V, M_lr=lr_M, adam_eps=eps)
     tr = Trainer(solver, opt, aux["B"], normalization_const=norm0, sync_timing=False, **trainer_kw)
     rec = dict(loss=[], weight_mean=[], norm=[])
+    static = torch.empty_like(aux["noise"][0]) if trainer_kw.get("hip_graph") else None   # a captured graph reads ONE buffer
     for it in range(int(z["train_iters"])):
-        solver.noise_in = aux["noise"][it]
+        if static is not None:
+            static.copy_(aux["noise"][it])
+        solver.noise_in = aux["noise"][it] if static is None else static
         out = tr.step()
         rec["loss"].append(float(out["loss"]))
         rec["weight_mean"].append(float(out["weight_mean"]))
