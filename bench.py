@@ -106,6 +106,7 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
         return 1e3 * (time.perf_counter() - t0) / steps, info
     it_ms_eager, info = time_iterations(False)
     it_ms, mode = it_ms_eager, "eager (two HIP streams)"
+    it_ms_graph = None
     if not use_dist:
         it_ms_graph, info = time_iterations(True)
         if it_ms_graph < it_ms:
@@ -113,7 +114,7 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
     fl = flops_per_traj_step(d, HDIMS) * B * K
     out = {"workload": label, "rollout_ms": roll_ms, "trajectory_steps_per_s": B * K / (roll_ms * 1e-3),
            "socm_ms_per_iter": it_ms, "socm_iters_per_sec": 1e3 / it_ms, "iteration_mode": mode,
-           "socm_ms_per_iter_eager": it_ms_eager, "last_loss": float(info["loss"]),
+           "socm_ms_per_iter_eager": it_ms_eager, "socm_ms_per_iter_graph": it_ms_graph, "last_loss": float(info["loss"]),
            "rollout_roofline": {"bound": "mfma", "achieved": fl / (roll_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": fl / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                                 "active_workgroups": (B + 15) // 16}}
@@ -270,6 +271,7 @@ def main():
     # captured hipGraph (Trainer(hip_graph=True)): same arithmetic, no host work between the launches
     it_elapsed_eager, last_loss = time_iterations(False)
     it_elapsed, it_mode = it_elapsed_eager, "eager (two HIP streams)"
+    it_elapsed_graph = None
     if not use_dist:
         it_elapsed_graph, last_loss_g = time_iterations(True)
         if it_elapsed_graph < it_elapsed:
@@ -341,6 +343,7 @@ def main():
             "socm_iters_per_sec": it_steps / it_elapsed, "socm_ms_per_iter": 1e3 * it_elapsed / it_steps,
             "socm_iters_timed": it_steps, "socm_last_loss": last_loss, "socm_iteration_mode": it_mode,
             "socm_ms_per_iter_eager": 1e3 * it_elapsed_eager / it_steps,
+            "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps,
             "roofline": {"bound": "mfma", "kernel": "socmx::rollout_kernel<8,false,false,StaticNet<16,256,128,64,16>,true>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

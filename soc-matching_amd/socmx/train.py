@@ -157,6 +157,8 @@ class Trainer:
     # (main.py:280-359) are unchanged -- test_gpu_graph.py replays reference-generated training fixtures through it.
     def _graph_state(self):
         if self._dev is None:
+            import gc
+            gc.collect()           # drop unreachable autograd graphs of earlier eager iterations (see _eager_step's note)
             from .rollout import PhiloxKey
             dev = self.solver.x0.device
             f = lambda v: torch.tensor(float(v), dtype=torch.float32, device=dev)
@@ -189,7 +191,13 @@ class Trainer:
         out = solver.loss(self.batch_size, algorithm="SOCM", use_warm_start=False, use_stopping_time=False, **loss_kwargs)
         norm_before = D["norm"].clone()
         loss = out[0] / D["norm"]                                        # main.py:313-320
-        loss.backward()                                                  # main.py:323
+        # main.py:323 -- as torch.autograd.grad: `.backward()` routes every parameter's gradient through its AccumulateGrad
+        # node, which is pinned to the stream that was current when the node was first created.  If any earlier autograd
+        # graph is still alive (an eager iteration's outputs kept by the caller) that is the DEFAULT stream, and the
+        # engine's synchronisation with it inside a capture invalidates the capture (observed: segfault in capture_end).
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        for p, g in zip(params, torch.autograd.grad(loss, params, allow_unused=True)):
+            p.grad = g
         zero = torch.zeros((), device=D["norm"].device)
         gn = ema_gn = gne = zero
         if self.grad_telemetry:                                          # main.py:325-345
@@ -344,5 +352,9 @@ class Trainer:
             self.normalization_const = compute_EMA(weight_mean.detach(), self.normalization_const,
                                                    EMA_coeff=self.coeff, itr=self.itr)   # main.py:354-359
         self.itr += 1
+        # the loss outputs leave DETACHED: the backward pass is done, and a caller that kept the objective's autograd graph
+        # alive would also keep the parameters' AccumulateGrad nodes alive -- pinned to the stream of this eager
+        # iteration, which breaks a later hipGraph capture (see _body_dev)
+        out = tuple(o.detach() if torch.is_tensor(o) else o for o in out)
         return dict(loss=loss_val, time_per_iteration=time_per_iteration, weight_mean=weight_mean.detach(),
-                    weight_std=out[6].detach(), out=out, **telemetry)
+                    weight_std=out[6], out=out, **telemetry)
