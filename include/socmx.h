@@ -191,6 +191,33 @@ int socmx_rollout_ex_f32(const socmx_problem* problem, const float* packed_unet,
                          const socmx_rollout_extra* extra, socmx_stream_t stream);
 int socmx_philox_advance(uint64_t* key, uint64_t inc, socmx_stream_t stream);
 
+/*
+ * The rollout of utils.py:17-128 under a TABULATED control instead of the network: the ground-truth controls of
+ * models.py:10-150 that method.py:103-107 evaluates when `use_learned_control` is off (the optimal-SDE bursts of
+ * main.py:137-150).  Same outputs, layouts, Philox contract and costs-only rule as socmx_rollout_f32.
+ *   LINEAR    u = table[tidx[k]] (d,d) . x      models.py:10-41  LinearControl (LQ Riccati, utils.py:234-254)
+ *   CONSTANT  u = table[tidx[k]] (d,)           models.py:61-83  ConstantControlLinear
+ *   TABLE     u_j = table[tidx[k], clamp(floor((x_j + xb) / delta_x), 0, n_x - 1), j]   models.py:98-150 LowDimControl
+ * tidx (K,) int32 device: the table row of step k, evaluated by the caller with the reference's fp32 index formula
+ * for a scalar time (floor((n-1) t / T), floor(n t / T), ceil(t / delta_t) respectively).
+ * molecular_dynamics has no ground truth (settings.py:112-114): SOCMX_E_KIND.
+ */
+enum { SOCMX_CTRL_LINEAR = 1, SOCMX_CTRL_CONSTANT = 2, SOCMX_CTRL_TABLE = 3 };
+typedef struct socmx_control {
+  int32_t kind;
+  int32_t n_t;          /* rows of the table along time */
+  int32_t n_x;          /* TABLE: entries along x */
+  int32_t reserved;
+  const float* table;   /* LINEAR (n_t,d,d); CONSTANT (n_t,d); TABLE (n_t,n_x,d) */
+  const int32_t* tidx;  /* (K,) */
+  float xb, delta_x;    /* TABLE only */
+} socmx_control;
+int socmx_rollout_control_f32(const socmx_problem* problem, const socmx_control* control, const float* x0,
+                              const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed, uint64_t offset,
+                              int64_t row0, const float* noise_in, float* states, float* noises, float* controls,
+                              float* stop_indicators, float* fractional_timesteps, float* lpd, float* lps,
+                              float* ltw, socmx_stream_t stream);
+
 /* Diagnostics: the same rollout instrumented with s_memtime; cycles ((B+15)/16, 64) int64 device receives, per
  * workgroup, shader cycles summed over the K steps for: [0] input tile build, [1..6] the six network stages
  * (down_0, down_1, down_2, up_2+res_2, up_1+res_1, up_0+res_0), [7] control+noise, [8] EM update,

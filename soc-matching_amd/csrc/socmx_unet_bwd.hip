@@ -81,28 +81,50 @@ __host__ __device__ constexpr int layer_act_tensor(int l) {
   return a[l];
 }
 
-// ---- LDS of kernel A: the forward tile layout of socmx_unet.h, the backward tiles behind it, nibble masks last ------
+// ---- LDS of kernel A ----------------------------------------------------------------------------------------------------
+// Forward tiles X0 R1 R2 R3 O2 O1 G (row stride width + 4, as in socmx_unet.h).  Every forward tile is dead once the
+// forward part has consumed and exported it -- only the SIGN of R1/R2/R3 and of the up-path pre-activations is needed
+// later, kept as nibble masks (4 units per byte) -- so the backward tiles reuse the same memory:
+//     ZU0 -> X0,  GO1 -> R1,  ZU1 -> O1,  GO2 -> R2,  ZU2 -> O2,  ZD2 -> R3;   ZD1 has its own tile, which also holds the
+// biases (read by the forward stages only) until stage 9 writes it.  The split-K scratch is sized by the stages that
+// split.  Default widths: 75-77 KiB per workgroup = two workgroups per CU (the barriers of one overlap the MFMAs of
+// the other).
 struct BwdLayout {
   TileLayout t;                                   // x0, r1, r2, r3, o2, o1, gv (= the G tile here), scratch, bias
   int zu0, go1, zu1, go2, zu2, zd2, zd1;          // float offsets
-  int mu2, mu1, mu0;                              // float offsets of the byte arrays [16][width/4]
+  int mu2, mu1, mr1, mr2, mr3;                    // float offsets of the byte arrays [16][width / 4]
   int floats;
 };
 
-__host__ __device__ constexpr BwdLayout make_bwd_layout(const UnetDesc& u, int nwaves) {
+__host__ __device__ constexpr int k2_scratch_floats(const UnetDesc& u, int nwaves, int rt);
+
+// rt = 16-row tiles per workgroup (the tiles hold 16 rt rows): with rt = 2 every weight fragment that arrives from L2
+// feeds two MFMA column tiles -- half the weight traffic and half the barriers per row
+__host__ __device__ constexpr BwdLayout make_bwd_layout(const UnetDesc& u, int nwaves, int rt) {
   BwdLayout b{};
-  b.t = make_tile_layout(u, nwaves);
-  int off = b.t.floats;
-  b.zu0 = off; off += 16 * b.t.sg;
-  b.go1 = off; off += 16 * b.t.s1;
-  b.zu1 = off; off += 16 * b.t.s1;
-  b.go2 = off; off += 16 * b.t.s2;
-  b.zu2 = off; off += 16 * b.t.s2;
-  b.zd2 = off; off += 16 * b.t.s3;
-  b.zd1 = off; off += 16 * b.t.s2;
-  b.mu2 = off; off += u.hp[1];                    // 16 rows x hp/4 bytes = hp floats
-  b.mu1 = off; off += u.hp[0];
-  b.mu0 = off; off += u.outp;
+  TileLayout& t = b.t;
+  const int rows = 16 * rt;
+  t.s0 = u.in0p + 4; t.s1 = u.hp[0] + 4; t.s2 = u.hp[1] + 4; t.s3 = u.hp[2] + 4; t.sg = u.outp + 4;
+  int off = 0;
+  t.x0 = off; off += rows * t.s0;
+  t.r1 = off; off += rows * t.s1;
+  t.r2 = off; off += rows * t.s2;
+  t.r3 = off; off += rows * t.s3;
+  t.o2 = off; off += rows * t.s2;
+  t.o1 = off; off += rows * t.s1;
+  t.gv = off; off += rows * t.sg;
+  b.zu0 = t.x0; b.go1 = t.r1; b.zu1 = t.o1; b.go2 = t.r2; b.zu2 = t.o2; b.zd2 = t.r3;
+  b.zd1 = off;
+  t.bias = off;
+  const int zd1_floats = rows * t.s2;
+  off += zd1_floats > u.bias_floats ? zd1_floats : u.bias_floats;
+  b.mu2 = off; off += rt * u.hp[1];               // rows x (width / 4) bytes = rt x width floats
+  b.mu1 = off; off += rt * u.hp[0];
+  b.mr1 = off; off += rt * u.hp[0];
+  b.mr2 = off; off += rt * u.hp[1];
+  b.mr3 = off; off += rt * u.hp[2];
+  t.scratch = off; off += k2_scratch_floats(u, nwaves, rt);
+  t.floats = off;
   b.floats = off;
   return b;
 }
@@ -142,22 +164,22 @@ __host__ __device__ constexpr K2Stage make_k2_stage(const UnetDesc& u, const Bwd
     s.sd.has2 = has2; s.img1 = 1; s.img2 = 1;
   };
   switch (si) {
-    case 0: fwd(0, t.x0, t.s0, 0, 0, t.x0, t.s0, t.r1, t.s1); s.epi = EPI_RELU; s.ex1 = T_R1; break;
-    case 1: fwd(1, t.r1, t.s1, 0, 1, t.r1, t.s1, t.r2, t.s2); s.epi = EPI_RELU; s.ex1 = T_R2; break;
-    case 2: fwd(2, t.r2, t.s2, 0, 2, t.r2, t.s2, t.r3, t.s3); s.epi = EPI_RELU; s.ex1 = T_R3; break;
+    case 0: fwd(0, t.x0, t.s0, 0, 0, t.x0, t.s0, t.r1, t.s1); s.epi = EPI_RELU; s.mask = b.mr1; s.ex1 = T_R1; break;
+    case 1: fwd(1, t.r1, t.s1, 0, 1, t.r1, t.s1, t.r2, t.s2); s.epi = EPI_RELU; s.mask = b.mr2; s.ex1 = T_R2; break;
+    case 2: fwd(2, t.r2, t.s2, 0, 2, t.r2, t.s2, t.r3, t.s3); s.epi = EPI_RELU; s.mask = b.mr3; s.ex1 = T_R3; break;
     case 3: fwd(6, t.r3, t.s3, 1, 5, t.r2, t.s2, t.o2, t.s2); s.epi = EPI_RES; s.mask = b.mu2; s.ex1 = T_O2; break;
     case 4: fwd(7, t.o2, t.s2, 1, 4, t.r1, t.s1, t.o1, t.s1); s.epi = EPI_RES; s.mask = b.mu1; s.ex1 = T_O1; break;
-    case 5: fwd(8, t.o1, t.s1, 0, 8, t.o1, t.s1, -1, 0); s.epi = EPI_MASK0; s.mask = b.mu0; s.aux = t.gv; s.saux = t.sg;
+    case 5: fwd(8, t.o1, t.s1, 0, 8, t.o1, t.s1, -1, 0); s.epi = EPI_MASK0; s.aux = t.gv; s.saux = t.sg;
             s.y2 = b.zu0; s.sy2 = t.sg; s.ex2 = T_ZU0; break;
     case 6: bwd(KT_U0, b.zu0, t.sg, 0, KT_U0, b.zu0, t.sg, b.go1, t.s1); s.epi = EPI_DUAL; s.mask = b.mu1;
             s.y2 = b.zu1; s.sy2 = t.s1; s.ex1 = T_GO1; s.ex2 = T_ZU1; break;
     case 7: bwd(KT_U1, b.zu1, t.s1, 0, KT_U1, b.zu1, t.s1, b.go2, t.s2); s.epi = EPI_DUAL; s.mask = b.mu2;
             s.y2 = b.zu2; s.sy2 = t.s2; s.ex1 = T_GO2; s.ex2 = T_ZU2; break;
-    case 8: bwd(KT_U2, b.zu2, t.s2, 0, KT_U2, b.zu2, t.s2, b.zd2, t.s3); s.epi = EPI_ACTMASK; s.aux = t.r3; s.saux = t.s3;
+    case 8: bwd(KT_U2, b.zu2, t.s2, 0, KT_U2, b.zu2, t.s2, b.zd2, t.s3); s.epi = EPI_ACTMASK; s.mask = b.mr3;
             s.ex1 = T_ZD2; break;
-    case 9: bwd(KT_D2, b.zd2, t.s3, 1, KT_R2, b.go2, t.s2, b.zd1, t.s2); s.epi = EPI_ACTMASK; s.aux = t.r2; s.saux = t.s2;
+    case 9: bwd(KT_D2, b.zd2, t.s3, 1, KT_R2, b.go2, t.s2, b.zd1, t.s2); s.epi = EPI_ACTMASK; s.mask = b.mr2;
             s.ex1 = T_ZD1; break;
-    default: bwd(KT_D1, b.zd1, t.s2, 1, KT_R1, b.go1, t.s1, -1, 0); s.epi = EPI_ACTMASK; s.aux = t.r1; s.saux = t.s1;
+    default: bwd(KT_D1, b.zd1, t.s2, 1, KT_R1, b.go1, t.s1, -1, 0); s.epi = EPI_ACTMASK; s.mask = b.mr1;
             s.ex1 = T_ZD0; break;
   }
   s.w1 = s.ex1 >= 0 ? tensor_width(u, s.ex1) : 0;
@@ -173,6 +195,26 @@ __host__ __device__ constexpr void k2_first_layer(const UnetDesc& u, const BwdDe
   constexpr int b1[5] = {KT_U0, KT_U1, KT_U2, KT_D2, KT_D1};
   if (si < 6) { L = u.L[f1[si]]; img = 0; }
   else { L = bd.L[b1[si - 6]]; img = 1; }
+}
+
+// split-K scratch of kernel A: the largest (1 + has2) * parts * 16 * out_pad over the stages whose GEMM 1 has fewer than four
+// 16-wide output blocks (the work-split rule of wave_work_of)
+__host__ __device__ constexpr int k2_scratch_floats(const UnetDesc& u, int nwaves, int rt) {
+  const BwdDesc bd = make_bwd_desc(u);
+  // (out_pad of GEMM 1, has2) per stage, in stage order
+  const int outs[kBwdStages] = {u.hp[0], u.hp[1], u.hp[2], u.hp[1], u.hp[0], u.outp,
+                                bd.L[KT_U0].out_pad, bd.L[KT_U1].out_pad, bd.L[KT_U2].out_pad, bd.L[KT_D2].out_pad,
+                                bd.L[KT_D1].out_pad};
+  const int two[kBwdStages] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1};
+  int need = 0;
+  for (int si = 0; si < kBwdStages; ++si) {
+    const int nblk = outs[si] >> 4;
+    if (nblk >= kSimds || nblk >= nwaves) continue;
+    const int parts = nwaves / nblk;
+    const int n = (1 + two[si]) * parts * 16 * rt * outs[si];
+    need = n > need ? n : need;
+  }
+  return need;
 }
 
 struct K2Program {      // (the per-wave work split is evaluated on the device: the table would not fit the kernel arguments)
@@ -212,7 +254,7 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void export4(float* slab, int r, int n0, const f32x4 v) {
   if (!slab) return;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) slab[(size_t)(n0 + i) * 16 + r] = v[i];
+  for (int i = 0; i < 4; ++i) slab[(size_t)(n0 + i) * 16 + (r & 15)] = v[i];
 }
 
 struct EpiCtx {
@@ -220,15 +262,15 @@ struct EpiCtx {
   float* ws;               // workspace base (nullptr: developer switch SOCMX_K2_DBG=1, no exports -- timing only)
   const float* bias_lds;
   int64_t tile_rows;       // 16 * ntiles
-  int tile;
+  int tile;                // first 16-row tile of this workgroup (row r of the LDS tiles belongs to tile + r / 16)
 };
 
 template <int EPI>
 struct Epi {
   const K2Stage& s;
   const EpiCtx& c;
-  __device__ __forceinline__ float* slab(int prefix, int width) const {
-    return c.ws ? c.ws + (size_t)c.tile_rows * prefix + (size_t)c.tile * width * 16 : nullptr;
+  __device__ __forceinline__ float* slab(int prefix, int width, int r) const {
+    return c.ws ? c.ws + (size_t)c.tile_rows * prefix + (size_t)(c.tile + (r >> 4)) * width * 16 : nullptr;
   }
   __device__ __forceinline__ f32x4 init(int n0) const {
     if constexpr (EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_MASK0) return lds4(c.bias_lds + s.sd.L1.b_lds + n0);
@@ -246,20 +288,22 @@ struct Epi {
   }
   __device__ __forceinline__ void fin(f32x4 v, int r, int n0, const UnetDesc& u) const {
     if constexpr (EPI == EPI_RELU) {
+      unsigned m = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = relu_keep_nan(v[i]);
+      for (int i = 0; i < 4; ++i) { m |= (v[i] > 0.f ? 1u : 0u) << i; v[i] = relu_keep_nan(v[i]); }
+      reinterpret_cast<unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)] = (unsigned char)m;
       *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
-      export4(slab(s.p1, s.w1), r, n0, v);
+      export4(slab(s.p1, s.w1, r), r, n0, v);
     } else if constexpr (EPI == EPI_RES) {
       *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
-      export4(slab(s.p1, s.w1), r, n0, v);
+      export4(slab(s.p1, s.w1, r), r, n0, v);
     } else if constexpr (EPI == EPI_MASK0) {
       const f32x4 g = lds4(c.lds + s.aux + r * s.saux + n0);
       f32x4 z;
 #pragma unroll
       for (int i = 0; i < 4; ++i) z[i] = v[i] > 0.f ? g[i] : 0.f;
       *reinterpret_cast<f32x4*>(c.lds + s.y2 + r * s.sy2 + n0) = z;
-      export4(slab(s.p2, s.w2), r, n0, z);
+      export4(slab(s.p2, s.w2, r), r, n0, z);
     } else if constexpr (EPI == EPI_DUAL) {
       const unsigned m = reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
       f32x4 z;
@@ -267,20 +311,78 @@ struct Epi {
       for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
       *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
       *reinterpret_cast<f32x4*>(c.lds + s.y2 + r * s.sy2 + n0) = z;
-      export4(slab(s.p1, s.w1), r, n0, v);
-      export4(slab(s.p2, s.w2), r, n0, z);
-    } else {   // EPI_ACTMASK
-      const f32x4 a = lds4(c.lds + s.aux + r * s.saux + n0);
+      export4(slab(s.p1, s.w1, r), r, n0, v);
+      export4(slab(s.p2, s.w2, r), r, n0, z);
+    } else {   // EPI_ACTMASK: the sign of the forward activation, saved as a nibble by that stage's EPI_RELU
+      const unsigned m = reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
       f32x4 z;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) z[i] = a[i] > 0.f ? v[i] : 0.f;
+      for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
       if (s.sd.y >= 0) *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = z;
-      export4(slab(s.p1, s.w1), r, n0, z);
+      export4(slab(s.p1, s.w1, r), r, n0, z);
     }
   }
 };
 
-template <int NB, int NW, bool PINNED, class EPI>
+// gemm_run of socmx_unet.h with RT batch-column tiles per weight fragment: acc[h][j] += W-block j . X rows [16 h, 16 h + 16)
+template <int NB, int RT>
+__device__ __forceinline__ void mfma_chunk_rt(f32x4 (&acc)[RT][NB], const f32x4 (&a)[NB], const f32x4 (&bx)[RT]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int h = 0; h < RT; ++h) acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], bx[h][i], acc[h][j], 0, 0, 0);
+}
+
+template <int NB, int RT, bool PINNED>
+__device__ __forceinline__ void k2_gemm_run(f32x4 (&acc)[RT][NB], Ring<NB>& r, const GemmPlan<NB>& p, int half) {
+  constexpr int PD = Ring<NB>::PD;
+  const int last = p.kc1 - 1;
+  int kc = p.kc0;
+  f32x4 bx[RT], bx_next[RT];
+#pragma unroll
+  for (int h = 0; h < RT; ++h) {
+    bx[h] = lds4(p.xrow + h * half + min(kc, last) * 16);
+    bx_next[h] = lds4(p.xrow + h * half + min(kc + 1, last) * 16);
+  }
+  for (; kc + PD <= p.kc1; kc += PD) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      f32x4 bx_next2[RT];
+#pragma unroll
+      for (int h = 0; h < RT; ++h) bx_next2[h] = lds4(p.xrow + h * half + min(kc + s + 2, last) * 16);
+      mfma_chunk_rt<NB, RT>(acc, r.slot[s], bx);
+      if constexpr (PINNED) {           // see gemm_run: the refill stays where it is written
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + s + PD <= last) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)(kc + s + PD) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        const int nk = min(kc + s + PD, last);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) r.slot[s][j] = p.wb[j][(size_t)nk * 64];
+      }
+#pragma unroll
+      for (int h = 0; h < RT; ++h) { bx[h] = bx_next[h]; bx_next[h] = bx_next2[h]; }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < PD - 1; ++s) {
+    if (kc + s < p.kc1) {
+      f32x4 bx_next2[RT];
+#pragma unroll
+      for (int h = 0; h < RT; ++h) bx_next2[h] = lds4(p.xrow + h * half + min(kc + s + 2, last) * 16);
+      mfma_chunk_rt<NB, RT>(acc, r.slot[s], bx);
+#pragma unroll
+      for (int h = 0; h < RT; ++h) { bx[h] = bx_next[h]; bx_next[h] = bx_next2[h]; }
+    }
+  }
+}
+
+template <int NB, int NW, int RT, bool PINNED, class EPI>
 __device__ __forceinline__ void k2_direct(const float* __restrict__ W1, const float* __restrict__ W2, const StageDesc& sd,
                                           float* lds, int blk0, int lane, const Pre& pre, bool use_pre, const EPI& epi,
                                           const UnetDesc& u) {
@@ -288,24 +390,30 @@ __device__ __forceinline__ void k2_direct(const float* __restrict__ W1, const fl
   const bool has2 = sd.has2 != 0;
   const GemmPlan<NB> p1 = make_plan<NB>(W1, sd.L1, blk0, NW, lds + sd.x1, sd.s1, lane, 0, sd.L1.in_pad >> 4);
   const GemmPlan<NB> p2 = make_plan<NB>(W2, sd.L2, blk0, NW, lds + sd.x2, sd.s2, lane, 0, sd.L2.in_pad >> 4);
+  f32x4 acc[RT][NB];
+#pragma unroll
+  for (int h = 0; h < RT; ++h)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[h][j] = epi.init((blk0 + j * NW) * 16 + 4 * g);
   Ring<NB> r1, r2;
   if (use_pre) ring_fill<NB, true>(r1, p1, pre); else ring_fill<NB, false>(r1, p1, pre);
-  if (has2) ring_fill<NB, false>(r2, p2, pre);
-  f32x4 acc[NB];
+  if (has2) ring_fill<NB, false>(r2, p2, pre);     // the residual GEMM's first chunks fly while GEMM 1 runs
+  k2_gemm_run<NB, RT, PINNED>(acc, r1, p1, 16 * sd.s1);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) acc[j] = epi.init((blk0 + j * NW) * 16 + 4 * g);
-  gemm_run<NB, PINNED>(acc, r1, p1);
+  for (int h = 0; h < RT; ++h)
 #pragma unroll
-  for (int j = 0; j < NB; ++j) epi.mid(acc[j], row, (blk0 + j * NW) * 16 + 4 * g);
-  if (has2) gemm_run<NB, PINNED>(acc, r2, p2);
+    for (int j = 0; j < NB; ++j) epi.mid(acc[h][j], h * 16 + row, (blk0 + j * NW) * 16 + 4 * g);
+  if (has2) k2_gemm_run<NB, RT, PINNED>(acc, r2, p2, 16 * sd.s2);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) epi.fin(acc[j], row, (blk0 + j * NW) * 16 + 4 * g, u);
+  for (int h = 0; h < RT; ++h)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) epi.fin(acc[h][j], h * 16 + row, (blk0 + j * NW) * 16 + 4 * g, u);
 }
 
 // One stage on the 16-row tile; same work split as socmx_unet.h's unet_stage (direct: neuron blocks dealt to the waves;
 // fewer than four blocks: the reduction dimension is split over the waves and combined through LDS), generalised
 // epilogue.  Ends with a workgroup barrier.
-template <int NW, bool PINNED, class EPI>
+template <int NW, int RT, bool PINNED, class EPI>
 __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const float* __restrict__ W2,
                                          const float* __restrict__ Wn, const StageDesc& sd, const WaveWorkS& w, float* lds,
                                          float* scratch, Pre& pre, const EPI& epi, const UnetDesc& u) {
@@ -317,10 +425,10 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
     bool use_pre = w.use_pre != 0;
     int blk0 = w.blk0;
     for (int cnt = w.cnt; cnt > 0; cnt -= 4, blk0 += 4 * NW) {
-      if (cnt >= 4)      k2_direct<4, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
-      else if (cnt == 3) k2_direct<3, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, false, epi, u);
-      else if (cnt == 2) k2_direct<2, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
-      else               k2_direct<1, NW, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
+      if (cnt >= 4)      k2_direct<4, NW, RT, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
+      else if (cnt == 3) k2_direct<3, NW, RT, PINNED>(W1, W2, sd, lds, blk0, lane, pre, false, epi, u);
+      else if (cnt == 2) k2_direct<2, NW, RT, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
+      else               k2_direct<1, NW, RT, PINNED>(W1, W2, sd, lds, blk0, lane, pre, use_pre, epi, u);
       use_pre = false;
     }
     pre = prefetch_fragments(Wn, sd.Ln, w, lane);
@@ -329,8 +437,9 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
     const int parts = w.parts, blk = w.blk0, part = w.part;
     const int outp = sd.L1.out_pad;
     const int row = lane & 15, g = lane >> 4;
+    constexpr int ROWS = 16 * RT;
     float* P1 = scratch;
-    float* P2 = scratch + parts * 16 * outp;
+    float* P2 = scratch + parts * ROWS * outp;
     if (w.active) {
       const GemmPlan<1> p1 = make_plan<1>(W1, sd.L1, blk, 0, lds + sd.x1, sd.s1, lane, w.kc0a, w.kc1a);
       const GemmPlan<1> p2 = make_plan<1>(W2, sd.L2, blk, 0, lds + sd.x2, sd.s2, lane, w.kc0b, w.kc1b);
@@ -338,13 +447,21 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
       const bool w1 = p1.kc1 > p1.kc0, w2 = has2 && p2.kc1 > p2.kc0;
       if (w1) ring_fill<1, true>(r1, p1, pre);
       if (w2) ring_fill<1, false>(r2, p2, pre);
-      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      if (w1) gemm_run<1>(acc, r1, p1);
-      *reinterpret_cast<f32x4*>(P1 + (part * 16 + row) * outp + blk * 16 + 4 * g) = acc[0];
+      f32x4 acc[RT][1];
+#pragma unroll
+      for (int h = 0; h < RT; ++h) acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (w1) k2_gemm_run<1, RT, false>(acc, r1, p1, 16 * sd.s1);
+#pragma unroll
+      for (int h = 0; h < RT; ++h)
+        *reinterpret_cast<f32x4*>(P1 + (part * ROWS + h * 16 + row) * outp + blk * 16 + 4 * g) = acc[h][0];
       if (has2) {
-        f32x4 acc2[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (w2) gemm_run<1>(acc2, r2, p2);
-        *reinterpret_cast<f32x4*>(P2 + (part * 16 + row) * outp + blk * 16 + 4 * g) = acc2[0];
+        f32x4 acc2[RT][1];
+#pragma unroll
+        for (int h = 0; h < RT; ++h) acc2[h][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (w2) k2_gemm_run<1, RT, false>(acc2, r2, p2, 16 * sd.s2);
+#pragma unroll
+        for (int h = 0; h < RT; ++h)
+          *reinterpret_cast<f32x4*>(P2 + (part * ROWS + h * 16 + row) * outp + blk * 16 + 4 * g) = acc2[h][0];
       }
     }
     pre = prefetch_fragments(Wn, sd.Ln, w, lane);
@@ -352,20 +469,20 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
     // combine: thread e owns the quad (row e / Q, units 4 (e % Q) ..), Q = outp / 4 <= 12
     const int Q = outp >> 2;
     const int e = threadIdx.x;
-    if (e < 16 * Q) {
+    if (e < ROWS * Q) {                                    // (Q <= 12, ROWS <= 32: at most 384 of the 512 threads)
       const int r = (int)(((float)e + 0.5f) * __builtin_amdgcn_rcpf((float)Q)), n0 = 4 * (e - r * Q);
       f32x4 v = epi.init(n0);
-      for (int p = 0; p < parts; ++p) v += lds4(P1 + (p * 16 + r) * outp + n0);
+      for (int p = 0; p < parts; ++p) v += lds4(P1 + (p * ROWS + r) * outp + n0);
       epi.mid(v, r, n0);
       if (has2)
-        for (int p = 0; p < parts; ++p) v += lds4(P2 + (p * 16 + r) * outp + n0);
+        for (int p = 0; p < parts; ++p) v += lds4(P2 + (p * ROWS + r) * outp + n0);
       epi.fin(v, r, n0, u);
     }
     __syncthreads();
   }
 }
 
-template <int NW, class NET, int SI>
+template <int NW, class NET, int RT, int SI>
 __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre& carry, const EpiCtx& ctx, int wave) {
   constexpr bool kStatic = !std::is_same<NET, void>::value;
   auto body = [&](const K2Stage& s, const WaveWorkS& w, const UnetDesc& u, const BwdLayout& lay) {
@@ -373,17 +490,17 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
     const float* W2 = s.img2 ? a.packedT : a.packed;
     const float* Wn = s.imgn ? a.packedT : a.packed;
     float* scratch = lds + lay.t.scratch;
-    if (s.epi == EPI_RELU)       k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RELU>{s, ctx}, u);
-    else if (s.epi == EPI_RES)   k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RES>{s, ctx}, u);
-    else if (s.epi == EPI_MASK0) k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_MASK0>{s, ctx}, u);
-    else if (s.epi == EPI_DUAL)  k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_DUAL>{s, ctx}, u);
-    else                         k2_stage<NW, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_ACTMASK>{s, ctx}, u);
+    if (s.epi == EPI_RELU)       k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RELU>{s, ctx}, u);
+    else if (s.epi == EPI_RES)   k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RES>{s, ctx}, u);
+    else if (s.epi == EPI_MASK0) k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_MASK0>{s, ctx}, u);
+    else if (s.epi == EPI_DUAL)  k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_DUAL>{s, ctx}, u);
+    else                         k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_ACTMASK>{s, ctx}, u);
   };
   if constexpr (kStatic) {
     // every descriptor is a compile-time value: offsets fold into immediates, one NB variant and one epilogue survive
     constexpr UnetDesc u = NET::desc();
     constexpr BwdDesc bd = make_bwd_desc(u);
-    constexpr BwdLayout lay = make_bwd_layout(u, NW);
+    constexpr BwdLayout lay = make_bwd_layout(u, NW, RT);
     constexpr K2Stage s = k2_stage_desc(u, bd, lay, SI);
     const WaveWork w0 = wave_work_of(s.sd, NW, wave);
     WaveWorkS w;
@@ -408,6 +525,11 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
 }
 
 // NET = StaticNet<...> (constexpr descriptors) or void (descriptors from the kernel arguments: any architecture)
+// constexpr instantiations: two 16-row tiles per workgroup; the descriptor-driven one: one (smaller LDS: more
+// architectures fit; it is the fallback for non-default widths)
+template <class NET> struct K2RowTiles { static constexpr int value = 2; };
+template <> struct K2RowTiles<void> { static constexpr int value = 1; };
+
 template <int NW, class NET>
 __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -416,7 +538,7 @@ __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a
   BwdLayout lay;
   if constexpr (kStatic) {
     constexpr UnetDesc uc = NET::desc();
-    constexpr BwdLayout lc = make_bwd_layout(uc, NW);
+    constexpr BwdLayout lc = make_bwd_layout(uc, NW, K2RowTiles<NET>::value);
     u = uc; lay = lc;
   } else {
     u = a.u; lay = a.lay;
@@ -425,7 +547,8 @@ __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a
   const int tid = threadIdx.x, nthr = NW * 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int d = a.u.d, in0p = u.in0p, outp = u.outp;
-  const int tile = blockIdx.x;
+  constexpr int RT = K2RowTiles<NET>::value, ROWS = 16 * RT;
+  const int tile = blockIdx.x * RT;                       // first 16-row tile of this workgroup
   const int64_t row0 = (int64_t)tile * 16;
   const int64_t tile_rows = (int64_t)a.ntiles * 16;
   float* X0 = lds + t.x0;
@@ -433,8 +556,10 @@ __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a
   // ---- input tile [t, x, 0..] and gradient tile (zero rows past N: they then contribute nothing to any gradient) ------
   float* slabX = a.ws + (size_t)tile_rows * tensor_prefix(u, T_X) + (size_t)tile * in0p * 16;
   float* slabG = a.ws + (size_t)tile_rows * tensor_prefix(u, T_G0) + (size_t)tile * outp * 16;
-  for (int e = tid; e < 16 * in0p; e += nthr) {
-    const int c = e >> 4, r = e & 15;                         // unit-major like the slab: coalesced slab stores
+  for (int e = tid; e < ROWS * in0p; e += nthr) {
+    // e = ((h in0p + c) 16 + r16): unit-major inside each 16-row tile like the slab -> coalesced slab stores
+    const int r16 = e & 15, hc = e >> 4;
+    const int h = hc >= in0p ? 1 : 0, c = hc - h * in0p, r = h * 16 + r16;
     const int64_t grow = min(row0 + r, a.N - 1);
     float v = 0.f;
     if (c == 0) v = a.ts[grow / a.rows_per_t];
@@ -442,8 +567,9 @@ __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a
     X0[r * t.s0 + c] = v;
     slabX[e] = v;
   }
-  for (int e = tid; e < 16 * outp; e += nthr) {
-    const int c = e >> 4, r = e & 15;
+  for (int e = tid; e < ROWS * outp; e += nthr) {
+    const int r16 = e & 15, hc = e >> 4;
+    const int h = hc >= outp ? 1 : 0, c = hc - h * outp, r = h * 16 + r16;
     const float v = (row0 + r < a.N && c < d) ? a.gout[(row0 + r) * d + c] : 0.f;
     G0[r * t.sg + c] = v;
     slabG[e] = v;
@@ -464,17 +590,17 @@ __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a
     carry = prefetch_fragments(a.packed, L0, w, lane);
   }
   __syncthreads();
-  k2_run_stage<NW, NET, 0>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 1>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 2>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 3>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 4>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 5>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 6>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 7>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 8>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 9>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, 10>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 0>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 1>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 2>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 3>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 4>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 5>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 6>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 7>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 8>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 9>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 10>(a, lds, carry, ctx, wave);
 }
 
 // ---- kernel B: weight / bias gradient partials -----------------------------------------------------------------------
@@ -573,13 +699,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
 __global__ __launch_bounds__(256) void unet_wgrad_kernel(const WgradArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slab = blockIdx.y * 4 + wave;
+  // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2): all block groups
+  // that read one slab of row tiles are numbered onto ONE XCD, so a tile's operands cross the fabric once and the
+  // other groups' re-reads hit that L2.  (Speed only: any placement is correct.)
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int item = q % a.n_items;
+  const int slab = ((q / a.n_items) * 8 + xcd) * 4 + wave;
   if (slab >= a.S) return;
   int l = 8;
-  while (l > 0 && (int)blockIdx.x < a.item0[l]) --l;
+  while (l > 0 && item < a.item0[l]) --l;
   WgItem it;
   {
-    const int rel = (int)blockIdx.x - a.item0[l];
+    const int rel = item - a.item0[l];
     const int nig = (a.IB[l] + 3) >> 2;
     const int og = rel / nig, ig = rel - og * nig;
     it.gt_off = a.gt_off[l]; it.at_off = a.at_off[l]; it.gW = a.gW[l]; it.aW = a.aW[l];
@@ -629,9 +760,17 @@ __global__ __launch_bounds__(256) void unet_wgrad_finish_kernel(const FinishArgs
     const int ob = cell / a.IB[l], ib = cell - ob * a.IB[l];
     const int o = ob * 16 + 4 * (lane >> 4) + rr, i = ib * 16 + (lane & 15);
     if (o < a.fout[l] && i < a.fin[l]) {
-      float s = 0.f;
-      for (int p = 0; p < a.S; ++p) s += a.part[(size_t)p * a.slab_floats + idx];
-      a.grads[a.gw_off[l] + (int64_t)o * a.fin[l] + i] = s;
+      // four independent chains (loads in flight), combined in a fixed order
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int p = 0;
+      for (; p + 3 < a.S; p += 4) {
+        s0 += a.part[(size_t)p * a.slab_floats + idx];
+        s1 += a.part[(size_t)(p + 1) * a.slab_floats + idx];
+        s2 += a.part[(size_t)(p + 2) * a.slab_floats + idx];
+        s3 += a.part[(size_t)(p + 3) * a.slab_floats + idx];
+      }
+      for (; p < a.S; ++p) s0 += a.part[(size_t)p * a.slab_floats + idx];
+      a.grads[a.gw_off[l] + (int64_t)o * a.fin[l] + i] = (s0 + s1) + (s2 + s3);
     }
     return;
   }
@@ -687,7 +826,18 @@ static bool k2_dims_ok(int d, const int32_t h[3]) {
   return true;
 }
 
+// which instantiation of kernel A: 0 = descriptor-driven, 1..3 = the constexpr ones (default hidden widths)
+static int k2_variant(const UnetDesc& u) {
+  static const bool force_generic = getenv("SOCMX_GENERIC") != nullptr;
+  if (force_generic || u.hp[0] != 256 || u.hp[1] != 128 || u.hp[2] != 64) return 0;
+  if (u.in0p == 16 && u.outp == 16) return 1;
+  if (u.in0p == 32 && u.outp == 32) return 2;
+  if (u.in0p == 80 && u.outp == 64) return 3;
+  return 0;
+}
+
 struct K2Plan {
+  int variant, rt;
   UnetDesc u;
   BwdDesc bd;
   BwdLayout lay;
@@ -708,10 +858,12 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   const int h[3] = {hdims[0], hdims[1], hdims[2]};
   p.u = make_unet_desc(d, h);
   p.bd = make_bwd_desc(p.u);
-  p.lay = make_bwd_layout(p.u, kK2Waves);
+  p.variant = k2_variant(p.u);
+  p.rt = p.variant ? 2 : 1;
+  p.lay = make_bwd_layout(p.u, kK2Waves, p.rt);
   if ((size_t)p.lay.floats * sizeof(float) > (size_t)kLdsBytesPerCU) return SOCMX_E_LDS;
   if ((N + 15) / 16 > (int64_t)1 << 27) return SOCMX_E_DIM;
-  p.ntiles = (int)((N + 15) / 16);
+  p.ntiles = (int)((N + 16 * p.rt - 1) / (16 * p.rt)) * p.rt;     // 16-row tiles, whole workgroups (padding tiles: zero gradient)
   int wsum = 0;
   for (int t = 0; t < T_N; ++t) wsum += tensor_width(p.u, t);
   p.ws_floats = (int64_t)p.ntiles * 16 * wsum;
@@ -733,12 +885,14 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   p.total_bias = off - p.total_cells_floats;
   p.slab_floats = off;
   p.n_items = items;
-  // Slabs of row tiles for kernel B (one wave per (block group, slab)): all waves should be resident at once -- a few
-  // waves past the chip's capacity would run a second round alone and double the kernel's time.  142 VGPRs -> 3 waves
-  // per SIMD = 12 per CU; at least 4 tiles per slab.
-  static const int n_cus = [] { int v = 256, dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256; return v > 0 ? v : 256; }();
-  int S = (int)(0.97 * n_cus * 12) / items;
-  if (S > p.ntiles / 4) S = p.ntiles / 4;
+  // Slabs of row tiles for kernel B (one wave per (block group, slab), four slabs per workgroup).  Measured on MI355X
+  // (tools/k2_prof.sh, SOCMX_K2_S sweep): the slab GROUPS must divide evenly over the 8 XCDs -- kernel B numbers them onto
+  // XCDs -- so S is a multiple of 32; 64 is within 5 % of the best for 400 ... 13,000 tiles, and more slabs only grow
+  // kernel C's reduction.  Small inputs: at least 4 tiles per slab.
+  (void)items;
+  int S = 64;
+  { const char* e = getenv("SOCMX_K2_S"); if (e) S = atoi(e); }       // developer switch
+  if (S > p.ntiles / 4) S = p.ntiles / 4 >= 32 ? 32 : p.ntiles / 4;
   p.S = S < 1 ? 1 : (S > 128 ? 128 : S);
   p.part_floats = (int64_t)p.S * p.slab_floats;
   return 0;
@@ -796,15 +950,12 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles;
   { const char* e = getenv("SOCMX_K2_DBG"); ta.dbg = e ? atoi(e) : 0; }
   const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
-  static const bool force_generic = getenv("SOCMX_GENERIC") != nullptr;
-  const UnetDesc& u = p.u;
-  const bool widths_default = !force_generic && u.hp[0] == 256 && u.hp[1] == 128 && u.hp[2] == 64;
   void (*kern)(const TileArgs) = unet_bwd_tile_kernel<kK2Waves, void>;
-  if (widths_default && u.in0p == 16 && u.outp == 16) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<16, 256, 128, 64, 16>>;
-  else if (widths_default && u.in0p == 32 && u.outp == 32) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<32, 256, 128, 64, 32>>;
-  else if (widths_default && u.in0p == 80 && u.outp == 64) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<80, 256, 128, 64, 64>>;
+  if (p.variant == 1) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<16, 256, 128, 64, 16>>;
+  else if (p.variant == 2) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<32, 256, 128, 64, 32>>;
+  else if (p.variant == 3) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<80, 256, 128, 64, 64>>;
   if (const int err = ensure_max_lds(kern)) return err;
-  if (const int err = launch(kern, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, ta)) return err;
+  if (const int err = launch(kern, dim3(p.ntiles / p.rt), dim3(kK2Waves * 64), lds_bytes, stream, ta)) return err;
   // ---- kernel B ----
   WgradArgs wa;
   wa.n_items = 0; wa.S = p.S; wa.ntiles = p.ntiles; wa.slab_floats = p.slab_floats;
@@ -818,7 +969,8 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
     wa.n_items += ((p.OB[l] + 3) / 4) * ((p.IB[l] + 3) / 4);
   }
   wa.item0[9] = wa.n_items;
-  if (const int err = launch(unet_wgrad_kernel, dim3(wa.n_items, (p.S + 3) / 4), dim3(256), 0, stream, wa)) return err;
+  const int slab_groups = (((p.S + 3) / 4) + 7) & ~7;       // padded to a multiple of the XCD count
+  if (const int err = launch(unet_wgrad_kernel, dim3(wa.n_items * slab_groups), dim3(256), 0, stream, wa)) return err;
   // ---- kernel C ----
   FinishArgs fa;
   for (int l = 0; l < 9; ++l) {

@@ -32,6 +32,14 @@ class RolloutExtra(C.Structure):
     _fields_ = [("key", _fp), ("nabla_v", _fp)]
 
 
+class Control(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_t", C.c_int32), ("n_x", C.c_int32), ("reserved", C.c_int32),
+                ("table", _fp), ("tidx", _fp), ("xb", C.c_float), ("delta_x", C.c_float)]
+
+
+CTRL_LINEAR, CTRL_CONSTANT, CTRL_TABLE = 1, 2, 3
+
+
 class Unet(C.Structure):
     _fields_ = [("d", C.c_int32), ("hdims", C.c_int32 * 3), ("weight", _fp * 9), ("bias", _fp * 9)]
 
@@ -59,6 +67,9 @@ PROTOTYPES = {
     "socmx_rollout_ex_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                        C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
                                        _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.POINTER(RolloutExtra), _fp]),
+    "socmx_rollout_control_f32": (C.c_int, [C.POINTER(Problem), C.POINTER(Control), _fp, _fp, C.c_int32, C.c_int32,
+                                            C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
+                                            _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "socmx_philox_advance": (C.c_int, [_fp, C.c_uint64, _fp]),
     "socmx_rollout_phase_cycles_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                                  C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,

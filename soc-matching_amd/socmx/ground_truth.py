@@ -26,6 +26,12 @@ class LinearControl:
     def _index(self, t):
         return torch.floor((self.U.shape[0] - 1) * t / self.T).to(torch.int64)
 
+    def hip_descriptor(self, ts):
+        """(kind, table, per-step table row, n_x, xb, delta_x) for socmx_rollout_control_f32: the scalar-time lookup of
+        __call__ evaluated for every step of the grid with the same fp32 arithmetic."""
+        from . import _lib
+        return _lib.CTRL_LINEAR, self.U, self._index(ts[:-1]), 0, 0.0, 1.0
+
     def __call__(self, t, x, t_is_tensor=False):
         if not t_is_tensor:
             Ut = self.U[self._index(t)]
@@ -42,6 +48,11 @@ class ConstantControl:
 
     def __init__(self, C, ts, T):
         self.C, self.ts, self.T = C, ts, T
+
+    def hip_descriptor(self, ts):
+        from . import _lib
+        n = self.C.shape[0]
+        return _lib.CTRL_CONSTANT, self.C, torch.floor(n * ts[:-1] / self.T).to(torch.int64), 0, 0.0, 1.0
 
     def __call__(self, t, x, t_is_tensor=False):
         n = self.C.shape[0]
@@ -116,6 +127,11 @@ class LowDimControl:
 
     def __init__(self, ut, T, xb, dim, delta_t, delta_x):
         self.ut, self.T, self.xb, self.dim, self.delta_t, self.delta_x = ut, T, xb, dim, delta_t, delta_x
+
+    def hip_descriptor(self, ts):
+        from . import _lib
+        ti = torch.ceil(ts[:-1] / self.delta_t).to(torch.int64)
+        return _lib.CTRL_TABLE, self.ut, ti, int(self.ut.shape[1]), float(self.xb), float(self.delta_x)
 
     def _lookup(self, t_idx, x):
         ix = torch.floor((x + self.xb) / self.delta_x).to(torch.int64).clamp_(0, self.ut.shape[1] - 1)

@@ -9,9 +9,13 @@ Routing (explicit, never silent):
     with the learned control, no warm start, `detach=True`
         -> ONE launch of the fused HIP kernel (csrc/socmx_rollout.hip).  If
            libsocmx.so is missing this RAISES.
-  * anything else (CPU tensors = BASELINE config 0 "plumbing"; a user-supplied
-    `sde.u` control such as the ground-truth controls; `detach=False` for the
-    rel_entropy loss; warm start; a foreign NeuralSDE subclass)
+  * the same with `use_learned_control` off and `sde.u` one of the tabulated
+    ground-truth controls of socmx.ground_truth (LQ Riccati, OU-linear closed
+    form, double-well PDE table: reference models.py:10-150), no stopping time
+        -> ONE launch of csrc/socmx_rollout_ctrl.hip.
+  * anything else (CPU tensors = BASELINE config 0 "plumbing"; a foreign
+    `sde.u` callable; `detach=False` for the rel_entropy loss; warm start; a
+    foreign NeuralSDE subclass)
         -> `eager_trajectories`, a device-agnostic torch implementation of the
            same recurrence.
 Extra keyword-only arguments (not in the reference): `noise_in` injects the
@@ -38,9 +42,18 @@ def _eligible_for_hip(sde, x0, detach):
     )
 
 
+def _eligible_for_hip_control(sde, x0, detach):
+    """A tabulated ground-truth control (socmx.ground_truth: LinearControl, ConstantControl, LowDimControl) on a known
+    setting without stopping times: socmx_rollout_control_f32."""
+    pb = getattr(sde, "problem", None)
+    return (x0.is_cuda and detach and pb is not None and not pb.has_phi
+            and not getattr(sde, "use_learned_control", False)
+            and hasattr(getattr(sde, "u", None), "hip_descriptor"))
+
+
 def burst_eligible(sde, x0):
-    """True when an evaluation burst (utils.py:131-231, method.py:185-221) can run as one fused launch."""
-    return _eligible_for_hip(sde, x0, True)
+    """True when an evaluation burst (utils.py:131-231, method.py:185-221) can run as fused launches."""
+    return _eligible_for_hip(sde, x0, True) or _eligible_for_hip_control(sde, x0, True)
 
 
 def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noise_in=None, seed=None,
@@ -49,6 +62,8 @@ def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noi
     if _eligible_for_hip(sde, x0, detach):
         return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0, key=key,
                                 want_nabla_v=want_nabla_v)
+    if _eligible_for_hip_control(sde, x0, detach):
+        return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0)
     return eager_trajectories(sde, x0, t, lmbd, detach=detach, verbose=verbose, noise_in=noise_in)
 
 
@@ -102,6 +117,27 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
         noise_in = noise_in.detach().to(**f32).contiguous()
         assert noise_in.shape == (K, B, d), noise_in.shape
     nabla_v = torch.empty(K + 1, B, d, **f32) if want_nabla_v else None
+    if not getattr(sde, "use_learned_control", False):
+        # tabulated ground-truth control (models.py:10-150): socmx_rollout_control_f32
+        assert key is None and phase_cycles is None and not want_nabla_v
+        ckind, table, tidx, n_x, xb, dx = sde.u.hip_descriptor(tc)
+        table = table.detach().to(**f32).contiguous()
+        tidx = tidx.to(device=dev, dtype=torch.int32).contiguous()
+        ctrl = _lib.Control(kind=ckind, n_t=int(table.shape[0]), n_x=int(n_x), table=_lib.ptr(table),
+                            tidx=tidx.data_ptr(), xb=float(xb), delta_x=float(dx))
+        if seed is None:
+            seed = torch.initial_seed()
+        if offset is None:
+            offset = _philox_calls
+            _philox_calls += 1
+        with _lib.on_device(dev):
+            status = L.socmx_rollout_control_f32(
+                pb.c_struct(), ctrl, _lib.ptr(x0c), _lib.ptr(tc), B, K, float(lmbd), int(seed) & (2**64 - 1),
+                int(offset) & (2**64 - 1), int(row0), _lib.ptr(noise_in), _lib.ptr(states), _lib.ptr(noises),
+                _lib.ptr(controls), _lib.ptr(stop), _lib.ptr(frac), _lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw),
+                _lib.stream_ptr(dev))
+        _lib.check(status, "socmx_rollout_control_f32")
+        return states, noises, stop, frac, lpd, lps, ltw, controls
     net = sde.nabla_V
     with _lib.on_device(dev):
         head = (pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,

@@ -1084,3 +1084,73 @@ def test_loss_with_and_without_the_fused_nabla_V_path_agree():
     num = sum(float(((a - b) ** 2).sum()) for a, b in zip(res[0][1], res[1][1]))
     den = sum(float((b ** 2).sum()) for b in res[1][1])
     assert (num / den) ** 0.5 < 2e-4
+
+
+@pytest.mark.parametrize("overrides,B", [
+    (["method.setting=OU_quadratic_easy", "method.d=2", "method.num_steps=50"], 37),
+    (["method.setting=OU_quadratic_hard", "method.d=20", "method.num_steps=30"], 40),
+    (["method.setting=OU_linear", "method.d=10", "method.num_steps=40"], 33),
+    (["method.setting=OU_linear", "method.d=64", "method.num_steps=25"], 20),
+    (["method.setting=double_well", "method.d=10", "method.num_steps=60", "method.delta_t_optimal=0.01",
+      "method.delta_x_optimal=0.01"], 50),
+])
+def test_ground_truth_control_rollout_kernel_vs_eager(overrides, B):
+    """f1/f2: the optimal-SDE rollouts (main.py:137-150: `sde.u` = LinearControl / ConstantControlLinear / LowDimControl,
+    models.py:10-150) as ONE launch of socmx_rollout_control_f32, against the eager per-step path with the reference's
+    lookups (itself pinned on the CPU by the LQ / PDE known answers) on the same injected noise -- and the Philox contract."""
+    import contextlib, io
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from socmx import rollout as R
+    cfg = load_config(overrides)
+    cfg.method.device = DEV
+    torch.manual_seed(0)
+    K, d = cfg.method.num_steps, cfg.method.d
+    ts = torch.linspace(0, cfg.method.T, K + 1).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, optimal_sde, sde, _ = define_variables(cfg, ts)
+    assert optimal_sde is not None and not optimal_sde.use_learned_control
+    state0 = (x0 + 0.3 * torch.randn(B, d, device=DEV)).contiguous()     # distinct rows
+    noise = torch.randn(K, B, d, generator=torch.Generator().manual_seed(2)).to(DEV)
+    assert R.burst_eligible(optimal_sde, state0)
+    got = R.stochastic_trajectories(optimal_sde, state0, ts, cfg.method.lmbd, noise_in=noise)
+    want = R.eager_trajectories(optimal_sde, state0, ts, cfg.method.lmbd, noise_in=noise)
+    names = ["states", "noises", "stop_indicators", "fractional_timesteps", "lpd", "lps", "ltw", "controls"]
+    for n, a, b in zip(names, got, want):
+        assert a.shape == b.shape, n
+        scale = max(1.0, float(b.abs().max()))
+        np.testing.assert_allclose(_np(a), _np(b.to(torch.float32)), rtol=2e-4, atol=2e-4 * scale, err_msg=n)
+    # device noise: documented draws, costs-only launch, chunked burst
+    full = R.hip_trajectories(optimal_sde, state0, ts, cfg.method.lmbd, seed=9, offset=2, row0=11)
+    for (k, m) in [(0, 0), (K - 1, B - 1)]:
+        np.testing.assert_allclose(_np(full[1][k, m]), O.philox_normals(9, 2, 11 + m, k, d), rtol=2e-4, atol=2e-5)
+    cost = R.hip_trajectories(optimal_sde, state0, ts, cfg.method.lmbd, seed=9, offset=2, row0=11, costs_only=True)
+    for i in (4, 5, 6):
+        assert torch.equal(full[i], cost[i])
+
+
+def test_optimal_control_objective_burst_is_fused():
+    """utils.control_objective(optimal_sde, ...) (main.py:142): chunked costs-only launches of the ground-truth kernel,
+    against the batch-by-batch eager loop on the same injected noise."""
+    import contextlib, io
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from SOC_matching import utils
+    from socmx import rollout as R
+    cfg = load_config(["method.setting=OU_quadratic_hard", "method.d=6", "method.num_steps=20"])
+    cfg.method.device = DEV
+    torch.manual_seed(0)
+    K, d = 20, 6
+    ts = torch.linspace(0, 1.0, K + 1).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, optimal_sde, sde, _ = define_variables(cfg, ts)
+    Bb, nb = 24, 5
+    noise = torch.randn(K, Bb * nb, d, generator=torch.Generator().manual_seed(3)).to(DEV)
+    m, e = utils.control_objective(optimal_sde, x0, ts, 1.0, Bb, total_n_samples=Bb * nb, noise_in=noise, chunk_rows=50)
+    costs = []
+    for k in range(nb):
+        out = R.eager_trajectories(optimal_sde, x0.repeat(Bb, 1), ts, 1.0, noise_in=noise[:, k * Bb:(k + 1) * Bb])
+        costs.append(-(out[4] + out[6]))
+    costs = torch.cat(costs)
+    np.testing.assert_allclose(m.item(), costs.mean().item(), rtol=1e-4)
+    np.testing.assert_allclose(e.item(), (costs.std() / np.sqrt(costs.numel() - 1)).item(), rtol=1e-3)
