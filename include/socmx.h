@@ -300,6 +300,25 @@ int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* 
                                   float* g_dnet, float* g_gamma_part, socmx_stream_t stream);
 
 /*
+ * Stopping-time SOCM target (method.py:484-507, 548-564, 597-613, 649-660, 692-701 with models.py:278-393
+ * TwoBoundarySigmoidMLP): the pair matrices depend on the SAMPLE through its stopping time,
+ *     M[p,m]     =      w I +  c0 N0[p] +  c1 N1[p]
+ *     dM/ds[p,m] = ok ( dw I + dc0 N0[p] + c0 dN0[p] + dc1 N1[p] + c1 dN1[p] )        (ok = 0 where nan_to_num zeroes it)
+ *     target[i,m] = sum_{j>=i} ( M[p,m] qx[j,m] - dM/ds[p,m] vx[j,m] ),  qx = q | nabla_g at j = K,  vx = v | 0.
+ * coef (8, Np, B) = the scalar gate fields [w, c0, c1, ok dw, ok dc0, ok dc1, ok c0, ok c1]; N0, N1, dN0, dN1
+ * (Np, d, d) = the two network evaluations and their s-tangents; q, v (K,B,d) built with the per-sample fractional time
+ * steps (socmx_socm_prep_f32 with `frac`).  The (Np, B, d, d) tensors of the reference are never formed; d <= 4.
+ * The backward returns d obj / d coef (8, Np, B) and d obj / d (N0, N1, dN0, dN1) from gtarget = d obj / d target.
+ */
+int socmx_socm_stopping_target_fwd_f32(int32_t d, int32_t K, int32_t B, const float* coef, const float* N0,
+                                       const float* N1, const float* dN0, const float* dN1, const float* q,
+                                       const float* v, const float* gT, float* target, socmx_stream_t stream);
+int socmx_socm_stopping_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* coef, const float* N0,
+                                       const float* N1, const float* dN0, const float* dN1, const float* q,
+                                       const float* v, const float* gT, const float* gtarget, float* gcoef,
+                                       float* gN0, float* gN1, float* gdN0, float* gdN1, socmx_stream_t stream);
+
+/*
  * Column sums of a tall row-major (R, C) matrix: out[c] = sum_r x[r][c].  Bias gradients of the nn.Linear layers
  * (models.py:212-228, 253-257) over the (K+1)*B trajectory rows / the Np pair rows; no reference counterpart beyond
  * autograd's reduction.  partial is a caller-owned workspace of socmx_colsum_blocks(R, C) * C floats; the result

@@ -202,6 +202,46 @@ class _TargetResidualNetHip(torch.autograd.Function):
         return g_net, g_dnet, g_gamma, gV, None, None, None, None, None, None
 
 
+class _StoppingTargetHip(torch.autograd.Function):
+    """target (Kp,B,d) of the stopping-time SOCM loss from the gate fields and the two network evaluations
+    (socmx_socm_stopping_target_{fwd,bwd}_f32): the per-sample (Np,B,d,d) matrices are formed in registers."""
+
+    @staticmethod
+    def forward(ctx, coef, N0, N1, dN0, dN1, ops, K):
+        L = _lib.lib()
+        B, d = ops["gT"].shape
+        c = lambda t: t.detach().to(torch.float32).contiguous()
+        coef, N0, N1, dN0, dN1 = map(c, (coef, N0, N1, dN0, dN1))
+        target = torch.empty(K + 1, B, d, dtype=torch.float32, device=coef.device)
+        with _lib.on_device(coef.device):
+            _lib.check(L.socmx_socm_stopping_target_fwd_f32(
+                d, K, B, _lib.ptr(coef), _lib.ptr(N0), _lib.ptr(N1), _lib.ptr(dN0), _lib.ptr(dN1), _lib.ptr(ops["q"]),
+                _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]), _lib.ptr(target), _lib.stream_ptr(coef.device)),
+                "socmx_socm_stopping_target_fwd_f32")
+        ctx.save_for_backward(coef, N0, N1, dN0, dN1, ops["q"], ops["v"], ops["gT"])
+        ctx.K = K
+        return target
+
+    @staticmethod
+    def backward(ctx, gtarget):
+        L = _lib.lib()
+        coef, N0, N1, dN0, dN1, q, v, gT = ctx.saved_tensors
+        B, d = gT.shape
+        gtarget = gtarget.detach().to(torch.float32).contiguous()
+        gcoef = torch.empty_like(coef)
+        gN0, gN1, gdN0, gdN1 = (torch.empty_like(N0) for _ in range(4))
+        with _lib.on_device(coef.device):
+            _lib.check(L.socmx_socm_stopping_target_bwd_f32(
+                d, ctx.K, B, _lib.ptr(coef), _lib.ptr(N0), _lib.ptr(N1), _lib.ptr(dN0), _lib.ptr(dN1), _lib.ptr(q),
+                _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gtarget), _lib.ptr(gcoef), _lib.ptr(gN0), _lib.ptr(gN1),
+                _lib.ptr(gdN0), _lib.ptr(gdN1), _lib.stream_ptr(coef.device)), "socmx_socm_stopping_target_bwd_f32")
+        return gcoef, gN0, gN1, gdN0, gdN1, None, None
+
+
+def stopping_target_hip(coef, N0, N1, dN0, dN1, ops, K):
+    return _StoppingTargetHip.apply(coef, N0, N1, dN0, dN1, ops, K)
+
+
 def socm_objective_net(pb, ts, lmbd, K, states, noises, controls, net, dnet, gamma, delta, nablaV, w, inv_norm):
     """SOCM objective from the raw SigmoidMLP outputs (GPU only; raises if libsocmx.so is missing)."""
     ops = socm_operands_hip(pb, ts, lmbd, states, noises, controls)

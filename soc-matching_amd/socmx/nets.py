@@ -356,6 +356,32 @@ class TwoBoundarySigmoidMLP(nn.Module):
         self.scaling_factor = scaling_factor
         _scale_(self.sigmoid_layers, scaling_factor)
 
+    def gates(self, t, s, tau):
+        """The scalar gate fields of models.py:341-392, each (N, B):  M = w I + c0 net(t,s,0) + c1 net(t,s,1)."""
+        st = (s - t).unsqueeze(1)
+        ratio = (1 - torch.exp(-self.gamma * st)) / (1 - torch.exp(-self.gamma * torch.abs(tau - t.unsqueeze(1))) + 1e-7)
+        factor1 = torch.nan_to_num(1 - torch.minimum(ratio, torch.ones(1, device=t.device)), nan=0.0)
+        factor1 = factor1 * (tau - 1e-3 > s.unsqueeze(1)).to(torch.int)
+        running = (tau > self.T - 1e-3).to(torch.int)
+        e3 = torch.exp(-self.gamma3 * st)
+        g2 = lambda x: (1 - torch.exp(-self.gamma2 * x)) * (torch.exp(-self.gamma2 * x) - torch.exp(-self.gamma2))
+        return (1 - running) * factor1 + running * e3, (1 - running) * g2(factor1), running * (1 - e3)
+
+    def nets_with_ds(self, t, s):
+        """net(t,s,0), net(t,s,1) (N,d,d) and their s-derivatives as analytic forward tangents."""
+        l0, l2, l4 = self.sigmoid_layers[0], self.sigmoid_layers[2], self.sigmoid_layers[4]
+        d = self.dim
+        out = []
+        for flag in (0.0, 1.0):
+            x = torch.stack((t, s, torch.full_like(s, flag)), 1)
+            h1 = torch.relu(torch.addmm(l0.bias, x, l0.weight.T))
+            h2 = torch.relu(torch.addmm(l2.bias, h1, l2.weight.T))
+            net = torch.addmm(l4.bias, h2, l4.weight.T).reshape(-1, d, d)
+            t1 = (h1 > 0).to(h1.dtype) * l0.weight[:, 1]
+            t2 = (h2 > 0).to(h2.dtype) * (t1 @ l2.weight.T)
+            out.append((net, (t2 @ l4.weight.T).reshape(-1, d, d)))
+        return out[0][0], out[1][0], out[0][1], out[1][1]
+
     def forward(self, t, s, stopping_timestep_values):
         tau = stopping_timestep_values                       # (N, B)
         d = self.dim

@@ -129,6 +129,23 @@ class SOC_Solver(nn.Module):
         Kp, B, d = states.shape
         tau = ((sde.Phi(states) > 0).to(torch.int).sum(dim=0) - 1) / (Kp - 1)            # method.py:525-530
         tau_vec = tau.unsqueeze(0).expand(t_vec.shape[0], B)
+        if states.is_cuda and d <= 4 and getattr(self, "fused_stopping", True):
+            # HIP path: the gates are (Np,B) scalar fields (torch: differentiable w.r.t. gamma, gamma2, gamma3; their
+            # s-derivatives by forward mode), the (Np,B,d,d) matrices are formed per (pair, sample) inside
+            # socmx_socm_stopping_target_*_f32.  nan_to_num(dM/ds) (method.py:553-555): an entry of dM/ds is NaN exactly
+            # when one of the gate derivatives is (every entry contains all three) -> `ok` zeroes the whole matrix.
+            M = sde.M
+            (w, c0, c1), (dw, dc0, dc1) = torch.func.jvp(lambda s_: M.gates(t_vec, s_, tau_vec), (s_vec,),
+                                                         (torch.ones_like(s_vec),))
+            ok = torch.isfinite(dw) & torch.isfinite(dc0) & torch.isfinite(dc1)
+            z = torch.zeros_like(w)
+            keep = lambda x: torch.where(ok, x, z)
+            coef = torch.stack([w, c0, c1, keep(dw), keep(dc0), keep(dc1), keep(c0), keep(c1)])
+            N0, N1, dN0, dN1 = M.nets_with_ds(t_vec, s_vec)
+            ops = L.socm_operands_hip(pb, ts, self.lmbd, states, noises, controls, frac=frac)
+            target = L.stopping_target_hip(coef, N0, N1, dN0, dN1, ops, K)
+            r = stop_indicators.unsqueeze(2) * ((nabla_V - target) @ pb.sigma)
+            return torch.sum(r * r * weight.reshape(1, -1, 1)) / torch.sum(stop_indicators)
         # dM/ds as a forward-mode tangent (the reference: functorch.jacrev over the batch-summed output)
         M_all, dM_all = torch.func.jvp(lambda s_: sde.M(t_vec, s_, tau_vec), (s_vec,), (torch.ones_like(s_vec),))
         dM_all = torch.nan_to_num(dM_all)                                                   # method.py:553-555

@@ -61,10 +61,9 @@ class Trainer:
         if gemm_select and solver.x0.is_cuda:
             from . import gemm_select as _gs
             _gs.enable(tune_new_shapes=tune_new_shapes)
-        # hipGraph mode (single GPU, SOCM without stopping times): the whole iteration -- rollout, loss, backward, Adam,
+        # hipGraph mode (single GPU, SOCM with or without stopping times): the whole iteration -- rollout, loss, backward, Adam,
         # EMA normaliser, gradient telemetry -- is captured once and replayed; see _graph_step
-        self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None
-                              and not getattr(solver.neural_sde, "use_stopping_time", False))
+        self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None)
         self.graph_warmup = int(graph_warmup)
         self._graphs = {}
         self._dev = None
@@ -149,7 +148,7 @@ class Trainer:
             self._step_groups(self._groups_side)
         return telemetry
 
-    # ---- hipGraph replay of the iteration -------------------------------------------------------------------------
+    # ---- hipGraph replay of the iteration (SOCM, with or without stopping times) --------------------------------------
     # Everything the iteration needs between launches lives on the device: the Philox key (socmx.rollout.PhiloxKey,
     # advanced by a one-thread node behind the rollout), the iteration counter and the EMA normaliser (the
     # reference's host-side compute_EMA, utils.py:389-396, written with torch.where on a device counter), Adam's step
@@ -188,7 +187,8 @@ class Trainer:
         """One iteration expressed on device-resident state only (capturable); returns a (7,) tensor
         [loss, weight_mean, weight_std, grad_norm_sqd, EMA_grad_norm_sqd, sqd_norm_EMA_grad, normaliser before]."""
         solver, D = self.solver, self._graph_state()
-        out = solver.loss(self.batch_size, algorithm="SOCM", use_warm_start=False, use_stopping_time=False, **loss_kwargs)
+        out = solver.loss(self.batch_size, algorithm="SOCM", use_warm_start=False,
+                          use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)), **loss_kwargs)
         norm_before = D["norm"].clone()
         loss = out[0] / D["norm"]                                        # main.py:313-320
         # main.py:323 -- as torch.autograd.grad: `.backward()` routes every parameter's gradient through its AccumulateGrad

@@ -276,6 +276,9 @@ FIXTURES = [
     ("tiny_molecular_dynamics_d1_stopping", "molecular_dynamics", 1, 24, 16, TINY, 1.0, 5,
      dict(T=2.0, lmbd=2.0, use_stopping_time=True)),
     ("tiny_molecular_dynamics_d2", "molecular_dynamics", 2, 20, 16, TINY, 1.0, 6, {}),
+    # d = 2 with the stopping-time loss: per-sample 2 x 2 pair matrices (TwoBoundarySigmoidMLP), off-diagonal terms
+    ("tiny_molecular_dynamics_d2_stopping", "molecular_dynamics", 2, 20, 16, TINY, 1.0, 6,
+     dict(T=2.0, lmbd=2.0, use_stopping_time=True)),
     # default architecture at the BASELINE configs, small batch (weights dominate the size)
     ("cfg1_ou_quadratic_easy_d2_K50", "OU_quadratic_easy", 2, 50, 8, DEFAULT, 2.0, 0,
      dict(with_pairs=False)),

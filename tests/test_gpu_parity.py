@@ -540,13 +540,19 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
             np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=2e-5, err_msg=k)
 
 
-def test_stopping_time_socm_loss_on_gpu_vs_golden():
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", ["tiny_molecular_dynamics_d1_stopping", "tiny_molecular_dynamics_d2_stopping"])
+def test_stopping_time_socm_loss_on_gpu_vs_golden(name, fused):
+    """a7': SOCM with per-sample pair matrices (TwoBoundarySigmoidMLP, models.py:278-393).  fused = the HIP contraction
+    (socmx_socm_stopping_target_*_f32: gates as (Np,B) fields, matrices in registers); otherwise the torch restatement
+    that materialises (Np,B,d,d).  Objective and the gradients of gamma, gamma2, the M network and nabla_V against the
+    reference-generated fixture."""
     from SOC_matching.method import SOC_Solver
-    name = "tiny_molecular_dynamics_d1_stopping"
     sde, aux = build_sde(name, DEV)
     z = aux["z"]
     solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
                         sigma=sde.sigma)
+    solver.fused_stopping = fused
     solver.noise_in = aux["noise"]
     out = solver.loss(aux["B"], algorithm="SOCM", use_warm_start=False, use_stopping_time=True)
     # stopping decisions are sign tests on fp32 values: require the same stopping pattern, then the loss
@@ -554,6 +560,15 @@ def test_stopping_time_socm_loss_on_gpu_vs_golden():
     np.testing.assert_allclose(out[0].item(), z["loss_objective"], rtol=5e-4)
     out[0].backward()
     np.testing.assert_allclose(_np(sde.gamma.grad), z["grad_gamma"], rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(_np(sde.gamma2.grad), z["grad_gamma2"], rtol=5e-3, atol=1e-6)
+
+    def relnorm(pairs):
+        num = sum(float(((_np(p.grad) - g) ** 2).sum()) for p, g in pairs)
+        den = sum(float((g ** 2).sum()) for _, g in pairs)
+        return (num / max(den, 1e-30)) ** 0.5
+
+    assert relnorm([(p, z["grad_nablaV." + k]) for k, p in sde.nabla_V.named_parameters()]) < 2e-3
+    assert relnorm([(p, z["grad_M.sigmoid_layers." + k]) for k, p in sde.M.sigmoid_layers.named_parameters()]) < 2e-3
 
 
 def test_solver_pickles_after_hip_calls(tmp_path):
