@@ -20,7 +20,7 @@ class Shard:
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
-        self._flat = None
+        self._flat = {}          # one flat buffer per call site ("slot"): collectives of different streams never share one
 
     def local_rows(self, B_global):
         """(B_local, row0): contiguous split, first (B % G) ranks take one extra row."""
@@ -39,26 +39,30 @@ class Shard:
         dist.all_gather(gathered, stats, group=self.group)
         return L.combine_stats(torch.stack(gathered))
 
-    def allreduce_gradients(self, params, extra=None):
+    def allreduce_gradients(self, params, extra=None, slot="main"):
         """Sum `.grad` of all params (and the optional 0-dim tensors in `extra`) across ranks with ONE
-        collective on one flat buffer.  Returns the reduced extras."""
+        collective on one flat buffer, enqueued behind the CURRENT stream.  Returns the reduced extras.
+        Every rank must issue its collectives in the same order (Trainer: "main" first, then "side")."""
         params = [p for p in params if p.grad is not None]
         extra = list(extra or [])
         if self.world_size == 1 and not dist.is_initialized():
             return extra
         n = sum(p.grad.numel() for p in params) + len(extra)
         dev = params[0].grad.device if params else extra[0].device
-        if self._flat is None or self._flat.numel() != n or self._flat.device != dev:
-            self._flat = torch.empty(n, dtype=torch.float32, device=dev)
-        flat = self._flat
+        flat = self._flat.get(slot)
+        if flat is None or flat.numel() != n or flat.device != dev:
+            flat = self._flat[slot] = torch.empty(n, dtype=torch.float32, device=dev)
         views, off = [], 0
         for p in params:
             k = p.grad.numel()
             views.append(flat[off:off + k].view_as(p.grad))
             off += k
-        torch._foreach_copy_(views, [p.grad for p in params])
-        for i, e in enumerate(extra):
-            flat[off + i] = e.detach()
+        if views:
+            torch._foreach_copy_(views, [p.grad for p in params])
+        if extra:
+            flat[off:] = torch.stack([e.detach().reshape(()) for e in extra])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        torch._foreach_copy_([p.grad for p in params], views)
-        return [flat[off + i].clone() for i in range(len(extra))]
+        if views:
+            torch._foreach_copy_([p.grad for p in params], views)
+        red = flat[off:].clone()
+        return [red[i] for i in range(len(extra))]

@@ -248,7 +248,7 @@ class SOC_Solver(nn.Module):
                         net, dnet = sde.M.forward_with_ds(t_vec, s_vec, raw=True)
                     else:
                         torch.cuda.current_stream(state0.device).wait_stream(side)
-                        if getattr(self, "defer_M_backward", False) and shard is None:
+                        if getattr(self, "defer_M_backward", False):
                             # Trainer finishes the M-network's backward + Adam update on the second stream, beside
                             # the NEXT rollout (which needs only nabla_V): cut the graph at (net, dnet)
                             cut = (net.detach().requires_grad_(True), dnet.detach().requires_grad_(True))

@@ -71,7 +71,9 @@ class Trainer:
             overlap_M_backward = False     # inside a graph the pair-grid network's backward forks and joins within the iteration
         # SOCM on one GPU: the pair-grid network's backward and its Adam groups run on the solver's second stream
         # and overlap with the next iteration's rollout (same arithmetic, same order of updates per parameter)
-        self.defer_M = (overlap_M_backward and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None
+        # (sharded runs too: the pair-grid network's gradients then get their own all-reduce on that stream -- two
+        #  collectives per iteration, issued in the same order on every rank)
+        self.defer_M = (overlap_M_backward and algorithm == "SOCM" and solver.x0.is_cuda
                         and not getattr(solver.neural_sde, "use_stopping_time", False))
         sde = solver.neural_sde
         ids_M = {id(p) for p in sde.M.parameters()} | {id(sde.gamma)} if self.defer_M else set()
@@ -141,6 +143,8 @@ class Trainer:
                 g.record_stream(side)
             with torch.enable_grad():
                 torch.autograd.backward([net, dnet], grads)
+            if solver.shard is not None:      # second collective of the iteration: the M network's and gamma's gradients
+                solver.shard.allreduce_gradients([p for g in self._groups_side for p in g["params"]], slot="side")
             for grp in self._groups_side:
                 for p in grp["params"]:
                     if p.grad is not None:
@@ -328,8 +332,11 @@ class Trainer:
             # one flat all-reduce: every gradient + the loss value + (when computed) this rank's share of the weighted
             # L2 error, which solver.loss already divided by the GLOBAL (K+1) B
             extra = [loss.detach()] + ([out[1].detach()] if out[1] is not None else [])
-            reduced = solver.shard.allreduce_gradients(
-                [p for g in self.optimizer.param_groups for p in g["params"]], extra=extra)
+            # with the pair-grid network's backward deferred to the second stream, its gradients do not exist yet: they
+            # are reduced there (_finish_M_on_side_stream); gamma's direct gradient from the contraction kernel is
+            # already complete, but it belongs to that group and is reduced with it
+            groups = self._groups_main if "_pending_M" in solver.__dict__ else self.optimizer.param_groups
+            reduced = solver.shard.allreduce_gradients([p for g in groups for p in g["params"]], extra=extra)
             loss_val = reduced[0]
             if out[1] is not None:
                 out = (out[0], reduced[1]) + tuple(out[2:])

@@ -1021,8 +1021,20 @@ losses = []
 for it in range(3):
     solver.noise_in = aux['noise']
     losses.append(float(tr.step()['loss']))
-torch.cuda.synchronize()
+tr.join(); torch.cuda.synchronize()
 res['losses'] = losses
+res['deferred_M'] = bool(tr.defer_M)
+# the same three iterations without sharding: identical parameters (one rank: the collectives are identities)
+sde2, aux2 = build_sde(name, 'cuda:0')
+solver2 = SOC_Solver(sde2, aux2['x0'], None, T=aux2['T'], num_steps=aux2['K'], lmbd=aux2['lmbd'], d=aux2['d'], sigma=sde2.sigma)
+tr2 = Trainer(solver2, make_optimizer(solver2, M_lr=1e-3), aux2['B'], sync_timing=False)
+for it in range(3):
+    solver2.noise_in = aux2['noise']
+    tr2.step()
+tr2.join(); torch.cuda.synchronize()
+num = sum(float(((a - b) ** 2).sum()) for a, b in zip(sde.state_dict().values(), sde2.state_dict().values()))
+den = sum(float((b ** 2).sum()) for b in sde2.state_dict().values())
+res['param_rel_diff'] = (num / den) ** 0.5
 print('RESULT ' + json.dumps(res))
 dist.barrier(); dist.destroy_process_group()
 """
@@ -1054,6 +1066,7 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
     den = sum(float((z[n] ** 2).sum()) for n in names)
     assert (num / den) ** 0.5 < 1e-3
     assert all(np.isfinite(r["losses"])) and len(r["losses"]) == 3
+    assert r["deferred_M"] and r["param_rel_diff"] < 1e-6, r
     np.testing.assert_allclose(r["losses"][0], float(z["loss_objective"]), rtol=2e-4)   # normalisation constant 1.0
 
 

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Profiling recipe of a round (run on the GPU box through gpurun): bash tools/profile_round.sh r2
+# 1) rocprofv3 kernel trace + stats of the benchmark command, 2) separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ counters:
+# never combined with the trace domains), condensed by tools/summarize_profile.py into gpurun_out/refresh/<round>/.
+set -u
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+RND=${1:-r2}
+OUT=gpurun_out/prof_$RND
+R=gpurun_out/refresh/$RND
+rm -rf $OUT $R; mkdir -p $OUT $R
+CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-burst"
+KERNELS="rollout_kernel|rollout_ctrl|socm_|stopping_|colsum|weights_stats|unet_bwd|unet_wgrad"
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o $RND -- $CMD > $OUT/trace_bench.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KERNELS" -f csv -d $OUT/pmc_fetch -o $RND -- $CMD > $OUT/pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KERNELS" -f csv -d $OUT/pmc_write -o $RND -- $CMD > $OUT/pmc_write.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-include-regex "rollout_kernel|unet_bwd|unet_wgrad_kernel" -f csv -d $OUT/pmc_sq -o $RND -- $CMD > $OUT/pmc_sq.log 2>&1
+python3 tools/summarize_profile.py $OUT $R > $R/summarize.log 2>&1
+python3 bench.py > $R/bench.json 2> $R/bench.err
+# the fused control-network backward alone (cfg3 and the cfg5 slice), the iteration in both modes, the stage-chain floor
+for c in cfg3 cfg5r; do bash tools/k2_prof.sh $c > $R/k2_$c.txt 2>&1; done
+for c in cfg2 cfg3; do for m in eager graph; do bash tools/iter_prof.sh $c $m > $R/iter_${c}_$m.txt 2>&1; done; done
+python3 tools/iter_bench.py md eager > $R/iter_md.txt 2>&1; python3 tools/iter_bench.py md graph >> $R/iter_md.txt 2>&1
+(cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o stage_chain stage_chain.hip 2>/dev/null && ./stage_chain) > $R/stage_chain.txt 2>&1
+python3 tools/quick_bench.py cfg3 cfg2 ouq20 cfg5r burst 2>&1 | grep -E "parity|rollout|iteration" > $R/quick.txt
+rm -rf $OUT gpurun_out/k2prof gpurun_out/iterprof
+ls -la $R
