@@ -144,6 +144,30 @@ int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d
                             const float* x, const float* ts, int32_t rows_per_t, int64_t N, const float* gout,
                             float* workspace, float* grads, socmx_stream_t stream);
 
+/*
+ * The pair-grid network of the SOCM loss: SigmoidMLP.sigmoid_layers (models.py:245-257: Linear(2,h0) ReLU Linear(h0,h1) ReLU
+ * Linear(h1,d*d)) evaluated on the Np pairs (t_p, s_p) TOGETHER with its derivative in s, which the reference obtains by
+ * functorch.jacrev (method.py:510-515):
+ *     net[p]  = L2 relu(L1 relu(L0 [t,s] + b0) + b1) + b2            (Np, d*d)
+ *     dnet[p] = L2 ( m2 (.) L1 ( m1 (.) L0[:,1] ) )                   (Np, d*d)   m = the ReLU signs of the value path
+ * (the exp(-gamma (s-t)) blend of models.py:263-275 is applied inside socmx_socm_target_*_net_f32).  Forward tangent and
+ * value share every weight fragment (two MFMA column tiles per fragment).  The backward takes g_net, g_dnet
+ * = d objective / d (net, dnet) (what socmx_socm_target_bwd_net_f32 writes) and returns the parameter gradients as one flat
+ * buffer [W0 (h0,2) | b0 | W1 (h1,h0) | b1 | W2 (d*d,h1) | b2] (torch layouts); the forward is recomputed tile by tile.
+ * packed: socmx_mnet_packed_floats floats, rebuilt by socmx_mnet_pack_f32 whenever the weights changed.
+ * SOCMX_E_LDS when the (d*d)-wide tile does not fit (d > 22 with 128-wide hidden layers): callers keep library autograd.
+ */
+size_t socmx_mnet_packed_floats(int32_t d, const int32_t hdims_M[2]);
+int socmx_mnet_pack_f32(int32_t d, const int32_t hdims_M[2], const float* w0, const float* b0, const float* w1,
+                        const float* b1, const float* w2, const float* b2, float* packed, socmx_stream_t stream);
+int socmx_mnet_forward_f32(const float* packed, int32_t d, const int32_t hdims_M[2], const float* t, const float* s,
+                           int64_t Np, float* net, float* dnet, socmx_stream_t stream);
+int socmx_mnet_backward_sizes(int32_t d, const int32_t hdims_M[2], int64_t Np, int64_t* workspace_floats,
+                              int64_t* grad_floats);
+int socmx_mnet_backward_f32(const float* packed, int32_t d, const int32_t hdims_M[2], const float* t, const float* s,
+                            int64_t Np, const float* g_net, const float* g_dnet, float* workspace, float* grads,
+                            socmx_stream_t stream);
+
 /* ---- rollout ------------------------------------------------------------ */
 
 /*

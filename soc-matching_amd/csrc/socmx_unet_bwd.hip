@@ -623,6 +623,8 @@ struct WgradArgs {
   int64_t slab_floats;     // floats per slab of partials
   const float* ws;
   float* part;             // (S, slab_floats)
+  int bias_even_tiles;     // 1: only even 16-row tiles count towards the bias gradients (pair network: the odd tiles hold
+                           //    the forward TANGENT rows, which pass through the weights but not the biases)
 };
 
 template <int NOB, int NIB>
@@ -672,7 +674,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
             for (int k = 0; k < NIB; ++k)
               acc[j][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][j][i], ab[s][k][i], acc[j][k], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NOB; ++j) bsum[j] += (ga[s][j][0] + ga[s][j][1]) + (ga[s][j][2] + ga[s][j][3]);
+        for (int j = 0; j < NOB; ++j)
+          if (!a.bias_even_tiles || !((t + s) & 1)) bsum[j] += (ga[s][j][0] + ga[s][j][1]) + (ga[s][j][2] + ga[s][j][3]);
         if (t + s + PD < t1) load(t + s + PD, s);
       }
     }
@@ -812,6 +815,318 @@ __global__ void unet_pack_bwd_kernel(const PackTArgs a) {
 }
 
 #endif  // __HIPCC__
+
+// =====================================================================================================================
+// K3: the pair-grid network M (SigmoidMLP, reference models.py:245-275) and its s-tangent (method.py:510-515 obtains
+// d/ds by functorch.jacrev) as tile kernels.  net = L2 relu(L1 relu(L0 [t,s] + b0) + b1) + b2 on the Np pairs, and the
+// forward tangent  dnet = L2 (m2 (.) L1 (m1 (.) L0 e_s))  shares every weight fragment with it: a workgroup holds 16 pairs
+// as 32 tile rows -- rows 0..15 the values, rows 16..31 the tangents -- so each fragment from L2 feeds two MFMA column
+// tiles (the RT = 2 machinery of kernel A), and a lane that holds a value quad also holds the tangent quad of the same
+// (pair, units): the ReLU sign is applied to both in registers.
+//   forward kernel : F1, F2, F3 -> net, dnet (Np, d*d) row-major (what the contraction kernels consume)
+//   backward kernel: F1, F2 recomputed, then  (g_h2, g_t2) = L2^T (g_net, g_dnet),  (g_h1, g_t1) = L1^T (m2 (.) ...);
+//                    activations and pre-activation gradients leave as slabs, value and tangent rows as CONSECUTIVE 16-row
+//                    tiles, so kernel B / C above produce dW_l = sum over value AND tangent rows (biases: value tiles only).
+// Supported while the widest tile (d*d + 4 floats per row, 32 rows) fits LDS: d <= 22 with 128-wide hidden layers.
+struct MDesc {
+  int d2, d2p, h0, h0p, h1, h1p;
+  LayerDesc L[3];      // forward image: L0 (16 -> h0p), L1 (h0p -> h1p), L2 (h1p -> d2p), weights then bias per layer
+  LayerDesc LT[2];     // transposed image: L2^T (d2p -> h1p), L1^T (h1p -> h0p)
+  int total_floats, totalT_floats, bias_floats;
+  // LDS (floats): tiles of 32 rows
+  int sx, s1, s2, so;
+  int x, hh1, hh2, gout, gz2, m1, m2, bias, scratch, lds_floats;
+  // slab tensors [tile][unit][16]: X, H1, H2, GOUT, GZ2, GZ1 -- prefix = sum of widths before
+  int pre[6], wid[6];
+};
+enum { MT_X = 0, MT_H1, MT_H2, MT_GOUT, MT_GZ2, MT_GZ1, MT_N };
+
+inline MDesc make_mdesc(int d, int h0, int h1, int nwaves) {
+  MDesc m{};
+  m.d2 = d * d; m.d2p = pad16(d * d); m.h0 = h0; m.h0p = pad16(h0); m.h1 = h1; m.h1p = pad16(h1);
+  const int fin[3] = {16, m.h0p, m.h1p}, fout[3] = {m.h0p, m.h1p, m.d2p};
+  int off = 0, boff = 0;
+  for (int l = 0; l < 3; ++l) {
+    m.L[l].in_pad = fin[l]; m.L[l].out_pad = fout[l];
+    m.L[l].w_off = off; off += fin[l] * fout[l];
+    m.L[l].b_off = off; off += fout[l];
+    m.L[l].b_lds = boff; boff += fout[l];
+  }
+  m.total_floats = off; m.bias_floats = boff;
+  m.LT[0].in_pad = m.d2p; m.LT[0].out_pad = m.h1p; m.LT[0].w_off = 0;
+  m.LT[1].in_pad = m.h1p; m.LT[1].out_pad = m.h0p; m.LT[1].w_off = m.d2p * m.h1p;
+  m.totalT_floats = m.d2p * m.h1p + m.h1p * m.h0p;
+  m.sx = 20; m.s1 = m.h0p + 4; m.s2 = m.h1p + 4; m.so = m.d2p + 4;
+  int o = 0;
+  m.x = o; o += 32 * m.sx;
+  m.hh1 = o; o += 32 * m.s1;
+  m.hh2 = o; o += 32 * m.s2;
+  m.gout = o; o += 32 * m.so;          // backward only (the forward kernel's F3 writes straight to HBM)
+  m.gz2 = o; o += 32 * m.s2;
+  m.m1 = o; o += m.h0p;                // 16 rows x (width / 4) bytes
+  m.m2 = o; o += m.h1p;
+  m.bias = o; o += boff;
+  // split-K scratch: stages whose GEMM has fewer than four 16-wide output blocks (widths < 64)
+  int need = 0;
+  const int outs[5] = {m.h0p, m.h1p, m.d2p, m.h1p, m.h0p};
+  for (int i = 0; i < 5; ++i) {
+    const int nblk = outs[i] >> 4;
+    if (nblk >= kSimds || nblk >= nwaves) continue;
+    const int n = (nwaves / nblk) * 32 * outs[i];
+    need = n > need ? n : need;
+  }
+  m.scratch = o; o += need;
+  m.lds_floats = o;
+  const int wid[6] = {16, m.h0p, m.h1p, m.d2p, m.h1p, m.h0p};
+  int pre = 0;
+  for (int t = 0; t < 6; ++t) { m.wid[t] = wid[t]; m.pre[t] = pre; pre += wid[t]; }
+  return m;
+}
+
+#if defined(__HIPCC__)
+struct MArgs {
+  MDesc m;
+  const float* packed;     // forward image
+  const float* packedT;    // transposed image (backward kernel)
+  const float *t, *s;      // (Np,) pair times
+  int64_t Np;
+  int ntiles;              // 16-pair tiles (= workgroups); slab tiles = 2 ntiles (value, tangent alternating)
+  float *net, *dnet;       // forward kernel outputs (Np, d2)
+  const float *gnet, *gdnet;   // backward kernel inputs (Np, d2)
+  float* ws;               // backward kernel: slabs
+};
+
+enum { ME_RELU = 0, ME_OUT, ME_MASK };
+
+struct MEpi {
+  int kind;
+  float* lds;
+  const float* bias;       // LDS bias of the GEMM's layer (value rows), or nullptr
+  int y, sy;               // output tile (float offset, stride) or -1
+  int mask, mw;            // nibble-mask array (float offset) written (ME_RELU) / read (ME_MASK), its width in units
+  float* slab; int sw;     // export slab base of this workgroup's VALUE tile for the output tensor (nullptr: none), width
+  float *net, *dnet; int d2; int64_t p0, Np;   // ME_OUT
+  __device__ __forceinline__ f32x4 init(int n0) const { return bias ? lds4(bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // value quad vq and tangent quad tq of pair-row r (0..15), units n0 .. n0+3
+  __device__ __forceinline__ void fin(f32x4 vq, f32x4 tq, int r, int n0) const {
+    if (kind == ME_OUT) {
+      if (p0 + r < Np) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n0 + i < d2) { net[(size_t)(p0 + r) * d2 + n0 + i] = vq[i]; dnet[(size_t)(p0 + r) * d2 + n0 + i] = tq[i]; }
+      }
+      return;
+    }
+    unsigned msk;
+    unsigned char* mp = reinterpret_cast<unsigned char*>(lds + mask) + r * (mw >> 2) + (n0 >> 2);
+    if (kind == ME_RELU) {
+      msk = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { msk |= (vq[i] > 0.f ? 1u : 0u) << i; vq[i] = relu_keep_nan(vq[i]); }
+      *mp = (unsigned char)msk;
+    } else {
+      msk = *mp;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vq[i] = ((msk >> i) & 1u) ? vq[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tq[i] = ((msk >> i) & 1u) ? tq[i] : 0.f;
+    if (y >= 0) {
+      *reinterpret_cast<f32x4*>(lds + y + r * sy + n0) = vq;
+      *reinterpret_cast<f32x4*>(lds + y + (16 + r) * sy + n0) = tq;
+    }
+    if (slab) {
+      export4(slab, r, n0, vq);                         // value tile
+      export4(slab + (size_t)sw * 16, r, n0, tq);       // the tangent tile follows it
+    }
+  }
+};
+
+// one GEMM stage on the 32-row (value | tangent) tile: Y = L . X, paired epilogue; work split as in socmx_unet.h
+template <int NB, int NW>
+__device__ __forceinline__ void m_direct(const float* __restrict__ Wp, const LayerDesc& L, const float* X, int S, int blk0,
+                                         int lane, const MEpi& epi) {
+  const int row = lane & 15, g = lane >> 4;
+  const GemmPlan<NB> p = make_plan<NB>(Wp, L, blk0, NW, X, S, lane, 0, L.in_pad >> 4);
+  f32x4 acc[2][NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { acc[0][j] = epi.init((blk0 + j * NW) * 16 + 4 * g); acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  Ring<NB> r;
+  Pre none;
+  ring_fill<NB, false>(r, p, none);
+  k2_gemm_run<NB, 2, false>(acc, r, p, 16 * S);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) epi.fin(acc[0][j], acc[1][j], row, (blk0 + j * NW) * 16 + 4 * g);
+}
+
+template <int NW>
+__device__ __forceinline__ void m_stage(const float* __restrict__ Wp, const LayerDesc& L, float* lds, int x, int S,
+                                        float* scratch, const MEpi& epi) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NBLK = L.out_pad >> 4, KC = L.in_pad >> 4;
+  if (NBLK >= kSimds || NBLK >= NW) {
+    int cnt = wave < NBLK ? (NBLK - wave + NW - 1) / NW : 0;
+    for (int blk0 = wave; cnt > 0; cnt -= 4, blk0 += 4 * NW) {
+      if (cnt >= 4)      m_direct<4, NW>(Wp, L, lds + x, S, blk0, lane, epi);
+      else if (cnt == 3) m_direct<3, NW>(Wp, L, lds + x, S, blk0, lane, epi);
+      else if (cnt == 2) m_direct<2, NW>(Wp, L, lds + x, S, blk0, lane, epi);
+      else               m_direct<1, NW>(Wp, L, lds + x, S, blk0, lane, epi);
+    }
+    __syncthreads();
+    return;
+  }
+  // fewer than four output blocks: split K over the waves, combine through LDS
+  const int parts = NW / NBLK, blk = wave % NBLK, part = wave / NBLK, outp = L.out_pad;
+  const int row = lane & 15, g = lane >> 4;
+  if (part < parts) {
+    const int kc0 = (part * KC) / parts, kc1 = ((part + 1) * KC) / parts;
+    f32x4 acc[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
+    if (kc1 > kc0) {
+      const GemmPlan<1> p = make_plan<1>(Wp, L, blk, 0, lds + x, S, lane, kc0, kc1);
+      Ring<1> r;
+      Pre none;
+      ring_fill<1, false>(r, p, none);
+      k2_gemm_run<1, 2, false>(acc, r, p, 16 * S);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      *reinterpret_cast<f32x4*>(scratch + (part * 32 + h * 16 + row) * outp + blk * 16 + 4 * g) = acc[h][0];
+  }
+  __syncthreads();
+  const int Q = outp >> 2, e = threadIdx.x;
+  if (e < 16 * Q) {
+    const int r = (int)(((float)e + 0.5f) * __builtin_amdgcn_rcpf((float)Q)), n0 = 4 * (e - r * Q);
+    f32x4 v = epi.init(n0), t = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < parts; ++p) {
+      v += lds4(scratch + (p * 32 + r) * outp + n0);
+      t += lds4(scratch + (p * 32 + 16 + r) * outp + n0);
+    }
+    epi.fin(v, t, r, n0);
+  }
+  __syncthreads();
+}
+
+// F1, F2 (both kernels): H1 = relu-pair(L0 X), H2 = relu-pair(L1 H1); `ws` non-null: export X, H1, H2 slabs
+template <int NW>
+__device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int tile, int64_t tile_rows) {
+  const MDesc& m = a.m;
+  const int tid = threadIdx.x, nthr = NW * 64;
+  const int64_t p0 = (int64_t)tile * 16;
+  float* X = lds + m.x;
+  for (int e = tid; e < 32 * 16; e += nthr) {
+    const int r = e >> 4, c = e & 15;
+    float v = 0.f;
+    if (r < 16) {
+      const int64_t p = min(p0 + r, a.Np - 1);
+      v = c == 0 ? a.t[p] : (c == 1 ? a.s[p] : 0.f);
+    } else {
+      v = c == 1 ? 1.f : 0.f;                          // d [t, s] / d s
+    }
+    X[r * m.sx + c] = v;
+  }
+  for (int l = 0; l < 3; ++l)
+    for (int e = tid; e < m.L[l].out_pad; e += nthr) lds[m.bias + m.L[l].b_lds + e] = a.packed[m.L[l].b_off + e];
+  __syncthreads();
+  if (a.ws) {
+    float* sl = a.ws + (size_t)tile_rows * m.pre[MT_X] + (size_t)(2 * tile) * 16 * 16;
+    for (int e = tid; e < 2 * 16 * 16; e += nthr) {     // [h][unit][row16]
+      const int r16 = e & 15, c = (e >> 4) & 15, h = e >> 8;
+      sl[e] = X[(h * 16 + r16) * m.sx + c];
+    }
+  }
+  float* scratch = lds + m.scratch;
+  MEpi e1{ME_RELU, lds, lds + m.bias + m.L[0].b_lds, m.hh1, m.s1, m.m1, m.h0p,
+          a.ws ? a.ws + (size_t)tile_rows * m.pre[MT_H1] + (size_t)(2 * tile) * m.h0p * 16 : nullptr, m.h0p,
+          nullptr, nullptr, 0, 0, 0};
+  m_stage<NW>(a.packed, m.L[0], lds, m.x, m.sx, scratch, e1);
+  MEpi e2{ME_RELU, lds, lds + m.bias + m.L[1].b_lds, m.hh2, m.s2, m.m2, m.h1p,
+          a.ws ? a.ws + (size_t)tile_rows * m.pre[MT_H2] + (size_t)(2 * tile) * m.h1p * 16 : nullptr, m.h1p,
+          nullptr, nullptr, 0, 0, 0};
+  m_stage<NW>(a.packed, m.L[1], lds, m.hh1, m.s1, scratch, e2);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mnet_forward_kernel(const MArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tile = blockIdx.x;
+  m_forward_hidden<NW>(a, lds, tile, 0);
+  const MDesc& m = a.m;
+  MEpi e3{ME_OUT, lds, lds + m.bias + m.L[2].b_lds, -1, 0, 0, 0, nullptr, 0, a.net, a.dnet, m.d2, (int64_t)tile * 16, a.Np};
+  m_stage<NW>(a.packed, m.L[2], lds, m.hh2, m.s2, lds + m.scratch, e3);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mnet_backward_kernel(const MArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MDesc& m = a.m;
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = NW * 64;
+  const int64_t tile_rows = (int64_t)a.ntiles * 32;      // slab tiles are 16 rows: two per workgroup
+  const int64_t p0 = (int64_t)tile * 16;
+  // upstream gradients: rows 0..15 d obj / d net, rows 16..31 d obj / d dnet (zero past Np and in the padding units)
+  float* G = lds + m.gout;
+  float* slG = a.ws + (size_t)tile_rows * m.pre[MT_GOUT] + (size_t)(2 * tile) * m.d2p * 16;
+  for (int e = tid; e < 32 * m.d2p; e += nthr) {
+    const int r16 = e & 15, hc = e >> 4;
+    const int h = hc >= m.d2p ? 1 : 0, c = hc - h * m.d2p;
+    const float* src = h ? a.gdnet : a.gnet;
+    const float v = (p0 + r16 < a.Np && c < m.d2) ? src[(size_t)(p0 + r16) * m.d2 + c] : 0.f;
+    G[(h * 16 + r16) * m.so + c] = v;
+    slG[e] = v;
+  }
+  m_forward_hidden<NW>(a, lds, tile, tile_rows);          // (its first barrier also covers the G tile)
+  float* scratch = lds + m.scratch;
+  MEpi b1{ME_MASK, lds, nullptr, m.gz2, m.s2, m.m2, m.h1p,
+          a.ws + (size_t)tile_rows * m.pre[MT_GZ2] + (size_t)(2 * tile) * m.h1p * 16, m.h1p, nullptr, nullptr, 0, 0, 0};
+  m_stage<NW>(a.packedT, m.LT[0], lds, m.gout, m.so, scratch, b1);
+  MEpi b2{ME_MASK, lds, nullptr, -1, 0, m.m1, m.h0p,
+          a.ws + (size_t)tile_rows * m.pre[MT_GZ1] + (size_t)(2 * tile) * m.h0p * 16, m.h0p, nullptr, nullptr, 0, 0, 0};
+  m_stage<NW>(a.packedT, m.LT[1], lds, m.gz2, m.s2, scratch, b2);
+}
+
+struct MPackArgs {
+  MDesc m;
+  int d, h0, h1;
+  const float *w0, *b0, *w1, *b1, *w2, *b2;   // torch layouts: (h0,2) (h0,) (h1,h0) (h1,) (d2,h1) (d2,)
+  float *packed, *packedT;
+};
+
+__global__ void mnet_pack_kernel(const MPackArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int fin[3] = {2, a.h0, a.h1}, fout[3] = {a.h0, a.h1, a.d * a.d};
+  const float* W[3] = {a.w0, a.w1, a.w2};
+  const float* Bv[3] = {a.b0, a.b1, a.b2};
+  if (idx < a.m.total_floats) {
+    int l = 2;
+    while (l > 0 && idx < a.m.L[l].w_off) --l;
+    const LayerDesc L = a.m.L[l];
+    float v = 0.f;
+    if (idx >= L.b_off) {
+      const int n = idx - L.b_off;
+      if (n < fout[l]) v = Bv[l][n];
+    } else {
+      const int rel = idx - L.w_off, i = rel & 3, lane = (rel >> 2) & 63, chunk = rel >> 8, KC = L.in_pad >> 4;
+      const int nb = chunk / KC, kc = chunk - nb * KC;
+      const int n = nb * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + i;
+      if (n < fout[l] && kk < fin[l]) v = W[l][(size_t)n * fin[l] + kk];
+    }
+    a.packed[idx] = v;
+    return;
+  }
+  const int j = idx - a.m.total_floats;
+  if (j < a.m.totalT_floats) {
+    const int t = j >= a.m.LT[1].w_off ? 1 : 0;      // LT[0] = L2^T, LT[1] = L1^T
+    const int l = t == 0 ? 2 : 1;
+    const LayerDesc L = a.m.LT[t];
+    const int rel = j - L.w_off, i = rel & 3, lane = (rel >> 2) & 63, chunk = rel >> 8, KC = L.in_pad >> 4;
+    const int nb = chunk / KC, kc = chunk - nb * KC;
+    const int n = nb * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + i;   // W^T[n][kk] = W[kk][n]
+    float v = 0.f;
+    if (n < fin[l] && kk < fout[l]) v = W[l][(size_t)kk * fin[l] + n];
+    a.packedT[j] = v;
+  }
+}
+#endif  // __HIPCC__ (K3)
 }  // namespace socmx
 
 // =================================================================================================
@@ -958,7 +1273,7 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   if (const int err = launch(kern, dim3(p.ntiles / p.rt), dim3(kK2Waves * 64), lds_bytes, stream, ta)) return err;
   // ---- kernel B ----
   WgradArgs wa;
-  wa.n_items = 0; wa.S = p.S; wa.ntiles = p.ntiles; wa.slab_floats = p.slab_floats;
+  wa.n_items = 0; wa.S = p.S; wa.ntiles = p.ntiles; wa.slab_floats = p.slab_floats; wa.bias_even_tiles = 0;
   wa.ws = workspace; wa.part = workspace + p.ws_floats;
   for (int l = 0; l < 9; ++l) {
     const int gt = layer_grad_tensor(l), at = layer_act_tensor(l);
@@ -976,6 +1291,142 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   for (int l = 0; l < 9; ++l) {
     fa.w_cell_off[l] = p.w_cell_off[l]; fa.b_part_off[l] = p.b_part_off[l]; fa.OB[l] = p.OB[l]; fa.IB[l] = p.IB[l];
     fa.fin[l] = p.fin[l]; fa.fout[l] = p.fout[l]; fa.gw_off[l] = p.gw_off[l]; fa.gb_off[l] = p.gb_off[l];
+  }
+  fa.total_cells_floats = p.total_cells_floats; fa.total_bias = p.total_bias; fa.S = p.S; fa.slab_floats = p.slab_floats;
+  fa.part = wa.part; fa.grads = grads;
+  const int nthreads = p.total_cells_floats + p.total_bias;
+  return launch(unet_wgrad_finish_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, stream, fa);
+}
+
+// ---- K3: the pair-grid network ---------------------------------------------------------------------------------------
+static int mnet_plan(int32_t d, const int32_t hdims[2], MDesc& m) {
+  if (!hdims) return SOCMX_E_NULL;
+  if (d < 1 || d > 1024 || hdims[0] < 1 || hdims[0] > 4096 || hdims[1] < 1 || hdims[1] > 4096) return SOCMX_E_DIM;
+  m = make_mdesc(d, hdims[0], hdims[1], kK2Waves);
+  if ((size_t)m.lds_floats * sizeof(float) > (size_t)kLdsBytesPerCU) return SOCMX_E_LDS;
+  return 0;
+}
+
+extern "C" size_t socmx_mnet_packed_floats(int32_t d, const int32_t hdims[2]) {
+  MDesc m;
+  if (mnet_plan(d, hdims, m)) return 0;
+  return (size_t)m.total_floats + (size_t)m.totalT_floats;
+}
+
+extern "C" int socmx_mnet_pack_f32(int32_t d, const int32_t hdims[2], const float* w0, const float* b0, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, float* packed,
+                                   socmx_stream_t stream) {
+  if (!w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !packed) return SOCMX_E_NULL;
+  MPackArgs a;
+  if (const int rc = mnet_plan(d, hdims, a.m)) return rc;
+  a.d = d; a.h0 = hdims[0]; a.h1 = hdims[1];
+  a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+  a.packed = packed; a.packedT = packed + a.m.total_floats;
+  const int n = a.m.total_floats + a.m.totalT_floats;
+  return launch(mnet_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+}
+
+extern "C" int socmx_mnet_forward_f32(const float* packed, int32_t d, const int32_t hdims[2], const float* t,
+                                      const float* s, int64_t Np, float* net, float* dnet, socmx_stream_t stream) {
+  if (!packed || !t || !s || !net || !dnet) return SOCMX_E_NULL;
+  if (Np < 1 || Np > ((int64_t)1 << 30)) return SOCMX_E_DIM;
+  MArgs a{};
+  if (const int rc = mnet_plan(d, hdims, a.m)) return rc;
+  a.packed = packed; a.packedT = packed + a.m.total_floats; a.t = t; a.s = s; a.Np = Np;
+  a.ntiles = (int)((Np + 15) / 16); a.net = net; a.dnet = dnet; a.ws = nullptr;
+  const size_t lds_bytes = (size_t)a.m.lds_floats * sizeof(float);
+  if (const int err = ensure_max_lds(mnet_forward_kernel<kK2Waves>)) return err;
+  return launch(mnet_forward_kernel<kK2Waves>, dim3(a.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a);
+}
+
+struct MnetBwdPlan {
+  MDesc m;
+  int ntiles, S;
+  int OB[3], IB[3], w_cell_off[3], b_part_off[3], fin[3], fout[3];
+  int total_cells_floats, total_bias;
+  int64_t ws_floats, slab_floats, part_floats, gw_off[3], gb_off[3], grad_floats;
+};
+
+static int mnet_bwd_plan(int32_t d, const int32_t hdims[2], int64_t Np, MnetBwdPlan& p) {
+  if (const int rc = mnet_plan(d, hdims, p.m)) return rc;
+  if (Np < 1 || Np > ((int64_t)1 << 30)) return SOCMX_E_DIM;
+  p.ntiles = (int)((Np + 15) / 16);
+  int wsum = 0;
+  for (int t = 0; t < MT_N; ++t) wsum += p.m.wid[t];
+  p.ws_floats = (int64_t)p.ntiles * 32 * wsum;
+  const int fin[3] = {2, hdims[0], hdims[1]}, fout[3] = {hdims[0], hdims[1], d * d};
+  int off = 0;
+  int64_t goff = 0;
+  for (int l = 0; l < 3; ++l) {
+    p.fin[l] = fin[l]; p.fout[l] = fout[l];
+    p.OB[l] = p.m.L[l].out_pad >> 4; p.IB[l] = p.m.L[l].in_pad >> 4;
+    p.w_cell_off[l] = off; off += p.OB[l] * p.IB[l] * 256;
+    p.gw_off[l] = goff; goff += (int64_t)fin[l] * fout[l];
+    p.gb_off[l] = goff; goff += fout[l];
+  }
+  p.grad_floats = goff;
+  p.total_cells_floats = off;
+  for (int l = 0; l < 3; ++l) { p.b_part_off[l] = off; off += p.m.L[l].out_pad; }
+  p.total_bias = off - p.total_cells_floats;
+  p.slab_floats = off;
+  const int nt16 = 2 * p.ntiles;
+  int S = 64;
+  if (S > nt16 / 4) S = nt16 / 4 >= 32 ? 32 : nt16 / 4;
+  p.S = S < 1 ? 1 : S;
+  p.part_floats = (int64_t)p.S * p.slab_floats;
+  return 0;
+}
+
+extern "C" int socmx_mnet_backward_sizes(int32_t d, const int32_t hdims[2], int64_t Np, int64_t* workspace_floats,
+                                         int64_t* grad_floats) {
+  MnetBwdPlan p;
+  if (const int rc = mnet_bwd_plan(d, hdims, Np, p)) return rc;
+  if (workspace_floats) *workspace_floats = p.ws_floats + p.part_floats;
+  if (grad_floats) *grad_floats = p.grad_floats;
+  return 0;
+}
+
+extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int32_t hdims[2], const float* t,
+                                       const float* s, int64_t Np, const float* gnet, const float* gdnet,
+                                       float* workspace, float* grads, socmx_stream_t stream) {
+  if (!packed || !t || !s || !gnet || !gdnet || !workspace || !grads) return SOCMX_E_NULL;
+  MnetBwdPlan p;
+  if (const int rc = mnet_bwd_plan(d, hdims, Np, p)) return rc;
+  MArgs a{};
+  a.m = p.m; a.packed = packed; a.packedT = packed + p.m.total_floats; a.t = t; a.s = s; a.Np = Np; a.ntiles = p.ntiles;
+  a.gnet = gnet; a.gdnet = gdnet; a.ws = workspace;
+  const size_t lds_bytes = (size_t)p.m.lds_floats * sizeof(float);
+  if (const int err = ensure_max_lds(mnet_backward_kernel<kK2Waves>)) return err;
+  if (const int err = launch(mnet_backward_kernel<kK2Waves>, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a)) return err;
+  // weight / bias gradient partials: kernel B over the 2 ntiles slab tiles (value, tangent alternating)
+  WgradArgs wa{};
+  wa.S = p.S; wa.ntiles = 2 * p.ntiles; wa.slab_floats = p.slab_floats; wa.bias_even_tiles = 1;
+  wa.ws = workspace; wa.part = workspace + p.ws_floats;
+  const int gt[3] = {MT_GZ1, MT_GZ2, MT_GOUT}, at[3] = {MT_X, MT_H1, MT_H2};
+  wa.n_items = 0;
+  for (int l = 0; l < 9; ++l) {
+    if (l < 3) {
+      wa.gt_off[l] = p.m.pre[gt[l]]; wa.at_off[l] = p.m.pre[at[l]]; wa.gW[l] = p.m.wid[gt[l]]; wa.aW[l] = p.m.wid[at[l]];
+      wa.OB[l] = p.OB[l]; wa.IB[l] = p.IB[l]; wa.w_cell_off[l] = p.w_cell_off[l]; wa.b_part_off[l] = p.b_part_off[l];
+      wa.item0[l] = wa.n_items;
+      wa.n_items += ((p.OB[l] + 3) / 4) * ((p.IB[l] + 3) / 4);
+    } else {
+      wa.gt_off[l] = wa.at_off[l] = 0; wa.gW[l] = wa.aW[l] = 16; wa.OB[l] = wa.IB[l] = 1;
+      wa.w_cell_off[l] = p.total_cells_floats; wa.b_part_off[l] = (int)p.slab_floats; wa.item0[l] = 1 << 30;
+    }
+  }
+  wa.item0[9] = wa.n_items;
+  const int slab_groups = (((p.S + 3) / 4) + 7) & ~7;
+  if (const int err = launch(unet_wgrad_kernel, dim3(wa.n_items * slab_groups), dim3(256), 0, stream, wa)) return err;
+  FinishArgs fa{};
+  for (int l = 0; l < 9; ++l) {
+    if (l < 3) {
+      fa.w_cell_off[l] = p.w_cell_off[l]; fa.b_part_off[l] = p.b_part_off[l]; fa.OB[l] = p.OB[l]; fa.IB[l] = p.IB[l];
+      fa.fin[l] = p.fin[l]; fa.fout[l] = p.fout[l]; fa.gw_off[l] = p.gw_off[l]; fa.gb_off[l] = p.gb_off[l];
+    } else {
+      fa.w_cell_off[l] = 1 << 30; fa.b_part_off[l] = 1 << 30; fa.OB[l] = fa.IB[l] = 1; fa.fin[l] = fa.fout[l] = 0;
+      fa.gw_off[l] = fa.gb_off[l] = 0;
+    }
   }
   fa.total_cells_floats = p.total_cells_floats; fa.total_bias = p.total_bias; fa.S = p.S; fa.slab_floats = p.slab_floats;
   fa.part = wa.part; fa.grads = grads;

@@ -290,6 +290,63 @@ def unet_forward_hip(net, tx):
     return out
 
 
+class _PairNetHip(torch.autograd.Function):
+    """(net, d net / d s) of SigmoidMLP.sigmoid_layers on the pair grid: socmx_mnet_forward_f32 / socmx_mnet_backward_f32
+    (value and forward tangent share every weight fragment; the backward recomputes the forward in LDS)."""
+
+    @staticmethod
+    def forward(ctx, t, s, d, hdims, w0, b0, w1, b1, w2, b2):
+        L = _lib.lib()
+        dev = t.device
+        c = lambda x: x.detach().to(torch.float32).contiguous()
+        t, s = c(t), c(s)
+        params = [c(p) for p in (w0, b0, w1, b1, w2, b2)]
+        h2 = _lib.i2(hdims)
+        packed = torch.empty(L.socmx_mnet_packed_floats(d, h2), dtype=torch.float32, device=dev)
+        Np = t.shape[0]
+        net = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+        dnet = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(L.socmx_mnet_pack_f32(d, h2, *[_lib.ptr(p) for p in params], _lib.ptr(packed), _lib.stream_ptr(dev)),
+                       "socmx_mnet_pack_f32")
+            _lib.check(L.socmx_mnet_forward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(net),
+                                                _lib.ptr(dnet), _lib.stream_ptr(dev)), "socmx_mnet_forward_f32")
+        ctx.save_for_backward(packed, t, s)
+        ctx.meta = (d, tuple(hdims), [p.shape for p in params])
+        return net, dnet
+
+    @staticmethod
+    def backward(ctx, g_net, g_dnet):
+        L = _lib.lib()
+        packed, t, s = ctx.saved_tensors
+        d, hdims, shapes = ctx.meta
+        dev = t.device
+        Np = t.shape[0]
+        h2 = _lib.i2(hdims)
+        c = lambda x: x.detach().to(torch.float32).contiguous()
+        g_net, g_dnet = c(g_net), c(g_dnet)
+        ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
+        _lib.check(L.socmx_mnet_backward_sizes(d, h2, Np, _lib.C.byref(ws), _lib.C.byref(ng)), "socmx_mnet_backward_sizes")
+        work = torch.empty(ws.value, dtype=torch.float32, device=dev)
+        flat = torch.empty(ng.value, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(L.socmx_mnet_backward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(g_net),
+                                                 _lib.ptr(g_dnet), _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
+                       "socmx_mnet_backward_f32")
+        grads, off = [], 0
+        for shp in shapes:
+            n = int(torch.Size(shp).numel())
+            grads.append(flat[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None) + tuple(grads)
+
+
+def pair_net_supported(mlp, n_pairs):
+    L = _lib.lib()
+    ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
+    return L.socmx_mnet_backward_sizes(mlp.dim, _lib.i2(mlp.hdims), int(n_pairs), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
+
+
 class SigmoidMLP(nn.Module):
     def __init__(self, dim=10, hdims=(128, 128), gamma=3.0, scaling_factor=1.0):
         super().__init__()
@@ -318,6 +375,11 @@ class SigmoidMLP(nn.Module):
         raw=True returns (net, d net/ds) instead: the exp(-gamma (s-t)) blend is then fused into the HIP
         contraction (loss.socm_objective_net)."""
         l0, l2, l4 = self.sigmoid_layers[0], self.sigmoid_layers[2], self.sigmoid_layers[4]
+        if (raw and t.is_cuda and t.dtype == torch.float32 and getattr(self, "fused_pair_net", True)
+                and pair_net_supported(self, t.shape[0])):
+            # hand-written tile kernels (csrc/socmx_unet_bwd.hip, K3): no library GEMM, value + tangent in one pass
+            return _PairNetHip.apply(t, s, self.dim, tuple(self.hdims), l0.weight, l0.bias, l2.weight, l2.bias, l4.weight,
+                                     l4.bias)
         sk = t.is_cuda and t.shape[0] >= 8192 and torch.is_grad_enabled()
         lin = (lambda x, w, b: _LinearSplitK.apply(x, w, b)) if sk else (lambda x, w, b: torch.addmm(b, x, w.T))
         if sk:      # fused Linear+ReLU (the ReLU mask of the tangent path is h > 0, same set as a > 0)

@@ -87,3 +87,39 @@ def test_unet_backward_zero_gradient_rows_contribute_nothing():
     more = nets.unet_backward_hip(net, x, ts, 1, gz)
     for a, b in zip(base, more):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,extra", [("tiny_double_well_d10", {}), ("tiny_ou_linear_d6", {}), ("tiny_ou_linear_d20", {}),
+                                        ("cfg1_ou_quadratic_easy_d2_K50", {}), ("cfg3_double_well_d10_K200", {}),
+                                        ("ouq20_ou_quadratic_easy_d20_K12", {})])
+def test_pair_network_kernels_vs_library_autograd(name, extra):
+    """K3: socmx_mnet_forward_f32 / _backward_f32 (SigmoidMLP.sigmoid_layers and its s-tangent on the pair grid) against
+    the library path of the same module (torch GEMMs + analytic tangent, itself pinned by the reference's jacrev fixtures):
+    net, dnet and the six parameter gradients for random upstream gradients."""
+    from socmx import loss as L
+    sde, aux = build_sde(name, DEV)
+    M = sde.M
+    K, d = aux["K"], aux["d"]
+    ts = aux["ts"]
+    t_vec, s_vec, _, _ = L.pair_times(ts, aux["T"], K)
+    Np = t_vec.shape[0]
+    g = torch.Generator().manual_seed(1)
+    gn = torch.randn(Np, d, d, generator=g).to(DEV)
+    gd = torch.randn(Np, d, d, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        M.fused_pair_net = fused
+        for p in M.parameters():
+            p.grad = None
+        net, dnet = M.forward_with_ds(t_vec, s_vec, raw=True)
+        assert (type(net.grad_fn).__name__ == "_PairNetHipBackward") == fused
+        torch.autograd.backward([net, dnet], [gn, gd])
+        res.append((net.detach().double(), dnet.detach().double(), [p.grad.double().clone() for p in M.sigmoid_layers.parameters()]))
+    (n1, d1, g1), (n0, d0, g0) = res
+    sc = lambda x: max(1.0, float(x.abs().max()))
+    np.testing.assert_allclose(n1.cpu().numpy(), n0.cpu().numpy(), rtol=1e-5, atol=2e-6 * sc(n0))
+    np.testing.assert_allclose(d1.cpu().numpy(), d0.cpu().numpy(), rtol=1e-5, atol=2e-6 * sc(d0))
+    for (k, _), a, b in zip(M.sigmoid_layers.named_parameters(), g1, g0):
+        e = float(((a - b) ** 2).sum()) ** 0.5
+        n_ = float((b ** 2).sum()) ** 0.5
+        assert e <= 2e-4 * n_ + 1e-6 * sc(b), (k, e, n_)
