@@ -343,6 +343,18 @@ int socmx_socm_stopping_target_bwd_f32(int32_t d, int32_t K, int32_t B, const fl
                                        float* gN0, float* gN1, float* gdN0, float* gdN1, socmx_stream_t stream);
 
 /*
+ * The scalar bookkeeping of one training iteration (main.py:313-322, 325-345, 354-359 with compute_EMA, utils.py:389-396) on
+ * DEVICE-resident state, so that a captured iteration needs no host arithmetic: itr (1,) the iteration counter, norm (1,) the
+ * EMA normalisation constant, ema_gn (1,) the EMA of the squared gradient norm.
+ *   phase 0: ab[0..1] = the coefficients (A, B) of  ema_grad <- A ema_grad + B grad  for the current itr.
+ *   phase 1: out[0..6] = [objective / norm, mean(w), std(w), gn, EMA(gn), gne, norm used]; then norm <- EMA(mean(w)),
+ *            itr <- itr + 1.   gn / gne / ema_gn may be NULL (no gradient telemetry).
+ */
+int socmx_iteration_scalars_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
+                                const float* w_std, const float* obj, const float* gn, const float* gne,
+                                double c_norm, double c_grad, float* ab, float* out, socmx_stream_t stream);
+
+/*
  * Column sums of a tall row-major (R, C) matrix: out[c] = sum_r x[r][c].  Bias gradients of the nn.Linear layers
  * (models.py:212-228, 253-257) over the (K+1)*B trajectory rows / the Np pair rows; no reference counterpart beyond
  * autograd's reduction.  partial is a caller-owned workspace of socmx_colsum_blocks(R, C) * C floats; the result

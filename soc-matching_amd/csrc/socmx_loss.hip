@@ -1181,12 +1181,69 @@ __global__ __launch_bounds__(256) void linear_bwd_finish_kernel(const float* __r
   }
 }
 
+// ---- per-iteration scalar bookkeeping of main.py:313-359 on device-resident state (hipGraph mode) ------------------------
+// compute_EMA (utils.py:389-396): value at itr 0, running mean while itr <= floor(1/c), then c v + (1-c) ema.
+struct ScalarArgs {
+  int phase;
+  float *itr, *norm, *ema_gn;
+  const float *w_mean, *w_std, *obj, *gn, *gne;
+  float c_norm, one_minus_c_norm, warm_norm, c_grad, one_minus_c_grad, warm_grad;
+  float *ab, *out;
+};
+
+__device__ __forceinline__ float ema_update(float v, float ema, float c, float omc, float warm, float itr) {
+  if (itr == 0.f) return v;
+  if (itr <= warm) return (v + itr * ema) / (itr + 1.f);
+  return c * v + omc * ema;
+}
+
+__global__ void iteration_scalars_kernel(const ScalarArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float itr = a.itr[0];
+  if (a.phase == 0) {
+    // ema_grad <- A ema_grad + B grad  (the tensor form of the same EMA: main.py:330-345)
+    float A, B;
+    if (itr == 0.f) { A = 0.f; B = 1.f; }
+    else if (itr <= a.warm_grad) { A = itr / (itr + 1.f); B = 1.f / (itr + 1.f); }
+    else { A = a.one_minus_c_grad; B = a.c_grad; }
+    a.ab[0] = A; a.ab[1] = B;
+    return;
+  }
+  const float norm = a.norm[0];
+  const float gn = a.gn ? a.gn[0] : 0.f;
+  float ema_gn = 0.f;
+  if (a.gn) { ema_gn = ema_update(gn, a.ema_gn[0], a.c_grad, a.one_minus_c_grad, a.warm_grad, itr); a.ema_gn[0] = ema_gn; }
+  a.out[0] = a.obj[0] * (1.f / norm);                      // loss = objective / normaliser   (main.py:313-320)
+  a.out[1] = a.w_mean[0];
+  a.out[2] = a.w_std[0];
+  a.out[3] = gn;
+  a.out[4] = ema_gn;
+  a.out[5] = a.gne ? a.gne[0] : 0.f;
+  a.out[6] = norm;                                         // the normaliser this iteration used
+  a.norm[0] = ema_update(a.w_mean[0], norm, a.c_norm, a.one_minus_c_norm, a.warm_norm, itr);   // main.py:354-359
+  a.itr[0] = itr + 1.f;
+}
+
 }  // namespace socmx
 
 // =================================================================================================
 // C ABI
 // =================================================================================================
 using namespace socmx;
+
+extern "C" int socmx_iteration_scalars_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
+                                           const float* w_std, const float* obj, const float* gn, const float* gne,
+                                           double c_norm, double c_grad, float* ab, float* out, socmx_stream_t stream) {
+  if (!itr) return SOCMX_E_NULL;
+  if (phase == 0 ? !ab : (!norm || !w_mean || !w_std || !obj || !out || (gn && !ema_gn))) return SOCMX_E_NULL;
+  if (!(c_norm > 0.0) || !(c_grad > 0.0)) return SOCMX_E_DIM;
+  ScalarArgs a;
+  a.phase = phase; a.itr = itr; a.norm = norm; a.ema_gn = ema_gn; a.w_mean = w_mean; a.w_std = w_std; a.obj = obj;
+  a.gn = gn; a.gne = gne; a.ab = ab; a.out = out;
+  a.c_norm = (float)c_norm; a.one_minus_c_norm = (float)(1.0 - c_norm); a.warm_norm = (float)(int)floor(1.0 / c_norm);
+  a.c_grad = (float)c_grad; a.one_minus_c_grad = (float)(1.0 - c_grad); a.warm_grad = (float)(int)floor(1.0 / c_grad);
+  return launch(iteration_scalars_kernel, dim3(1), dim3(64), 0, stream, a);
+}
 
 extern "C" int socmx_weights_stats_f32(const float* lpd, const float* lps, const float* ltw, int32_t B, float* w,
                                        float* stats, socmx_stream_t stream) {

@@ -103,12 +103,13 @@ def socm_operands_hip(pb, ts, lmbd, states, noises, controls, frac=None):
     v, q = torch.empty(K, B, d, **f32), torch.empty(K, B, d, **f32)
     gT = torch.empty(B, d, **f32)
     tsc = ts.detach().to(**f32).contiguous()
-    _lib.check(L.socmx_socm_prep_f32(
-        pb.c_struct(), _lib.ptr(tsc), K, B, float(lmbd), _lib.ptr(states.contiguous()),
-        _lib.ptr(noises.contiguous()), _lib.ptr(controls.contiguous()),
-        _lib.ptr(frac.contiguous()) if frac is not None else None,
-        _lib.ptr(v), _lib.ptr(q), _lib.ptr(gT), None, None, None,
-        _lib.stream_ptr(dev)), "socmx_socm_prep_f32")
+    with _lib.on_device(dev):
+        _lib.check(L.socmx_socm_prep_f32(
+            pb.c_struct(), _lib.ptr(tsc), K, B, float(lmbd), _lib.ptr(states.contiguous()),
+            _lib.ptr(noises.contiguous()), _lib.ptr(controls.contiguous()),
+            _lib.ptr(frac.contiguous()) if frac is not None else None,
+            _lib.ptr(v), _lib.ptr(q), _lib.ptr(gT), None, None, None,
+            _lib.stream_ptr(dev)), "socmx_socm_prep_f32")
     return dict(v=v, q=q, gT=gT)
 
 
@@ -155,25 +156,52 @@ class _TargetResidualHip(torch.autograd.Function):
         return gM, gdM, gV, None, None, None, None, None, None
 
 
+def target_fwd_net(pb, K, net, dnet, delta, gam, ops, nablaV, w, inv_norm):
+    """socmx_socm_target_fwd_net_f32 on plain tensors: (objective (1,), G = d obj / d nablaV, target)."""
+    L = _lib.lib()
+    dev = net.device
+    B, d = ops["gT"].shape
+    G = torch.empty_like(nablaV)
+    target = torch.empty_like(nablaV)
+    obj = torch.zeros(1, dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(L.socmx_socm_target_fwd_net_f32(
+            pb.c_struct(), K, B, _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(ops["q"]),
+            _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm),
+            _lib.ptr(target), _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_net_f32")
+    return obj, G, target
+
+
+def target_bwd_net(d, K, B, G, ops, gout, net, dnet, delta, gam, g_net=None, g_dnet=None):
+    """socmx_socm_target_bwd_net_f32 on plain tensors: (g_net, g_dnet, partial sums of d obj / d gamma); `gout` (1,) is
+    the upstream gradient on the device; g_net / g_dnet may be caller-owned buffers (hipGraph mode keeps them)."""
+    L = _lib.lib()
+    dev = G.device
+    Np = net.shape[0]
+    nb = (d + 15) // 16
+    if g_net is None:
+        g_net = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+        g_dnet = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+    part = torch.empty(Np * nb * nb, dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(L.socmx_socm_target_bwd_net_f32(
+            d, K, B, _lib.ptr(G), _lib.ptr(ops["q"]), _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]), _lib.ptr(gout),
+            _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(g_net), _lib.ptr(g_dnet),
+            _lib.ptr(part), _lib.stream_ptr(dev)), "socmx_socm_target_bwd_net_f32")
+    return g_net, g_dnet, part
+
+
 class _TargetResidualNetHip(torch.autograd.Function):
     """Same objective with M = e I + (1-e) net, dM = gamma e (net - I) + (1-e) dnet formed inside the kernels
     (socmx_socm_target_{fwd,bwd}_net_f32): M and dM/ds never exist in HBM."""
 
     @staticmethod
     def forward(ctx, net, dnet, gamma, nablaV, w, delta, ops, pb, K, inv_norm):
-        L = _lib.lib()
-        dev = net.device
         B, d = ops["gT"].shape
         c = lambda t: t.detach().to(torch.float32).contiguous()
         net, dnet, nablaV, w, delta = map(c, (net, dnet, nablaV, w, delta))
         gam = gamma.detach().to(torch.float32).reshape(1).contiguous()
-        G = torch.empty_like(nablaV)
-        target = torch.empty_like(nablaV)
-        obj = torch.zeros(1, dtype=torch.float32, device=dev)
-        _lib.check(L.socmx_socm_target_fwd_net_f32(
-            pb.c_struct(), K, B, _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(ops["q"]),
-            _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm),
-            _lib.ptr(target), _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_net_f32")
+        obj, G, _ = target_fwd_net(pb, K, net, dnet, delta, gam, ops, nablaV, w, inv_norm)
         ctx.save_for_backward(G, ops["q"], ops["v"], ops["gT"], net, dnet, delta, gam)
         ctx.dims = (d, K, B, net.shape[0])
         ctx.gamma_shape = gamma.shape
@@ -181,20 +209,12 @@ class _TargetResidualNetHip(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        L = _lib.lib()
         G, q, v, gT, net, dnet, delta, gam = ctx.saved_tensors
         d, K, B, Np = ctx.dims
         g_net = g_dnet = g_gamma = gV = None
         gout = gout.detach().to(torch.float32).reshape(1).contiguous()
         if any(ctx.needs_input_grad[:3]):
-            nb = (d + 15) // 16
-            g_net = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
-            g_dnet = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
-            part = torch.empty(Np * nb * nb, dtype=torch.float32, device=G.device)
-            _lib.check(L.socmx_socm_target_bwd_net_f32(
-                d, K, B, _lib.ptr(G), _lib.ptr(q), _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gout), _lib.ptr(net),
-                _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(g_net), _lib.ptr(g_dnet), _lib.ptr(part),
-                _lib.stream_ptr(G.device)), "socmx_socm_target_bwd_net_f32")
+            g_net, g_dnet, part = target_bwd_net(d, K, B, G, dict(q=q, v=v, gT=gT), gout, net, dnet, delta, gam)
             if ctx.needs_input_grad[2]:
                 g_gamma = part.sum().reshape(ctx.gamma_shape)
         if ctx.needs_input_grad[3]:
@@ -272,9 +292,10 @@ def weights_and_stats(lpd, lps, ltw):
         B = lpd.shape[0]
         w = torch.empty_like(lpd)
         stats = torch.empty(5, dtype=torch.float32, device=lpd.device)
-        _lib.check(L.socmx_weights_stats_f32(_lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), B, _lib.ptr(w),
-                                             _lib.ptr(stats), _lib.stream_ptr(lpd.device)),
-                   "socmx_weights_stats_f32")
+        with _lib.on_device(lpd.device):
+            _lib.check(L.socmx_weights_stats_f32(_lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), B, _lib.ptr(w),
+                                                 _lib.ptr(stats), _lib.stream_ptr(lpd.device)),
+                       "socmx_weights_stats_f32")
         return w, stats
     w = torch.exp(lpd + lps + ltw)
     return w, torch.stack([w.sum(), ((w - w.mean()) ** 2).sum(), torch.tensor(float(w.shape[0]))])

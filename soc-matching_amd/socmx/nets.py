@@ -221,7 +221,7 @@ def unet_backward_supported(net, n_rows):
     return L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
 
 
-def unet_backward_hip(net, x, ts, rows_per_t, gout):
+def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False):
     """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
     x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
     `net.parameters()` order (views of one flat buffer)."""
@@ -253,7 +253,7 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout):
     out = []
     for name, _, _ in _UNET_SPEC:                  # parameters() order: construction order of the Sequentials
         out += list(grads[name])
-    return out
+    return (out, flat) if return_flat else out
 
 
 class UnetOnTrajectory(torch.autograd.Function):
@@ -290,54 +290,67 @@ def unet_forward_hip(net, tx):
     return out
 
 
+def pair_net_forward(d, hdims, params, t, s, packed=None):
+    """(net, dnet, packed): socmx_mnet_pack_f32 + socmx_mnet_forward_f32 on plain fp32 tensors; `packed` may be a
+    caller-owned buffer (hipGraph mode keeps the image for the deferred backward)."""
+    L = _lib.lib()
+    dev = t.device
+    h2 = _lib.i2(hdims)
+    if packed is None:
+        packed = torch.empty(L.socmx_mnet_packed_floats(d, h2), dtype=torch.float32, device=dev)
+    Np = t.shape[0]
+    net = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+    dnet = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(L.socmx_mnet_pack_f32(d, h2, *[_lib.ptr(p) for p in params], _lib.ptr(packed), _lib.stream_ptr(dev)),
+                   "socmx_mnet_pack_f32")
+        _lib.check(L.socmx_mnet_forward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(net),
+                                            _lib.ptr(dnet), _lib.stream_ptr(dev)), "socmx_mnet_forward_f32")
+    return net, dnet, packed
+
+
+def pair_net_backward(d, hdims, shapes, packed, t, s, g_net, g_dnet):
+    """Parameter gradients [W0, b0, W1, b1, W2, b2] (views of one flat buffer): socmx_mnet_backward_f32."""
+    L = _lib.lib()
+    dev = t.device
+    Np = t.shape[0]
+    h2 = _lib.i2(hdims)
+    ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
+    _lib.check(L.socmx_mnet_backward_sizes(d, h2, Np, _lib.C.byref(ws), _lib.C.byref(ng)), "socmx_mnet_backward_sizes")
+    work = torch.empty(ws.value, dtype=torch.float32, device=dev)
+    flat = torch.empty(ng.value, dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(L.socmx_mnet_backward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(g_net),
+                                             _lib.ptr(g_dnet), _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
+                   "socmx_mnet_backward_f32")
+    grads, off = [], 0
+    for shp in shapes:
+        n = int(torch.Size(shp).numel())
+        grads.append(flat[off:off + n].view(shp))
+        off += n
+    return grads
+
+
 class _PairNetHip(torch.autograd.Function):
     """(net, d net / d s) of SigmoidMLP.sigmoid_layers on the pair grid: socmx_mnet_forward_f32 / socmx_mnet_backward_f32
     (value and forward tangent share every weight fragment; the backward recomputes the forward in LDS)."""
 
     @staticmethod
     def forward(ctx, t, s, d, hdims, w0, b0, w1, b1, w2, b2):
-        L = _lib.lib()
-        dev = t.device
         c = lambda x: x.detach().to(torch.float32).contiguous()
         t, s = c(t), c(s)
         params = [c(p) for p in (w0, b0, w1, b1, w2, b2)]
-        h2 = _lib.i2(hdims)
-        packed = torch.empty(L.socmx_mnet_packed_floats(d, h2), dtype=torch.float32, device=dev)
-        Np = t.shape[0]
-        net = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
-        dnet = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
-        with _lib.on_device(dev):
-            _lib.check(L.socmx_mnet_pack_f32(d, h2, *[_lib.ptr(p) for p in params], _lib.ptr(packed), _lib.stream_ptr(dev)),
-                       "socmx_mnet_pack_f32")
-            _lib.check(L.socmx_mnet_forward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(net),
-                                                _lib.ptr(dnet), _lib.stream_ptr(dev)), "socmx_mnet_forward_f32")
+        net, dnet, packed = pair_net_forward(d, hdims, params, t, s)
         ctx.save_for_backward(packed, t, s)
         ctx.meta = (d, tuple(hdims), [p.shape for p in params])
         return net, dnet
 
     @staticmethod
     def backward(ctx, g_net, g_dnet):
-        L = _lib.lib()
         packed, t, s = ctx.saved_tensors
         d, hdims, shapes = ctx.meta
-        dev = t.device
-        Np = t.shape[0]
-        h2 = _lib.i2(hdims)
         c = lambda x: x.detach().to(torch.float32).contiguous()
-        g_net, g_dnet = c(g_net), c(g_dnet)
-        ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
-        _lib.check(L.socmx_mnet_backward_sizes(d, h2, Np, _lib.C.byref(ws), _lib.C.byref(ng)), "socmx_mnet_backward_sizes")
-        work = torch.empty(ws.value, dtype=torch.float32, device=dev)
-        flat = torch.empty(ng.value, dtype=torch.float32, device=dev)
-        with _lib.on_device(dev):
-            _lib.check(L.socmx_mnet_backward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(g_net),
-                                                 _lib.ptr(g_dnet), _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
-                       "socmx_mnet_backward_f32")
-        grads, off = [], 0
-        for shp in shapes:
-            n = int(torch.Size(shp).numel())
-            grads.append(flat[off:off + n].view(shp))
-            off += n
+        grads = pair_net_backward(d, hdims, shapes, packed, t, s, c(g_net), c(g_dnet))
         return (None, None, None, None) + tuple(grads)
 
 

@@ -67,6 +67,7 @@ class Trainer:
         self.graph_warmup = int(graph_warmup)
         self._graphs = {}
         self._dev = None
+        self._m_pending = False          # hipGraph mode: the pair-grid network's update of the last iteration is outstanding
         if self.hip_graph:
             overlap_M_backward = False     # inside a graph the pair-grid network's backward forks and joins within the iteration
         # SOCM on one GPU: the pair-grid network's backward and its Adam groups run on the solver's second stream
@@ -107,6 +108,8 @@ class Trainer:
         reads M / gamma outside `step()` / `solver.loss()` while `sync_timing=False` (with the default
         `sync_timing=True` every step ends with a device synchronisation, like the reference's timing does)."""
         dev = self.solver.x0.device
+        if self.hip_graph:
+            self._flush_M()
         if self.defer_M and dev.type == "cuda":
             side = self.solver._side_stream(dev)
             if side is not None:
@@ -169,6 +172,9 @@ class Trainer:
             self._dev = dict(norm=(nc.detach().clone().to(dev, torch.float32).reshape(()) if torch.is_tensor(nc) else f(nc)),
                              itr=f(self.itr), ema_gn=f(0.0),
                              ema_grad=[torch.zeros_like(p) for p in self.solver.neural_sde.nabla_V.parameters()])
+            D = self._dev          # (1,) views of the 0-dim state tensors for the C ABI, and the (A, B) pair of the EMA
+            D["itr1"], D["norm1"], D["ema_gn1"] = D["itr"].reshape(1), D["norm"].reshape(1), D["ema_gn"].reshape(1)
+            D["ab"] = torch.zeros(2, dtype=torch.float32, device=dev)
             if getattr(self.solver, "philox_key", None) is None:
                 self.solver.philox_key = PhiloxKey(dev)
             for g in self.optimizer.param_groups:            # device-side step counters: required under capture
@@ -226,35 +232,190 @@ class Trainer:
             return torch.stack([loss.detach().reshape(()), out[5].detach().reshape(()), out[6].detach().reshape(()),
                                 gn.reshape(()), ema_gn.reshape(()), gne.reshape(()), norm_before] + extra)
 
+    # ---- the iteration without autograd (plain SOCM, every network on the hand-written kernels) -----------------------
+    # rollout (+ nabla_V values) -> weights -> operands -> contraction forward (objective, G) -> contraction backward
+    # (g_net, g_dnet, g_gamma into PERSISTENT buffers) -> control-network backward -> Adam(nabla_V).  The pair-grid
+    # network's backward + its Adam groups for iteration n run at the START of iteration n+1 on the second stream, beside
+    # that iteration's rollout, followed by its forward for iteration n+1 -- the schedule of the eager two-stream path
+    # (_finish_M_on_side_stream), but expressible inside ONE captured graph because nothing of it lives in an autograd
+    # graph: the buffers that cross the iteration boundary (g_net, g_dnet, g_gamma, the packed weight image the
+    # backward recomputes from) are owned by the Trainer.
+    def _manual_ok(self, loss_kwargs):
+        from . import nets
+        solver, sde = self.solver, self.solver.neural_sde
+        if loss_kwargs or getattr(sde, "use_stopping_time", False) or type(sde.M) is not nets.SigmoidMLP:
+            return False
+        if not getattr(solver, "fused_nabla_V", True) or not getattr(sde.M, "fused_pair_net", True):
+            return False
+        K = solver.num_steps
+        return (nets.unet_backward_supported(sde.nabla_V, (K + 1) * self.batch_size)
+                and nets.pair_net_supported(sde.M, (K + 1) * (K + 2) // 2))
+
+    def _m_update(self, t_vec, s_vec):
+        """Backward of the pair-grid network from the kept gradients + Adam for (M, gamma): iteration n's update."""
+        from . import nets
+        sde, D = self.solver.neural_sde, self._dev
+        layers = [sde.M.sigmoid_layers[i] for i in (0, 2, 4)]
+        params = [p for l in layers for p in (l.weight, l.bias)]
+        grads = nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
+                                       D["g_net"], D["g_dnet"])
+        for p, g in zip(params, grads):
+            p.grad = g
+        sde.gamma.grad = D["g_gamma"].reshape(sde.gamma.shape).clone()
+        self._step_groups(D["groups_side"])
+        for p in params + [sde.gamma]:
+            p.grad = None
+
+    def _flush_M(self):
+        """Apply the outstanding pair-grid-network update now (before anything outside the replayed graph reads or
+        trains M / gamma: checkpoints, eager fallback iterations, the end of training)."""
+        if not self._m_pending:
+            return
+        solver = self.solver
+        dev = solver.x0.device
+        side = solver._side_stream(dev)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+        t_vec, s_vec = solver._pair_grid(solver.ts.to(dev), solver.num_steps)[:2]
+        with torch.no_grad():
+            self._m_update(t_vec, s_vec)
+        self._m_pending = False
+
+    @torch.no_grad()
+    def _body_manual(self):
+        from . import loss as L, nets, rollout as R
+        solver, D = self.solver, self._graph_state()
+        sde, pb = solver.neural_sde, solver.neural_sde.problem
+        dev = solver.x0.device
+        B, K, d = self.batch_size, solver.num_steps, solver.dim
+        Kp = K + 1
+        ts = solver.ts.to(dev)
+        t_vec, s_vec, ii, jj, delta = solver._pair_grid(ts, K)
+        Np = t_vec.shape[0]
+        M = sde.M
+        if "packed" not in D:
+            from . import _lib
+            D["packed"] = torch.empty(_lib.lib().socmx_mnet_packed_floats(d, _lib.i2(M.hdims)), dtype=torch.float32,
+                                      device=dev)
+            D["g_net"] = torch.zeros(Np, d, d, dtype=torch.float32, device=dev)
+            D["g_dnet"] = torch.zeros(Np, d, d, dtype=torch.float32, device=dev)
+            D["g_gamma"] = torch.zeros(1, dtype=torch.float32, device=dev)
+            ids_M = {id(p) for p in M.parameters()} | {id(sde.gamma)}
+            D["groups_side"] = [g for g in self.optimizer.param_groups if all(id(p) in ids_M for p in g["params"])]
+            D["groups_main"] = [g for g in self.optimizer.param_groups if not all(id(p) in ids_M for p in g["params"])]
+            # the telemetry EMA of the control-network gradient as one flat buffer, in parameters() order (= the order of
+            # socmx_unet_backward_f32's output); D["ema_grad"] (shared with the autograd body / the eager mirrors) = its views
+            vp = list(sde.nabla_V.parameters())
+            D["ema_flat"] = torch.cat([e.reshape(-1) for e in D["ema_grad"]])
+            off = 0
+            for i, p_ in enumerate(vp):
+                D["ema_grad"][i] = D["ema_flat"][off:off + p_.numel()].view_as(p_)
+                off += p_.numel()
+        layers = [M.sigmoid_layers[i] for i in (0, 2, 4)]
+        mparams = [p.detach() for l in layers for p in (l.weight, l.bias)]
+
+        def m_branch():
+            if self._m_pending:
+                self._m_update(t_vec, s_vec)
+            net, dnet, _ = nets.pair_net_forward(d, M.hdims, mparams, t_vec, s_vec, packed=D["packed"])
+            return net, dnet
+
+        main = torch.cuda.current_stream(dev)
+        side = solver._side_stream(dev) if Np >= 4096 else None
+        if side is not None:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                net, dnet = m_branch()
+        else:
+            net, dnet = m_branch()
+        state0 = solver.x0.repeat(B, 1)
+        noise_in, solver.noise_in = solver.noise_in, None
+        (states, noises, stop, frac, lpd, lps, ltw, controls, nabla_v) = R.stochastic_trajectories(
+            sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True)
+        if side is not None:
+            main.wait_stream(side)
+            net.record_stream(main)
+            dnet.record_stream(main)
+        weight, stats = L.weights_and_stats(lpd, lps, ltw)
+        w_mean, w_std = L.mean_std_from_stats(stats)
+        ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls)
+        gam = sde.gamma.detach().to(torch.float32).reshape(1).contiguous()
+        obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B))
+        gout = (1.0 / D["norm"]).reshape(1)                               # d loss / d objective  (main.py:313-320)
+        _, _, part = L.target_bwd_net(d, K, B, G, ops, gout, net, dnet, delta, gam, g_net=D["g_net"], g_dnet=D["g_dnet"])
+        torch.sum(part, dim=0, keepdim=True, out=D["g_gamma"])
+        vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
+                                               (G * gout).reshape(Kp * B, d), return_flat=True)
+        vparams = list(sde.nabla_V.parameters())
+        for p, g in zip(vparams, vgrads):
+            p.grad = g
+        # scalar bookkeeping (loss, EMA normaliser, iteration counter, telemetry EMAs): two one-thread kernels instead of
+        # ~35 elementwise launches (socmx_iteration_scalars_f32)
+        from . import _lib
+        Lh, f = _lib.lib(), _lib.ptr
+        gn = gne = None
+        if self.grad_telemetry:                                          # main.py:325-345
+            # the control-network gradients are views of ONE flat buffer (socmx_unet_backward_f32), and so is their EMA:
+            # squared norms are dot products, the EMA  A ema + B g  (A = 1 - B in every branch of compute_EMA) one lerp
+            gn = torch.dot(vflat, vflat).reshape(1)
+            with _lib.on_device(dev):
+                _lib.check(Lh.socmx_iteration_scalars_f32(0, f(D["itr1"]), None, None, None, None, None, None, None,
+                                                          self.coeff, 0.01, f(D["ab"]), None, _lib.stream_ptr(dev)),
+                           "socmx_iteration_scalars_f32")
+            D["ema_flat"].lerp_(vflat, D["ab"][1])
+            gne = torch.dot(D["ema_flat"], D["ema_flat"]).reshape(1)
+        self._step_groups(D["groups_main"])                               # main.py:347-349 (nabla_V: the next rollout needs it)
+        for p in vparams:
+            p.grad = None
+        out = torch.empty(7, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(Lh.socmx_iteration_scalars_f32(
+                1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(stats[3:4].contiguous()),
+                f(stats[4:5].contiguous()), f(obj), f(gn) if gn is not None else None, f(gne) if gne is not None else None,
+                self.coeff, 0.01, None, f(out), _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
+        self._m_pending = True
+        return out
+
     def _graph_step(self, loss_kwargs):
         solver = self.solver
         dev = solver.x0.device
-        key = tuple(sorted((k, id(v) if callable(v) else v) for k, v in loss_kwargs.items()))
+        manual = self._manual_ok(loss_kwargs)
+        if not manual:
+            self._flush_M()
+        body = self._body_manual if manual else (lambda: self._body_dev(loss_kwargs))
+        key = ("manual",) if manual else tuple(sorted((k, id(v) if callable(v) else v) for k, v in loss_kwargs.items()))
         if self.sync_timing:
             torch.cuda.synchronize(dev)
         start = time.time()
         entry = self._graphs.get(key)
         if entry is None:
             self._graph_state()
-            self.join()
             # first calls with this signature: `graph_warmup` iterations run eagerly on a side stream (they are real
             # training iterations), the next one is captured while it runs
             n = self._graphs.setdefault(("warm",) + key, 0)
-            if n < self.graph_warmup:
+            # (the manual body needs two eager iterations: the second one is the first to run the pair-grid network's
+            #  update, which creates that group's Adam state -- it must exist before a capture)
+            if n < (max(2, self.graph_warmup) if manual else self.graph_warmup) or (manual and not self._m_pending):
                 self._graphs[("warm",) + key] = n + 1
                 side = torch.cuda.Stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
-                    vals = self._body_dev(loss_kwargs)
+                    vals = body()
                 torch.cuda.current_stream(dev).wait_stream(side)
                 vals.record_stream(torch.cuda.current_stream(dev))
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    static_vals = self._body_dev(loss_kwargs)
+                    static_vals = body()
                 self._graphs[key] = entry = (g, static_vals)
                 g.replay()                                   # capture does not execute: this replay IS the iteration
                 vals = static_vals.clone()
+        elif manual and not self._m_pending:
+            # a flush (checkpoint, eager fallback) consumed the outstanding update the captured graph starts with: this one
+            # iteration runs the same body eagerly (it skips the update), the next one replays again
+            vals = body()
         else:
             entry[0].replay()
             vals = entry[1].clone()
@@ -297,6 +458,7 @@ class Trainer:
             return self._graph_step(loss_kwargs)
         if self.hip_graph:
             self._graph_state()
+            self._flush_M()
             self._sync_from_device_state()
             if self._dev is not None and self.itr > 0:
                 self._ema_grad = [g.clone() for g in self._dev["ema_grad"]]
