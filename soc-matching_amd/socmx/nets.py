@@ -221,7 +221,7 @@ def unet_backward_supported(net, n_rows):
     return L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
 
 
-def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False):
+def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None):
     """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
     x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
     `net.parameters()` order (views of one flat buffer)."""
@@ -239,7 +239,10 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False):
     work = torch.empty(ws.value, dtype=torch.float32, device=dev)
     flat = torch.empty(ng.value, dtype=torch.float32, device=dev)
     with _lib.on_device(dev):
-        _lib.check(L.socmx_unet_backward_f32(_lib.ptr(net.packed()), _lib.ptr(net.packed_bwd()), d, _lib.i3(net.hdims),
+        # (`packed`: the forward image of the CURRENT weights when the caller knows it is fresh -- e.g. the one this
+        #  iteration's rollout just used -- instead of re-packing)
+        _lib.check(L.socmx_unet_backward_f32(_lib.ptr(packed if packed is not None else net.packed()),
+                                             _lib.ptr(net.packed_bwd()), d, _lib.i3(net.hdims),
                                              _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N, _lib.ptr(gout),
                                              _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
                    "socmx_unet_backward_f32")

@@ -347,7 +347,8 @@ class Trainer:
         _, _, part = L.target_bwd_net(d, K, B, G, ops, gout, net, dnet, delta, gam, g_net=D["g_net"], g_dnet=D["g_dnet"])
         torch.sum(part, dim=0, keepdim=True, out=D["g_gamma"])
         vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
-                                               (G * gout).reshape(Kp * B, d), return_flat=True)
+                                               (G * gout).reshape(Kp * B, d), return_flat=True,
+                                               packed=sde.nabla_V._packed)     # (the image this iteration's rollout packed)
         vparams = list(sde.nabla_V.parameters())
         for p, g in zip(vparams, vgrads):
             p.grad = g
