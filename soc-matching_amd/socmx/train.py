@@ -243,7 +243,12 @@ class Trainer:
     def _manual_ok(self, loss_kwargs):
         from . import nets
         solver, sde = self.solver, self.solver.neural_sde
-        if loss_kwargs or getattr(sde, "use_stopping_time", False) or type(sde.M) is not nets.SigmoidMLP:
+        # (keyword arguments of solver.loss the manual body implements itself: the weighted L2 error against a ground truth)
+        extra = {k: v for k, v in loss_kwargs.items()
+                 if k not in ("compute_L2_error", "optimal_control", "total_n_samples") and v}
+        if loss_kwargs.get("compute_L2_error") and loss_kwargs.get("optimal_control") is None:
+            return False
+        if extra or getattr(sde, "use_stopping_time", False) or type(sde.M) is not nets.SigmoidMLP:
             return False
         if not getattr(solver, "fused_nabla_V", True) or not getattr(sde.M, "fused_pair_net", True):
             return False
@@ -282,7 +287,7 @@ class Trainer:
         self._m_pending = False
 
     @torch.no_grad()
-    def _body_manual(self):
+    def _body_manual(self, loss_kwargs=None):
         from . import loss as L, nets, rollout as R
         solver, D = self.solver, self._graph_state()
         sde, pb = solver.neural_sde, solver.neural_sde.problem
@@ -377,6 +382,13 @@ class Trainer:
                 f(stats[4:5].contiguous()), f(obj), f(gn) if gn is not None else None, f(gne) if gne is not None else None,
                 self.coeff, 0.01, None, f(out), _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
         self._m_pending = True
+        if loss_kwargs and loss_kwargs.get("compute_L2_error"):
+            # method.py:858-873: weighted squared distance between the learned control and the ground truth on this batch
+            target_control = loss_kwargs["optimal_control"](solver.ts, states, t_is_tensor=True)
+            learned = -(nabla_v @ solver.sigma)
+            nsd = torch.sum((target_control - learned) ** 2 * weight.reshape(1, -1, 1)
+                            / (target_control.shape[0] * target_control.shape[1]))
+            out = torch.cat([out, nsd.reshape(1)])
         return out
 
     def _graph_step(self, loss_kwargs):
@@ -385,8 +397,9 @@ class Trainer:
         manual = self._manual_ok(loss_kwargs)
         if not manual:
             self._flush_M()
-        body = self._body_manual if manual else (lambda: self._body_dev(loss_kwargs))
-        key = ("manual",) if manual else tuple(sorted((k, id(v) if callable(v) else v) for k, v in loss_kwargs.items()))
+        body = (lambda: self._body_manual(loss_kwargs)) if manual else (lambda: self._body_dev(loss_kwargs))
+        key = tuple(sorted((k, id(v) if callable(v) else v) for k, v in loss_kwargs.items()))
+        key = (("manual",) + key) if manual else key
         if self.sync_timing:
             torch.cuda.synchronize(dev)
         start = time.time()

@@ -47,7 +47,7 @@ def test_graph_replay_equals_the_eager_iteration(name, B):
     rec_g, par_g, tr, solver = _run(name, True, 7, B)
     assert tr.hip_graph and len([k for k in tr._graphs if not (isinstance(k, tuple) and k and k[0] == "warm")]) == 1
     if "molecular" not in name:
-        assert ("manual",) in tr._graphs         # the autograd-free body with the deferred pair-grid-network update
+        assert any(k and k[0] == "manual" for k in tr._graphs)   # the autograd-free body, deferred pair-grid-network update
     np.testing.assert_allclose(rec_g, rec_e, rtol=2e-5, atol=1e-7)
     assert len(set(np.round(rec_g[:, 0], 9))) == 7                    # every replay drew fresh noise
     assert solver.philox_key.key.cpu().tolist()[1] == 5 + 7
@@ -75,3 +75,36 @@ def test_graph_mode_falls_back_to_eager_for_checkpoint_iterations():
     again = tr.step()                # replays again
     assert torch.isfinite(after["loss"]) and torch.isfinite(again["loss"]) and tr.itr == 7
     assert float(tr._dev["itr"]) == 7.0
+
+
+def test_graph_mode_with_the_ground_truth_L2_error():
+    """main.py passes compute_L2_error + the ground-truth control every iteration (main.py:298-309): the manual graph body
+    computes the weighted L2 error itself; values equal the eager Trainer's on the same Philox stream."""
+    import contextlib, io
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from socmx.rollout import PhiloxKey
+    from socmx.train import Trainer, make_optimizer
+    from SOC_matching.method import SOC_Solver
+    recs = []
+    for graph in (False, True):
+        cfg = load_config(["method.setting=OU_quadratic_easy", "method.d=2", "method.num_steps=50", "method.gamma=2.0",
+                           "method.scaling_factor_M=0.1", "optim.M_lr=1e-3"])
+        cfg.method.device = DEV
+        torch.manual_seed(0)
+        ts = torch.linspace(0, 1.0, 51).to(DEV)
+        with contextlib.redirect_stdout(io.StringIO()):
+            x0, sigma, optimal_sde, sde, _ = define_variables(cfg, ts)
+        solver = SOC_Solver(sde, x0, optimal_sde.u, T=1.0, num_steps=50, lmbd=1.0, d=2, sigma=sigma)
+        solver.philox_key = PhiloxKey(torch.device(DEV), seed=5, offset=0)
+        tr = Trainer(solver, make_optimizer(solver, M_lr=1e-3), 64, sync_timing=False, hip_graph=graph, overlap_M_backward=False)
+        rec = []
+        for _ in range(6):
+            info = tr.step(compute_L2_error=True, optimal_control=optimal_sde.u)
+            rec.append([float(info["loss"]), float(info["out"][1])])
+        tr.join()
+        if graph:
+            assert any(k and k[0] == "manual" for k in tr._graphs if isinstance(k, tuple))
+        recs.append(np.array(rec))
+    np.testing.assert_allclose(recs[1], recs[0], rtol=2e-5, atol=1e-7)
+    assert (recs[0][:, 1] > 0).all()

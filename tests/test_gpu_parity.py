@@ -599,6 +599,12 @@ def test_solver_pickles_after_hip_calls(tmp_path):
      "method.T=2.0", "method.lmbd=2.0"],
     ["method.setting=double_well", "method.d=3", "method.num_steps=40", "method.delta_t_optimal=0.02",
      "method.delta_x_optimal=0.02", "method.algorithm=log-variance"],
+    # the iteration as a replayed hipGraph (backend.hip_graph): ground-truth L2 error inside the graph, checkpoint
+    # iterations eager, 12 iterations so that several replays happen
+    ["method.setting=OU_quadratic_easy", "method.d=2", "method.num_steps=20", "backend.hip_graph=True",
+     "method.num_iterations=12", "method.compute_control_objective_every=5"],
+    ["method.setting=molecular_dynamics", "method.d=1", "method.num_steps=30", "method.use_stopping_time=True",
+     "method.T=2.0", "method.lmbd=2.0", "backend.hip_graph=True", "method.num_iterations=10"],
 ])
 def test_main_trains_on_the_gpu(tmp_path, overrides):
     """The reference's entry point end to end on the GPU (main.py:33-481 flow): normalisation-constant burst,
