@@ -126,10 +126,11 @@ class _TargetResidualHip(torch.autograd.Function):
         G = torch.empty_like(nablaV)
         target = torch.empty_like(nablaV)   # the contraction's output; the residual kernel reads it back
         obj = torch.zeros(1, dtype=torch.float32, device=dev)
-        _lib.check(L.socmx_socm_target_fwd_f32(
-            pb.c_struct(), K, B, _lib.ptr(M_all), _lib.ptr(dM_all), _lib.ptr(ops["q"]), _lib.ptr(ops["v"]),
-            _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm), _lib.ptr(target),
-            _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_f32")
+        with _lib.on_device(dev):
+            _lib.check(L.socmx_socm_target_fwd_f32(
+                pb.c_struct(), K, B, _lib.ptr(M_all), _lib.ptr(dM_all), _lib.ptr(ops["q"]), _lib.ptr(ops["v"]),
+                _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm), _lib.ptr(target),
+                _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_f32")
         ctx.save_for_backward(G, ops["q"], ops["v"], ops["gT"])
         ctx.dims = (d, K, B, M_all.shape[0])
         if want_target:
@@ -146,9 +147,10 @@ class _TargetResidualHip(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             gM = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
             gdM = torch.empty(Np, d, d, dtype=torch.float32, device=G.device)
-            _lib.check(L.socmx_socm_target_bwd_f32(
-                d, K, B, _lib.ptr(G), _lib.ptr(q), _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gM), _lib.ptr(gdM),
-                _lib.stream_ptr(G.device)), "socmx_socm_target_bwd_f32")
+            with _lib.on_device(G.device):
+                _lib.check(L.socmx_socm_target_bwd_f32(
+                    d, K, B, _lib.ptr(G), _lib.ptr(q), _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gM), _lib.ptr(gdM),
+                    _lib.stream_ptr(G.device)), "socmx_socm_target_bwd_f32")
             gM = gM * gout
             gdM = gdM * gout
         if ctx.needs_input_grad[2]:

@@ -83,8 +83,9 @@ def _colsum(gy):
     nblk = L.socmx_colsum_blocks(R, C)
     partial = torch.empty(nblk * C, dtype=torch.float32, device=gy.device)
     out = torch.empty(C, dtype=torch.float32, device=gy.device)
-    _lib.check(L.socmx_colsum_f32(_lib.ptr(gy), R, C, _lib.ptr(partial), _lib.ptr(out), _lib.stream_ptr(gy.device)),
-               "socmx_colsum_f32")
+    with _lib.on_device(gy.device):
+        _lib.check(L.socmx_colsum_f32(_lib.ptr(gy), R, C, _lib.ptr(partial), _lib.ptr(out), _lib.stream_ptr(gy.device)),
+                   "socmx_colsum_f32")
     return out
 
 
@@ -111,19 +112,22 @@ def _wgrad_bias_fused(gz, x, y=None, S=16):
     partial = torch.empty(nblk * C, **f32)
     if y is not None:
         gy, gz = gz, torch.empty_like(gz)
-        _lib.check(L.socmx_relu_bwd_colsum_f32(_lib.ptr(gy), _lib.ptr(y), R, C, _lib.ptr(gz), _lib.ptr(partial), None,
-                                               _lib.stream_ptr(dev)), "socmx_relu_bwd_colsum_f32")
+        with _lib.on_device(dev):
+            _lib.check(L.socmx_relu_bwd_colsum_f32(_lib.ptr(gy), _lib.ptr(y), R, C, _lib.ptr(gz), _lib.ptr(partial), None,
+                                                   _lib.stream_ptr(dev)), "socmx_relu_bwd_colsum_f32")
     else:
-        _lib.check(L.socmx_colsum_f32(_lib.ptr(gz), R, C, _lib.ptr(partial), None, _lib.stream_ptr(dev)),
-                   "socmx_colsum_f32")
+        with _lib.on_device(dev):
+            _lib.check(L.socmx_colsum_f32(_lib.ptr(gz), R, C, _lib.ptr(partial), None, _lib.stream_ptr(dev)),
+                       "socmx_colsum_f32")
     main = (R // S) * S
     parts = torch.bmm(gz[:main].view(S, main // S, -1).transpose(1, 2), x[:main].view(S, main // S, -1))
     tail = (gz[main:].t() @ x[main:]).contiguous() if main < R else None
     gw = torch.empty(C, x.shape[1], **f32)
     gb = torch.empty(C, **f32)
-    _lib.check(L.socmx_linear_bwd_finish_f32(_lib.ptr(parts), S, gw.numel(), _lib.ptr(tail), _lib.ptr(gw),
-                                             _lib.ptr(partial), nblk, C, _lib.ptr(gb), _lib.stream_ptr(dev)),
-               "socmx_linear_bwd_finish_f32")
+    with _lib.on_device(dev):
+        _lib.check(L.socmx_linear_bwd_finish_f32(_lib.ptr(parts), S, gw.numel(), _lib.ptr(tail), _lib.ptr(gw),
+                                                 _lib.ptr(partial), nblk, C, _lib.ptr(gb), _lib.stream_ptr(dev)),
+                   "socmx_linear_bwd_finish_f32")
     return gz, gw, gb
 
 
@@ -190,7 +194,8 @@ class FullyConnectedUNet(nn.Module):
         if self._packed is None or self._packed.numel() != n or self._packed.device != dev:
             self._packed = torch.empty(n, dtype=torch.float32, device=dev)
         s, keep = self.c_struct()
-        _lib.check(L.socmx_unet_pack_f32(s, _lib.ptr(self._packed), _lib.stream_ptr(dev)), "socmx_unet_pack_f32")
+        with _lib.on_device(dev):
+            _lib.check(L.socmx_unet_pack_f32(s, _lib.ptr(self._packed), _lib.stream_ptr(dev)), "socmx_unet_pack_f32")
         return self._packed
 
     def packed_bwd(self):
@@ -287,9 +292,10 @@ def unet_forward_hip(net, tx):
     L = _lib.lib()
     tx = tx.detach().to(torch.float32).contiguous()
     out = torch.empty(tx.shape[0], net.dim, dtype=torch.float32, device=tx.device)
-    _lib.check(L.socmx_unet_forward_f32(_lib.ptr(net.packed()), net.dim, _lib.i3(net.hdims), _lib.ptr(tx),
-                                        tx.shape[0], _lib.ptr(out), _lib.stream_ptr(tx.device)),
-               "socmx_unet_forward_f32")
+    with _lib.on_device(tx.device):
+        _lib.check(L.socmx_unet_forward_f32(_lib.ptr(net.packed()), net.dim, _lib.i3(net.hdims), _lib.ptr(tx),
+                                            tx.shape[0], _lib.ptr(out), _lib.stream_ptr(tx.device)),
+                   "socmx_unet_forward_f32")
     return out
 
 
