@@ -554,7 +554,11 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_wide_kernel(con
 // wave) stay on a three-deep register ring.
 constexpr int kAStride = 20;   // floats per staged row (16 + 4 pad: 80-byte stride spreads the 16 rows over the banks)
 
-template <bool NET, int KB>
+// AL4 = (d % 4 == 0): every 16-byte piece lies inside its row, so ALL loads are 16-byte loads (padding pieces re-read the
+// row's last piece and are zeroed at use).  Otherwise the last pairs of a row switch to guarded scalar reads; the compiler
+// then merges both forms into one register set and waits for the 16-byte loads right where they are issued (the loader waves
+// stall for a full HBM round trip per iteration: 8.07 ms instead of the AL4 form's time at the configs[4] slice).
+template <bool NET, int KB, bool AL4>
 __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(const TargetArgs a) {
   constexpr int CT = 2, ROWS = KB * 16;
   __shared__ __attribute__((aligned(16))) float As[3][2][ROWS][kAStride];
@@ -597,11 +601,11 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       int jr, lb;
       geom(it, jr, lb);
       const int j = i + jr;
-      const int l0 = min(lb + 4 * aq, d - 1);
+      const int l0 = AL4 ? min(lb + 4 * aq, d - 4) : min(lb + 4 * aq, d - 1);
       const float* Ap = a.M_all + prow_dd + (int64_t)jr * dd;
       const float* Dp = a.dM_all + prow_dd + (int64_t)jr * dd;
       const int aoff = min(ak, d - 1) * d + l0;
-      if (j + 1 < K) {
+      if (AL4 || j + 1 < K) {
         p.nt = load4<true>(Ap, aoff, 0);
         p.dn = load4<true>(Dp, aoff, 0);
       } else {
@@ -641,10 +645,10 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       int jr, lb;
       geom(it, jr, lb);
       const int j = i + jr;
-      const int l0 = min(lb + 4 * g4, d - 1);
+      const int l0 = AL4 ? min(lb + 4 * g4, d - 4) : min(lb + 4 * g4, d - 1);
       const float* qs = (j < K) ? a.q + (size_t)j * B * d : a.gT;
       const float* vs = a.v + (size_t)(j < K ? j : 0) * B * d;
-      if (j + 1 < K) {
+      if (AL4 || j + 1 < K) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           b.q[c] = load4<true>(qs, boff0[c] + l0, 0);
@@ -712,13 +716,21 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       for (int u = 0; u < 3; ++u) {
         const int it = it0 + u;                   // it % 3 == u
         if (it < nit) {
+#ifndef SOCMX_EXP_NOSYNC
           __syncthreads();                        // stage of `it` (and it+1) written; readers of it-1 finished
+#endif
           if (loader && it + 2 < nit) {
+#ifndef SOCMX_EXP_NOSTAGE
             stageA(it + 2, pend[(u + 2) % 3], (u + 2) % 3);
+#endif
+#ifndef SOCMX_EXP_NOA
             if (it + 5 < nit) loadA(it + 5, pend[(u + 2) % 3]);
+#endif
           }
           consume(it, bs[u], u);
+#ifndef SOCMX_EXP_NOB
           if (it + 3 < nit) loadB(it + 3, bs[u]);
+#endif
         }
       }
     }
@@ -963,14 +975,19 @@ __global__ __launch_bounds__(256) void socm_target_bwd_wide_kernel(const TargetB
 }
 
 // d <= 64, d % 4 == 0: the same contraction with the three operand tiles of 16 batch rows (G_i, q_j, v_j: 16 x d floats
-// each) staged through a double-buffered LDS tile by coalesced 16-byte loads -- 3 global loads per thread and 16 batch
-// rows instead of 36 four-byte loads per lane; the waves read their MFMA fragments from LDS (rows padded to 80 floats).
-constexpr int kBwdStride = 80;   // row r starts 16 banks after row r-1: the four rows a wave reads per MFMA cover each bank twice (the minimum)
+// each) staged through a double-buffered LDS tile, TRANSPOSED: Ts[tensor][column][batch row], 20 floats per column.  The
+// batch is the MFMA reduction index and its assignment to (MFMA u, lane group g4) is free, so row m = 4*g4 + u: the four
+// u-values of a lane are four consecutive floats of one column -- nine ds_read_b128 per 16-row chunk and wave feed its
+// 32 MFMAs (the row-major tile needed 36 ds_read_b32, each predicated and waited for right before its MFMA: 8.2 ms at the
+// configs[4] slice, 57 % MFMA-busy).  Loaders: waves 0..2 take one tensor each; lane (rg = lane & 3, pc = lane >> 2) loads
+// the 4 x 4 block rows 4rg.., columns 4pc.. with four 16-byte loads and writes it as four 16-byte column pieces (an
+// 8-lane group covers all 32 banks exactly once on the write and on the read side).  Columns >= d and rows >= B are zero
+// in LDS, so the consumer needs no predicates.
+constexpr int kBwdStride = 20;
 
-template <bool NET>
-__global__ __launch_bounds__(256) void socm_target_bwd_lds_kernel(const TargetBwdArgs a) {
-  constexpr int LB = 4;
-  __shared__ __attribute__((aligned(16))) float Ts[2][3][16][kBwdStride];   // [stage][G, q, v][batch row][column]
+template <bool NET, int LB>               // LB = ceil(d / 16) l-blocks (2..4)
+__global__ __launch_bounds__(256, 2) void socm_target_bwd_lds_kernel(const TargetBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ts[2][3][64][kBwdStride];   // [stage][G, q, v][column][batch row]
   const int d = a.d, K = a.K, B = a.B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -986,64 +1003,93 @@ __global__ __launch_bounds__(256) void socm_target_bwd_lds_kernel(const TargetBw
   const int c16 = lane & 15, g4 = lane >> 4;
   const int kb = wave * 16;
   const bool wave_on = kb < d;
-  const float* Gp = a.G + (size_t)i * B * d;
-  const float* Qp = last ? a.gT : a.q + (size_t)j * B * d;
-  const float* Vp = a.v + (size_t)(last ? 0 : j) * B * d;
-  // loader role: (batch row mr of the chunk, 16-byte piece pc of the row)
-  const int mr = tid >> 4, pc = tid & 15;
+  // loader role (waves 0..2): tensor `wave`, rows 4*rg .. 4*rg+3 of the chunk, columns 4*pc .. 4*pc+3
+  const int rg = lane & 3, pc = lane >> 2;
+  const bool loader = wave < 3;
   const bool piece_on = 4 * pc < d;
-  f32x4 pg, pq, pv;                       // the chunk after next, in flight
-  auto gload = [&](int m0) {
-    const int m = min(m0 + mr, B - 1);
-    const size_t off = (size_t)m * d + 4 * pc;
+  const bool tensor_zero = (wave == 2) && last;            // the terminal pair has no v operand
+  const float* src = wave == 0 ? a.G + (size_t)i * B * d
+                   : wave == 1 ? (last ? a.gT : a.q + (size_t)j * B * d)
+                               : a.v + (size_t)(last ? 0 : j) * B * d;
+  f32x4 pr[2][4];                         // chunks c+1 and c+2 in flight (slot = chunk & 1): pr[slot][row][column]
+  auto gload = [&](int m0, int sl) {
     if (piece_on) {
-      pg = load4<true>(Gp, (int)off, 0);
-      pq = load4<true>(Qp, (int)off, 0);
-      pv = load4<true>(Vp, (int)off, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pr[sl][s] = load4<true>(src, min(m0 + 4 * rg + s, B - 1) * d + 4 * pc, 0);
     }
   };
-  auto stage = [&](int m0, int st) {      // rows past the batch and (for the terminal pair) v are zeroed here
-    const bool okm = m0 + mr < B;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if (piece_on) {
-      *reinterpret_cast<f32x4*>(&Ts[st][0][mr][4 * pc]) = okm ? pg : z;
-      *reinterpret_cast<f32x4*>(&Ts[st][1][mr][4 * pc]) = okm ? pq : z;
-      *reinterpret_cast<f32x4*>(&Ts[st][2][mr][4 * pc]) = (okm && !last) ? pv : z;
+  auto stage = [&](int m0, int st, int sl) {   // rows past the batch, columns past d and (terminal pair) v are zeroed here
+    float* col = &Ts[st][loader ? wave : 0][4 * pc][4 * rg];
+    if (!piece_on || tensor_zero) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(col + s * kBwdStride) = z;
+    } else if (m0 + 16 <= B) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        *reinterpret_cast<f32x4*>(col + s * kBwdStride) = f32x4{pr[sl][0][s], pr[sl][1][s], pr[sl][2][s], pr[sl][3][s]};
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f32x4 t;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) t[rr] = (m0 + 4 * rg + rr < B) ? pr[sl][rr][s] : 0.f;
+        *reinterpret_cast<f32x4*>(col + s * kBwdStride) = t;
+      }
     }
   };
   f32x4 accq[LB], accv[LB];
 #pragma unroll
   for (int b = 0; b < LB; ++b) { accq[b] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const int nch = (B + 15) >> 4;
-  gload(0);
-  stage(0, 0);
-  if (nch > 1) gload(16);
-  for (int c = 0; c < nch; ++c) {
-    __syncthreads();                      // stage c%2 visible; everyone is done reading stage (c+1)%2
-    if (c + 1 < nch) {
-      stage((c + 1) * 16, (c + 1) & 1);
-      if (c + 2 < nch) gload((c + 2) * 16);
-    }
-    if (wave_on) {
-      const int st = c & 1;
+  if (loader) {
+    gload(0, 0);
+    if (nch > 1) gload(16, 1);
+    stage(0, 0, 0);
+    if (nch > 2) gload(32, 0);
+  }
+  // Chunk loop, unrolled by two so that the register slots are static.  Two copies (waves with / without a k-block of
+  // their own): with the MFMAs behind a branch inside ONE loop the accumulators travel between VGPRs and AccVGPRs on
+  // every trip (64 moves per chunk).  A chunk is staged two trips after its loads were issued (one trip is shorter than a
+  // round trip to L2: the loader waves -- which also multiply -- then stall in front of their own MFMAs).
+  auto chunk_loop = [&](auto with_mfma) {
+    for (int c0 = 0; c0 < nch; c0 += 2) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int mrow = 4 * u + g4;
-        const float af = (kb + c16 < d) ? Ts[st][0][mrow][kb + c16] : 0.f;
+      for (int h = 0; h < 2; ++h) {
+        const int c = c0 + h;             // c & 1 == h
+        if (c < nch) {
+          __syncthreads();                // stage h visible; everyone is done reading stage 1-h
+          if (loader && c + 1 < nch) {
+            stage((c + 1) * 16, 1 - h, 1 - h);
+            if (c + 3 < nch) gload((c + 3) * 16, 1 - h);
+          }
+          if constexpr (decltype(with_mfma)::value) {
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(&Ts[h][0][kb + c16][4 * g4]);
+            f32x4 qb[LB], vb[LB];
 #pragma unroll
-        for (int b = 0; b < LB; ++b) {
-          const int l = b * 16 + c16;
-          accq[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, l < d ? Ts[st][1][mrow][min(l, d - 1)] : 0.f, accq[b], 0, 0, 0);
-        }
+            for (int b = 0; b < LB; ++b) {
+              qb[b] = *reinterpret_cast<const f32x4*>(&Ts[h][1][b * 16 + c16][4 * g4]);
+              vb[b] = *reinterpret_cast<const f32x4*>(&Ts[h][2][b * 16 + c16][4 * g4]);
+            }
 #pragma unroll
-        for (int b = 0; b < LB; ++b) {
-          const int l = b * 16 + c16;
-          accv[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, l < d ? Ts[st][2][mrow][min(l, d - 1)] : 0.f, accv[b], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+              for (int b = 0; b < LB; ++b)
+                accq[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[u], qb[b][u], accq[b], 0, 0, 0);
+#pragma unroll
+              for (int b = 0; b < LB; ++b)
+                accv[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[u], vb[b][u], accv[b], 0, 0, 0);
+            }
+          }
         }
       }
     }
+  };
+  if (!wave_on) {
+    chunk_loop(std::false_type{});
+    return;
   }
-  if (!wave_on) return;
+  chunk_loop(std::true_type{});
   const float go = a.gout ? a.gout[0] : 1.f;
   const size_t base = (size_t)p * d * d;
   float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
@@ -1307,13 +1353,18 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
     static const bool use_regs = getenv("SOCMX_TARGET_WIDE_REGS") != nullptr;   // A/B switch: register-only form
     if (!use_regs) {
       wgrid.x = K + 1;
+      const bool al4 = d % 4 == 0;
+#define SOCMX_LDS_LAUNCH(NETV, KBV) \
+  lerr = al4 ? launch(socm_target_lds_kernel<NETV, KBV, true>, wgrid, wblk, 0, st0, a) \
+             : launch(socm_target_lds_kernel<NETV, KBV, false>, wgrid, wblk, 0, st0, a)
       if (delta) {
-        if (d <= 32) lerr = launch(socm_target_lds_kernel<true, 2>, wgrid, wblk, 0, st0, a);
-        else         lerr = launch(socm_target_lds_kernel<true, 4>, wgrid, wblk, 0, st0, a);
+        if (d <= 32) SOCMX_LDS_LAUNCH(true, 2);
+        else         SOCMX_LDS_LAUNCH(true, 4);
       } else {
-        if (d <= 32) lerr = launch(socm_target_lds_kernel<false, 2>, wgrid, wblk, 0, st0, a);
-        else         lerr = launch(socm_target_lds_kernel<false, 4>, wgrid, wblk, 0, st0, a);
+        if (d <= 32) SOCMX_LDS_LAUNCH(false, 2);
+        else         SOCMX_LDS_LAUNCH(false, 4);
       }
+#undef SOCMX_LDS_LAUNCH
     } else if (delta) {
       if (d <= 32) lerr = launch(socm_target_wide_kernel<true, 2, 2>, wgrid, wblk, 0, st0, a);
       else         lerr = launch(socm_target_wide_kernel<true, 4, 2>, wgrid, wblk, 0, st0, a);
@@ -1379,8 +1430,14 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
   if (d > 16 && d <= 64 && d % 4 == 0 && !bwd_regs) {
     // (reads of whole 16-byte pieces stay inside the rows because d % 4 == 0)
     dim3 lgrid((unsigned)np);
-    return net ? launch(socm_target_bwd_lds_kernel<true>, lgrid, dim3(256), 0, stream, a)
-               : launch(socm_target_bwd_lds_kernel<false>, lgrid, dim3(256), 0, stream, a);
+    const int lb = (d + 15) / 16;
+#define SOCMX_BWD_LDS(LBV) \
+  return net ? launch(socm_target_bwd_lds_kernel<true, LBV>, lgrid, dim3(256), 0, stream, a) \
+             : launch(socm_target_bwd_lds_kernel<false, LBV>, lgrid, dim3(256), 0, stream, a)
+    if (lb == 2) { SOCMX_BWD_LDS(2); }
+    if (lb == 3) { SOCMX_BWD_LDS(3); }
+    SOCMX_BWD_LDS(4);
+#undef SOCMX_BWD_LDS
   }
   if (d > 16) {
     const int nblk = (d + 15) / 16;
