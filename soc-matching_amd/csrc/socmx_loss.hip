@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/socmx.h"
 #include "socmx_launch.h"
@@ -554,11 +555,7 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_wide_kernel(con
 // wave) stay on a three-deep register ring.
 constexpr int kAStride = 20;   // floats per staged row (16 + 4 pad: 80-byte stride spreads the 16 rows over the banks)
 
-// AL4 = (d % 4 == 0): every 16-byte piece lies inside its row, so ALL loads are 16-byte loads (padding pieces re-read the
-// row's last piece and are zeroed at use).  Otherwise the last pairs of a row switch to guarded scalar reads; the compiler
-// then merges both forms into one register set and waits for the 16-byte loads right where they are issued (the loader waves
-// stall for a full HBM round trip per iteration: 8.07 ms instead of the AL4 form's time at the configs[4] slice).
-template <bool NET, int KB, bool AL4>
+template <bool NET, int KB>
 __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(const TargetArgs a) {
   constexpr int CT = 2, ROWS = KB * 16;
   __shared__ __attribute__((aligned(16))) float As[3][2][ROWS][kAStride];
@@ -601,11 +598,11 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       int jr, lb;
       geom(it, jr, lb);
       const int j = i + jr;
-      const int l0 = AL4 ? min(lb + 4 * aq, d - 4) : min(lb + 4 * aq, d - 1);
+      const int l0 = min(lb + 4 * aq, d - 1);
       const float* Ap = a.M_all + prow_dd + (int64_t)jr * dd;
       const float* Dp = a.dM_all + prow_dd + (int64_t)jr * dd;
       const int aoff = min(ak, d - 1) * d + l0;
-      if (AL4 || j + 1 < K) {
+      if (j + 1 < K) {
         p.nt = load4<true>(Ap, aoff, 0);
         p.dn = load4<true>(Dp, aoff, 0);
       } else {
@@ -645,10 +642,10 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       int jr, lb;
       geom(it, jr, lb);
       const int j = i + jr;
-      const int l0 = AL4 ? min(lb + 4 * g4, d - 4) : min(lb + 4 * g4, d - 1);
+      const int l0 = min(lb + 4 * g4, d - 1);
       const float* qs = (j < K) ? a.q + (size_t)j * B * d : a.gT;
       const float* vs = a.v + (size_t)(j < K ? j : 0) * B * d;
-      if (AL4 || j + 1 < K) {
+      if (j + 1 < K) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           b.q[c] = load4<true>(qs, boff0[c] + l0, 0);
@@ -716,21 +713,13 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       for (int u = 0; u < 3; ++u) {
         const int it = it0 + u;                   // it % 3 == u
         if (it < nit) {
-#ifndef SOCMX_EXP_NOSYNC
           __syncthreads();                        // stage of `it` (and it+1) written; readers of it-1 finished
-#endif
           if (loader && it + 2 < nit) {
-#ifndef SOCMX_EXP_NOSTAGE
             stageA(it + 2, pend[(u + 2) % 3], (u + 2) % 3);
-#endif
-#ifndef SOCMX_EXP_NOA
             if (it + 5 < nit) loadA(it + 5, pend[(u + 2) % 3]);
-#endif
           }
           consume(it, bs[u], u);
-#ifndef SOCMX_EXP_NOB
           if (it + 3 < nit) loadB(it + 3, bs[u]);
-#endif
         }
       }
     }
@@ -746,6 +735,295 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
           }
         }
   }
+}
+
+// ---- d % 4 == 0: the LDS-staged form, scheduled by hand around what the SIMD issues beside an MFMA stream ------------
+// Same decomposition as socm_target_lds_kernel (row i per workgroup; 8 multiplying waves x 2 column tiles of 16 x all KB
+// k-blocks; the pair matrices reach the waves through LDS).  Two measured facts (in-kernel cycle counters,
+// tools/ubench/contraction_bench.hip -DSOCMX_CONTRACTION_PROF; tools/ubench/mfma_valu_overlap.hip) shape everything else:
+//  (1) the compiler's wait-count insertion cannot see through a loop with conditional prefetches and waits for ALL loads
+//      (vmcnt(0)) in front of every use: operands requested one iteration earlier were waited for at full latency.  Here
+//      every global load is an asm statement the compiler does not track and every wait is written out with the exact
+//      number of younger requests that may stay in flight; to keep that number constant the trip count is padded to a
+//      multiple of four (padded trips multiply a zero A tile) and requests past the row's end re-read its last pieces.
+//  (2) while one wave of a SIMD streams fp32 MFMAs, every other instruction on that SIMD -- vector, scalar, LDS, from any
+//      other wave -- gets about one issue slot per MFMA (~40 cycles each), whereas a wave's OWN instructions placed
+//      between its MFMAs are free.  Staging inside the multiplying waves cost 2,700 of 6,000 cycles per iteration (the
+//      stagers crawled behind their SIMD neighbour's MFMAs, then multiplied while the neighbour idled at the barrier).
+//      So: four extra waves (one per SIMD) do nothing but stage, with as few instructions as possible (~75 per
+//      iteration, under the 128 slots two multiplying waves leave), and the multiplying waves issue their own operand
+//      requests, cursor arithmetic and LDS reads BETWEEN their MFMAs.  Per iteration: 6,000 -> 4,700 cycles (4,096 is
+//      the MFMA time), 7.6 -> 6.3 ms at the configs[4] slice (107 TFLOP/s, 0.68 of the fp32 MFMA peak).
+__device__ __forceinline__ const void* scalar_ptr(const void* p) {     // a wave-uniform pointer, pinned to scalar registers
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ f32x4 async_load16(const void* sbase, uint32_t voff) {
+  sbase = scalar_ptr(sbase);
+  f32x4 r;
+  // (s_nop: the base may have just been written by v_readfirstlane -- VALU-written SGPR read by VMEM needs 5 wait states,
+  //  and the hazard recogniser does not look inside asm statements)
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+__device__ __forceinline__ float async_load4(const void* sbase, uint32_t voff) {
+  sbase = scalar_ptr(sbase);
+  float r;
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+
+constexpr int kStageWaves = 4;
+#ifdef SOCMX_CONTRACTION_PROF
+__device__ long long g_contraction_prof[kTargetWaves][4];
+#endif
+
+template <bool NET, int KB>
+__global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target_lds4_kernel(const TargetArgs a) {
+  constexpr int CT = 2, ROWS = KB * 16;
+  constexpr int NA = NET ? 3 : 2;            // requests per A prefetch: net piece, dnet piece [, delta]
+  __shared__ __attribute__((aligned(16))) float As[4][2][ROWS][kAStride];
+  const int d = a.d, K = a.K, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lbl = ((d - 1) >> 4) << 4;       // the last l-block: pieces past the row re-read its last piece (zero on the A side)
+  const int nlb = (d + 15) >> 4;
+  const int dd = d * d;
+  const int i = blockIdx.x;                  // one row per workgroup, longest rows first
+  const int nit = (K - i + 1) * nlb;
+  const int nitp = (nit + 3) / 4 * 4;        // trips are unrolled by four (request slots and LDS stages: rings of four)
+  const int lb_end = 16 * nlb;
+  if (wave >= kTargetWaves) {
+    // ---- staging waves: thread = (row ak, 16-byte piece aq) of the 16-column tile, both tensors ----
+    // (every instruction here costs about one MFMA time: scalar bookkeeping is kept to one cursor whose per-request state
+    //  travels with the request slot, 32-bit offsets against per-row base pointers, one hazard nop per request group)
+    constexpr bool ALL_ON = 4 * ROWS >= 64 * kStageWaves;
+    const int piece = tid - 64 * kTargetWaves;
+    const bool on = ALL_ON || piece < 4 * ROWS;   // (KB = 2: two of the four waves have no piece)
+    const int ak = (piece >> 2) & (ROWS - 1), aq = piece & 3;
+    const uint32_t alane = (uint32_t)(min(ak, d - 1) * d + 4 * aq) * 4u;
+    const uint32_t alane_last = (uint32_t)(min(ak, d - 1) * d + min(lbl + 4 * aq, d - 4) - lbl) * 4u;
+    const float gam = NET ? a.gamma[0] : 0.f;
+    const int64_t prow = pair_row_offset(i, K);
+    const float* rowN = reinterpret_cast<const float*>(scalar_ptr(a.M_all + prow * dd));    // this row's first pair matrix
+    const float* rowD = reinterpret_cast<const float*>(scalar_ptr(a.dM_all + prow * dd));
+    const float* rowL = NET ? reinterpret_cast<const float*>(scalar_ptr(a.delta + prow)) : nullptr;
+    const float rowmask = (on && ak < d) ? 1.f : 0.f;
+    const int d_minus_aq = d - 4 * aq, diag0 = ak - 4 * aq;   // the tile's diagonal element of this row is piece element diag0 - lb
+    // blend coefficients of the pair being staged (renewed at its first l-block), times this thread's row mask:
+    //   M = e I + f net,   -dM/ds = ge I - ge net - f dnet      (e = exp(-gamma (s_j - t_i)), f = 1 - e, ge = gamma e)
+    float ce = 0.f, cf = 0.f, cged = 0.f, cfd = 0.f;
+    struct APend { f32x4 nt, dn; float dl; int lb, flags; };   // flags: 1 = first l-block of a pair, 2 = partial / padded, 4 = dead, 8 = terminal pair
+    // request cursor: iteration t of the row = (pair jr, l-block lb); off = element offset of (jr, lb) inside the row's matrices
+    int ct = 0, cjr = 0, clb = 0;
+    uint32_t coff = 0;
+    const uint32_t wrap_step = (uint32_t)(dd - 16 * (nlb - 1));
+    auto issueA = [&](APend& p) {             // NA requests for iteration ct (the row's last one once ct runs past it)
+      const uint32_t lane_off = clb + 16 <= d ? alane : alane_last;
+      const void* pn = scalar_ptr(rowN + coff);
+      const void* pd = scalar_ptr(rowD + coff);
+      const void* pl = scalar_ptr(NET ? rowL + cjr : rowN);
+      if (NET)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %5\n\tglobal_load_dword %2, %6, %7"
+                     : "=&v"(p.nt), "=&v"(p.dn), "=&v"(p.dl) : "v"(lane_off), "s"(pn), "s"(pd), "v"(0u), "s"(pl) : "memory");
+      else
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %4"
+                     : "=&v"(p.nt), "=&v"(p.dn) : "v"(lane_off), "s"(pn), "s"(pd) : "memory");
+      p.lb = clb;
+      p.flags = (clb == 0 ? 1 : 0) | ((clb + 16 > d || ct >= nit) ? 2 : 0) | (ct >= nit ? 4 : 0) | (i + cjr >= K ? 8 : 0);
+      ++ct;
+      if (ct < nit) {
+        const bool wrap = clb + 16 == lb_end;
+        coff += wrap ? wrap_step : 16u;
+        clb = wrap ? 0 : clb + 16;
+        cjr += wrap ? 1 : 0;
+      }
+    };
+    auto stageA = [&](const APend& p, int st) {   // blend + zero padding, then two 16-byte LDS writes
+      if (p.flags & 1) {
+        const float e = NET ? expf(-gam * p.dl) : 0.f;
+        const float dm = (p.flags & 8) ? 0.f : rowmask;                   // terminal pair: -dM/ds = 0
+        ce = rowmask * e; cf = NET ? rowmask * (1.f - e) : rowmask;
+        cfd = NET ? dm * (1.f - e) : dm; cged = dm * gam * e;
+      }
+      f32x4 xm, xd;
+      const int es = diag0 - p.lb;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        xm[s2] = NET ? fmaf(cf, p.nt[s2], es == s2 ? ce : 0.f) : cf * p.nt[s2];
+        xd[s2] = NET ? fmaf(-cfd, p.dn[s2], fmaf(-cged, p.nt[s2], es == s2 ? cged : 0.f)) : -cfd * p.dn[s2];
+      }
+      if (p.flags & 2) {                        // the row's partial last l-block / a padded iteration: zero the tail
+        const int na = (p.flags & 4) ? 0 : max(0, min(4, d_minus_aq - p.lb));
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { xm[s2] = (s2 < na) ? xm[s2] : 0.f; xd[s2] = (s2 < na) ? xd[s2] : 0.f; }
+      }
+      if (on) {
+        *reinterpret_cast<f32x4*>(&As[st][0][ak][4 * aq]) = xm;
+        *reinterpret_cast<f32x4*>(&As[st][1][ak][4 * aq]) = xd;
+      }
+    };
+#define SOCMX_WAIT_A(N, P) asm volatile("s_waitcnt vmcnt(%3)" : "+v"((P).nt), "+v"((P).dn), "+v"((P).dl) : "n"(N) : "memory")
+    APend pend[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pend[u].dl = 0.f;
+    // prologue: stages 0 and 1 staged synchronously, A(2) .. A(5) in flight
+    issueA(pend[0]);
+    issueA(pend[1]);
+    SOCMX_WAIT_A(0, pend[0]);
+    SOCMX_WAIT_A(0, pend[1]);
+    stageA(pend[0], 0);
+    stageA(pend[1], 1);
+    issueA(pend[2]);
+    issueA(pend[3]);
+    issueA(pend[0]);
+    issueA(pend[1]);
+    __syncthreads();                             // stages 0 and 1 visible
+    for (int it0 = 0; it0 < nitp; it0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        __syncthreads();                         // (it = it0 + u) everyone has issued its reads of stage it (end of it-1)
+        SOCMX_WAIT_A(3 * NA, pend[(u + 2) % 4]); // younger than A(it+2): A(it+3) A(it+4) A(it+5)
+        stageA(pend[(u + 2) % 4], (u + 2) % 4);  // iteration it+2 -> the stage that held it-2
+        issueA(pend[(u + 2) % 4]);               // iteration it+6
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-fetched requests of the last trips
+#undef SOCMX_WAIT_A
+    return;
+  }
+  // ---- multiplying waves ----
+  const int c16 = lane & 15, g4 = lane >> 4;
+  int mcol[CT];
+  uint32_t blane[CT], blane_last[CT];        // byte offset of this lane's piece relative to (operand row block + l-block)
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    mcol[c] = ((blockIdx.y * kTargetWaves + wave) * CT + c) * 16 + c16;
+    const int boff = min(mcol[c], B - 1) * d;
+    blane[c] = (uint32_t)(boff + 4 * g4) * 4u;
+    blane_last[c] = (uint32_t)(boff + min(lbl + 4 * g4, d - 4) - lbl) * 4u;
+  }
+  f32x4 acc[KB][CT];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[kb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  struct BSlot { f32x4 q[CT], v[CT]; };
+  // request cursor of the B side: the operand pointers of iteration bt = (pair bjr, l-block blb) move by 16 floats inside a
+  // pair and by the rest of the (B, d) block at a pair boundary; the terminal pair reads gT (and any finite v: its A is zero)
+  static_assert(CT == 2, "the request group below is written for two column tiles");
+  int bt = 0, bjr = 0, blb = 0;
+  const float* pq = reinterpret_cast<const float*>(scalar_ptr(i < K ? a.q + (size_t)i * B * d : a.gT));
+  const float* pv = reinterpret_cast<const float*>(scalar_ptr(a.v + (size_t)(i < K ? i : 0) * B * d));
+  const int64_t pair_step = (int64_t)B * d - 16 * (nlb - 1);
+  auto requestB = [&](BSlot& b) {              // 2 * CT requests for iteration bt (one hazard nop)
+    const bool whole = blb + 16 <= d;
+    const uint32_t o0 = whole ? blane[0] : blane_last[0], o1 = whole ? blane[1] : blane_last[1];
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %4, %7\n\t"
+                 "global_load_dwordx4 %2, %5, %6\n\tglobal_load_dwordx4 %3, %5, %7"
+                 : "=&v"(b.q[0]), "=&v"(b.v[0]), "=&v"(b.q[1]), "=&v"(b.v[1])
+                 : "v"(o0), "v"(o1), "s"(scalar_ptr(pq)), "s"(scalar_ptr(pv)) : "memory");
+  };
+  auto advanceB = [&]() {
+    ++bt;
+    if (bt < nit) {
+      if (blb + 16 == lb_end) {
+        blb = 0; ++bjr;
+        if (i + bjr < K) { pq += pair_step; pv += pair_step; }
+        else { pq = a.gT; pv = a.v; }
+      } else {
+        blb += 16; pq += 16; pv += 16;
+      }
+    }
+  };
+  f32x4 xm[KB], xd[KB];
+  auto readM = [&](int st) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xm[kb] = *reinterpret_cast<const f32x4*>(&As[st][0][kb * 16 + c16][4 * g4]);
+  };
+  auto readD = [&](int st) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xd[kb] = *reinterpret_cast<const f32x4*>(&As[st][1][kb * 16 + c16][4 * g4]);
+  };
+  // One iteration of a multiplying wave: 16 * KB MFMAs with everything else it has to do placed BETWEEN them -- a wave's own
+  // instructions issue in the shadow of its MFMAs for free, while anything it executes outside its MFMA stream competes
+  // for the one issue slot per MFMA the SIMD grants beside the other wave's stream.  Placed: the request for iteration it+3
+  // (into the ring's fourth slot), the cursor update, and the LDS reads of the next iteration's A fragments (M after the last
+  // MFMA that uses the current M fragments, -dM/ds after the last MFMA; their stage was written during it-1).
+  // (the staged A tile is zero in every padded row / column / iteration and, for the terminal pair, in all of -dM/ds; the
+  //  clamped reads return finite operand values there: no masks on the B side)
+  auto iteration = [&](const BSlot& b, BSlot& req, int st_next) {
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm[kb][s2], b.q[c][s2], acc[kb][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s2 == 0) requestB(req);
+      if (s2 == 1) advanceB();
+      if (s2 == 3) readM(st_next);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[kb][s2], b.v[c][s2], acc[kb][c], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    readD(st_next);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define SOCMX_WAIT_B(N, S) \
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"((S).q[0]), "+v"((S).q[1]), "+v"((S).v[0]), "+v"((S).v[1]) : "n"(N) : "memory")
+  BSlot bs[4];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { requestB(bs[u]); advanceB(); }
+  __syncthreads();                               // stages 0 and 1 visible
+  readM(0);
+  readD(0);
+  // developer switch (tools/ubench/contraction_bench.hip builds this file with it): per-wave cycle counters of the three
+  // phases of an iteration -- waiting at the barrier, waiting for the operands, multiplying
+#ifdef SOCMX_CONTRACTION_PROF
+  long long tp[3] = {0, 0, 0};
+  long long tlast = clock64();
+#define TICK(k) { const long long tn = clock64(); tp[k] += tn - tlast; tlast = tn; }
+#else
+#define TICK(k)
+#endif
+  for (int it0 = 0; it0 < nitp; it0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      __syncthreads();                           // (it = it0 + u) stage of it+1 written
+      TICK(0)
+      SOCMX_WAIT_B(8, bs[u]);                    // younger than B(it): B(it+1) B(it+2)
+      TICK(1)
+      iteration(bs[u], bs[(u + 3) % 4], (u + 1) % 4);
+      TICK(2)
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the over-fetched requests of the last trips
+#undef SOCMX_WAIT_B
+#undef TICK
+#ifdef SOCMX_CONTRACTION_PROF
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+    for (int k2 = 0; k2 < 3; ++k2) g_contraction_prof[wave][k2] = tp[k2];
+    g_contraction_prof[wave][3] = nitp;
+  }
+#endif
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (mcol[c] < B) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = kb * 16 + 4 * g4 + r;
+          if (k < d) a.target[((size_t)i * B + mcol[c]) * d + k] = acc[kb][c][r];
+        }
+      }
 }
 
 // r = sigma^T (nablaV - target), objective += inv_norm * sum w |r|^2, G = 2 w inv_norm sigma r.
@@ -1355,8 +1633,8 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
       wgrid.x = K + 1;
       const bool al4 = d % 4 == 0;
 #define SOCMX_LDS_LAUNCH(NETV, KBV) \
-  lerr = al4 ? launch(socm_target_lds_kernel<NETV, KBV, true>, wgrid, wblk, 0, st0, a) \
-             : launch(socm_target_lds_kernel<NETV, KBV, false>, wgrid, wblk, 0, st0, a)
+  lerr = al4 ? launch(socm_target_lds4_kernel<NETV, KBV>, wgrid, dim3(64 * (kTargetWaves + kStageWaves)), 0, st0, a) \
+             : launch(socm_target_lds_kernel<NETV, KBV>, wgrid, wblk, 0, st0, a)
       if (delta) {
         if (d <= 32) SOCMX_LDS_LAUNCH(true, 2);
         else         SOCMX_LDS_LAUNCH(true, 4);

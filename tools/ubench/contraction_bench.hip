@@ -1,5 +1,6 @@
-// Stand-alone timing of the SOCM contraction kernels at one shape (developer tool; used for A/B experiments with -D switches):
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -o /tmp/cb tools/ubench/contraction_bench.hip && /tmp/cb 64 400 512
+// Stand-alone timing of the SOCM contraction kernels at one shape (developer tool):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include [-DSOCMX_CONTRACTION_PROF] -o /tmp/cb tools/ubench/contraction_bench.hip
+//   /tmp/cb 64 400 512        (d K B [repetitions]; -DSOCMX_CONTRACTION_PROF adds the forward kernel's in-kernel cycle counters)
 // Includes the product translation unit, so it times exactly the shipped kernels through the C ABI entry points.
 #include "../../soc-matching_amd/csrc/socmx_loss.hip"
 #include <cstdio>
@@ -39,6 +40,15 @@ int main(int argc, char** argv) {
     }
     hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     printf("%s d=%d K=%d B=%d: %.3f ms  %.1f TFLOP/s\n", pass == 0 ? "fwd(+residual)" : "bwd", d, K, B, ms / reps, fl / (ms / reps) / 1e9);
+#ifdef SOCMX_CONTRACTION_PROF
+    if (pass == 0) {      // d % 4 == 0, 16 < d <= 64, B >= 256: socm_target_lds4_kernel's counters (workgroup 0 = the longest row)
+      long long h[8][4];
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(socmx::g_contraction_prof), sizeof(h));
+      for (int w2 = 0; w2 < 8; ++w2)
+        printf("  wave %d: cycles per iteration: barrier %6.0f  operand wait %6.0f  multiply (64 MFMAs = 2048) %6.0f   (%lld iterations)\n", w2,
+               (double)h[w2][0] / h[w2][3], (double)h[w2][1] / h[w2][3], (double)h[w2][2] / h[w2][3], h[w2][3]);
+    }
+#endif
   }
   return 0;
 }
