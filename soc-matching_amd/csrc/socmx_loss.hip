@@ -1337,11 +1337,9 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_lds_kernel(const Targe
         const int c = c0 + h;             // c & 1 == h
         if (c < nch) {
           __syncthreads();                // stage h visible; everyone is done reading stage 1-h
-          if (loader && c + 1 < nch) {
-            stage((c + 1) * 16, 1 - h, 1 - h);
-            if (c + 3 < nch) gload((c + 3) * 16, 1 - h);
-          }
           if constexpr (decltype(with_mfma)::value) {
+            // The loader work sits BETWEEN this wave's MFMAs: beside the MFMA streams of the other workgroups' waves on
+            // this SIMD an instruction outside one's own stream gets one issue slot per MFMA (see socm_target_lds4_kernel).
             const f32x4 ga = *reinterpret_cast<const f32x4*>(&Ts[h][0][kb + c16][4 * g4]);
             f32x4 qb[LB], vb[LB];
 #pragma unroll
@@ -1354,10 +1352,17 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_lds_kernel(const Targe
 #pragma unroll
               for (int b = 0; b < LB; ++b)
                 accq[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[u], qb[b][u], accq[b], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (u == 0 && loader && c + 1 < nch) stage((c + 1) * 16, 1 - h, 1 - h);
+              if (u == 1 && loader && c + 3 < nch) gload((c + 3) * 16, 1 - h);
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int b = 0; b < LB; ++b)
                 accv[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[u], vb[b][u], accv[b], 0, 0, 0);
             }
+          } else if (loader && c + 1 < nch) {
+            stage((c + 1) * 16, 1 - h, 1 - h);
+            if (c + 3 < nch) gload((c + 3) * 16, 1 - h);
           }
         }
       }
@@ -1372,6 +1377,48 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_lds_kernel(const Targe
   const size_t base = (size_t)p * d * d;
   float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
   if (NET) { gam = a.gamma[0]; dl = a.delta[p]; e = expf(-gam * dl); }
+  if (kb + 16 <= d && 16 * LB <= d) {
+    // Whole 16 x (16 LB) block (d = 64: always).  The epilogue runs beside the other workgroups' MFMA streams, where every
+    // instruction costs about one MFMA time (see socm_target_lds4_kernel): wave-uniform base pointers + four lane offsets
+    // (one per accumulator row, the l-block as an immediate) instead of 64-bit address arithmetic per element, no
+    // predicates, all 2 x 4 LB loads in flight before the arithmetic, constants folded (844 -> ~300 instructions).
+    const size_t blk = base + (size_t)kb * d;
+    const char* netb = reinterpret_cast<const char*>(a.net + blk);
+    const char* dnetb = reinterpret_cast<const char*>(a.dnet + blk);
+    char* gMb = reinterpret_cast<char*>(a.gM + blk);
+    char* gdMb = reinterpret_cast<char*>(a.gdM + blk);
+    uint32_t off[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) off[rr] = (uint32_t)((4 * g4 + rr) * d + c16) * 4u;
+    const float f = NET ? 1.f - e : 1.f, ge = gam * e;
+    const float kq = -f * go, kv = ge * go, kd = f * go;                  // gM = kq accq + kv accv,  gdM = kd accv
+    const float c1 = dl * e * go, c2 = e * (1.f - gam * dl) * go;         // d/dgamma: -accq c1 nmi + accv (c2 nmi + c1 dnet)
+    float nt[LB][4], dn[LB][4];
+    if (NET) {
+#pragma unroll
+      for (int b = 0; b < LB; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          nt[b][rr] = *reinterpret_cast<const float*>(netb + (size_t)off[rr] + 64 * b);
+          dn[b][rr] = *reinterpret_cast<const float*>(dnetb + (size_t)off[rr] + 64 * b);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < LB; ++b)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float aq_ = accq[b][rr], av_ = accv[b][rr];
+        if (NET) {
+          const float nmi = nt[b][rr] - ((b == wave && c16 == 4 * g4 + rr) ? 1.f : 0.f);
+          part += av_ * fmaf(c2, nmi, c1 * dn[b][rr]) - aq_ * (c1 * nmi);
+          *reinterpret_cast<float*>(gMb + (size_t)off[rr] + 64 * b) = fmaf(kq, aq_, kv * av_);
+          *reinterpret_cast<float*>(gdMb + (size_t)off[rr] + 64 * b) = kd * av_;
+        } else {
+          *reinterpret_cast<float*>(gMb + (size_t)off[rr] + 64 * b) = -go * aq_;
+          *reinterpret_cast<float*>(gdMb + (size_t)off[rr] + 64 * b) = go * av_;
+        }
+      }
+  } else
 #pragma unroll
   for (int b = 0; b < LB; ++b) {
     const int l = b * 16 + c16;
