@@ -27,6 +27,12 @@ python3 bench.py > $R/bench.json 2> $R/bench.err
 # the fused control-network backward alone (cfg3 and the cfg5 slice), the iteration in both modes, the stage-chain floor
 for c in cfg3 cfg5r; do bash tools/k2_prof.sh $c > $R/k2_$c.txt 2>&1; done
 for c in cfg2 cfg3; do for m in eager graph; do bash tools/iter_prof.sh $c $m > $R/iter_${c}_$m.txt 2>&1; done; done
+bash tools/iter_prof.sh cfg5r eager > $R/iter_cfg5r_eager.txt 2>&1
+# the d = 64 contraction kernels alone (with the forward kernel's in-kernel cycle counters) and the two issue micro-benchmarks
+# their schedule is built on
+(hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -DSOCMX_CONTRACTION_PROF -o /tmp/cb tools/ubench/contraction_bench.hip 2>/dev/null && /tmp/cb 64 400 512 5) > $R/contraction_cfg5r.txt 2>&1
+(hipcc -O3 --offload-arch=gfx950 -o /tmp/mi tools/ubench/mfma_issue.hip 2>/dev/null && /tmp/mi) > $R/mfma_issue.txt 2>&1
+(hipcc -O3 --offload-arch=gfx950 -o /tmp/ov tools/ubench/mfma_valu_overlap.hip 2>/dev/null && /tmp/ov) > $R/mfma_valu_overlap.txt 2>&1
 python3 tools/iter_bench.py md eager > $R/iter_md.txt 2>&1; python3 tools/iter_bench.py md graph >> $R/iter_md.txt 2>&1
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o stage_chain stage_chain.hip 2>/dev/null && ./stage_chain) > $R/stage_chain.txt 2>&1
 python3 tools/quick_bench.py cfg3 cfg2 ouq20 cfg5r burst 2>&1 | grep -E "parity|rollout|iteration" > $R/quick.txt
