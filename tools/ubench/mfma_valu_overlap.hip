@@ -38,12 +38,6 @@ __global__ __launch_bounds__(512) void k(int do_mfma, int do_other, int n, float
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("v_add_u32 %0, %0, %0" : "+v"(x));
       r = x;
-    } else if (KIND == 2) {     // scalar chain
-      int x = wave;
-      for (int it = 0; it < n; ++it)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("s_add_u32 %0, %0, %0" : "+s"(x));
-      r = x;
     } else if (KIND == 3) {     // LDS reads
       float x = 0.f;
       for (int it = 0; it < n; ++it)
@@ -88,7 +82,6 @@ int main() {
   run<0>("dependent v_fma_f32", out, cyc);
   run<4>("4 independent v_fma_f32", out, cyc);
   run<1>("dependent v_add_u32", out, cyc);
-  run<2>("dependent s_add_u32", out, cyc);
   run<3>("ds_read_b32 + add", out, cyc);
   return 0;
 }
