@@ -277,6 +277,12 @@ __device__ __forceinline__ f32x4 load4(const float* base, int off, int limit) {
   return r;
 }
 
+__device__ __forceinline__ const void* scalar_ptr(const void* p) {     // a wave-uniform pointer, pinned to scalar registers
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+}
+
 constexpr int kTargetWaves = 8;  // waves per workgroup: the (pair, l-block) iterations of a row are dealt round-robin
 
 // CT = 16-column batch tiles per wave: the A fragments (and, for NET, the blend that forms them) are built once
@@ -754,11 +760,6 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
 //      iteration, under the 128 slots two multiplying waves leave), and the multiplying waves issue their own operand
 //      requests, cursor arithmetic and LDS reads BETWEEN their MFMAs.  Per iteration: 6,000 -> 4,700 cycles (4,096 is
 //      the MFMA time), 7.6 -> 6.3 ms at the configs[4] slice (107 TFLOP/s, 0.68 of the fp32 MFMA peak).
-__device__ __forceinline__ const void* scalar_ptr(const void* p) {     // a wave-uniform pointer, pinned to scalar registers
-  const uint64_t u = reinterpret_cast<uint64_t>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-  return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
-}
 __device__ __forceinline__ f32x4 async_load16(const void* sbase, uint32_t voff) {
   sbase = scalar_ptr(sbase);
   f32x4 r;
@@ -1075,7 +1076,7 @@ struct TargetBwdArgs {
 // Consecutive waves take consecutive j of one row i, so the A operand stays in L1/L2.  NET = true chains the
 // derivative of M = e I + (1-e) net, dM = gamma e (net - I) + (1-e) dnet in the epilogue.
 template <bool NET>
-__global__ __launch_bounds__(256) void socm_target_bwd_mfma_kernel(const TargetBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void socm_target_bwd_mfma_kernel(const TargetBwdArgs a) {
   const int d = a.d, K = a.K, B = a.B;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1087,6 +1088,7 @@ __global__ __launch_bounds__(256) void socm_target_bwd_mfma_kernel(const TargetB
   int r = (int)((sqrtf(8.f * (float)pe + 1.f) - 1.f) * 0.5f);
   while ((int64_t)(r + 1) * (r + 2) / 2 <= pe) ++r;
   while ((int64_t)r * (r + 1) / 2 > pe) --r;
+  r = __builtin_amdgcn_readfirstlane(r);     // (came through the float unit: pin it -- and every pointer derived from it -- to scalar registers)
   const int i = K - r;
   const int jr = (int)(p - pair_row_offset(i, K));
   const int j = i + jr;
@@ -1094,47 +1096,111 @@ __global__ __launch_bounds__(256) void socm_target_bwd_mfma_kernel(const TargetB
   const int c16 = lane & 15, g4 = lane >> 4;
   const int kb = blockIdx.y * 16, lb = blockIdx.z * 16;
   const int k = kb + c16, l = lb + c16;
-  const bool okk = k < d, okl = l < d;
-  const float* Ap = a.G + (size_t)i * B * d + (okk ? k : d - 1);
-  const float* Bq = (last ? a.gT : a.q + (size_t)j * B * d) + (okl ? l : d - 1);
-  const float* Bv = a.v + (size_t)(last ? 0 : j) * B * d + (okl ? l : d - 1);
+  const bool okl = l < d;
+  // Lean instruction stream (this kernel is bound by instruction issue, not by the MFMA pipe or memory: 10 vector
+  // instructions per MFMA before, `profiles/r2`): wave-uniform base pointers advanced per chunk + four loop-invariant lane
+  // offsets per operand instead of 64-bit address arithmetic per load; NO operand masks -- lanes of padded rows / columns
+  // read clamped (finite) addresses and feed accumulator elements that are never stored; the terminal pair skips the v
+  // products; only a ragged last chunk zeroes its missing batch rows.
+  const uint32_t cola = (uint32_t)min(k, d - 1) * 4u, colb = (uint32_t)min(l, d - 1) * 4u;
+  uint32_t offa[4], offb[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    offa[u] = (uint32_t)((4 * u + g4) * d) * 4u + cola;
+    offb[u] = (uint32_t)((4 * u + g4) * d) * 4u + colb;
+  }
+  const char* Ap = reinterpret_cast<const char*>(a.G + (size_t)i * B * d);
+  const char* Bq = reinterpret_cast<const char*>(last ? a.gT : a.q + (size_t)j * B * d);
+  const char* Bv = reinterpret_cast<const char*>(a.v + (size_t)(last ? 0 : j) * B * d);
+  const size_t chunk_bytes = (size_t)16 * d * 4;
   f32x4 accq = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
-  for (int m0 = 0; m0 < B; m0 += 16) {   // 12 loads in flight, then 8 MFMAs
-    float af[4], qf[4], vf[4];
+  struct Chunk { float af[4], qf[4], vf[4]; };
+  const char *ap = Ap, *qp = Bq, *vp = Bv;     // running chunk bases (scalar registers: the loads need no vector address arithmetic)
+  auto load = [&](Chunk& ch) {                 // 12 loads: the next 16 rows (4u + g4), this lane's k / l column
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ch.af[u] = *reinterpret_cast<const float*>(ap + (size_t)offa[u]);
+      ch.qf[u] = *reinterpret_cast<const float*>(qp + (size_t)offb[u]);
+      ch.vf[u] = *reinterpret_cast<const float*>(vp + (size_t)offb[u]);
+    }
+    ap += chunk_bytes; qp += chunk_bytes; vp += chunk_bytes;
+  };
+  auto multiply = [&](const Chunk& ch) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) accq = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.af[u], ch.qf[u], accq, 0, 0, 0);
+    if (!last) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accv = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.af[u], ch.vf[u], accv, 0, 0, 0);
+    }
+  };
+  const int nfull = B >> 4;                    // whole 16-row chunks; the next one is requested before the current is multiplied
+  Chunk c0, c1;
+  if (nfull > 0) load(c0);
+  for (int c = 0; c < nfull; c += 2) {
+    if (c + 1 < nfull) load(c1);
+    multiply(c0);
+    if (c + 1 < nfull) {
+      if (c + 2 < nfull) load(c0);
+      multiply(c1);
+    }
+  }
+  if (B & 15) {                                // ragged last chunk: rows past the batch are clamped and their A values zeroed
+    const int m0 = nfull * 16;
+    Chunk ct;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int m = m0 + 4 * u + g4;
-      const bool okm = m < B;
-      const size_t off = (size_t)(okm ? m : B - 1) * d;
-      const float av = Ap[off], qv = Bq[off], vv = Bv[off];
-      af[u] = (okm && okk) ? av : 0.f;
-      qf[u] = okl ? qv : 0.f;
-      vf[u] = (okl && !last) ? vv : 0.f;
+      const size_t ro = (size_t)min(m, B - 1) * d * 4;
+      const float av = *reinterpret_cast<const float*>(Ap + ro + cola);
+      ct.af[u] = m < B ? av : 0.f;
+      ct.qf[u] = *reinterpret_cast<const float*>(Bq + ro + colb);
+      ct.vf[u] = *reinterpret_cast<const float*>(Bv + ro + colb);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      accq = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u], qf[u], accq, 0, 0, 0);
-      accv = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u], vf[u], accv, 0, 0, 0);
-    }
+    multiply(ct);
   }
   const float go = a.gout ? a.gout[0] : 1.f;
-  const size_t base = (size_t)p * d * d;
   float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
   if (NET) { gam = a.gamma[0]; dl = a.delta[p]; e = expf(-gam * dl); }
+  {
+    // epilogue: wave-uniform block base + one lane offset per accumulator row, constants folded
+    const size_t blk = (size_t)p * d * d + (size_t)kb * d;
+    const char* netb = reinterpret_cast<const char*>(a.net + blk);
+    const char* dnetb = reinterpret_cast<const char*>(a.dnet + blk);
+    char* gMb = reinterpret_cast<char*>(a.gM + blk);
+    char* gdMb = reinterpret_cast<char*>(a.gdM + blk);
+    const float f = NET ? 1.f - e : 1.f, ge = gam * e;
+    const float kq = -f * go, kv = ge * go, kd = f * go;                  // gM = kq accq + kv accv,  gdM = kd accv
+    const float c1g = dl * e * go, c2g = e * (1.f - gam * dl) * go;       // d/dgamma: -accq c1 nmi + accv (c2 nmi + c1 dnet)
+    float nt[4], dn[4];
+    bool ok[4];
+    uint32_t off[4];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int kk = kb + 4 * g4 + rr;
-    if (kk < d && okl) {
-      const size_t idx = base + (size_t)kk * d + l;
-      const float gm = -accq[rr] * go, gd = accv[rr] * go;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int kl = 4 * g4 + rr;              // row inside the block
+      ok[rr] = kb + kl < d && okl;
+      off[rr] = (uint32_t)(min(kl, d - 1 - kb) * d + min(l, d - 1)) * 4u;
       if (NET) {
-        const float nmi = a.net[idx] - (kk == l ? 1.f : 0.f);
-        a.gM[idx] = (1.f - e) * gm + gam * e * gd;
-        a.gdM[idx] = (1.f - e) * gd;
-        part += gm * dl * e * nmi + gd * (e * (1.f - gam * dl) * nmi + dl * e * a.dnet[idx]);
+        nt[rr] = *reinterpret_cast<const float*>(netb + (size_t)off[rr]);
+        dn[rr] = *reinterpret_cast<const float*>(dnetb + (size_t)off[rr]);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float aq_ = accq[rr], av_ = accv[rr];
+      float gm_, gd_;
+      if (NET) {
+        const float nmi = nt[rr] - ((kb + 4 * g4 + rr == l) ? 1.f : 0.f);
+        const float t = av_ * fmaf(c2g, nmi, c1g * dn[rr]) - aq_ * (c1g * nmi);
+        part += ok[rr] ? t : 0.f;
+        gm_ = fmaf(kq, aq_, kv * av_);
+        gd_ = kd * av_;
       } else {
-        a.gM[idx] = gm;
-        a.gdM[idx] = gd;
+        gm_ = -go * aq_;
+        gd_ = go * av_;
+      }
+      if (ok[rr]) {
+        *reinterpret_cast<float*>(gMb + (size_t)off[rr]) = gm_;
+        *reinterpret_cast<float*>(gdMb + (size_t)off[rr]) = gd_;
       }
     }
   }
@@ -1159,6 +1225,7 @@ __global__ __launch_bounds__(256) void socm_target_bwd_wide_kernel(const TargetB
   int r = (int)((sqrtf(8.f * (float)pe + 1.f) - 1.f) * 0.5f);
   while ((int64_t)(r + 1) * (r + 2) / 2 <= pe) ++r;
   while ((int64_t)r * (r + 1) / 2 > pe) --r;
+  r = __builtin_amdgcn_readfirstlane(r);     // (came through the float unit: pin it -- and every pointer derived from it -- to scalar registers)
   const int i = K - r;
   const int j = i + (int)(p - pair_row_offset(i, K));
   const bool last = (j == K);
@@ -1275,6 +1342,7 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_lds_kernel(const Targe
   int r = (int)((sqrtf(8.f * (float)pe + 1.f) - 1.f) * 0.5f);
   while ((int64_t)(r + 1) * (r + 2) / 2 <= pe) ++r;
   while ((int64_t)r * (r + 1) / 2 > pe) --r;
+  r = __builtin_amdgcn_readfirstlane(r);     // (came through the float unit: pin it -- and every pointer derived from it -- to scalar registers)
   const int i = K - r;
   const int j = i + (int)(p - pair_row_offset(i, K));
   const bool last = (j == K);
