@@ -651,34 +651,51 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
 #pragma unroll
     for (int k = 0; k < NIB; ++k) acc[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  constexpr int PD = 3;                         // tiles in flight
+  // Three tiles of operands in flight.  The loads are asm statements and the waits are written out: with `if (t < t1) load`
+  // in the loop the compiler's wait-count insertion falls back to (nearly) vmcnt(0) in front of every tile's MFMAs, i.e. one
+  // tile in flight (the socm_target_lds4_kernel story, socmx_loss.hip).  Requests past the slab's last tile re-read it, so
+  // that "two younger tiles may stay in flight" is the same number on every trip.
+  constexpr int PD = 3, NL = NOB + NIB;
   f32x4 ga[PD][NOB], ab[PD][NIB];
   auto load = [&](int t, int s) {
+    const int tc = min(t, t1 - 1);
 #pragma unroll
-    for (int j = 0; j < NOB; ++j) ga[s][j] = *reinterpret_cast<const f32x4*>(gbase + (size_t)t * gstep + oo[j]);
+    for (int j = 0; j < NOB; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ga[s][j]) : "v"(gbase + (size_t)tc * gstep + oo[j]) : "memory");
 #pragma unroll
-    for (int k = 0; k < NIB; ++k) ab[s][k] = *reinterpret_cast<const f32x4*>(abase + (size_t)t * astep + io[k]);
+    for (int k = 0; k < NIB; ++k)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ab[s][k]) : "v"(abase + (size_t)tc * astep + io[k]) : "memory");
   };
+  auto wait_slot = [&](int s) {                 // the two younger tiles may stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
 #pragma unroll
-  for (int s = 0; s < PD; ++s)
-    if (t0 + s < t1) load(t0 + s, s);
-  for (int t = t0; t < t1; t += PD) {
+    for (int j = 0; j < NOB; ++j) asm volatile("" : "+v"(ga[s][j]));
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
-      if (t + s < t1) {
+    for (int k = 0; k < NIB; ++k) asm volatile("" : "+v"(ab[s][k]));
+  };
+  if (t0 < t1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int s = 0; s < PD; ++s) load(t0 + s, s);
+    for (int t = t0; t < t1; t += PD) {
+#pragma unroll
+      for (int s = 0; s < PD; ++s) {
+        wait_slot(s);
+        if (t + s < t1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NOB; ++j)
+#pragma unroll
+              for (int k = 0; k < NIB; ++k)
+                acc[j][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][j][i], ab[s][k][i], acc[j][k], 0, 0, 0);
 #pragma unroll
           for (int j = 0; j < NOB; ++j)
-#pragma unroll
-            for (int k = 0; k < NIB; ++k)
-              acc[j][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][j][i], ab[s][k][i], acc[j][k], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NOB; ++j)
-          if (!a.bias_even_tiles || !((t + s) & 1)) bsum[j] += (ga[s][j][0] + ga[s][j][1]) + (ga[s][j][2] + ga[s][j][3]);
-        if (t + s + PD < t1) load(t + s + PD, s);
+            if (!a.bias_even_tiles || !((t + s) & 1)) bsum[j] += (ga[s][j][0] + ga[s][j][1]) + (ga[s][j][2] + ga[s][j][3]);
+        }
+        load(t + s + PD, s);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   float* out = a.part + (size_t)slab * a.slab_floats;
   // D: lane (c, g) holds out-units 4g .. 4g+3 of in-unit c -> the cell's 256 floats in (lane, component) order
@@ -699,7 +716,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
   }
 }
 
-__global__ __launch_bounds__(256) void unet_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void unet_wgrad_kernel(const WgradArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2): all block groups
