@@ -164,15 +164,20 @@ def cpu_baseline(budget_s=12.0):
     n, el = timed(1, budget_s / 2)
     used, note = 1, "1 thread"
     if ncpu > 1:
-        p1, pn = probe(1), probe(ncpu)
-        if pn < 0.9 * p1:
-            n2, el2 = timed(ncpu, budget_s / 2)
+        # thread counts between one and all cores are probed on 10 steps each; the best one gets the second half of the budget
+        cands = sorted({c for c in (2, 4, 8, 16, 32, ncpu) if 1 < c <= ncpu})
+        p1 = probe(1)
+        probes = {c: probe(c) for c in cands}
+        best_c = min(probes, key=probes.get)
+        shown = ", ".join(f"{c}: {1e3 * probes[c]:.0f}" for c in cands)
+        if probes[best_c] < 0.9 * p1:
+            n2, el2 = timed(best_c, budget_s / 2)
             if n2 / el2 > n / el:
-                n, el, used = n2, el2, ncpu
-            note = f"best of 1 and {ncpu} threads"
+                n, el, used = n2, el2, best_c
+            note = f"best of 1 and {best_c} threads (10-step probes, ms per thread count: 1: {1e3 * p1:.0f}, {shown})"
         else:
-            note = (f"1 thread; all {ncpu} threads probed on {10} steps: {1e3 * pn:.0f} ms vs {1e3 * p1:.0f} ms "
-                    f"with 1 thread (dispatch-bound), full all-core leg skipped")
+            note = (f"1 thread; 10-step probes, ms per thread count: 1: {1e3 * p1:.0f}, {shown} "
+                    f"(dispatch-bound: no multi-thread leg)")
     torch.set_num_threads(1)
     best = dict(value=n * B * K / el, unit="trajectory-steps/s", cores=used, kind="port",
                 sample=f"{n} rollouts of double_well d=10 K=200 B=128 (oracle eager torch-CPU, {el:.1f} s, {note})",
