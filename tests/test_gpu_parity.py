@@ -256,7 +256,13 @@ def test_fused_pair_matrix_kernels_vs_materialised(name):
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=2e-6 * max(1e-3, np.abs(b).max()), err_msg=nm)
 
 
-@pytest.mark.parametrize("d,K,B", [(20, 7, 24), (40, 5, 70), (64, 4, 16), (3, 9, 130), (24, 3, 300), (64, 2, 256)])
+@pytest.mark.parametrize("d,K,B", [(20, 7, 24), (40, 5, 70), (64, 4, 16), (3, 9, 130), (24, 3, 300), (64, 2, 256),
+                                   # B >= 256, d % 4 == 0: the twelve-wave forward kernel / transposed-tile backward kernel --
+                                   # partial last l-block at two and four k-blocks, three l-blocks, ragged batch, rows long
+                                   # enough for the request rings to wrap several times
+                                   (36, 6, 272), (48, 9, 260), (60, 5, 512), (32, 11, 257), (20, 12, 256), (64, 7, 300),
+                                   # d % 4 != 0 at B >= 256: the compiler-scheduled LDS form
+                                   (22, 4, 256), (50, 3, 270)])
 def test_contraction_kernels_multi_block_shapes(d, K, B):
     """d > 16 takes several 16-wide k/l blocks per pair matrix, B > 32 four batch tiles per wave (ragged last tile):
     none of the reference-generated fixtures is that large, so the HIP contraction (materialised and fused forms,
