@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 110 /* 0.1.1 */
+#define SOCMX_VERSION 111 /* 0.1.1 + socmx_adam_step_f32 */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -353,6 +353,31 @@ int socmx_socm_stopping_target_bwd_f32(int32_t d, int32_t K, int32_t B, const fl
 int socmx_iteration_scalars_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
                                 const float* w_std, const float* obj, const float* gn, const float* gne,
                                 double c_norm, double c_grad, float* ab, float* out, socmx_stream_t stream);
+
+/*
+ * Adam update of one parameter group from a FLAT gradient buffer, fused with the gradient telemetry of main.py:325-345:
+ * torch.optim.Adam's rule as main.py:174-238, 347-349 configure it (no weight decay, no amsgrad) -- ONE launch instead of the
+ * optimiser's multi-tensor launches, two dot products, an EMA update and a coefficient kernel per iteration.
+ *   tensors (ntensors <= 64 records in DEVICE memory): per parameter tensor its data / exp_avg / exp_avg_sq / step pointers,
+ *     its element count and its offset into grad; the step tensors hold the number of updates so far (float, all equal) and
+ *     are advanced by the call.
+ *   grad (total,): the flat gradient (socmx_unet_backward_f32's output order).
+ *   ema_grad (total,) or NULL: telemetry  ema <- A ema + B grad, (A, B) from the iteration counter itr (1,) exactly as
+ *     socmx_iteration_scalars_f32 phase 0 computes them (c_grad = the EMA coefficient).
+ *   sums_out[0..1] = |grad|^2, |ema_grad|^2 (0 without ema_grad).
+ *   scratch: 4 floats of caller-owned device memory, zero before the first call (the call leaves it zero again).
+ */
+typedef struct socmx_adam_tensor {
+  float* p;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* step;
+  int64_t n;
+  int64_t offset;
+} socmx_adam_tensor;
+int socmx_adam_step_f32(const socmx_adam_tensor* tensors, int32_t ntensors, int64_t total, const float* grad,
+                        float* ema_grad, const float* itr, double c_grad, float lr, float beta1, float beta2, float eps,
+                        float* scratch, float* sums_out, socmx_stream_t stream);
 
 /*
  * Column sums of a tall row-major (R, C) matrix: out[c] = sum_r x[r][c].  Bias gradients of the nn.Linear layers

@@ -1663,12 +1663,108 @@ __global__ void iteration_scalars_kernel(const ScalarArgs a) {
   a.itr[0] = itr + 1.f;
 }
 
+// ---- Adam on a flat gradient + gradient telemetry (main.py:174-238, 325-349) ------------------------------------------
+struct AdamArgs {
+  const socmx_adam_tensor* tensors;
+  int ntensors;
+  int64_t total;
+  const float* grad;
+  float* ema;
+  const float* itr;
+  float c_grad, one_minus_c_grad, warm_grad;
+  float lr, beta1, beta2, eps;
+  float* scratch;      // [0] = sum g^2, [1] = sum ema^2, [2] = finished-workgroup ticket (as unsigned)
+  float* sums_out;
+};
+
+constexpr int kAdamPerBlock = 1024;
+
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
+  __shared__ socmx_adam_tensor tab[64];
+  __shared__ float red[2][4];
+  __shared__ unsigned last_flag;
+  const int tid = threadIdx.x;
+  if (tid < a.ntensors) tab[tid] = a.tensors[tid];
+  __syncthreads();
+  // step count BEFORE this update (every workgroup reads it before the last one to finish advances it)
+  const float t = tab[0].step[0] + 1.f;
+  const float bc1 = 1.f - powf(a.beta1, t), bc2s = sqrtf(1.f - powf(a.beta2, t));
+  const float step_size = a.lr / bc1;
+  float A = 0.f, Bc = 1.f;
+  if (a.ema) {
+    const float itr = a.itr[0];
+    if (itr == 0.f) { A = 0.f; Bc = 1.f; }
+    else if (itr <= a.warm_grad) { A = itr / (itr + 1.f); Bc = 1.f / (itr + 1.f); }
+    else { A = a.one_minus_c_grad; Bc = a.c_grad; }
+  }
+  float sg = 0.f, se = 0.f;
+  const int64_t f0 = (int64_t)blockIdx.x * kAdamPerBlock;
+  int ti = 0;
+#pragma unroll
+  for (int r = 0; r < kAdamPerBlock / 256; ++r) {
+    const int64_t f = f0 + r * 256 + tid;
+    if (f < a.total) {
+      while (ti + 1 < a.ntensors && f >= tab[ti + 1].offset) ++ti;      // offsets ascend; f ascends with r
+      const int64_t k = f - tab[ti].offset;
+      const float g = a.grad[f];
+      sg += g * g;
+      if (a.ema) {
+        const float em = A * a.ema[f] + Bc * g;
+        a.ema[f] = em;
+        se += em * em;
+      }
+      float m = tab[ti].exp_avg[k], v = tab[ti].exp_avg_sq[k];
+      m = m + (g - m) * (1.f - a.beta1);
+      v = a.beta2 * v + (1.f - a.beta2) * g * g;
+      tab[ti].exp_avg[k] = m;
+      tab[ti].exp_avg_sq[k] = v;
+      const float denom = sqrtf(v) / bc2s + a.eps;
+      tab[ti].p[k] -= step_size * m / denom;
+    }
+  }
+  sg = wave_sum(sg); se = wave_sum(se);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sg; red[1][tid >> 6] = se; }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&a.scratch[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&a.scratch[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    __threadfence();
+    const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(a.scratch + 2), 1u);
+    last_flag = (ticket == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last_flag) {                           // every workgroup has finished: publish the sums, re-arm, advance the step counters
+    __threadfence();
+    if (tid == 0) {
+      a.sums_out[0] = atomicAdd(&a.scratch[0], 0.f);
+      a.sums_out[1] = atomicAdd(&a.scratch[1], 0.f);
+      a.scratch[0] = 0.f; a.scratch[1] = 0.f;
+      *reinterpret_cast<unsigned*>(a.scratch + 2) = 0u;
+    }
+    if (tid < a.ntensors) tab[tid].step[0] = t;
+  }
+}
+
 }  // namespace socmx
 
 // =================================================================================================
 // C ABI
 // =================================================================================================
 using namespace socmx;
+
+extern "C" int socmx_adam_step_f32(const socmx_adam_tensor* tensors, int32_t ntensors, int64_t total, const float* grad,
+                                   float* ema_grad, const float* itr, double c_grad, float lr, float beta1, float beta2,
+                                   float eps, float* scratch, float* sums_out, socmx_stream_t stream) {
+  if (!tensors || !grad || !scratch || !sums_out || (ema_grad && !itr)) return SOCMX_E_NULL;
+  if (ntensors < 1 || ntensors > 64 || total < 1 || (ema_grad && !(c_grad > 0.0))) return SOCMX_E_DIM;
+  AdamArgs a;
+  a.tensors = tensors; a.ntensors = ntensors; a.total = total; a.grad = grad; a.ema = ema_grad; a.itr = itr;
+  a.c_grad = (float)c_grad; a.one_minus_c_grad = (float)(1.0 - c_grad);
+  a.warm_grad = ema_grad ? (float)(int)floor(1.0 / c_grad) : 0.f;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.scratch = scratch; a.sums_out = sums_out;
+  const unsigned blocks = (unsigned)((total + kAdamPerBlock - 1) / kAdamPerBlock);
+  return launch(adam_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
 
 extern "C" int socmx_iteration_scalars_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
                                            const float* w_std, const float* obj, const float* gn, const float* gne,

@@ -43,7 +43,7 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
                  ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=False, overlap_M_backward=True,
-                 grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2):
+                 grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2, fused_adam=True):
         self.solver, self.optimizer = solver, optimizer
         self.batch_size = batch_size
         self.normalization_const = normalization_const
@@ -65,6 +65,7 @@ class Trainer:
         # EMA normaliser, gradient telemetry -- is captured once and replayed; see _graph_step
         self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None)
         self.graph_warmup = int(graph_warmup)
+        self.fused_adam = bool(fused_adam)    # hipGraph body: control-network Adam + telemetry as one launch (socmx_adam_step_f32)
         self._graphs = {}
         self._dev = None
         self._m_pending = False          # hipGraph mode: the pair-grid network's update of the last iteration is outstanding
@@ -355,14 +356,29 @@ class Trainer:
                                                (G * gout).reshape(Kp * B, d), return_flat=True,
                                                packed=sde.nabla_V._packed)     # (the image this iteration's rollout packed)
         vparams = list(sde.nabla_V.parameters())
-        for p, g in zip(vparams, vgrads):
-            p.grad = g
-        # scalar bookkeeping (loss, EMA normaliser, iteration counter, telemetry EMAs): two one-thread kernels instead of
-        # ~35 elementwise launches (socmx_iteration_scalars_f32)
         from . import _lib
         Lh, f = _lib.lib(), _lib.ptr
         gn = gne = None
-        if self.grad_telemetry:                                          # main.py:325-345
+        adam = self._fused_adam_table(D, vparams, vflat)
+        if adam is not None:
+            # control-network Adam step + gradient telemetry in ONE launch on the flat gradient (socmx_adam_step_f32):
+            # replaces the optimiser's multi-tensor launches, two dot products, the EMA lerp and the coefficient kernel
+            table, grp, sums = adam
+            b1, b2 = grp["betas"]
+            with _lib.on_device(dev):
+                _lib.check(Lh.socmx_adam_step_f32(table.data_ptr(), len(vparams), vflat.numel(), f(vflat),
+                                                  f(D["ema_flat"]) if self.grad_telemetry else None, f(D["itr1"]),
+                                                  0.01, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
+                                                  f(D["adam_scratch"]), f(sums), _lib.stream_ptr(dev)),
+                           "socmx_adam_step_f32")
+            if self.grad_telemetry:
+                gn, gne = sums[0:1], sums[1:2]
+        else:
+            for p, g in zip(vparams, vgrads):
+                p.grad = g
+        # scalar bookkeeping (loss, EMA normaliser, iteration counter, telemetry EMAs): two one-thread kernels instead of
+        # ~35 elementwise launches (socmx_iteration_scalars_f32)
+        if adam is None and self.grad_telemetry:                         # main.py:325-345
             # the control-network gradients are views of ONE flat buffer (socmx_unet_backward_f32), and so is their EMA:
             # squared norms are dot products, the EMA  A ema + B g  (A = 1 - B in every branch of compute_EMA) one lerp
             gn = torch.dot(vflat, vflat).reshape(1)
@@ -372,9 +388,10 @@ class Trainer:
                            "socmx_iteration_scalars_f32")
             D["ema_flat"].lerp_(vflat, D["ab"][1])
             gne = torch.dot(D["ema_flat"], D["ema_flat"]).reshape(1)
-        self._step_groups(D["groups_main"])                               # main.py:347-349 (nabla_V: the next rollout needs it)
-        for p in vparams:
-            p.grad = None
+        if adam is None:
+            self._step_groups(D["groups_main"])                           # main.py:347-349 (nabla_V: the next rollout needs it)
+            for p in vparams:
+                p.grad = None
         out = torch.empty(7, dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             _lib.check(Lh.socmx_iteration_scalars_f32(
@@ -390,6 +407,39 @@ class Trainer:
                             / (target_control.shape[0] * target_control.shape[1]))
             out = torch.cat([out, nsd.reshape(1)])
         return out
+
+    def _fused_adam_table(self, D, vparams, vflat):
+        """Device table for socmx_adam_step_f32, or None while the fused step does not apply: the control network must be
+        exactly one torch.optim.Adam group (no weight decay / amsgrad / maximize, float lr) whose state already exists (the
+        first eager iterations create it through torch's own step) with device-resident fp32 step counters."""
+        if not self.fused_adam:
+            return None
+        if "adam_table" in D:
+            return D["adam_table"]
+        opt, groups = self.optimizer, D["groups_main"]
+        if type(opt) is not torch.optim.Adam or len(groups) != 1:
+            return None
+        grp = groups[0]
+        if ([id(p) for p in grp["params"]] != [id(p) for p in vparams] or grp.get("weight_decay", 0) != 0
+                or grp.get("amsgrad", False) or grp.get("maximize", False) or torch.is_tensor(grp["lr"])
+                or len(vparams) > 64):
+            return None
+        rows, off = [], 0
+        for p in vparams:
+            st = opt.state.get(p)
+            if (not st or not torch.is_tensor(st.get("step")) or st["step"].device != p.device
+                    or st["step"].dtype != torch.float32 or p.dtype != torch.float32 or not p.is_contiguous()):
+                return None
+            rows.append([p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
+                         p.numel(), off])
+            off += p.numel()
+        if off != vflat.numel():
+            return None
+        dev = vflat.device
+        D["adam_scratch"] = torch.zeros(4, dtype=torch.float32, device=dev)
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        D["adam_table"] = (torch.tensor(rows, dtype=torch.int64, device=dev), grp, sums)     # socmx_adam_tensor records
+        return D["adam_table"]
 
     def _graph_step(self, loss_kwargs):
         solver = self.solver

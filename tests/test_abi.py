@@ -32,10 +32,31 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.PROTOTYPES) == declared_symbols()
 
 
+def declared_parameter_counts():
+    """name -> number of parameters of its prototype in socmx.h (`void` = 0)."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for name, params in re.findall(r"\b(socmx_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        params = params.strip()
+        out[name] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_binding_prototypes_have_the_declared_parameter_counts():
+    """A ctypes prototype one argument short still 'works' until a 64-bit argument lands in the untyped tail (the stream
+    pointer is the last parameter of every launcher): compare the arities of the binding table with the header."""
+    from socmx import _lib
+    counts = declared_parameter_counts()
+    assert sorted(counts) == declared_symbols()
+    for name, (_, argtypes) in _lib.PROTOTYPES.items():
+        assert len(argtypes) == counts[name], f"{name}: binding has {len(argtypes)} parameters, socmx.h declares {counts[name]}"
+
+
 def test_argument_validation_needs_no_gpu():
     from socmx import _lib
     L = _lib.lib()
-    assert L.socmx_version() == 110
+    assert L.socmx_version() == 111
     assert L.socmx_num_pairs(200) == 201 * 202 // 2
     assert L.socmx_unet_packed_floats(10, _lib.i3([256, 128, 64])) > 170562      # padded image >= parameter count
     assert L.socmx_unet_packed_floats(0, _lib.i3([256, 128, 64])) == 0
