@@ -760,6 +760,12 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
 //      iteration, under the 128 slots two multiplying waves leave), and the multiplying waves issue their own operand
 //      requests, cursor arithmetic and LDS reads BETWEEN their MFMAs.  Per iteration: 6,000 -> 4,700 cycles (4,096 is
 //      the MFMA time), 7.6 -> 6.3 ms at the configs[4] slice (107 TFLOP/s, 0.68 of the fp32 MFMA peak).
+// NOTE on the asm loads of this section: the compiler believes an asm statement's outputs are valid when the statement
+// retires.  That is harmless only as long as it never touches those registers before the matching SOCMX_WAIT_* statement
+// (whose "+v" operands tie them to the wait) -- in particular the register allocator must keep each request slot in the same
+// registers around the loop (no copies on the back edge).  The loops are unrolled by the ring length for exactly that reason,
+// and the GPU parity tests over many shapes (test_contraction_kernels_multi_block_shapes, the full-size configs[4] slice
+// tests) are what guards it: a toolchain that inserted such a copy would fail them, not corrupt results silently.
 __device__ __forceinline__ f32x4 async_load16(const void* sbase, uint32_t voff) {
   sbase = scalar_ptr(sbase);
   f32x4 r;
