@@ -13,6 +13,7 @@
 // operand load is a contiguous 256-byte wave access, the d x d pair matrices are shared through LDS
 // (transposed, 16-byte broadcast reads), and block/wave reductions feed one atomic per workgroup.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <math.h>
 #include <stdint.h>
@@ -1066,6 +1067,93 @@ __global__ __launch_bounds__(64) void socm_residual_kernel(const TargetArgs a) {
   if (ml == 0) atomicAdd(a.objective, obj * a.inv_norm);
 }
 
+// The same residual for d % 4 == 0, d <= 64 on the MFMA: with S = sigma sigma^T (formed once per workgroup in LDS, its 16
+// fragments then live in registers) the row needs ONE product y = S diff:  objective += w diff.y,  G = 2 w inv_norm y.
+// Orientation D (16 c x 16 rows) += A (S: 16 c x 4 k) . B (diff^T: 4 k x 16 rows) with k-slot s of lane group g carrying
+// k = 16 q + 4 g + s: a lane (row m, group g) then holds diff[m][16 q + 4 g ..+3] (one 16-byte load of nablaV and target per q)
+// AND receives y[m][16 cb + 4 g ..+3] -- the same positions, so diff.y is a lane-local sum and G leaves as 16-byte stores.
+// The (K+1) B rows are one flat row range; workgroups loop over 16-row tiles (thread-per-row version: 0.63 ms at the
+// configs[4] slice for 157 MB of traffic).
+__global__ __launch_bounds__(256) void socm_residual_mfma_kernel(const TargetArgs a) {
+  constexpr int SS = 68;                               // LDS row stride of sigma / S (64 + 4: conflict-free 16-byte reads)
+  __shared__ __attribute__((aligned(16))) float Sg[64 * SS];
+  __shared__ __attribute__((aligned(16))) float Ss[64 * SS];
+  const int d = a.d, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int nq = (d + 15) >> 4;
+  // sigma (zero-padded to 64 x 64) -> LDS, then S = sigma sigma^T (zero beyond d)
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Sg[r * SS + c] = (r < d && c < d) ? a.sigma[r * d + c] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    float acc = 0.f;
+    if (r < d && c < d)
+      for (int j = 0; j < d; ++j) acc += Sg[r * SS + j] * Sg[c * SS + j];
+    Ss[r * SS + c] = acc;
+  }
+  __syncthreads();
+  // A fragments: S[c = 16 cb + c16][k = 16 q + 4 g4 .. +3]
+  f32x4 sf[4][4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sf[cb][q] = *reinterpret_cast<const f32x4*>(&Ss[(cb * 16 + c16) * SS + q * 16 + 4 * g4]);
+  const int64_t R = (int64_t)(a.K + 1) * B;
+  const int64_t ntiles = (R + 15) >> 4;
+  float obj = 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t row = t * 16 + c16;
+    const bool valid = row < R;
+    const int64_t rc = valid ? row : R - 1;
+    const float* nv = a.nablaV + rc * d;
+    const float* tg = a.target + rc * d;
+    f32x4 df[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      df[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < nq) {
+        const int col = min(q * 16 + 4 * g4, d - 4);     // pieces past the row re-read its last piece (S is zero there)
+        const f32x4 x = *reinterpret_cast<const f32x4*>(nv + col), y = *reinterpret_cast<const f32x4*>(tg + col);
+        df[q] = x - y;
+      }
+    }
+    f32x4 yv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      yv[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (cb < nq) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nq) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+              yv[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(sf[cb][q][s2], df[q][s2], yv[cb], 0, 0, 0);
+          }
+      }
+    }
+    const float wm = a.w[(int)(rc % B)];
+    float dot = 0.f;
+    const float gs = 2.f * wm * a.inv_norm;
+    float* go = a.G + rc * d;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = cb * 16 + 4 * g4;
+      if (cb < nq && col < d) {                          // (d % 4 == 0: a piece is inside the row or outside it)
+        dot += (df[cb][0] * yv[cb][0] + df[cb][1] * yv[cb][1]) + (df[cb][2] * yv[cb][2] + df[cb][3] * yv[cb][3]);
+        if (valid) *reinterpret_cast<f32x4*>(go + col) = f32x4{gs * yv[cb][0], gs * yv[cb][1], gs * yv[cb][2], gs * yv[cb][3]};
+      }
+    }
+    if (valid) obj += wm * dot;
+  }
+  obj = wave_sum(obj);
+  if (lane == 0) atomicAdd(a.objective, obj * a.inv_norm);
+}
+
 // ---- backward: gradients w.r.t. the pair matrices ---------------------------------------------------
 struct TargetBwdArgs {
   int d, K, B;
@@ -1889,6 +1977,12 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   if (lerr) return lerr;
   const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
   if (lds > 160 * 1024) return SOCMX_E_LDS;
+  static const bool residual_valu = getenv("SOCMX_RESIDUAL_VALU") != nullptr;     // A/B switch: thread-per-row form
+  if (d % 4 == 0 && d <= 64 && !residual_valu) {
+    const int64_t tiles = ((int64_t)(K + 1) * B + 15) / 16;
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 3) / 4, 1024);
+    return launch(socm_residual_mfma_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  }
   if (const int err = ensure_max_lds(socm_residual_kernel)) return err;
   return launch(socm_residual_kernel, dim3(K + 1, (B + 63) / 64), dim3(64), lds, stream, a);
 }
