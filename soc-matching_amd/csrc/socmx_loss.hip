@@ -1154,6 +1154,104 @@ __global__ __launch_bounds__(256) void socm_residual_mfma_kernel(const TargetArg
   if (lane == 0) atomicAdd(a.objective, obj * a.inv_norm);
 }
 
+// The operands v, q for d % 4 == 0, d <= 64 on the MFMA (same orientation as socm_residual_mfma_kernel: a lane (row m, group g)
+// holds 16-byte pieces [m][16 q + 4 g .. +3] of its inputs AND of each product):
+//   z = sqrt(lambda dt) eps + dt u,   v = -sigma^{-T} z,   q = A^T v [+ 2 dt P x]   (OU settings; elementwise for the others)
+// Matrices (zero-padded to 64 x 64) live in LDS, one workgroup loops over 16-row tiles of the flat (K B, d) row range.
+// (thread-per-element version with LDS tiles: 0.42 ms at the configs[4] slice for 260 MB of traffic)
+__global__ __launch_bounds__(256) void socm_prep_mfma_kernel(const PrepArgs a) {
+  constexpr int SS = 68;
+  __shared__ __attribute__((aligned(16))) float Ms[3][64 * SS];      // sigma^{-T}, A^T, P  as  [out index l][in index c]
+  const int d = a.d, B = a.B, K = a.K;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int nq = (d + 15) >> 4;
+  const bool is_ou = (a.kind == SOCMX_OU_QUADRATIC || a.kind == SOCMX_OU_LINEAR);
+  const bool quad = a.kind == SOCMX_OU_QUADRATIC;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int l = e >> 6, c = e & 63;
+    const bool in = l < d && c < d;
+    Ms[0][l * SS + c] = in ? a.sit[l * d + c] : 0.f;
+    Ms[1][l * SS + c] = (in && is_ou) ? a.A[c * d + l] : 0.f;           // (A^T)[l][n] = A[n][l]
+    Ms[2][l * SS + c] = (in && quad) ? a.P[l * d + c] : 0.f;
+  }
+  __syncthreads();
+  // D (16 l x 16 rows) += A (M: 16 l x 4 c) . B (x^T: 4 c x 16 rows): out[lb] = sum_q M[lb][q] x[q]
+  auto product = [&](const float* M, const f32x4 (&x)[4], f32x4 (&out)[4]) {
+#pragma unroll
+    for (int lb = 0; lb < 4; ++lb) {
+      out[lb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (lb < nq) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nq) {
+            const f32x4 mf = *reinterpret_cast<const f32x4*>(&M[(lb * 16 + c16) * SS + q * 16 + 4 * g4]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) out[lb] = __builtin_amdgcn_mfma_f32_16x16x4f32(mf[s2], x[q][s2], out[lb], 0, 0, 0);
+          }
+      }
+    }
+  };
+  const int64_t R = (int64_t)K * B;
+  const int64_t ntiles = (R + 15) >> 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t row = t * 16 + c16;
+    const bool valid = row < R;
+    const int64_t rc = valid ? row : R - 1;
+    const int j = (int)(rc / B);
+    const float dt = a.frac ? a.frac[rc] : (a.ts[j + 1] - a.ts[j]);
+    const float ce = a.sqrt_lmbd * sqrtf(dt);
+    f32x4 z[4], xs[4], v[4], qv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      z[q] = f32x4{0.f, 0.f, 0.f, 0.f}; xs[q] = z[q];
+      if (q < nq) {
+        const int64_t off = rc * d + min(q * 16 + 4 * g4, d - 4);      // pieces past the row re-read its last piece (zero matrix columns)
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.noises + off), u4 = *reinterpret_cast<const f32x4*>(a.controls + off);
+        z[q] = ce * e4 + dt * u4;
+        if (!is_ou || quad) xs[q] = *reinterpret_cast<const f32x4*>(a.states + off);
+      }
+    }
+    product(Ms[0], z, v);
+#pragma unroll
+    for (int lb = 0; lb < 4; ++lb) v[lb] = -v[lb];
+    if (is_ou) {
+      product(Ms[1], v, qv);
+      if (quad) {
+        f32x4 px[4];
+        product(Ms[2], xs, px);
+#pragma unroll
+        for (int lb = 0; lb < 4; ++lb) qv[lb] += (2.f * dt) * px[lb];
+      }
+    } else {
+#pragma unroll
+      for (int lb = 0; lb < 4; ++lb) {
+        qv[lb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int col = lb * 16 + 4 * g4;
+        if (lb < nq && col < d) {
+          const f32x4 kap = *reinterpret_cast<const f32x4*>(a.kappa + col);
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const float xl = xs[lb][s2];
+            qv[lb][s2] = -(8.f * kap[s2] * xl * xl + 4.f * kap[s2] * (xl * xl - 1.f)) * v[lb][s2];
+          }
+        }
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int lb = 0; lb < 4; ++lb) {
+        const int col = lb * 16 + 4 * g4;
+        if (lb < nq && col < d) {
+          *reinterpret_cast<f32x4*>(a.v + rc * d + col) = v[lb];
+          *reinterpret_cast<f32x4*>(a.q + rc * d + col) = qv[lb];
+        }
+      }
+    }
+  }
+}
+
 // ---- backward: gradients w.r.t. the pair matrices ---------------------------------------------------
 struct TargetBwdArgs {
   int d, K, B;
@@ -1903,6 +2001,13 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
   a.ts = ts; a.states = states; a.noises = noises; a.controls = controls; a.frac = frac;
   a.v = v; a.q = q; a.gT = gT; a.vT = vT; a.qT = qT; a.gTT = gTT;
   const size_t tile_lds = (size_t)4 * 64 * (pb->d + 1) * sizeof(float);
+  static const bool prep_valu = getenv("SOCMX_PREP_VALU") != nullptr;             // A/B switch: LDS-tile VALU form
+  if (pb->d % 4 == 0 && pb->d <= 64 && !vT && !qT && !prep_valu) {
+    const int64_t tiles = ((int64_t)K * B + 15) / 16;
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 3) / 4, 1024);
+    if (const int err = launch(socm_prep_mfma_kernel, dim3(blocks), dim3(256), 0, stream, a)) return err;
+    return launch(socm_prep_terminal_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
+  }
   if (pb->d <= 128 && tile_lds <= 160 * 1024) {
     if (const int err = ensure_max_lds(socm_prep_tiled_kernel)) return err;
     const int64_t rows = (int64_t)K * B;
