@@ -327,7 +327,8 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       l0 = min(lb + 4 * g4, d - 1);                 // this lane's four l: l0 .. l0+3 (clamped into the row)
       nl = max(0, min(4, d - (lb + 4 * g4)));       // how many of them exist
     };
-    auto load = [&](int t, Slot& sl) {
+    auto load = [&](int t, Slot& sl, auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
       int jr, j, l0, nl;
       geom(t, jr, j, l0, nl);
       const float* Ap = a.M_all + prow_dd + (int64_t)jr * dd;         // wave-uniform bases + small lane offsets
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       const float* qs = (j < K) ? a.q + (size_t)j * B * d : a.gT;
       const float* vs = a.v + (size_t)(j < K ? j : 0) * B * d;
       // a 16-byte read can cross the end of a buffer only in the last pair matrix / the last operand rows:
-      // those (wave-uniform) iterations take clamped scalar reads
-      if (j + 1 < K) {
+      // those iterations (j + 1 >= K: the row's last two pairs) take clamped scalar reads -- in a loop of their own (below)
+      if (FAST) {
         sl.nt = load4<true>(Ap, aoff, 0);
         sl.dn = load4<true>(Dp, aoff, 0);
 #pragma unroll
@@ -384,19 +385,32 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       }
     };
     // PF iterations of this wave are in flight: one (pair, l-block) is 8*CT MFMAs, shorter than a trip to L2/HBM
+    // The pipelined loop covers the iterations whose 16-byte reads are always in bounds (pairs j + 1 < K) and requests
+    // UNCONDITIONALLY (past the wave's last such iteration it re-reads that one): with two load forms or an `if (more) load`
+    // inside the loop the compiler's wait counts assume the worst path and leave about one slot in flight instead of PF.
+    // The row's last two pairs follow in a plain loop with the guarded scalar reads.
     constexpr int PF = CT >= 4 ? 3 : (CT >= 2 ? 3 : 4);
-    Slot ring[PF];
+    const int nfast = max(0, K - 1 - i) * nlb;           // iterations t with j + 1 < K  (t = jr * nlb + l-block, j = i + jr)
+    if (wave < nfast) {
+      const int tmax = wave + ((nfast - 1 - wave) / kTargetWaves) * kTargetWaves;     // this wave's last fast iteration
+      Slot ring[PF];
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
-      if (wave + p * kTargetWaves < niter) load(wave + p * kTargetWaves, ring[p]);
-    for (int t = wave; t < niter; t += PF * kTargetWaves) {
+      for (int p = 0; p < PF; ++p) load(min(wave + p * kTargetWaves, tmax), ring[p], std::true_type{});
+      for (int t = wave; t < nfast; t += PF * kTargetWaves) {
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        const int tt = t + p * kTargetWaves;
-        if (tt < niter) {
-          consume(tt, ring[p]);
-          if (tt + PF * kTargetWaves < niter) load(tt + PF * kTargetWaves, ring[p]);
+        for (int p = 0; p < PF; ++p) {
+          const int tt = t + p * kTargetWaves;
+          if (tt < nfast) consume(tt, ring[p]);
+          load(min(tt + PF * kTargetWaves, tmax), ring[p], std::true_type{});
         }
+      }
+    }
+    {
+      const int t0 = nfast + ((wave - nfast % kTargetWaves) + kTargetWaves) % kTargetWaves;   // first t >= nfast with t = wave (mod 8)
+      for (int t = t0; t < niter; t += kTargetWaves) {
+        Slot sl;
+        load(t, sl, std::false_type{});
+        consume(t, sl);
       }
     }
     // combine the waves' partial tiles (fixed order: deterministic)
