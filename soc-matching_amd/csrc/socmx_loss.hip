@@ -890,25 +890,35 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
     APend pend[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) pend[u].dl = 0.f;
-    // prologue: stages 0 and 1 staged synchronously, A(2) .. A(5) in flight
+    // ONE barrier per TWO iterations (period p = iterations 2p, 2p+1).  During period p the multiplying waves read the
+    // fragments of 2p+1 and 2p+2 (the fragments of 2p are in registers since the end of 2p-1), so those stages were written
+    // during period p-1, and this period writes the stages of 2p+3 and 2p+4 -- the ring of four holds exactly these (stage of
+    // 2p+4 = stage of 2p, whose reads were issued before this period's barrier).
+    // prologue: stages 0, 1, 2 staged synchronously, then A(3) .. A(6) in flight (slots 3, 0, 1, 2)
     issueA(pend[0]);
     issueA(pend[1]);
+    issueA(pend[2]);
     SOCMX_WAIT_A(0, pend[0]);
     SOCMX_WAIT_A(0, pend[1]);
+    SOCMX_WAIT_A(0, pend[2]);
     stageA(pend[0], 0);
     stageA(pend[1], 1);
-    issueA(pend[2]);
+    stageA(pend[2], 2);
     issueA(pend[3]);
     issueA(pend[0]);
     issueA(pend[1]);
-    __syncthreads();                             // stages 0 and 1 visible
+    issueA(pend[2]);
+    __syncthreads();                             // stages 0, 1, 2 visible
     for (int it0 = 0; it0 < nitp; it0 += 4) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        __syncthreads();                         // (it = it0 + u) everyone has issued its reads of stage it (end of it-1)
-        SOCMX_WAIT_A(3 * NA, pend[(u + 2) % 4]); // younger than A(it+2): A(it+3) A(it+4) A(it+5)
-        stageA(pend[(u + 2) % 4], (u + 2) % 4);  // iteration it+2 -> the stage that held it-2
-        issueA(pend[(u + 2) % 4]);               // iteration it+6
+      for (int u = 0; u < 4; u += 2) {           // it = it0 + u: an even iteration opens a period
+        __syncthreads();
+        SOCMX_WAIT_A(3 * NA, pend[(u + 3) % 4]); // younger than A(it+3): A(it+4) A(it+5) A(it+6)
+        stageA(pend[(u + 3) % 4], (u + 3) % 4);  // iteration it+3
+        issueA(pend[(u + 3) % 4]);               // iteration it+7
+        SOCMX_WAIT_A(3 * NA, pend[u % 4]);       // younger than A(it+4): A(it+5) A(it+6) A(it+7)
+        stageA(pend[u % 4], u % 4);              // iteration it+4 -> the stage that held it
+        issueA(pend[u % 4]);                     // iteration it+8
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-fetched requests of the last trips
@@ -1003,7 +1013,7 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
   BSlot bs[4];
 #pragma unroll
   for (int u = 0; u < 3; ++u) { requestB(bs[u]); advanceB(); }
-  __syncthreads();                               // stages 0 and 1 visible
+  __syncthreads();                               // stages 0, 1, 2 visible
   readM(0);
   readD(0);
   // developer switch (tools/ubench/contraction_bench.hip builds this file with it): per-wave cycle counters of the three
@@ -1018,7 +1028,7 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
   for (int it0 = 0; it0 < nitp; it0 += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      __syncthreads();                           // (it = it0 + u) stage of it+1 written
+      if ((u & 1) == 0) __syncthreads();         // (it = it0 + u) one barrier per two iterations: see the staging waves
       TICK(0)
       SOCMX_WAIT_B(8, bs[u]);                    // younger than B(it): B(it+1) B(it+2)
       TICK(1)
