@@ -1535,6 +1535,86 @@ __global__ __launch_bounds__(256) void socm_target_bwd_wide_kernel(const TargetB
   }
 }
 
+// Epilogue of the d <= 64 LDS backward kernels for one pair p: this wave's 16 x (16 LB) block of d obj / d (M, dM/ds) --
+// chained to (net, dnet) and the d obj / d gamma partial when NET -- from its accumulators.
+template <bool NET, int LB>
+__device__ __forceinline__ void bwd_lds_epilogue(const TargetBwdArgs& a, int64_t p, const f32x4 (&accq)[LB],
+                                                 const f32x4 (&accv)[LB], int kb, int wave, int lane) {
+  const int d = a.d;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const float go = a.gout ? a.gout[0] : 1.f;
+  const size_t base = (size_t)p * d * d;
+  float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
+  if (NET) { gam = a.gamma[0]; dl = a.delta[p]; e = expf(-gam * dl); }
+  if (kb + 16 <= d && 16 * LB <= d) {
+    // Whole 16 x (16 LB) block (d = 64: always).  The epilogue runs beside the other workgroups' MFMA streams, where every
+    // instruction costs about one MFMA time (see socm_target_lds4_kernel): wave-uniform base pointers + four lane offsets
+    // (one per accumulator row, the l-block as an immediate) instead of 64-bit address arithmetic per element, no
+    // predicates, all 2 x 4 LB loads in flight before the arithmetic, constants folded (844 -> ~300 instructions).
+    const size_t blk = base + (size_t)kb * d;
+    const char* netb = reinterpret_cast<const char*>(a.net + blk);
+    const char* dnetb = reinterpret_cast<const char*>(a.dnet + blk);
+    char* gMb = reinterpret_cast<char*>(a.gM + blk);
+    char* gdMb = reinterpret_cast<char*>(a.gdM + blk);
+    uint32_t off[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) off[rr] = (uint32_t)((4 * g4 + rr) * d + c16) * 4u;
+    const float f = NET ? 1.f - e : 1.f, ge = gam * e;
+    const float kq = -f * go, kv = ge * go, kd = f * go;                  // gM = kq accq + kv accv,  gdM = kd accv
+    const float c1 = dl * e * go, c2 = e * (1.f - gam * dl) * go;         // d/dgamma: -accq c1 nmi + accv (c2 nmi + c1 dnet)
+    float nt[LB][4], dn[LB][4];
+    if (NET) {
+#pragma unroll
+      for (int b = 0; b < LB; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          nt[b][rr] = *reinterpret_cast<const float*>(netb + (size_t)off[rr] + 64 * b);
+          dn[b][rr] = *reinterpret_cast<const float*>(dnetb + (size_t)off[rr] + 64 * b);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < LB; ++b)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float aq_ = accq[b][rr], av_ = accv[b][rr];
+        if (NET) {
+          const float nmi = nt[b][rr] - ((b == wave && c16 == 4 * g4 + rr) ? 1.f : 0.f);
+          part += av_ * fmaf(c2, nmi, c1 * dn[b][rr]) - aq_ * (c1 * nmi);
+          *reinterpret_cast<float*>(gMb + (size_t)off[rr] + 64 * b) = fmaf(kq, aq_, kv * av_);
+          *reinterpret_cast<float*>(gdMb + (size_t)off[rr] + 64 * b) = kd * av_;
+        } else {
+          *reinterpret_cast<float*>(gMb + (size_t)off[rr] + 64 * b) = -go * aq_;
+          *reinterpret_cast<float*>(gdMb + (size_t)off[rr] + 64 * b) = go * av_;
+        }
+      }
+  } else
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int l = b * 16 + c16;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int kk = kb + 4 * g4 + rr;
+      if (kk < d && l < d) {
+        const size_t idx = base + (size_t)kk * d + l;
+        const float gm = -accq[b][rr] * go, gd = accv[b][rr] * go;
+        if (NET) {
+          const float nmi = a.net[idx] - (kk == l ? 1.f : 0.f);
+          a.gM[idx] = (1.f - e) * gm + gam * e * gd;
+          a.gdM[idx] = (1.f - e) * gd;
+          part += gm * dl * e * nmi + gd * (e * (1.f - gam * dl) * nmi + dl * e * a.dnet[idx]);
+        } else {
+          a.gM[idx] = gm;
+          a.gdM[idx] = gd;
+        }
+      }
+    }
+  }
+  if (NET) {
+    part = wave_sum(part);
+    const int nb = (d + 15) >> 4;         // the caller's buffer has one slot per (pair, k-block, l-block)
+    if (lane < nb) a.ggamma_part[((size_t)p * nb + wave) * nb + lane] = lane == 0 ? part : 0.f;
+  }}
+
 // d <= 64, d % 4 == 0: the same contraction with the three operand tiles of 16 batch rows (G_i, q_j, v_j: 16 x d floats
 // each) staged through a double-buffered LDS tile, TRANSPOSED: Ts[tensor][column][batch row], 20 floats per column.  The
 // batch is the MFMA reduction index and its assignment to (MFMA u, lane group g4) is free, so row m = 4*g4 + u: the four
@@ -1657,78 +1737,133 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_lds_kernel(const Targe
     return;
   }
   chunk_loop(std::true_type{});
-  const float go = a.gout ? a.gout[0] : 1.f;
-  const size_t base = (size_t)p * d * d;
-  float e = 0.f, gam = 0.f, dl = 0.f, part = 0.f;
-  if (NET) { gam = a.gamma[0]; dl = a.delta[p]; e = expf(-gam * dl); }
-  if (kb + 16 <= d && 16 * LB <= d) {
-    // Whole 16 x (16 LB) block (d = 64: always).  The epilogue runs beside the other workgroups' MFMA streams, where every
-    // instruction costs about one MFMA time (see socm_target_lds4_kernel): wave-uniform base pointers + four lane offsets
-    // (one per accumulator row, the l-block as an immediate) instead of 64-bit address arithmetic per element, no
-    // predicates, all 2 x 4 LB loads in flight before the arithmetic, constants folded (844 -> ~300 instructions).
-    const size_t blk = base + (size_t)kb * d;
-    const char* netb = reinterpret_cast<const char*>(a.net + blk);
-    const char* dnetb = reinterpret_cast<const char*>(a.dnet + blk);
-    char* gMb = reinterpret_cast<char*>(a.gM + blk);
-    char* gdMb = reinterpret_cast<char*>(a.gdM + blk);
-    uint32_t off[4];
+  bwd_lds_epilogue<NET, LB>(a, p, accq, accv, kb, wave, lane);
+}
+
+// Two rows per workgroup: the pairs (i0, j) and (i0 + 1, j) share q_j and v_j.  At d = 64 every pair of the one-row kernel
+// pulls 3 x 128 KiB of operand rows out of L2 / the memory side (31 GB per launch at the configs[4] slice, 5 TB/s while it
+// runs); with two G tiles against one (q, v) tile that is 2 x 128 + 256 KiB per two pairs (-33 %), 10 instead of 18 fragment
+// reads and one instead of two barriers per 64 MFMAs.  Four waves = four loaders (G_i0, G_i1, q_j, v_j), four k-blocks.
+// Item x of the grid = (row pair r2, j >= 2 r2); rows counted in pairs hold K - 2 r2 + 1 items, C(r2) = r2 (K + 2 - r2) before.
+template <bool NET, int LB>
+__global__ __launch_bounds__(256, 2) void socm_target_bwd_lds2_kernel(const TargetBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ts[2][4][64][kBwdStride];   // [stage][G_i0, G_i1, q, v][column][batch row]
+  const int d = a.d, K = a.K, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t x = blockIdx.x;
+  const float kp2 = (float)(K + 2);
+  int r2 = (int)((kp2 - sqrtf(fmaxf(kp2 * kp2 - 4.f * (float)x, 0.f))) * 0.5f);
+  r2 = max(0, min(r2, (K + 2) / 2 - 1));
+  while ((int64_t)(r2 + 1) * (K + 2 - (r2 + 1)) <= x) ++r2;
+  while ((int64_t)r2 * (K + 2 - r2) > x) --r2;
+  r2 = __builtin_amdgcn_readfirstlane(r2);   // (came through the float unit: pin it -- and every pointer derived from it -- to scalar registers)
+  const int i0 = 2 * r2, i1 = i0 + 1;
+  const int j = i0 + (int)(x - (int64_t)r2 * (K + 2 - r2));
+  const bool two = i1 <= K && j >= i1;       // the pair (i1, j) exists
+  const bool last = (j == K);
+  const int64_t p0 = pair_row_offset(i0, K) + (j - i0);
+  const int64_t p1 = two ? pair_row_offset(i1, K) + (j - i1) : p0;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = wave * 16;
+  const bool wave_on = kb < d;
+  // loader role: tensor `wave`, rows 4*rg .. 4*rg+3 of the chunk, columns 4*pc .. 4*pc+3
+  const int rg = lane & 3, pc = lane >> 2;
+  const bool piece_on = 4 * pc < d;
+  const bool tensor_zero = (wave == 1 && !two) || (wave == 3 && last);      // no second pair / the terminal pair has no v operand
+  const float* src = wave == 0 ? a.G + (size_t)i0 * B * d
+                   : wave == 1 ? a.G + (size_t)(two ? i1 : i0) * B * d
+                   : wave == 2 ? (last ? a.gT : a.q + (size_t)j * B * d)
+                               : a.v + (size_t)(last ? 0 : j) * B * d;
+  f32x4 pr[2][4];                         // chunks c+1 and c+2 in flight (slot = chunk & 1): pr[slot][row][column]
+  auto gload = [&](int m0, int sl) {
+    if (piece_on && !tensor_zero) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) off[rr] = (uint32_t)((4 * g4 + rr) * d + c16) * 4u;
-    const float f = NET ? 1.f - e : 1.f, ge = gam * e;
-    const float kq = -f * go, kv = ge * go, kd = f * go;                  // gM = kq accq + kv accv,  gdM = kd accv
-    const float c1 = dl * e * go, c2 = e * (1.f - gam * dl) * go;         // d/dgamma: -accq c1 nmi + accv (c2 nmi + c1 dnet)
-    float nt[LB][4], dn[LB][4];
-    if (NET) {
-#pragma unroll
-      for (int b = 0; b < LB; ++b)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          nt[b][rr] = *reinterpret_cast<const float*>(netb + (size_t)off[rr] + 64 * b);
-          dn[b][rr] = *reinterpret_cast<const float*>(dnetb + (size_t)off[rr] + 64 * b);
-        }
+      for (int s = 0; s < 4; ++s) pr[sl][s] = load4<true>(src, min(m0 + 4 * rg + s, B - 1) * d + 4 * pc, 0);
     }
+  };
+  auto stage = [&](int m0, int st, int sl) {   // rows past the batch, columns past d and absent tensors are zeroed here
+    float* col = &Ts[st][wave][4 * pc][4 * rg];
+    if (!piece_on || tensor_zero) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < LB; ++b)
+      for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(col + s * kBwdStride) = z;
+    } else if (m0 + 16 <= B) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float aq_ = accq[b][rr], av_ = accv[b][rr];
-        if (NET) {
-          const float nmi = nt[b][rr] - ((b == wave && c16 == 4 * g4 + rr) ? 1.f : 0.f);
-          part += av_ * fmaf(c2, nmi, c1 * dn[b][rr]) - aq_ * (c1 * nmi);
-          *reinterpret_cast<float*>(gMb + (size_t)off[rr] + 64 * b) = fmaf(kq, aq_, kv * av_);
-          *reinterpret_cast<float*>(gdMb + (size_t)off[rr] + 64 * b) = kd * av_;
-        } else {
-          *reinterpret_cast<float*>(gMb + (size_t)off[rr] + 64 * b) = -go * aq_;
-          *reinterpret_cast<float*>(gdMb + (size_t)off[rr] + 64 * b) = go * av_;
-        }
+      for (int s = 0; s < 4; ++s)
+        *reinterpret_cast<f32x4*>(col + s * kBwdStride) = f32x4{pr[sl][0][s], pr[sl][1][s], pr[sl][2][s], pr[sl][3][s]};
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f32x4 t;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) t[rr] = (m0 + 4 * rg + rr < B) ? pr[sl][rr][s] : 0.f;
+        *reinterpret_cast<f32x4*>(col + s * kBwdStride) = t;
       }
-  } else
+    }
+  };
+  f32x4 accq0[LB], accv0[LB], accq1[LB], accv1[LB];
 #pragma unroll
   for (int b = 0; b < LB; ++b) {
-    const int l = b * 16 + c16;
+    accq0[b] = f32x4{0.f, 0.f, 0.f, 0.f}; accv0[b] = accq0[b]; accq1[b] = accq0[b]; accv1[b] = accq0[b];
+  }
+  const int nch = (B + 15) >> 4;
+  gload(0, 0);
+  if (nch > 1) gload(16, 1);
+  stage(0, 0, 0);
+  if (nch > 2) gload(32, 0);
+  // chunk loop (see socm_target_bwd_lds_kernel: unrolled by two for static register slots, loader work between the MFMA groups,
+  // one copy for waves without a k-block of their own)
+  auto chunk_loop = [&](auto with_mfma) {
+    for (int c0 = 0; c0 < nch; c0 += 2) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int kk = kb + 4 * g4 + rr;
-      if (kk < d && l < d) {
-        const size_t idx = base + (size_t)kk * d + l;
-        const float gm = -accq[b][rr] * go, gd = accv[b][rr] * go;
-        if (NET) {
-          const float nmi = a.net[idx] - (kk == l ? 1.f : 0.f);
-          a.gM[idx] = (1.f - e) * gm + gam * e * gd;
-          a.gdM[idx] = (1.f - e) * gd;
-          part += gm * dl * e * nmi + gd * (e * (1.f - gam * dl) * nmi + dl * e * a.dnet[idx]);
-        } else {
-          a.gM[idx] = gm;
-          a.gdM[idx] = gd;
+      for (int h = 0; h < 2; ++h) {
+        const int c = c0 + h;             // c & 1 == h
+        if (c < nch) {
+          __syncthreads();                // stage h visible; everyone is done reading stage 1-h
+          if constexpr (decltype(with_mfma)::value) {
+            const f32x4 ga0 = *reinterpret_cast<const f32x4*>(&Ts[h][0][kb + c16][4 * g4]);
+            const f32x4 ga1 = *reinterpret_cast<const f32x4*>(&Ts[h][1][kb + c16][4 * g4]);
+            f32x4 qb[LB], vb[LB];
+#pragma unroll
+            for (int b = 0; b < LB; ++b) {
+              qb[b] = *reinterpret_cast<const f32x4*>(&Ts[h][2][b * 16 + c16][4 * g4]);
+              vb[b] = *reinterpret_cast<const f32x4*>(&Ts[h][3][b * 16 + c16][4 * g4]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+              for (int b = 0; b < LB; ++b)
+                accq0[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0[u], qb[b][u], accq0[b], 0, 0, 0);
+#pragma unroll
+              for (int b = 0; b < LB; ++b)
+                accv0[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0[u], vb[b][u], accv0[b], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (u == 0 && c + 1 < nch) stage((c + 1) * 16, 1 - h, 1 - h);
+              if (u == 1 && c + 3 < nch) gload((c + 3) * 16, 1 - h);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int b = 0; b < LB; ++b)
+                accq1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1[u], qb[b][u], accq1[b], 0, 0, 0);
+#pragma unroll
+              for (int b = 0; b < LB; ++b)
+                accv1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1[u], vb[b][u], accv1[b], 0, 0, 0);
+            }
+          } else if (c + 1 < nch) {
+            stage((c + 1) * 16, 1 - h, 1 - h);
+            if (c + 3 < nch) gload((c + 3) * 16, 1 - h);
+          }
         }
       }
     }
+  };
+  if (!wave_on) {
+    chunk_loop(std::false_type{});
+    return;
   }
-  if (NET) {
-    part = wave_sum(part);
-    const int nb = (d + 15) >> 4;         // the caller's buffer has one slot per (pair, k-block, l-block)
-    if (lane < nb) a.ggamma_part[((size_t)p * nb + wave) * nb + lane] = lane == 0 ? part : 0.f;
-  }
+  chunk_loop(std::true_type{});
+  bwd_lds_epilogue<NET, LB>(a, p0, accq0, accv0, kb, wave, lane);
+  if (two) bwd_lds_epilogue<NET, LB>(a, p1, accq1, accv1, kb, wave, lane);
 }
 
 // ---- column sums (bias gradients) ---------------------------------------------------------------------
@@ -2149,9 +2284,16 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
     // (reads of whole 16-byte pieces stay inside the rows because d % 4 == 0)
     dim3 lgrid((unsigned)np);
     const int lb = (d + 15) / 16;
+    static const bool one_row = getenv("SOCMX_BWD_ONE_ROW") != nullptr;           // A/B switch: one pair per workgroup
+    if (!one_row) {
+      const int64_t r2n = (K + 2) / 2;
+      lgrid = dim3((unsigned)(r2n * (K + 2 - r2n)));                                // items (row pair, j)
+    }
 #define SOCMX_BWD_LDS(LBV) \
-  return net ? launch(socm_target_bwd_lds_kernel<true, LBV>, lgrid, dim3(256), 0, stream, a) \
-             : launch(socm_target_bwd_lds_kernel<false, LBV>, lgrid, dim3(256), 0, stream, a)
+  return one_row ? (net ? launch(socm_target_bwd_lds_kernel<true, LBV>, lgrid, dim3(256), 0, stream, a) \
+                        : launch(socm_target_bwd_lds_kernel<false, LBV>, lgrid, dim3(256), 0, stream, a)) \
+                 : (net ? launch(socm_target_bwd_lds2_kernel<true, LBV>, lgrid, dim3(256), 0, stream, a) \
+                        : launch(socm_target_bwd_lds2_kernel<false, LBV>, lgrid, dim3(256), 0, stream, a))
     if (lb == 2) { SOCMX_BWD_LDS(2); }
     if (lb == 3) { SOCMX_BWD_LDS(3); }
     SOCMX_BWD_LDS(4);
