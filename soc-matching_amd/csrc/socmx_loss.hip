@@ -838,9 +838,12 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
     float ce = 0.f, cf = 0.f, cged = 0.f, cfd = 0.f;
     struct APend { f32x4 nt, dn; float dl; int lb, flags; };   // flags: 1 = first l-block of a pair, 2 = partial / padded, 4 = dead, 8 = terminal pair
     // request cursor: iteration t of the row = (pair jr, l-block lb); off = element offset of (jr, lb) inside the row's matrices
-    int ct = 0, cjr = 0, clb = 0;
-    uint32_t coff = 0;
-    const uint32_t wrap_step = (uint32_t)(dd - 16 * (nlb - 1));
+    // The pairs of a row are taken from j = K DOWN to j = i: every workgroup then starts at the same operand tile (q_K = nabla g)
+    // and the workgroups running side by side sweep the q_j / v_j tiles in step -- the 20 GB of B-operand traffic of a launch
+    // at the configs[4] slice hit in L2 instead of going to the memory side.
+    int ct = 0, cjr = K - i, clb = 0;
+    uint32_t coff = (uint32_t)(K - i) * (uint32_t)dd;
+    const uint32_t wrap_step = 0u - (uint32_t)(dd + 16 * (nlb - 1));       // (mod 2^32) back to the previous pair's first l-block
     auto issueA = [&](APend& p) {             // NA requests for iteration ct (the row's last one once ct runs past it)
       const uint32_t lane_off = clb + 16 <= d ? alane : alane_last;
       const void* pn = scalar_ptr(rowN + coff);
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
         const bool wrap = clb + 16 == lb_end;
         coff += wrap ? wrap_step : 16u;
         clb = wrap ? 0 : clb + 16;
-        cjr += wrap ? 1 : 0;
+        cjr -= wrap ? 1 : 0;
       }
     };
     auto stageA = [&](const APend& p, int st) {   // blend + zero padding, then two 16-byte LDS writes
@@ -943,12 +946,12 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
     for (int c = 0; c < CT; ++c) acc[kb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   struct BSlot { f32x4 q[CT], v[CT]; };
   // request cursor of the B side: the operand pointers of iteration bt = (pair bjr, l-block blb) move by 16 floats inside a
-  // pair and by the rest of the (B, d) block at a pair boundary; the terminal pair reads gT (and any finite v: its A is zero)
+  // pair and to the previous (B, d) block at a pair boundary; the terminal pair reads gT (and any finite v: its A is zero)
   static_assert(CT == 2, "the request group below is written for two column tiles");
-  int bt = 0, bjr = 0, blb = 0;
-  const float* pq = reinterpret_cast<const float*>(scalar_ptr(i < K ? a.q + (size_t)i * B * d : a.gT));
-  const float* pv = reinterpret_cast<const float*>(scalar_ptr(a.v + (size_t)(i < K ? i : 0) * B * d));
-  const int64_t pair_step = (int64_t)B * d - 16 * (nlb - 1);
+  // (pairs from j = K down to j = i, l-blocks ascending inside a pair: the same order as the staging waves' cursor)
+  int bt = 0, bjr = K - i, blb = 0;
+  const float* pq = a.gT;
+  const float* pv = a.v;
   auto requestB = [&](BSlot& b) {              // 2 * CT requests for iteration bt (one hazard nop)
     const bool whole = blb + 16 <= d;
     const uint32_t o0 = whole ? blane[0] : blane_last[0], o1 = whole ? blane[1] : blane_last[1];
@@ -961,9 +964,9 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
     ++bt;
     if (bt < nit) {
       if (blb + 16 == lb_end) {
-        blb = 0; ++bjr;
-        if (i + bjr < K) { pq += pair_step; pv += pair_step; }
-        else { pq = a.gT; pv = a.v; }
+        blb = 0; --bjr;
+        pq = a.q + (size_t)(i + bjr) * B * d;
+        pv = a.v + (size_t)(i + bjr) * B * d;
       } else {
         blb += 16; pq += 16; pv += 16;
       }
