@@ -256,6 +256,14 @@ __device__ __forceinline__ void export4(float* slab, int r, int n0, const f32x4 
 #pragma unroll
   for (int i = 0; i < 4; ++i) slab[(size_t)(n0 + i) * 16 + (r & 15)] = v[i];
 }
+// the same from the direct stages, where the tile's slab and the 16-unit block are wave-uniform: scalar base + ONE lane
+// offset, the four units as immediates (no per-store 64-bit address arithmetic: 3 vector instructions per store before)
+__device__ __forceinline__ void export4_block(float* slab_block, uint32_t lane_off, const f32x4 v) {
+  if (!slab_block) return;
+  char* base = reinterpret_cast<char*>(slab_block);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<float*>(base + (size_t)lane_off + 64 * i) = v[i];
+}
 
 struct EpiCtx {
   float* lds;
@@ -272,6 +280,15 @@ struct Epi {
   __device__ __forceinline__ float* slab(int prefix, int width, int r) const {
     return c.ws ? c.ws + (size_t)c.tile_rows * prefix + (size_t)(c.tile + (r >> 4)) * width * 16 : nullptr;
   }
+  // h >= 0: called from a direct stage for row tile h and 16-unit block nblk (both wave-uniform)
+  __device__ __forceinline__ void put(int prefix, int width, int r, int n0, const f32x4 v, int h, int nblk) const {
+    if (h >= 0) {
+      float* sb = c.ws ? c.ws + (size_t)c.tile_rows * prefix + ((size_t)(c.tile + h) * width + (size_t)nblk * 16) * 16 : nullptr;
+      export4_block(sb, (uint32_t)(((n0 & 15) * 16 + (r & 15)) * 4), v);
+    } else {
+      export4(slab(prefix, width, r), r, n0, v);
+    }
+  }
   __device__ __forceinline__ f32x4 init(int n0) const {
     if constexpr (EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_MASK0) return lds4(c.bias_lds + s.sd.L1.b_lds + n0);
     return f32x4{0.f, 0.f, 0.f, 0.f};
@@ -286,24 +303,24 @@ struct Epi {
       v += lds4(c.bias_lds + s.sd.L2.b_lds + n0);
     }
   }
-  __device__ __forceinline__ void fin(f32x4 v, int r, int n0, const UnetDesc& u) const {
+  __device__ __forceinline__ void fin(f32x4 v, int r, int n0, const UnetDesc& u, int h = -1, int nblk = 0) const {
     if constexpr (EPI == EPI_RELU) {
       unsigned m = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) { m |= (v[i] > 0.f ? 1u : 0u) << i; v[i] = relu_keep_nan(v[i]); }
       reinterpret_cast<unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)] = (unsigned char)m;
       *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
-      export4(slab(s.p1, s.w1, r), r, n0, v);
+      put(s.p1, s.w1, r, n0, v, h, nblk);
     } else if constexpr (EPI == EPI_RES) {
       *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
-      export4(slab(s.p1, s.w1, r), r, n0, v);
+      put(s.p1, s.w1, r, n0, v, h, nblk);
     } else if constexpr (EPI == EPI_MASK0) {
       const f32x4 g = lds4(c.lds + s.aux + r * s.saux + n0);
       f32x4 z;
 #pragma unroll
       for (int i = 0; i < 4; ++i) z[i] = v[i] > 0.f ? g[i] : 0.f;
       *reinterpret_cast<f32x4*>(c.lds + s.y2 + r * s.sy2 + n0) = z;
-      export4(slab(s.p2, s.w2, r), r, n0, z);
+      put(s.p2, s.w2, r, n0, z, h, nblk);
     } else if constexpr (EPI == EPI_DUAL) {
       const unsigned m = reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
       f32x4 z;
@@ -311,15 +328,15 @@ struct Epi {
       for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
       *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
       *reinterpret_cast<f32x4*>(c.lds + s.y2 + r * s.sy2 + n0) = z;
-      export4(slab(s.p1, s.w1, r), r, n0, v);
-      export4(slab(s.p2, s.w2, r), r, n0, z);
+      put(s.p1, s.w1, r, n0, v, h, nblk);
+      put(s.p2, s.w2, r, n0, z, h, nblk);
     } else {   // EPI_ACTMASK: the sign of the forward activation, saved as a nibble by that stage's EPI_RELU
       const unsigned m = reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
       f32x4 z;
 #pragma unroll
       for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
       if (s.sd.y >= 0) *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = z;
-      export4(slab(s.p1, s.w1, r), r, n0, z);
+      put(s.p1, s.w1, r, n0, z, h, nblk);
     }
   }
 };
@@ -407,7 +424,7 @@ __device__ __forceinline__ void k2_direct(const float* __restrict__ W1, const fl
 #pragma unroll
   for (int h = 0; h < RT; ++h)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) epi.fin(acc[h][j], h * 16 + row, (blk0 + j * NW) * 16 + 4 * g, u);
+    for (int j = 0; j < NB; ++j) epi.fin(acc[h][j], h * 16 + row, (blk0 + j * NW) * 16 + 4 * g, u, h, blk0 + j * NW);
 }
 
 // One stage on the 16-row tile; same work split as socmx_unet.h's unet_stage (direct: neuron blocks dealt to the waves;
