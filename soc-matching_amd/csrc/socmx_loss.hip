@@ -1429,6 +1429,147 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_mfma_kernel(const Targ
   }
 }
 
+// d <= 16, two rows per wave: the pairs (i0, j) and (i0 + 1, j) share the q_j / v_j fragments (16 loads and one index
+// inversion per 16 MFMAs instead of 12 and one per 8; same item numbering as socm_target_bwd_lds2_kernel).
+template <bool NET>
+__global__ __launch_bounds__(256, 2) void socm_target_bwd_mfma2_kernel(const TargetBwdArgs a, int64_t nitems) {
+  const int d = a.d, K = a.K, B = a.B;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t x = (int64_t)blockIdx.x * 4 + wave;
+  if (x >= nitems) return;
+  const float kp2 = (float)(K + 2);
+  int r2 = (int)((kp2 - sqrtf(fmaxf(kp2 * kp2 - 4.f * (float)x, 0.f))) * 0.5f);
+  r2 = max(0, min(r2, (K + 2) / 2 - 1));
+  while ((int64_t)(r2 + 1) * (K + 2 - (r2 + 1)) <= x) ++r2;
+  while ((int64_t)r2 * (K + 2 - r2) > x) --r2;
+  r2 = __builtin_amdgcn_readfirstlane(r2);
+  const int i0 = 2 * r2, i1 = i0 + 1;
+  const int j = i0 + (int)(x - (int64_t)r2 * (K + 2 - r2));
+  const bool two = i1 <= K && j >= i1;
+  const bool last = (j == K);
+  const int64_t p0 = pair_row_offset(i0, K) + (j - i0);
+  const int64_t p1 = two ? pair_row_offset(i1, K) + (j - i1) : p0;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int kb = blockIdx.y * 16, lb = blockIdx.z * 16;
+  const int k = kb + c16, l = lb + c16;
+  const bool okl = l < d;
+  const uint32_t cola = (uint32_t)min(k, d - 1) * 4u, colb = (uint32_t)min(l, d - 1) * 4u;
+  uint32_t offa[4], offb[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    offa[u] = (uint32_t)((4 * u + g4) * d) * 4u + cola;
+    offb[u] = (uint32_t)((4 * u + g4) * d) * 4u + colb;
+  }
+  const char* A0 = reinterpret_cast<const char*>(a.G + (size_t)i0 * B * d);
+  const char* A1 = reinterpret_cast<const char*>(a.G + (size_t)(two ? i1 : i0) * B * d);
+  const char* Bq = reinterpret_cast<const char*>(last ? a.gT : a.q + (size_t)j * B * d);
+  const char* Bv = reinterpret_cast<const char*>(a.v + (size_t)(last ? 0 : j) * B * d);
+  const size_t chunk_bytes = (size_t)16 * d * 4;
+  f32x4 accq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  struct Chunk { float a0[4], a1[4], qf[4], vf[4]; };
+  const char *ap0 = A0, *ap1 = A1, *qp = Bq, *vp = Bv;
+  auto load = [&](Chunk& ch) {                 // 16 loads: the next 16 rows (4u + g4), this lane's k / l column
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ch.a0[u] = *reinterpret_cast<const float*>(ap0 + (size_t)offa[u]);
+      ch.a1[u] = *reinterpret_cast<const float*>(ap1 + (size_t)offa[u]);
+      ch.qf[u] = *reinterpret_cast<const float*>(qp + (size_t)offb[u]);
+      ch.vf[u] = *reinterpret_cast<const float*>(vp + (size_t)offb[u]);
+    }
+    ap0 += chunk_bytes; ap1 += chunk_bytes; qp += chunk_bytes; vp += chunk_bytes;
+  };
+  auto multiply = [&](const Chunk& ch) {       // (an absent second pair / the terminal pair's v products are computed and dropped)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      accq[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.a0[u], ch.qf[u], accq[0], 0, 0, 0);
+      accq[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.a1[u], ch.qf[u], accq[1], 0, 0, 0);
+      accv[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.a0[u], ch.vf[u], accv[0], 0, 0, 0);
+      accv[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.a1[u], ch.vf[u], accv[1], 0, 0, 0);
+    }
+  };
+  const int nfull = B >> 4;
+  Chunk c0, c1;
+  if (nfull > 0) load(c0);
+  for (int c = 0; c < nfull; c += 2) {
+    if (c + 1 < nfull) load(c1);
+    multiply(c0);
+    if (c + 1 < nfull) {
+      if (c + 2 < nfull) load(c0);
+      multiply(c1);
+    }
+  }
+  if (B & 15) {                                // ragged last chunk: rows past the batch are clamped and their A values zeroed
+    const int m0 = nfull * 16;
+    Chunk ct;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + 4 * u + g4;
+      const size_t ro = (size_t)min(m, B - 1) * d * 4;
+      const float av0 = *reinterpret_cast<const float*>(A0 + ro + cola), av1 = *reinterpret_cast<const float*>(A1 + ro + cola);
+      ct.a0[u] = m < B ? av0 : 0.f;
+      ct.a1[u] = m < B ? av1 : 0.f;
+      ct.qf[u] = *reinterpret_cast<const float*>(Bq + ro + colb);
+      ct.vf[u] = *reinterpret_cast<const float*>(Bv + ro + colb);
+    }
+    multiply(ct);
+  }
+  const float go = a.gout ? a.gout[0] : 1.f;
+  const float gam = NET ? a.gamma[0] : 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && !two) break;
+    const int64_t p = h ? p1 : p0;
+    float e = 0.f, dl = 0.f, part = 0.f;
+    if (NET) { dl = a.delta[p]; e = expf(-gam * dl); }
+    const size_t blk = (size_t)p * d * d + (size_t)kb * d;
+    const char* netb = reinterpret_cast<const char*>(a.net + blk);
+    const char* dnetb = reinterpret_cast<const char*>(a.dnet + blk);
+    char* gMb = reinterpret_cast<char*>(a.gM + blk);
+    char* gdMb = reinterpret_cast<char*>(a.gdM + blk);
+    const float f = NET ? 1.f - e : 1.f, ge = gam * e;
+    const float kq = -f * go, kv = ge * go, kd = f * go;                  // gM = kq accq + kv accv,  gdM = kd accv
+    const float c1g = dl * e * go, c2g = e * (1.f - gam * dl) * go;       // d/dgamma: -accq c1 nmi + accv (c2 nmi + c1 dnet)
+    const float vmask = last ? 0.f : 1.f;                                 // the terminal pair has no v operand
+    float nt[4], dn[4];
+    bool ok[4];
+    uint32_t off[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int kl = 4 * g4 + rr;
+      ok[rr] = kb + kl < d && okl;
+      off[rr] = (uint32_t)(min(kl, d - 1 - kb) * d + min(l, d - 1)) * 4u;
+      if (NET) {
+        nt[rr] = *reinterpret_cast<const float*>(netb + (size_t)off[rr]);
+        dn[rr] = *reinterpret_cast<const float*>(dnetb + (size_t)off[rr]);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float aq_ = accq[h][rr], av_ = vmask * accv[h][rr];
+      float gm_, gd_;
+      if (NET) {
+        const float nmi = nt[rr] - ((kb + 4 * g4 + rr == l) ? 1.f : 0.f);
+        const float t = av_ * fmaf(c2g, nmi, c1g * dn[rr]) - aq_ * (c1g * nmi);
+        part += ok[rr] ? t : 0.f;
+        gm_ = fmaf(kq, aq_, kv * av_);
+        gd_ = kd * av_;
+      } else {
+        gm_ = -go * aq_;
+        gd_ = go * av_;
+      }
+      if (ok[rr]) {
+        *reinterpret_cast<float*>(gMb + (size_t)off[rr]) = gm_;
+        *reinterpret_cast<float*>(gdMb + (size_t)off[rr]) = gd_;
+      }
+    }
+    if (NET) {
+      part = wave_sum(part);
+      if (lane == 0) a.ggamma_part[((size_t)p * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z] = part;
+    }
+  }
+}
+
 // d > 16: one workgroup (4 waves) per pair; wave w owns k-block 4*blockIdx.y + w and LB l-blocks, i.e. 2*LB
 // accumulators: an A fragment (G rows) is loaded once per 16 batch rows and multiplied into all of them, the B
 // fragments (q, v rows) are shared by the four waves through L1.  Operands of the next 16 batch rows are requested
@@ -2310,6 +2451,15 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
                              : launch(socm_target_bwd_wide_kernel<true, 2>, wgrid, dim3(256), 0, stream, a);
     return lbw == 4 ? launch(socm_target_bwd_wide_kernel<false, 4>, wgrid, dim3(256), 0, stream, a)
                     : launch(socm_target_bwd_wide_kernel<false, 2>, wgrid, dim3(256), 0, stream, a);
+  }
+  // two pairs per wave pay off once a wave has enough 16-row chunks to stream (B = 1,024: 0.40 -> 0.36 ms at d = 10, K = 200);
+  // at a training batch of 128 the halved wave count costs more than the shared fragments save (58 -> 61 us)
+  static const bool one_row_small = getenv("SOCMX_BWD_ONE_ROW") != nullptr;      // A/B switch: one pair per wave
+  if (!one_row_small && B >= 512) {
+    const int64_t r2n = (K + 2) / 2, nitems = r2n * (K + 2 - r2n);                // items (row pair, j): two pairs per wave
+    dim3 grid2((unsigned)((nitems + 3) / 4), (d + 15) / 16, (d + 15) / 16);
+    return net ? launch(socm_target_bwd_mfma2_kernel<true>, grid2, dim3(256), 0, stream, a, nitems)
+               : launch(socm_target_bwd_mfma2_kernel<false>, grid2, dim3(256), 0, stream, a, nitems);
   }
   dim3 grid((unsigned)((np + 3) / 4), (d + 15) / 16, (d + 15) / 16);
   return net ? launch(socm_target_bwd_mfma_kernel<true>, grid, dim3(256), 0, stream, a)

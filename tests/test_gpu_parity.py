@@ -262,7 +262,9 @@ def test_fused_pair_matrix_kernels_vs_materialised(name):
                                    # enough for the request rings to wrap several times
                                    (36, 6, 272), (48, 9, 260), (60, 5, 512), (32, 11, 257), (20, 12, 256), (64, 7, 300),
                                    # d % 4 != 0 at B >= 256: the compiler-scheduled LDS form
-                                   (22, 4, 256), (50, 3, 270)])
+                                   (22, 4, 256), (50, 3, 270),
+                                   # d <= 16 at B >= 512: two pairs per wave in the backward kernel (ragged batch, odd K)
+                                   (3, 9, 520), (10, 6, 515), (16, 5, 512)])
 def test_contraction_kernels_multi_block_shapes(d, K, B):
     """d > 16 takes several 16-wide k/l blocks per pair matrix, B > 32 four batch tiles per wave (ragged last tile):
     none of the reference-generated fixtures is that large, so the HIP contraction (materialised and fused forms,
