@@ -377,11 +377,13 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
         xd = (s < na && j < K) ? xd : 0.f;
         // consecutive MFMAs go to different accumulators (a dependent pair costs 40 cycles instead of 32)
 #pragma unroll
+        // (no masks on the B side: xm / xd are zero wherever the B element lies past the row or belongs to the terminal
+        //  pair's absent v operand, and the clamped reads return finite values there)
         for (int c = 0; c < CT; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm, (s < nl) ? sl.q[c][s] : 0.f, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm, sl.q[c][s], acc[c], 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < CT; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd, (s < nl && j < K) ? sl.v[c][s] : 0.f, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd, sl.v[c][s], acc[c], 0, 0, 0);
       }
     };
     // PF iterations of this wave are in flight: one (pair, l-block) is 8*CT MFMAs, shorter than a trip to L2/HBM
@@ -1352,7 +1354,19 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_mfma_kernel(const Targ
       for (int u = 0; u < 4; ++u) accv = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.af[u], ch.vf[u], accv, 0, 0, 0);
     }
   };
-  const int nfull = B >> 4;                    // whole 16-row chunks; the next one is requested before the current is multiplied
+  const int nfull = B >> 4;                    // whole 16-row chunks
+  if (nfull <= 8) {
+    // training batches up to 128 (BASELINE configs[1..3]): all chunks are requested up front (up to 96 loads per lane, one
+    // memory round trip per wave instead of eight half-overlapped ones: 58 -> 43 us at cfg3) and multiplied as they arrive
+    Chunk ch[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nfull) load(ch[c]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nfull) multiply(ch[c]);
+  } else {
+  // the next chunk is requested before the current one is multiplied
   Chunk c0, c1;
   if (nfull > 0) load(c0);
   for (int c = 0; c < nfull; c += 2) {
@@ -1362,6 +1376,7 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_mfma_kernel(const Targ
       if (c + 2 < nfull) load(c0);
       multiply(c1);
     }
+  }
   }
   if (B & 15) {                                // ragged last chunk: rows past the batch are clamped and their A values zeroed
     const int m0 = nfull * 16;
