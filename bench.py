@@ -107,10 +107,14 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
     it_ms_eager, info = time_iterations(False)
     it_ms, mode = it_ms_eager, "eager (two HIP streams)"
     it_ms_graph = None
-    if not use_dist:
-        it_ms_graph, info = time_iterations(True)
+    try:          # (sharded: the RCCL all-reduces are captured inside the graph; an RCCL build that cannot capture keeps eager)
+        it_ms_graph, info_g = time_iterations(True)
         if it_ms_graph < it_ms:
-            it_ms, mode = it_ms_graph, "hipGraph replay"
+            it_ms, mode, info = it_ms_graph, "hipGraph replay", info_g
+    except Exception as e:  # noqa: BLE001
+        if not use_dist:
+            raise
+        mode += f" (hipGraph capture with RCCL failed: {type(e).__name__})"
     fl = flops_per_traj_step(d, HDIMS) * B * K
     out = {"workload": label, "rollout_ms": roll_ms, "trajectory_steps_per_s": B * K / (roll_ms * 1e-3),
            "socm_ms_per_iter": it_ms, "socm_iters_per_sec": 1e3 / it_ms, "iteration_mode": mode,
@@ -185,6 +189,33 @@ def cpu_baseline(budget_s=12.0):
     return best
 
 
+def launch_ranks(args):
+    """One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` as a
+    CHILD process (never an exec: this process may not replace itself once anything has initialised the GPU, and the
+    launcher children start from a clean state).  stdout of the children is relayed; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
+           str(args.warmup)]
+    for flag in ("no_cpu_baseline", "no_burst", "no_secondary"):
+        if getattr(args, flag):
+            cmd.append("--" + flag.replace("_", "-"))
+    if args.force_dist or args.spawn:
+        cmd.append("--force-dist")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,9 +225,18 @@ def main():
     ap.add_argument("--no-burst", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4]-slice entries")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and take the sharded code path even at world_size 1")
+    ap.add_argument("--spawn", action="store_true", help="take the launcher path even for --gpus 1 (one child rank under "
+                    "torch.distributed.run; implies --force-dist in the child)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks under torch.distributed.run and relay rank 0's
+        # JSON line.  This parent has not touched the GPU (device_count() does not initialise it) and never does.
+        sys.exit(launch_ranks(args))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -272,15 +312,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), float(info["loss"])
 
-    # eager schedule (two HIP streams; the only one for sharded runs) and, on one GPU, the whole iteration replayed as ONE
-    # captured hipGraph (Trainer(hip_graph=True)): same arithmetic, no host work between the launches
+    # eager schedule (two HIP streams; sharded: ONE flat all-reduce per iteration) and the whole iteration replayed as ONE
+    # captured hipGraph (Trainer(hip_graph=True); sharded: with its all-reduces inside): same arithmetic, no host work between
+    # the launches
     it_elapsed_eager, last_loss = time_iterations(False)
     it_elapsed, it_mode = it_elapsed_eager, "eager (two HIP streams)"
     it_elapsed_graph = None
-    if not use_dist:
+    try:          # (sharded: the iteration's RCCL all-reduces are captured inside the graph)
         it_elapsed_graph, last_loss_g = time_iterations(True)
         if it_elapsed_graph < it_elapsed:
             it_elapsed, it_mode, last_loss = it_elapsed_graph, "hipGraph replay", last_loss_g
+    except Exception as e:  # noqa: BLE001
+        if not use_dist:
+            raise
+        it_mode += f" (hipGraph capture with RCCL failed: {type(e).__name__}: {str(e)[:200]})"
 
     # (after the iteration leg: its 2 GB of buffers and the empty_cache() would otherwise cost the next leg its warm
     #  allocator state)

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 111 /* 0.1.1 + socmx_adam_step_f32 */
+#define SOCMX_VERSION 120 /* 0.1.2: + socmx_shard_stats_f32; socmx_adam_step_f32 sums are deterministic (scratch layout) */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -262,6 +262,16 @@ int socmx_rollout_phase_cycles_f32(const socmx_problem* problem, const float* pa
 int socmx_weights_stats_f32(const float* lpd, const float* lps, const float* ltw, int32_t B,
                             float* w, float* stats, socmx_stream_t stream);
 
+/* The same statistics for a batch SHARD (one rank of a data-parallel run; no reference counterpart -- the reference is
+ * single-process), in a form that ONE all_reduce(SUM) combines, so they travel in the flat gradient buffer:
+ *   phase 0: tail[0..3] = (obj[0] (0 if obj is NULL), sum_m (w[m] - c), sum_m (w[m] - c)^2, B) with c = shift[0] read from
+ *            DEVICE memory -- the running normalisation constant (main.py:354-359), identical on every rank and close to
+ *            mean(w), which keeps the shifted sums well conditioned in fp32;
+ *   phase 1: mean_std[0..1] = (c + S1/N, sqrt((S2 - S1^2/N) / (N - 1))) from the reduced tail = torch.mean / torch.std of
+ *            method.py:903-904 over the GLOBAL batch. */
+int socmx_shard_stats_f32(int32_t phase, const float* w, int32_t B, const float* shift, const float* obj, float* tail,
+                          float* mean_std, socmx_stream_t stream);
+
 /* Number of (t_i <= s_j) pairs: (K+1)(K+2)/2, ordered i-major, j ascending (method.py:533-547).
  * M_all / dM_all below are (Np,d,d) in that order. */
 int64_t socmx_num_pairs(int32_t K);
@@ -364,8 +374,10 @@ int socmx_iteration_scalars_f32(int32_t phase, float* itr, float* norm, float* e
  *   grad (total,): the flat gradient (socmx_unet_backward_f32's output order).
  *   ema_grad (total,) or NULL: telemetry  ema <- A ema + B grad, (A, B) from the iteration counter itr (1,) exactly as
  *     socmx_iteration_scalars_f32 phase 0 computes them (c_grad = the EMA coefficient).
- *   sums_out[0..1] = |grad|^2, |ema_grad|^2 (0 without ema_grad).
- *   scratch: 4 floats of caller-owned device memory, zero before the first call (the call leaves it zero again).
+ *   sums_out[0..1] = |grad|^2, |ema_grad|^2 (0 without ema_grad): per-workgroup partials combined in a fixed order by the
+ *     last workgroup to finish -- deterministic, no floating-point atomics.
+ *   scratch: 4 + 2 * ceil(total / 1024) floats of caller-owned device memory; scratch[0] (the finished-workgroup ticket)
+ *     must be zero before the first call, and the call leaves it zero again.
  */
 typedef struct socmx_adam_tensor {
   float* p;

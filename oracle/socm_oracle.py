@@ -272,38 +272,16 @@ def dM_ds_analytic(mp, gamma, t, s, d):
     return gamma * e * (net - eye) + (1 - e) * dnet
 
 
-def socm_loss(pb, vp, mp, gamma, x0, ts, T, lmbd, B, noise, derivative="jacrev",
-              return_parts=False):
-    """SOC_Solver.loss(algorithm="SOCM", use_stopping_time=False).
-
-    vp / mp / gamma may require grad; the rollout is detached as in the
-    reference (`detach=True`, method.py:240).  Returns
-    (objective, mean(w), std(w)) and, with return_parts, a dict of intermediates.
-    """
-    K = ts.shape[0] - 1
-    d = x0.shape[-1]
+def socm_objective_dense(pb, ts, lmbd, states, noises, controls, M_all, dM_all, nabla_V, weight):
+    """The SOCM least-squares target and objective from the rollout buffers, the pair-grid matrices
+    `M_all`, `dM_all` (Np,d,d) and nabla_V on the trajectory -- method.py:517-522, 574-582, 591-720 in the
+    reference's dense zero-filled (Kp,Kp,...) form.  Returns (objective, target (Kp,B,d))."""
+    Kp, B, d = states.shape
+    K = Kp - 1
     sigma = pb["sigma"]
-    state0 = x0.repeat(B, 1)                                                   # :238
-    with torch.no_grad():
-        states, noises, stop_ind, frac, lpd, lps, ltw, controls = stochastic_trajectories(
-            pb, vp, state0, ts, lmbd, noise)
-    weight = torch.exp(lpd + lps + ltw)                                         # :258-262
-    ts_repeat = ts.unsqueeze(1).unsqueeze(2).repeat(1, B, 1)                   # :272-278
-    tx = torch.cat([ts_repeat, states], dim=-1).reshape(-1, d + 1)
-    nabla_V = unet_forward(vp, tx).reshape(states.shape)
-
     sit = torch.transpose(torch.inverse(sigma), 0, 1)                           # :481
-    Kp = K + 1
-    t_vec, s_vec = pair_grid(ts, T, K)
-    M_all = sigmoid_mlp(mp, gamma, t_vec, s_vec, d)                             # :566-569
-    if derivative == "jacrev":                                                  # :510-515, 570-573
-        from torch.func import jacrev
-        sum_M = lambda t, s: sigmoid_mlp(mp, gamma, t, s, d).sum(dim=0)
-        dM_all = torch.transpose(torch.transpose(jacrev(sum_M, argnums=1)(t_vec, s_vec), 1, 2), 0, 1)
-    else:
-        dM_all = dM_ds_analytic(mp, gamma, t_vec, s_vec, d)
-    M_evals = torch.zeros(Kp, Kp, d, d)                                         # :517-522
-    dM_evals = torch.zeros(Kp, Kp, d, d)
+    M_evals = torch.zeros(Kp, Kp, d, d, dtype=M_all.dtype)                      # :517-522
+    dM_evals = torch.zeros(Kp, Kp, d, d, dtype=M_all.dtype)
     c = 0
     for k in range(Kp):                                                         # :574-582
         n = K + 1 - k
@@ -327,6 +305,37 @@ def socm_loss(pb, vp, mp, gamma, x0, ts, T, lmbd, B, noise, derivative="jacrev",
     learned = -torch.einsum("ij,...j->...i", torch.transpose(sigma, 0, 1), nabla_V)          # :702-709
     tgt = -torch.einsum("ij,...j->...i", torch.transpose(sigma, 0, 1), target)
     objective = torch.sum((learned - tgt) ** 2 * weight.unsqueeze(0).unsqueeze(2)) / (Kp * B)  # :717-720
+    return objective, target
+
+
+def socm_loss(pb, vp, mp, gamma, x0, ts, T, lmbd, B, noise, derivative="jacrev",
+              return_parts=False):
+    """SOC_Solver.loss(algorithm="SOCM", use_stopping_time=False).
+
+    vp / mp / gamma may require grad; the rollout is detached as in the
+    reference (`detach=True`, method.py:240).  Returns
+    (objective, mean(w), std(w)) and, with return_parts, a dict of intermediates.
+    """
+    K = ts.shape[0] - 1
+    d = x0.shape[-1]
+    state0 = x0.repeat(B, 1)                                                   # :238
+    with torch.no_grad():
+        states, noises, stop_ind, frac, lpd, lps, ltw, controls = stochastic_trajectories(
+            pb, vp, state0, ts, lmbd, noise)
+    weight = torch.exp(lpd + lps + ltw)                                         # :258-262
+    ts_repeat = ts.unsqueeze(1).unsqueeze(2).repeat(1, B, 1)                   # :272-278
+    tx = torch.cat([ts_repeat, states], dim=-1).reshape(-1, d + 1)
+    nabla_V = unet_forward(vp, tx).reshape(states.shape)
+
+    t_vec, s_vec = pair_grid(ts, T, K)
+    M_all = sigmoid_mlp(mp, gamma, t_vec, s_vec, d)                             # :566-569
+    if derivative == "jacrev":                                                  # :510-515, 570-573
+        from torch.func import jacrev
+        sum_M = lambda t, s: sigmoid_mlp(mp, gamma, t, s, d).sum(dim=0)
+        dM_all = torch.transpose(torch.transpose(jacrev(sum_M, argnums=1)(t_vec, s_vec), 1, 2), 0, 1)
+    else:
+        dM_all = dM_ds_analytic(mp, gamma, t_vec, s_vec, d)
+    objective, target = socm_objective_dense(pb, ts, lmbd, states, noises, controls, M_all, dM_all, nabla_V, weight)
     out = (objective, torch.mean(weight), torch.std(weight))                                  # :903-904
     if return_parts:
         parts = dict(states=states, noises=noises, controls=controls, weight=weight,

@@ -70,6 +70,37 @@ __global__ __launch_bounds__(256) void weights_stats_kernel(const float* __restr
   }
 }
 
+// ---- importance-weight statistics of a batch SHARD, in a form ONE all_reduce(SUM) can combine --------------------
+// phase 0: tail = (objective, sum (w - c), sum (w - c)^2, n) with the shift c read from device memory (the running
+//          normalisation constant: identical on every rank and close to mean(w), so the sums stay well conditioned);
+// phase 1: from the REDUCED tail: mean = c + S1 / N, unbiased std = sqrt((S2 - S1^2 / N) / (N - 1))  (method.py:903-904).
+__global__ __launch_bounds__(256) void shard_stats_kernel(int phase, const float* __restrict__ w, int B,
+                                                          const float* __restrict__ shift, const float* __restrict__ obj,
+                                                          float* __restrict__ tail, float* __restrict__ mean_std) {
+  __shared__ float red[32];
+  const float c = shift[0];
+  if (phase == 0) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int m = threadIdx.x; m < B; m += blockDim.x) {
+      const float x = w[m] - c;
+      s1 += x;
+      s2 += x * x;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+      tail[0] = obj ? obj[0] : 0.f;
+      tail[1] = s1;
+      tail[2] = s2;
+      tail[3] = (float)B;
+    }
+  } else if (threadIdx.x == 0) {
+    const float s1 = tail[1], s2 = tail[2], n = tail[3];
+    mean_std[0] = c + s1 / n;
+    mean_std[1] = sqrtf(fmaxf(s2 - s1 * s1 / n, 0.f) / (n - 1.f));
+  }
+}
+
 // ---- operand preparation: method.py:591-646 -------------------------------------------------------
 struct PrepArgs {
   int kind, d, K, B;
@@ -2183,7 +2214,7 @@ struct AdamArgs {
   const float* itr;
   float c_grad, one_minus_c_grad, warm_grad;
   float lr, beta1, beta2, eps;
-  float* scratch;      // [0] = sum g^2, [1] = sum ema^2, [2] = finished-workgroup ticket (as unsigned)
+  float* scratch;      // [0] = finished-workgroup ticket (as unsigned); [4 + 2 b], [5 + 2 b] = workgroup b's sum g^2, sum ema^2
   float* sums_out;
 };
 
@@ -2235,21 +2266,31 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
   sg = wave_sum(sg); se = wave_sum(se);
   if ((tid & 63) == 0) { red[0][tid >> 6] = sg; red[1][tid >> 6] = se; }
   __syncthreads();
+  // per-workgroup partial sums in scratch[4 + 2 b], combined in a FIXED order by the last workgroup to finish (no float
+  // atomics: the telemetry is bit-reproducible like the rest of the library)
   if (tid == 0) {
-    atomicAdd(&a.scratch[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-    atomicAdd(&a.scratch[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    a.scratch[4 + 2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    a.scratch[5 + 2 * blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     __threadfence();
-    const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(a.scratch + 2), 1u);
+    const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(a.scratch), 1u);
     last_flag = (ticket == gridDim.x - 1) ? 1u : 0u;
   }
   __syncthreads();
   if (last_flag) {                           // every workgroup has finished: publish the sums, re-arm, advance the step counters
     __threadfence();
+    float pg = 0.f, pe = 0.f;
+    for (unsigned b = tid; b < gridDim.x; b += 256) {
+      pg += __builtin_nontemporal_load(&a.scratch[4 + 2 * b]);
+      pe += __builtin_nontemporal_load(&a.scratch[5 + 2 * b]);
+    }
+    pg = wave_sum(pg); pe = wave_sum(pe);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[0][tid >> 6] = pg; red[1][tid >> 6] = pe; }
+    __syncthreads();
     if (tid == 0) {
-      a.sums_out[0] = atomicAdd(&a.scratch[0], 0.f);
-      a.sums_out[1] = atomicAdd(&a.scratch[1], 0.f);
-      a.scratch[0] = 0.f; a.scratch[1] = 0.f;
-      *reinterpret_cast<unsigned*>(a.scratch + 2) = 0u;
+      a.sums_out[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      a.sums_out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      *reinterpret_cast<unsigned*>(a.scratch) = 0u;
     }
     if (tid < a.ntensors) tab[tid].step[0] = t;
   }
@@ -2295,6 +2336,13 @@ extern "C" int socmx_weights_stats_f32(const float* lpd, const float* lps, const
   if (!lpd || !lps || !ltw || !w || !stats) return SOCMX_E_NULL;
   if (B < 1) return SOCMX_E_DIM;
   return launch(weights_stats_kernel, dim3(1), dim3(256), 0, stream, lpd, lps, ltw, (int)B, w, stats);
+}
+
+extern "C" int socmx_shard_stats_f32(int32_t phase, const float* w, int32_t B, const float* shift, const float* obj,
+                                     float* tail, float* mean_std, socmx_stream_t stream) {
+  if (!shift || !tail || (phase == 0 ? !w : !mean_std)) return SOCMX_E_NULL;
+  if ((phase != 0 && phase != 1) || (phase == 0 && B < 1)) return SOCMX_E_DIM;
+  return launch(shard_stats_kernel, dim3(1), dim3(256), 0, stream, (int)phase, w, (int)B, shift, obj, tail, mean_std);
 }
 
 extern "C" int64_t socmx_num_pairs(int32_t K) { return K < 0 ? 0 : (int64_t)(K + 1) * (K + 2) / 2; }

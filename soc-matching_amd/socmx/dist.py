@@ -4,10 +4,15 @@ reference is single-process).
 Trajectories are independent (utils.py:37-101 has no cross-sample term) and the SOCM objective is a
 sum over samples (method.py:717-720), so rank r simulates rows [row0, row0+B_r) of the global batch
 with the Philox stream keyed by the GLOBAL row index, and the only communication per iteration is
-  * one all_gather of 3 floats per rank (sum w, centred sum of squares, n) -> mean/std of w,
-  * ONE all_reduce(SUM) of a flat fp32 buffer holding every gradient (+ the objective value),
+ONE all_reduce(SUM) of a flat fp32 buffer holding every gradient, the objective value, the shifted
+sums (sum (w - c), sum (w - c)^2, n) that give mean/std of w (c = the running normalisation constant,
+identical on every rank) and, when computed, this rank's share of the weighted L2 error --
 over RCCL (torch.distributed backend "nccl") on xGMI; "gloo" on CPU for tests.  The buffer is
 0.7-3 MB, i.e. latency-bound: it must stay a single collective, never one call per parameter.
+(hipGraph mode, train.py: the pair-grid network's gradients -- produced one iteration later on the
+second stream, beside the next rollout -- travel in a second, smaller all_reduce inside the same
+captured graph.  `SOC_Solver.loss` called directly on a sharded solver still pools the weight
+statistics itself, with an all_gather + Chan's rule.)
 """
 import torch
 import torch.distributed as dist
@@ -40,14 +45,14 @@ class Shard:
         return L.combine_stats(torch.stack(gathered))
 
     def allreduce_gradients(self, params, extra=None, slot="main"):
-        """Sum `.grad` of all params (and the optional 0-dim tensors in `extra`) across ranks with ONE
-        collective on one flat buffer, enqueued behind the CURRENT stream.  Returns the reduced extras.
-        Every rank must issue its collectives in the same order (Trainer: "main" first, then "side")."""
+        """Sum `.grad` of all params (and the optional tensors in `extra`, any shapes) across ranks with ONE
+        collective on one flat buffer, enqueued behind the CURRENT stream.  Returns the reduced extras (same shapes)."""
         params = [p for p in params if p.grad is not None]
-        extra = list(extra or [])
+        extra = [e.detach().reshape(-1).to(torch.float32) for e in (extra or [])]
         if self.world_size == 1 and not dist.is_initialized():
             return extra
-        n = sum(p.grad.numel() for p in params) + len(extra)
+        n_extra = sum(e.numel() for e in extra)
+        n = sum(p.grad.numel() for p in params) + n_extra
         dev = params[0].grad.device if params else extra[0].device
         flat = self._flat.get(slot)
         if flat is None or flat.numel() != n or flat.device != dev:
@@ -60,9 +65,33 @@ class Shard:
         if views:
             torch._foreach_copy_(views, [p.grad for p in params])
         if extra:
-            flat[off:] = torch.stack([e.detach().reshape(()) for e in extra])
+            flat[off:] = torch.cat(extra)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         if views:
             torch._foreach_copy_([p.grad for p in params], views)
         red = flat[off:].clone()
-        return [red[i] for i in range(len(extra))]
+        out, o = [], 0
+        for e in extra:
+            out.append(red[o:o + e.numel()])
+            o += e.numel()
+        return out
+
+    def allreduce_flat_(self, flat):
+        """In-place all_reduce(SUM) of a caller-owned flat fp32 buffer (the hipGraph body owns its buffers: gradients,
+        objective and weight statistics are written straight into one)."""
+        if self.world_size == 1 and not dist.is_initialized():
+            return flat
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+
+def shifted_weight_sums(weight, shift):
+    """(sum (w - c), sum (w - c)^2, n) of this shard's importance weights: summable across ranks (one all_reduce), and
+    well conditioned when c is close to mean(w) -- Trainer passes the running normalisation constant."""
+    wc = weight - shift
+    return torch.stack([wc.sum(), (wc * wc).sum(), torch.tensor(float(weight.numel()), device=weight.device)])
+
+
+def mean_std_from_shifted_sums(sums, shift):
+    s1, s2, n = sums[0], sums[1], sums[2]
+    return shift + s1 / n, torch.sqrt(torch.clamp(s2 - s1 * s1 / n, min=0.0) / (n - 1))

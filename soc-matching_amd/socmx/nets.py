@@ -226,7 +226,7 @@ def unet_backward_supported(net, n_rows):
     return L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
 
 
-def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None):
+def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None, out=None):
     """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
     x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
     `net.parameters()` order (views of one flat buffer)."""
@@ -242,7 +242,9 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=No
     _lib.check(L.socmx_unet_backward_sizes(d, _lib.i3(net.hdims), N, _lib.C.byref(ws), _lib.C.byref(ng)),
                "socmx_unet_backward_sizes")
     work = torch.empty(ws.value, dtype=torch.float32, device=dev)
-    flat = torch.empty(ng.value, dtype=torch.float32, device=dev)
+    # (`out`: a caller-owned fp32 buffer of >= n_grad floats -- a sharded Trainer appends its scalars behind the gradient
+    #  and all-reduces the whole buffer)
+    flat = torch.empty(ng.value, dtype=torch.float32, device=dev) if out is None else out[:ng.value]
     with _lib.on_device(dev):
         # (`packed`: the forward image of the CURRENT weights when the caller knows it is fresh -- e.g. the one this
         #  iteration's rollout just used -- instead of re-packing)
@@ -318,8 +320,8 @@ def pair_net_forward(d, hdims, params, t, s, packed=None):
     return net, dnet, packed
 
 
-def pair_net_backward(d, hdims, shapes, packed, t, s, g_net, g_dnet):
-    """Parameter gradients [W0, b0, W1, b1, W2, b2] (views of one flat buffer): socmx_mnet_backward_f32."""
+def pair_net_backward(d, hdims, shapes, packed, t, s, g_net, g_dnet, out=None):
+    """Parameter gradients [W0, b0, W1, b1, W2, b2] (views of one flat buffer -- `out` when given): socmx_mnet_backward_f32."""
     L = _lib.lib()
     dev = t.device
     Np = t.shape[0]
@@ -327,7 +329,7 @@ def pair_net_backward(d, hdims, shapes, packed, t, s, g_net, g_dnet):
     ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
     _lib.check(L.socmx_mnet_backward_sizes(d, h2, Np, _lib.C.byref(ws), _lib.C.byref(ng)), "socmx_mnet_backward_sizes")
     work = torch.empty(ws.value, dtype=torch.float32, device=dev)
-    flat = torch.empty(ng.value, dtype=torch.float32, device=dev)
+    flat = torch.empty(ng.value, dtype=torch.float32, device=dev) if out is None else out[:ng.value]
     with _lib.on_device(dev):
         _lib.check(L.socmx_mnet_backward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(g_net),
                                              _lib.ptr(g_dnet), _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),

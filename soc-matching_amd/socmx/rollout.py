@@ -123,6 +123,15 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
         ckind, table, tidx, n_x, xb, dx = sde.u.hip_descriptor(tc)
         table = table.detach().to(**f32).contiguous()
         tidx = tidx.to(device=dev, dtype=torch.int32).contiguous()
+        # the kernel indexes the table with tidx unchecked; an index past the table raises in the reference's lookup
+        # (models.py:15-23, 72-75, 98-150) -- checked once per (control, time grid), not per rollout
+        seen = (tc.data_ptr(), K, int(table.shape[0]))
+        if getattr(sde.u, "_tidx_checked", None) != seen:
+            lo, hi = int(tidx.min()), int(tidx.max())
+            if lo < 0 or hi >= table.shape[0]:
+                raise IndexError(f"ground-truth control: time index range [{lo}, {hi}] outside the table of "
+                                 f"{table.shape[0]} rows")
+            sde.u._tidx_checked = seen
         ctrl = _lib.Control(kind=ckind, n_t=int(table.shape[0]), n_x=int(n_x), table=_lib.ptr(table),
                             tidx=tidx.data_ptr(), xb=float(xb), delta_x=float(dx))
         if seed is None:

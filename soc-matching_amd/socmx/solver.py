@@ -196,7 +196,7 @@ class SOC_Solver(nn.Module):
         # SOCM on the GPU: the rollout kernel hands over nabla_V at all (K+1) B trajectory rows (it evaluates the network
         # there anyway) and socmx_unet_backward_f32 produces the parameter gradients -- no library forward/backward
         from . import nets as _nets
-        fused_V = (algorithm == "SOCM" and detach and R.burst_eligible(sde, state0) and getattr(self, "fused_nabla_V", True)
+        fused_V = (algorithm == "SOCM" and detach and R._eligible_for_hip(sde, state0, detach) and getattr(self, "fused_nabla_V", True)
                    and _nets.unet_backward_supported(sde.nabla_V, Kp * B))
         rolled = R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0,
                                            key=getattr(self, "philox_key", None), want_nabla_v=fused_V)
@@ -222,7 +222,13 @@ class SOC_Solver(nn.Module):
             return (objective, norm_sqd_diff, cm, ce, traj, torch.mean(weight), torch.std(weight), stop_indicators)
 
         weight, stats = L.weights_and_stats(lpd, lps, ltw)
-        if shard is not None:
+        shift = getattr(self, "defer_weight_stats", None)
+        if shard is not None and shift is not None:
+            # Trainer carries the statistics in its ONE flat all-reduce (socmx.dist): leave the shard's shifted sums for
+            # it; the mean / std returned below are this shard's own until Trainer replaces them
+            from .dist import shifted_weight_sums
+            self._local_w_sums = shifted_weight_sums(weight, shift)
+        elif shard is not None:
             stats = shard.combine_weight_stats(stats)
         w_mean, w_std = L.mean_std_from_stats(stats)
 

@@ -11,6 +11,9 @@ import numpy as np
 import torch
 
 
+KEYED_OFFSET_BASE = 1 << 31      # first Philox offset of the device-resident key (hipGraph mode)
+
+
 def compute_EMA(value, EMA_value, EMA_coeff=0.01, itr=0):
     warm = int(np.floor(1 / EMA_coeff))
     if itr == 0:
@@ -61,9 +64,10 @@ class Trainer:
         if gemm_select and solver.x0.is_cuda:
             from . import gemm_select as _gs
             _gs.enable(tune_new_shapes=tune_new_shapes)
-        # hipGraph mode (single GPU, SOCM with or without stopping times): the whole iteration -- rollout, loss, backward, Adam,
-        # EMA normaliser, gradient telemetry -- is captured once and replayed; see _graph_step
-        self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda and solver.shard is None)
+        # hipGraph mode (SOCM with or without stopping times; sharded runs: plain SOCM on the hand-written kernels, with the
+        # RCCL all-reduces captured inside the graph): the whole iteration -- rollout, loss, backward, collectives, Adam, EMA
+        # normaliser, gradient telemetry -- is captured once and replayed; see _graph_step
+        self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda)
         self.graph_warmup = int(graph_warmup)
         self.fused_adam = bool(fused_adam)    # hipGraph body: control-network Adam + telemetry as one launch (socmx_adam_step_f32)
         self._graphs = {}
@@ -73,8 +77,7 @@ class Trainer:
             overlap_M_backward = False     # inside a graph the pair-grid network's backward forks and joins within the iteration
         # SOCM on one GPU: the pair-grid network's backward and its Adam groups run on the solver's second stream
         # and overlap with the next iteration's rollout (same arithmetic, same order of updates per parameter)
-        # (sharded runs too: the pair-grid network's gradients then get their own all-reduce on that stream -- two
-        #  collectives per iteration, issued in the same order on every rank)
+        # (single-GPU eager runs only: a sharded eager iteration issues ONE collective, after the complete backward)
         self.defer_M = (overlap_M_backward and algorithm == "SOCM" and solver.x0.is_cuda
                         and not getattr(solver.neural_sde, "use_stopping_time", False))
         sde = solver.neural_sde
@@ -147,8 +150,6 @@ class Trainer:
                 g.record_stream(side)
             with torch.enable_grad():
                 torch.autograd.backward([net, dnet], grads)
-            if solver.shard is not None:      # second collective of the iteration: the M network's and gamma's gradients
-                solver.shard.allreduce_gradients([p for g in self._groups_side for p in g["params"]], slot="side")
             for grp in self._groups_side:
                 for p in grp["params"]:
                     if p.grad is not None:
@@ -177,13 +178,11 @@ class Trainer:
             D["itr1"], D["norm1"], D["ema_gn1"] = D["itr"].reshape(1), D["norm"].reshape(1), D["ema_gn"].reshape(1)
             D["ab"] = torch.zeros(2, dtype=torch.float32, device=dev)
             if getattr(self.solver, "philox_key", None) is None:
-                self.solver.philox_key = PhiloxKey(dev)
-            for g in self.optimizer.param_groups:            # device-side step counters: required under capture
-                g["capturable"] = True
-                for p in g["params"]:
-                    st = self.optimizer.state.get(p)
-                    if st and torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
-                        st["step"] = st["step"].to(dev)
+                # a stream of its own: the host-side counter (rollout._philox_calls: evaluation bursts, eager rollouts)
+                # counts 0, 1, 2, ... under the same seed, the device key counts from 2^31 -- the 32-bit offset word of the
+                # Philox counter (include/socmx.h) never coincides, so no burst re-draws noise an iteration trained on
+                self.solver.philox_key = PhiloxKey(dev, offset=KEYED_OFFSET_BASE)
+            self._make_capturable()
         return self._dev
 
     @staticmethod
@@ -263,11 +262,26 @@ class Trainer:
         sde, D = self.solver.neural_sde, self._dev
         layers = [sde.M.sigmoid_layers[i] for i in (0, 2, 4)]
         params = [p for l in layers for p in (l.weight, l.bias)]
-        grads = nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
-                                       D["g_net"], D["g_dnet"])
+        shard = self.solver.shard
+        if shard is None:
+            grads = nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
+                                           D["g_net"], D["g_dnet"])
+            g_gamma = D["g_gamma"].reshape(sde.gamma.shape).clone()
+        else:
+            # sharded: g_net / g_dnet / g_gamma are this rank's partial sums, and the network's backward is linear in them --
+            # its parameter gradients + gamma's travel in ONE small all-reduce (the iteration's second collective, on the
+            # second stream beside the rollout, inside the captured graph)
+            n = sum(p.numel() for p in params)
+            if "m_flat" not in D:
+                D["m_flat"] = torch.empty(n + 1, dtype=torch.float32, device=D["g_gamma"].device)
+            grads = nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
+                                           D["g_net"], D["g_dnet"], out=D["m_flat"])
+            D["m_flat"][n:].copy_(D["g_gamma"])
+            shard.allreduce_flat_(D["m_flat"])
+            g_gamma = D["m_flat"][n:].reshape(sde.gamma.shape).clone()
         for p, g in zip(params, grads):
             p.grad = g
-        sde.gamma.grad = D["g_gamma"].reshape(sde.gamma.shape).clone()
+        sde.gamma.grad = g_gamma
         self._step_groups(D["groups_side"])
         for p in params + [sde.gamma]:
             p.grad = None
@@ -293,7 +307,9 @@ class Trainer:
         solver, D = self.solver, self._graph_state()
         sde, pb = solver.neural_sde, solver.neural_sde.problem
         dev = solver.x0.device
-        B, K, d = self.batch_size, solver.num_steps, solver.dim
+        shard = solver.shard
+        B_global, K, d = self.batch_size, solver.num_steps, solver.dim
+        B, row0 = (B_global, 0) if shard is None else shard.local_rows(B_global)
         Kp = K + 1
         ts = solver.ts.to(dev)
         t_vec, s_vec, ii, jj, delta = solver._pair_grid(ts, K)
@@ -339,7 +355,7 @@ class Trainer:
         state0 = solver.x0.repeat(B, 1)
         noise_in, solver.noise_in = solver.noise_in, None
         (states, noises, stop, frac, lpd, lps, ltw, controls, nabla_v) = R.stochastic_trajectories(
-            sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True)
+            sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0)
         if side is not None:
             main.wait_stream(side)
             net.record_stream(main)
@@ -348,16 +364,49 @@ class Trainer:
         w_mean, w_std = L.mean_std_from_stats(stats)
         ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls)
         gam = sde.gamma.detach().to(torch.float32).reshape(1).contiguous()
-        obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B))
+        obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B_global))
         gout = (1.0 / D["norm"]).reshape(1)                               # d loss / d objective  (main.py:313-320)
         _, _, part = L.target_bwd_net(d, K, B, G, ops, gout, net, dnet, delta, gam, g_net=D["g_net"], g_dnet=D["g_dnet"])
         torch.sum(part, dim=0, keepdim=True, out=D["g_gamma"])
-        vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
-                                               (G * gout).reshape(Kp * B, d), return_flat=True,
-                                               packed=sde.nabla_V._packed)     # (the image this iteration's rollout packed)
-        vparams = list(sde.nabla_V.parameters())
         from . import _lib
         Lh, f = _lib.lib(), _lib.ptr
+        want_l2 = bool(loss_kwargs and loss_kwargs.get("compute_L2_error"))
+        main_flat = None
+        if shard is not None:
+            # the iteration's flat all-reduce buffer: [control-network gradient | objective, sum (w-c), sum (w-c)^2, n, L2 error]
+            ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
+            _lib.check(Lh.socmx_unet_backward_sizes(d, _lib.i3(sde.nabla_V.hdims), Kp * B, _lib.C.byref(ws), _lib.C.byref(ng)),
+                       "socmx_unet_backward_sizes")
+            main_flat = torch.zeros(ng.value + 5, dtype=torch.float32, device=dev)
+        vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
+                                               (G * gout).reshape(Kp * B, d), return_flat=True,
+                                               packed=sde.nabla_V._packed,     # (the image this iteration's rollout packed)
+                                               out=main_flat)
+        vparams = list(sde.nabla_V.parameters())
+        nsd = None
+        if want_l2:
+            # method.py:858-873: weighted squared distance between the learned control and the ground truth on this batch
+            # (a shard's share: divided by the GLOBAL batch, summed by the all-reduce)
+            target_control = loss_kwargs["optimal_control"](solver.ts, states, t_is_tensor=True)
+            learned = -(nabla_v @ solver.sigma)
+            nsd = torch.sum((target_control - learned) ** 2 * weight.reshape(1, -1, 1)
+                            / (target_control.shape[0] * B_global)).reshape(1)
+        w_mean, w_std = stats[3:4].contiguous(), stats[4:5].contiguous()
+        if shard is not None:
+            tail = main_flat[vflat.numel():]
+            with _lib.on_device(dev):
+                _lib.check(Lh.socmx_shard_stats_f32(0, f(weight), B, f(D["norm1"]), f(obj), f(tail), None, _lib.stream_ptr(dev)),
+                           "socmx_shard_stats_f32")
+            if nsd is not None:
+                tail[4:5].copy_(nsd)
+            shard.allreduce_flat_(main_flat)           # the iteration's ONE collective on this stream (captured in the graph)
+            mean_std = torch.empty(2, dtype=torch.float32, device=dev)
+            with _lib.on_device(dev):
+                _lib.check(Lh.socmx_shard_stats_f32(1, None, 0, f(D["norm1"]), None, f(tail), f(mean_std), _lib.stream_ptr(dev)),
+                           "socmx_shard_stats_f32")
+            obj, w_mean, w_std = tail[0:1], mean_std[0:1], mean_std[1:2]
+            if nsd is not None:
+                nsd = tail[4:5]
         gn = gne = None
         adam = self._fused_adam_table(D, vparams, vflat)
         if adam is not None:
@@ -395,16 +444,11 @@ class Trainer:
         out = torch.empty(7, dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             _lib.check(Lh.socmx_iteration_scalars_f32(
-                1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(stats[3:4].contiguous()),
-                f(stats[4:5].contiguous()), f(obj), f(gn) if gn is not None else None, f(gne) if gne is not None else None,
+                1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(w_mean),
+                f(w_std), f(obj), f(gn) if gn is not None else None, f(gne) if gne is not None else None,
                 self.coeff, 0.01, None, f(out), _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
         self._m_pending = True
-        if loss_kwargs and loss_kwargs.get("compute_L2_error"):
-            # method.py:858-873: weighted squared distance between the learned control and the ground truth on this batch
-            target_control = loss_kwargs["optimal_control"](solver.ts, states, t_is_tensor=True)
-            learned = -(nabla_v @ solver.sigma)
-            nsd = torch.sum((target_control - learned) ** 2 * weight.reshape(1, -1, 1)
-                            / (target_control.shape[0] * target_control.shape[1]))
+        if nsd is not None:
             out = torch.cat([out, nsd.reshape(1)])
         return out
 
@@ -415,7 +459,7 @@ class Trainer:
         if not self.fused_adam:
             return None
         if "adam_table" in D:
-            return D["adam_table"]
+            return D["adam_table"] if self._adam_signature(D["groups_main"][0], vparams) == D["adam_sig"] else None
         opt, groups = self.optimizer, D["groups_main"]
         if type(opt) is not torch.optim.Adam or len(groups) != 1:
             return None
@@ -436,10 +480,47 @@ class Trainer:
         if off != vflat.numel():
             return None
         dev = vflat.device
-        D["adam_scratch"] = torch.zeros(4, dtype=torch.float32, device=dev)
+        D["adam_scratch"] = torch.zeros(4 + 2 * ((off + 1023) // 1024), dtype=torch.float32, device=dev)
         sums = torch.zeros(2, dtype=torch.float32, device=dev)
         D["adam_table"] = (torch.tensor(rows, dtype=torch.int64, device=dev), grp, sums)     # socmx_adam_tensor records
+        D["adam_sig"] = self._adam_signature(grp, vparams)
         return D["adam_table"]
+
+    def _adam_signature(self, grp, vparams):
+        """What the device table and a captured iteration have baked in: every data pointer of the control network's Adam
+        state and the hyper-parameters of every group (the pair-grid network's groups are stepped by torch's capturable
+        Adam inside the same graph).  `optimizer.load_state_dict` (resume), a re-allocated parameter or state tensor, or an
+        lr schedule changes it -- `_graph_step` then drops the table and the captured graphs instead of stepping through
+        stale pointers or frozen hyper-parameters."""
+        st = self.optimizer.state
+        if not all(p in st and "exp_avg" in st[p] for p in vparams):
+            return None
+        ptrs = tuple(q.data_ptr() for p in vparams for q in (p, st[p]["exp_avg"], st[p]["exp_avg_sq"], st[p]["step"]))
+        hyper = tuple((float(g["lr"]) if not torch.is_tensor(g["lr"]) else id(g["lr"]), tuple(g["betas"]), float(g["eps"]),
+                       tuple(st[p]["exp_avg"].data_ptr() if p in st and "exp_avg" in st[p] else 0 for p in g["params"]))
+                      for g in self.optimizer.param_groups if g is not grp)
+        return (ptrs, float(grp["lr"]) if not torch.is_tensor(grp["lr"]) else None, tuple(grp["betas"]), float(grp["eps"]),
+                hyper)
+
+    def _make_capturable(self):
+        dev = self.solver.x0.device
+        for g in self.optimizer.param_groups:            # device-side step counters: required under capture
+            g["capturable"] = True
+            for p in g["params"]:
+                st = self.optimizer.state.get(p)
+                if st and torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
+                    st["step"] = st["step"].to(dev)
+
+    def _drop_stale_adam_state(self):
+        D = self._dev
+        if D is None or "adam_table" not in D:
+            return
+        vparams = list(self.solver.neural_sde.nabla_V.parameters())
+        if self._adam_signature(D["groups_main"][0], vparams) != D["adam_sig"]:
+            for k in ("adam_table", "adam_sig", "adam_scratch"):
+                D.pop(k, None)
+            self._graphs = {}          # warm-up iterations run eagerly again (they rebuild the table), then a new capture
+            self._make_capturable()
 
     def _graph_step(self, loss_kwargs):
         solver = self.solver
@@ -447,6 +528,8 @@ class Trainer:
         manual = self._manual_ok(loss_kwargs)
         if not manual:
             self._flush_M()
+        else:
+            self._drop_stale_adam_state()
         body = (lambda: self._body_manual(loss_kwargs)) if manual else (lambda: self._body_dev(loss_kwargs))
         key = tuple(sorted((k, id(v) if callable(v) else v) for k, v in loss_kwargs.items()))
         key = (("manual",) + key) if manual else key
@@ -496,8 +579,10 @@ class Trainer:
         return info
 
     def _graph_eligible(self, loss_kwargs):
+        # (sharded: only the autograd-free body carries its collectives inside the graph; anything else runs eagerly)
         return (self.hip_graph and not loss_kwargs.get("compute_control_objective", False)
-                and not loss_kwargs.get("verbose", False))
+                and not loss_kwargs.get("verbose", False)
+                and (self.solver.shard is None or self._manual_ok(loss_kwargs)))
 
     def _sync_from_device_state(self):
         """An eager iteration in hipGraph mode (checkpoint iterations: control-objective bursts, verbose prints) works
@@ -539,13 +624,22 @@ class Trainer:
         if self.sync_timing and dev.type == "cuda":
             torch.cuda.synchronize(dev)
         start = time.time()
-        solver.defer_M_backward = self.defer_M       # only for this call: direct users of .loss() get the full graph
+        shard = solver.shard
+        # a sharded eager iteration keeps the pair-grid network's backward inside loss.backward(): every gradient exists
+        # before the iteration's ONE collective
+        solver.defer_M_backward = self.defer_M and shard is None   # only for this call: direct users of .loss() get the full graph
+        shift = None
+        if shard is not None:
+            nc = self.normalization_const
+            shift = nc.detach().to(dev, torch.float32).reshape(()) if torch.is_tensor(nc) else torch.tensor(float(nc), device=dev)
+        solver.defer_weight_stats = shift
         try:
             out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
                               use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)),
                               **loss_kwargs)
         finally:
             solver.defer_M_backward = False
+            solver.defer_weight_stats = None
         objective, weight_mean = out[0], out[5]
         if self.algorithm in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
             loss = objective / self.normalization_const                  # main.py:313-320
@@ -554,18 +648,16 @@ class Trainer:
         else:
             loss = objective
         loss.backward()                                                  # main.py:323
-        if solver.shard is not None:
-            # one flat all-reduce: every gradient + the loss value + (when computed) this rank's share of the weighted
-            # L2 error, which solver.loss already divided by the GLOBAL (K+1) B
-            extra = [loss.detach()] + ([out[1].detach()] if out[1] is not None else [])
-            # with the pair-grid network's backward deferred to the second stream, its gradients do not exist yet: they
-            # are reduced there (_finish_M_on_side_stream); gamma's direct gradient from the contraction kernel is
-            # already complete, but it belongs to that group and is reduced with it
-            groups = self._groups_main if "_pending_M" in solver.__dict__ else self.optimizer.param_groups
-            reduced = solver.shard.allreduce_gradients([p for g in groups for p in g["params"]], extra=extra)
-            loss_val = reduced[0]
-            if out[1] is not None:
-                out = (out[0], reduced[1]) + tuple(out[2:])
+        if shard is not None:
+            # ONE flat all-reduce per iteration: every gradient + the loss value + the shifted weight sums + (when computed)
+            # this rank's share of the weighted L2 error, which solver.loss already divided by the GLOBAL (K+1) B
+            from .dist import mean_std_from_shifted_sums
+            extra = [loss.detach(), solver.__dict__.pop("_local_w_sums")] + ([out[1].detach()] if out[1] is not None else [])
+            reduced = shard.allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]], extra=extra)
+            loss_val = reduced[0].reshape(())
+            weight_mean, weight_std = mean_std_from_shifted_sums(reduced[1], shift)
+            out = (out[0], reduced[2].reshape(()) if out[1] is not None else None) + tuple(out[2:5]) + (weight_mean, weight_std) \
+                + tuple(out[7:])
         else:
             loss_val = loss.detach()
         pending = solver.__dict__.pop("_pending_M", None)

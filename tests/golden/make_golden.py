@@ -295,6 +295,13 @@ FIXTURES = [
     # default d = 20 (OU_quadratic_easy -> StaticNet<32,256,128,64,32>)
     ("cfg5_ou_linear_d64_K20", "OU_linear", 64, 20, 8, DEFAULT, 2.0, 0, dict(with_pairs=False)),
     ("ouq20_ou_quadratic_easy_d20_K12", "OU_quadratic_easy", 20, 12, 8, DEFAULT, 2.0, 0, dict(with_pairs=False)),
+    # LARGE BATCHES (round 3): the contraction kernels the BASELINE configs select by batch size -- d = 64 at B >= 256 takes
+    # the LDS-staged forward (socm_target_lds4_kernel) and the transposed-tile backward (socm_target_bwd_lds2_kernel);
+    # d <= 16 at B >= 512 the two-pairs-per-wave backward.  K is small so that the reference's own (Kp,Kp,B,d,d)
+    # intermediates stay at 67 MB (d = 64) / 10 MB (d = 10); T is shortened with it (time steps of 0.05 / 0.01 as at
+    # the other fixtures: with T = 1 the six-step double well diverges to NaN in the reference itself).
+    ("cfg5_ou_linear_d64_B256_K3", "OU_linear", 64, 3, 256, DEFAULT, 2.0, 0, dict(with_pairs=False, T=0.15)),
+    ("cfg4_double_well_d10_B512_K6", "double_well", 10, 6, 512, DEFAULT, 6.0, 0, dict(with_pairs=False, T=0.06)),
 ]
 
 

@@ -79,3 +79,86 @@ def test_combine_stats_is_exact_pooling():
     mean, std = L.mean_std_from_stats(L.combine_stats(stats))
     np.testing.assert_allclose(mean.item(), w.mean().item(), rtol=1e-6)
     np.testing.assert_allclose(std.item(), w.std().item(), rtol=1e-5)
+
+
+def _train_worker(rank, world, port, name, ret):
+    """Three-four `Trainer.step` iterations of a REFERENCE-generated training fixture (main.py:280-359 replayed by the
+    reference itself, tests/golden/make_golden_train.py) with the batch split over two ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from SOC_matching.method import SOC_Solver
+    from socmx.dist import Shard
+    from socmx.train import Trainer, make_optimizer
+    sde, aux = build_sde(name)
+    z = aux["z"]
+    lr_V, lr_M, eps, norm0 = [float(v) for v in z["meta_f"][5:9]]
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
+    solver.shard = Shard()
+    counts = {"all_reduce": 0, "all_gather": 0}
+    real_ar, real_ag = dist.all_reduce, dist.all_gather
+    dist.all_reduce = lambda *a, **k: (counts.__setitem__("all_reduce", counts["all_reduce"] + 1), real_ar(*a, **k))[1]
+    dist.all_gather = lambda *a, **k: (counts.__setitem__("all_gather", counts["all_gather"] + 1), real_ag(*a, **k))[1]
+    opt = make_optimizer(solver, nabla_V_lr=lr_V, M_lr=lr_M, adam_eps=eps)
+    tr = Trainer(solver, opt, aux["B"], normalization_const=norm0, sync_timing=False)
+    Bl, row0 = solver.shard.local_rows(aux["B"])
+    rec = dict(loss=[], weight_mean=[], weight_std=[], norm=[])
+    n_it = int(z["train_iters"])
+    for it in range(n_it):
+        solver.noise_in = aux["noise"][it][:, row0:row0 + Bl].contiguous()
+        out = tr.step()
+        rec["loss"].append(float(out["loss"]))
+        rec["weight_mean"].append(float(out["weight_mean"]))
+        rec["weight_std"].append(float(out["weight_std"]))
+        rec["norm"].append(float(tr.normalization_const))
+    tr.join()
+    dist.all_reduce, dist.all_gather = real_ar, real_ag
+    state = {("V." + k): v.detach().numpy().copy() for k, v in sde.nabla_V.state_dict().items()}
+    state.update({("M." + k): v.detach().numpy().copy() for k, v in sde.M.state_dict().items()})
+    state["gamma"] = sde.gamma.detach().numpy().copy()
+    ret[rank] = dict(rec=rec, state=state, collectives=dict(counts), iters=n_it)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["train_ou_quadratic_easy_d2", "train_double_well_d10"])
+def test_sharded_trainer_steps_equal_the_reference_training_run(name):
+    """world_size 2 (gloo): `Trainer.step` with a batch shard -- loss, backward, ONE flat all-reduce (gradients + loss value +
+    shifted weight sums), Adam with the reference's groups, EMA normaliser -- reproduces the reference's own training run on
+    the same noise, both ranks end with identical parameters, and exactly one collective is issued per iteration."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_train_worker, args=(world, port, name, ret), nprocs=world, join=True)
+        ret = {k: v for k, v in ret.items()}
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    r0, r1 = ret[0], ret[1]
+    assert r0["collectives"] == {"all_reduce": r0["iters"], "all_gather": 0}, r0["collectives"]
+    np.testing.assert_allclose(r0["rec"]["loss"], z["train_loss"], rtol=2e-4)
+    np.testing.assert_allclose(r0["rec"]["weight_mean"], z["train_weight_mean"], rtol=2e-4)
+    np.testing.assert_allclose(r0["rec"]["norm"], z["train_norm_const"], rtol=2e-4)
+    for k in ("loss", "weight_mean", "weight_std", "norm"):
+        assert r0["rec"][k] == r1["rec"][k], k                        # every rank reports the same reduced values
+    num = den = 0.0
+    for prefix, tag in (("final_nablaV.", "V."), ("final_M.", "M.")):
+        for k in [k for k in z.files if k.startswith(prefix)]:
+            a = r0["state"][tag + k[len(prefix):]]
+            num += float(((a - z[k]) ** 2).sum())
+            den += float((z[k] ** 2).sum())
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    np.testing.assert_allclose(r0["state"]["gamma"], z["final_gamma"], rtol=2e-3)
+    for k in r0["state"]:
+        assert np.array_equal(r0["state"][k], r1["state"][k]), k      # replicas stay bit-identical
+
+
+def test_shifted_weight_sums_pool_exactly():
+    from socmx.dist import shifted_weight_sums, mean_std_from_shifted_sums
+    g = torch.Generator().manual_seed(1)
+    w = 0.1 + 0.01 * torch.rand(300, generator=g)
+    shift = torch.tensor(0.104)
+    parts = [w[:100], w[100:170], w[170:]]
+    total = sum(shifted_weight_sums(p, shift) for p in parts)
+    mean, std = mean_std_from_shifted_sums(total, shift)
+    np.testing.assert_allclose(mean.item(), w.double().mean().item(), rtol=1e-6)
+    np.testing.assert_allclose(std.item(), w.double().std().item(), rtol=1e-4)

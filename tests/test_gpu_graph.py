@@ -137,7 +137,7 @@ def test_fused_adam_step_matches_torch_adam():
         rows.append([p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel(), off])
         off += p.numel()
     table = torch.tensor(rows, dtype=torch.int64, device=dev)
-    scratch, sums = torch.zeros(4, device=dev), torch.zeros(2, device=dev)
+    scratch, sums = torch.zeros(4 + 2 * ((total + 1023) // 1024), device=dev), torch.zeros(2, device=dev)
     ema = torch.zeros(total, device=dev)
     ema_ref = torch.zeros(total, device=dev)
     itr = torch.zeros(1, device=dev)
@@ -166,4 +166,64 @@ def test_fused_adam_step_matches_torch_adam():
         for a, b in zip(mine, ref):
             np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
         assert float(opt_mine.state[mine[0]]["step"]) == float(opt_ref.state[ref[0]]["step"]) == it + 2
-    assert float(scratch.abs().sum()) == 0.0
+    assert float(scratch[0]) == 0.0              # the ticket is re-armed; the rest holds per-workgroup partial sums
+
+
+def test_graph_mode_survives_an_optimizer_reload_and_an_lr_change():
+    """the captured iteration bakes in the Adam state's data pointers and the groups' hyper-parameters.  A resume
+    (`optimizer.load_state_dict`: new state tensors) or an lr change must drop the device table and the captured graphs --
+    the run must continue exactly like an eager Trainer that went through the same reload."""
+    import copy
+    out = {}
+    for graph in (False, True):
+        from SOC_matching.method import SOC_Solver
+        from socmx.rollout import PhiloxKey
+        from socmx.train import Trainer, make_optimizer
+        sde, aux = build_sde("cfg1_ou_quadratic_easy_d2_K50", DEV)
+        solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
+        solver.philox_key = PhiloxKey(torch.device(DEV), seed=3, offset=0)
+        opt = make_optimizer(solver, M_lr=1e-3)
+        tr = Trainer(solver, opt, 32, normalization_const=0.9, sync_timing=False, hip_graph=graph, overlap_M_backward=False)
+        rec = []
+        for it in range(12):
+            if it == 5:
+                tr.join()
+                torch.cuda.synchronize()
+                opt.load_state_dict(copy.deepcopy(opt.state_dict()))      # resume: every state tensor is a new allocation
+            if it == 8:
+                tr.join()
+                for g in opt.param_groups:
+                    g["lr"] = g["lr"] * 0.5
+            rec.append(float(tr.step()["loss"]))
+        tr.join()
+        torch.cuda.synchronize()
+        if graph:
+            assert any(k and k[0] == "manual" for k in tr._graphs if isinstance(k, tuple))
+        out[graph] = (np.array(rec), {k: _np(v) for k, v in sde.state_dict().items()})
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-5, atol=1e-7)
+    for k in out[False][1]:
+        np.testing.assert_allclose(out[True][1][k], out[False][1][k], rtol=5e-5, atol=1e-6, err_msg=k)
+
+
+def test_keyed_rollouts_and_bursts_draw_from_disjoint_philox_streams():
+    """hipGraph mode's device key must not re-use the offsets the host-side counter hands to the evaluation
+    bursts under the same seed (iteration n would train on the rows of the n-th burst)."""
+    from socmx import rollout as R
+    from socmx.train import KEYED_OFFSET_BASE
+    from SOC_matching.method import SOC_Solver
+    from socmx.train import Trainer, make_optimizer
+    sde, aux = build_sde("tiny_double_well_d10", DEV)
+    solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
+    tr = Trainer(solver, make_optimizer(solver, M_lr=1e-3), 16, sync_timing=False, hip_graph=True)
+    before = R._philox_calls
+    for _ in range(3):
+        tr.step()
+    tr.join()
+    key = solver.philox_key.key.cpu().tolist()
+    assert key[1] == KEYED_OFFSET_BASE + 3 and KEYED_OFFSET_BASE >= 1 << 31
+    assert R._philox_calls - before < 1 << 20          # the host counter stays far below the keyed stream's base
+    # the same seed at host offset 0 and at the keyed stream's first offset gives different noise
+    x0 = aux["x0"].repeat(16, 1)
+    a = R.stochastic_trajectories(sde, x0, aux["ts"], aux["lmbd"], seed=torch.initial_seed(), offset=0)[1]
+    b = R.stochastic_trajectories(sde, x0, aux["ts"], aux["lmbd"], seed=torch.initial_seed(), offset=KEYED_OFFSET_BASE)[1]
+    assert not torch.equal(a, b)

@@ -26,7 +26,7 @@ def _np(t):
 def test_library_is_loaded_and_reports_gfx950():
     from socmx import _lib
     L = _lib.lib()
-    assert L.socmx_version() == 111
+    assert L.socmx_version() == 120
     buf = (b" " * 512)
     import ctypes
     b = ctypes.create_string_buffer(512)
@@ -301,6 +301,21 @@ def test_contraction_kernels_multi_block_shapes(d, K, B):
     (2.0 * ref).backward()
     want = [t.grad.numpy() for t in (net, dnet, gam, nV)]
 
+    # B >= 256: these shapes select the kernels BASELINE configs[3] / configs[4] run (LDS-staged forward, transposed-tile
+    # backward at d > 16; two pairs per wave in the d <= 16 backward at B >= 512) -- also checked against the ORACLE's
+    # dense (Kp,Kp,B,d,d) form of method.py:591-720 and its autograd, fp32 like the reference
+    oracle = None
+    if B >= 256:
+        opb = dict(kind="ou_linear", sigma=sigma, A=A, omega=torch.ones(d))
+        o_net, o_dnet = net0.clone().requires_grad_(True), dnet0.clone().requires_grad_(True)
+        o_gam = torch.tensor(1.3, requires_grad=True)
+        o_nV = nablaV0.clone().requires_grad_(True)
+        oM, odM = blend(o_net, o_dnet, o_gam, delta, torch.eye(d))
+        o_obj, o_tgt = O.socm_objective_dense(opb, ts, 1.0, states, noises, controls, oM, odM, o_nV, w)
+        (2.0 * o_obj).backward()
+        oracle = (o_obj.item(), o_tgt.detach().numpy(), [t.grad.numpy() for t in (o_net, o_dnet, o_gam, o_nV)])
+        np.testing.assert_allclose(oracle[0], ref.item(), rtol=2e-4)      # the restated fp64 form IS the oracle's form
+
     to = lambda t: t.to(DEV).contiguous()
     args = (pb, to(ts), 1.0, K, to(states), to(noises), to(controls))
     for mode in ("fused", "materialised"):
@@ -319,10 +334,20 @@ def test_contraction_kernels_multi_block_shapes(d, K, B):
         for got, wn, nm in zip((net.grad, dnet.grad, gam.grad, nV.grad), want, ("g_net", "g_dnet", "g_gamma", "g_nablaV")):
             np.testing.assert_allclose(_np(got), wn, rtol=2e-3, atol=2e-5 * max(1e-6, np.abs(wn).max()),
                                        err_msg=f"{mode} {nm}")
+        if oracle is not None:
+            np.testing.assert_allclose(out.item(), oracle[0], rtol=2e-4, err_msg=f"{mode} vs oracle")
+            if mode == "materialised":
+                np.testing.assert_allclose(_np(tgt), oracle[1], rtol=2e-4, atol=5e-5 * np.abs(oracle[1]).max(),
+                                           err_msg="target vs oracle")
+            for got, wn, nm in zip((net.grad, dnet.grad, gam.grad, nV.grad), oracle[2], ("g_net", "g_dnet", "g_gamma", "g_nablaV")):
+                err = np.linalg.norm(_np(got).ravel() - wn.ravel()) / max(np.linalg.norm(wn.ravel()), 1e-30)
+                assert err < 1e-3, (mode, nm, "vs oracle", err)        # norm-wise 1e-3
 
 
 @pytest.mark.parametrize("name", LOSS + ["cfg1_ou_quadratic_easy_d2_K50", "cfg3_double_well_d10_K200",
-                                         "cfg5_ou_linear_d64_K20", "ouq20_ou_quadratic_easy_d20_K12"])
+                                         "cfg5_ou_linear_d64_K20", "ouq20_ou_quadratic_easy_d20_K12",
+                                         # B >= 256 at d = 64 / B >= 512 at d = 10: the kernels the BASELINE batch sizes select
+                                         "cfg5_ou_linear_d64_B256_K3", "cfg4_double_well_d10_B512_K6"])
 def test_full_socm_loss_on_gpu_vs_golden(name):
     from SOC_matching.method import SOC_Solver
     sde, aux = build_sde(name, DEV)
@@ -1049,6 +1074,29 @@ tr2.join(); torch.cuda.synchronize()
 num = sum(float(((a - b) ** 2).sum()) for a, b in zip(sde.state_dict().values(), sde2.state_dict().values()))
 den = sum(float((b ** 2).sum()) for b in sde2.state_dict().values())
 res['param_rel_diff'] = (num / den) ** 0.5
+# hipGraph mode WITH a shard: the autograd-free body, its two RCCL all-reduces captured inside the graph -- 2 eager warm-ups,
+# the capture, 3 replays, fresh Philox noise each; against the unsharded hipGraph Trainer on the same device key
+from socmx.rollout import PhiloxKey
+runs = []
+for sharded in (True, False):
+    sde3, aux3 = build_sde(name, 'cuda:0')
+    solver3 = SOC_Solver(sde3, aux3['x0'], None, T=aux3['T'], num_steps=aux3['K'], lmbd=aux3['lmbd'], d=aux3['d'], sigma=sde3.sigma)
+    if sharded:
+        solver3.shard = Shard()
+    solver3.philox_key = PhiloxKey(torch.device('cuda', 0), seed=9, offset=0)
+    tr3 = Trainer(solver3, make_optimizer(solver3, M_lr=1e-3), aux3['B'], normalization_const=0.8, sync_timing=False, hip_graph=True)
+    rec = []
+    for it in range(6):
+        info = tr3.step()
+        rec.append([float(info['loss']), float(info['weight_mean']), float(info['weight_std']), float(tr3.normalization_const)])
+    tr3.join(); torch.cuda.synchronize()
+    captured = [k for k in tr3._graphs if isinstance(k, tuple) and k and k[0] == 'manual']
+    runs.append((rec, [v.detach().cpu().numpy() for v in sde3.state_dict().values()], len(captured)))
+res['graph_captured'] = [r[2] for r in runs]
+res['graph_rec_sharded'], res['graph_rec_plain'] = runs[0][0], runs[1][0]
+num = sum(float(((a - b) ** 2).sum()) for a, b in zip(runs[0][1], runs[1][1]))
+den = sum(float((b ** 2).sum()) for b in runs[1][1])
+res['graph_param_rel_diff'] = (num / den) ** 0.5
 print('RESULT ' + json.dumps(res))
 dist.barrier(); dist.destroy_process_group()
 """
@@ -1057,8 +1105,9 @@ dist.barrier(); dist.destroy_process_group()
 @pytest.mark.parametrize("name", ["tiny_double_well_d10", "cfg3_double_well_d10_K200"])
 def test_rccl_shard_path_on_the_gpu(name, tmp_path):
     """The sharded code path with the real RCCL backend (torch.distributed 'nccl', world_size 1) in a fresh child
-    process: Shard(), the 3-float all-gather, the flat gradient all-reduce -- objective, weight statistics and every
-    gradient against the reference-generated fixture, then sharded Trainer iterations."""
+    process: Shard(), the 3-float all-gather of a direct `.loss()` call, the flat gradient all-reduce -- objective, weight
+    statistics and every gradient against the reference-generated fixture --, then sharded Trainer iterations, eager (ONE
+    all-reduce per iteration) and as a replayed hipGraph with the collectives captured inside."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gpath = str(tmp_path / "grads.npz")
@@ -1080,7 +1129,12 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
     den = sum(float((z[n] ** 2).sum()) for n in names)
     assert (num / den) ** 0.5 < 1e-3
     assert all(np.isfinite(r["losses"])) and len(r["losses"]) == 3
-    assert r["deferred_M"] and r["param_rel_diff"] < 1e-6, r
+    # (a sharded eager iteration keeps the pair-grid network's backward in loss.backward() -- one collective --, the unsharded
+    #  one defers it to the second stream: same arithmetic, same update order per parameter)
+    assert r["deferred_M"] and r["param_rel_diff"] < 2e-6, r
+    assert r["graph_captured"] == [1, 1], r["graph_captured"]
+    np.testing.assert_allclose(r["graph_rec_sharded"], r["graph_rec_plain"], rtol=2e-5, atol=1e-7)
+    assert r["graph_param_rel_diff"] < 2e-6, r["graph_param_rel_diff"]
     np.testing.assert_allclose(r["losses"][0], float(z["loss_objective"]), rtol=2e-4)   # normalisation constant 1.0
 
 

@@ -11,7 +11,7 @@ from oracle import socm_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-             if not os.path.basename(p).startswith(("dw_pde", "train_")))
+             if not os.path.basename(p).startswith(("dw_pde", "train_", "gt_")))
 TINY = [n for n in ALL if n.startswith("tiny_")]
 LOSS = [n for n in TINY if not n.endswith("_stopping")]
 

@@ -10,7 +10,7 @@ from oracle import socm_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-             if not os.path.basename(p).startswith(("dw_pde", "train_")))
+             if not os.path.basename(p).startswith(("dw_pde", "train_", "gt_")))
 TINY = [n for n in ALL if n.startswith("tiny_")]
 NON_STOPPING_LOSS = [n for n in TINY if not n.endswith("_stopping")]
 
@@ -77,7 +77,8 @@ def test_socm_loss_and_grads(name, derivative):
 
 
 @pytest.mark.parametrize("name", ["cfg1_ou_quadratic_easy_d2_K50", "ouq20_ou_quadratic_easy_d20_K12",
-                                  "cfg5_ou_linear_d64_K20"])
+                                  "cfg5_ou_linear_d64_K20", "cfg5_ou_linear_d64_B256_K3",
+                                  "cfg4_double_well_d10_B512_K6"])
 def test_socm_loss_default_arch(name):
     torch.set_num_threads(4)
     pb, vp, mp, gamma, aux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"), requires_grad=True)
