@@ -80,10 +80,29 @@ class Trainer:
         # (single-GPU eager runs only: a sharded eager iteration issues ONE collective, after the complete backward)
         self.defer_M = (overlap_M_backward and algorithm == "SOCM" and solver.x0.is_cuda
                         and not getattr(solver.neural_sde, "use_stopping_time", False))
-        sde = solver.neural_sde
-        ids_M = {id(p) for p in sde.M.parameters()} | {id(sde.gamma)} if self.defer_M else set()
-        self._groups_side = [g for g in optimizer.param_groups if all(id(p) in ids_M for p in g["params"])]
-        self._groups_main = [g for g in optimizer.param_groups if not all(id(p) in ids_M for p in g["params"])]
+        self._group_split = None
+
+    def _split_groups(self):
+        """(groups of the control network & co, groups of the pair-grid network + gamma) of the optimiser's CURRENT
+        param_groups -- `optimizer.load_state_dict` replaces the group dicts, so they are never cached by object: the split
+        is recomputed whenever the list's dicts change identity."""
+        groups = self.optimizer.param_groups
+        ident = tuple(id(g) for g in groups)
+        if self._group_split is None or self._group_split[0] != ident:
+            sde = self.solver.neural_sde
+            ids_M = {id(p) for p in sde.M.parameters()} | {id(sde.gamma)}
+            side = [g for g in groups if all(id(p) in ids_M for p in g["params"])]
+            main = [g for g in groups if not all(id(p) in ids_M for p in g["params"])]
+            self._group_split = (ident, main, side)
+        return self._group_split[1], self._group_split[2]
+
+    @property
+    def _groups_main(self):
+        return self._split_groups()[0]
+
+    @property
+    def _groups_side(self):
+        return self._split_groups()[1]
 
     @torch.no_grad()
     def _grad_telemetry(self):
@@ -282,7 +301,7 @@ class Trainer:
         for p, g in zip(params, grads):
             p.grad = g
         sde.gamma.grad = g_gamma
-        self._step_groups(D["groups_side"])
+        self._step_groups(self._groups_side)
         for p in params + [sde.gamma]:
             p.grad = None
 
@@ -322,9 +341,6 @@ class Trainer:
             D["g_net"] = torch.zeros(Np, d, d, dtype=torch.float32, device=dev)
             D["g_dnet"] = torch.zeros(Np, d, d, dtype=torch.float32, device=dev)
             D["g_gamma"] = torch.zeros(1, dtype=torch.float32, device=dev)
-            ids_M = {id(p) for p in M.parameters()} | {id(sde.gamma)}
-            D["groups_side"] = [g for g in self.optimizer.param_groups if all(id(p) in ids_M for p in g["params"])]
-            D["groups_main"] = [g for g in self.optimizer.param_groups if not all(id(p) in ids_M for p in g["params"])]
             # the telemetry EMA of the control-network gradient as one flat buffer, in parameters() order (= the order of
             # socmx_unet_backward_f32's output); D["ema_grad"] (shared with the autograd body / the eager mirrors) = its views
             vp = list(sde.nabla_V.parameters())
@@ -412,7 +428,8 @@ class Trainer:
         if adam is not None:
             # control-network Adam step + gradient telemetry in ONE launch on the flat gradient (socmx_adam_step_f32):
             # replaces the optimiser's multi-tensor launches, two dot products, the EMA lerp and the coefficient kernel
-            table, grp, sums = adam
+            table, _, sums = adam
+            grp = self._groups_main[0]
             b1, b2 = grp["betas"]
             with _lib.on_device(dev):
                 _lib.check(Lh.socmx_adam_step_f32(table.data_ptr(), len(vparams), vflat.numel(), f(vflat),
@@ -438,7 +455,7 @@ class Trainer:
             D["ema_flat"].lerp_(vflat, D["ab"][1])
             gne = torch.dot(D["ema_flat"], D["ema_flat"]).reshape(1)
         if adam is None:
-            self._step_groups(D["groups_main"])                           # main.py:347-349 (nabla_V: the next rollout needs it)
+            self._step_groups(self._groups_main)                          # main.py:347-349 (nabla_V: the next rollout needs it)
             for p in vparams:
                 p.grad = None
         out = torch.empty(7, dtype=torch.float32, device=dev)
@@ -459,8 +476,8 @@ class Trainer:
         if not self.fused_adam:
             return None
         if "adam_table" in D:
-            return D["adam_table"] if self._adam_signature(D["groups_main"][0], vparams) == D["adam_sig"] else None
-        opt, groups = self.optimizer, D["groups_main"]
+            return D["adam_table"] if self._adam_signature(self._groups_main[0], vparams) == D["adam_sig"] else None
+        opt, groups = self.optimizer, self._groups_main
         if type(opt) is not torch.optim.Adam or len(groups) != 1:
             return None
         grp = groups[0]
@@ -516,7 +533,7 @@ class Trainer:
         if D is None or "adam_table" not in D:
             return
         vparams = list(self.solver.neural_sde.nabla_V.parameters())
-        if self._adam_signature(D["groups_main"][0], vparams) != D["adam_sig"]:
+        if len(self._groups_main) != 1 or self._adam_signature(self._groups_main[0], vparams) != D["adam_sig"]:
             for k in ("adam_table", "adam_sig", "adam_scratch"):
                 D.pop(k, None)
             self._graphs = {}          # warm-up iterations run eagerly again (they rebuild the table), then a new capture
