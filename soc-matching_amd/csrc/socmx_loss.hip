@@ -468,141 +468,10 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
   }
 }
 
-// Wide form for 16 < d <= 64 and B >= 256 (the MFMA-bound regime, e.g. d = 64, K = 400, B = 512: 676 GFLOP):
-// a workgroup owns a row pair (i, K-i) and 8 x CT x 16 batch columns; its 8 waves split the COLUMNS, each wave keeps
-// all KB k-blocks x CT column tiles of the output in registers (KB*CT accumulators) and walks the (pair, l-block)
-// iterations in order.  Per iteration a wave loads 2*KB A fragments (shared by the 8 waves: one L2/HBM fetch,
-// L1 hits for the rest) and 2*CT B fragments for KB*CT*8 MFMAs; every pair matrix is fetched from HBM once.
-template <bool NET, int KB, int CT>
-__global__ __launch_bounds__(64 * kTargetWaves) void socm_target_wide_kernel(const TargetArgs a) {
-  const int d = a.d, K = a.K, B = a.B;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c16 = lane & 15, g4 = lane >> 4;
-  int mcol[CT], boff0[CT];
-#pragma unroll
-  for (int c = 0; c < CT; ++c) {
-    mcol[c] = ((blockIdx.y * kTargetWaves + wave) * CT + c) * 16 + c16;
-    boff0[c] = min(mcol[c], B - 1) * d;
-  }
-  const int nlb = (d + 15) >> 4;
-  const int dd = d * d;
-  const float gam = NET ? a.gamma[0] : 0.f;
-  for (int rep = 0; rep < 2; ++rep) {
-    const int i = rep == 0 ? (int)blockIdx.x : K - (int)blockIdx.x;
-    if (rep == 1 && i <= (int)blockIdx.x) break;
-    const float* drow = NET ? a.delta + pair_row_offset(i, K) : nullptr;
-    const int npair = K - i + 1;
-    f32x4 acc[KB][CT];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) acc[kb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int64_t prow_dd = pair_row_offset(i, K) * dd;
-    struct Slot { f32x4 nt[KB], dn[KB], q[CT], v[CT]; float dl; };
-    auto load = [&](int jr, int lb, Slot& sl) {
-      const int j = i + jr;
-      const int l0 = min(lb + 4 * g4, d - 1);
-      const float* Ap = a.M_all + prow_dd + (int64_t)jr * dd;
-      const float* Dp = a.dM_all + prow_dd + (int64_t)jr * dd;
-      const float* qs = (j < K) ? a.q + (size_t)j * B * d : a.gT;
-      const float* vs = a.v + (size_t)(j < K ? j : 0) * B * d;
-      if (j + 1 < K) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const int aoff = min(kb * 16 + c16, d - 1) * d + l0;
-          sl.nt[kb] = load4<true>(Ap, aoff, 0);
-          sl.dn[kb] = load4<true>(Dp, aoff, 0);
-        }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          sl.q[c] = load4<true>(qs, boff0[c] + l0, 0);
-          sl.v[c] = load4<true>(vs, boff0[c] + l0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const int aoff = min(kb * 16 + c16, d - 1) * d + l0;
-          sl.nt[kb] = load4<false>(Ap, aoff, dd);
-          sl.dn[kb] = load4<false>(Dp, aoff, dd);
-        }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          sl.q[c] = load4<false>(qs, boff0[c] + l0, B * d);
-          sl.v[c] = load4<false>(vs, boff0[c] + l0, B * d);
-        }
-      }
-      sl.dl = NET ? drow[jr] : 0.f;
-    };
-    auto consume = [&](int jr, int lb, const Slot& sl) {
-      const int j = i + jr;
-      const int l0 = min(lb + 4 * g4, d - 1);
-      const int nl = max(0, min(4, d - (lb + 4 * g4)));
-      const float e = NET ? expf(-gam * sl.dl) : 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float xq[CT], xv[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          xq[c] = (s < nl) ? sl.q[c][s] : 0.f;
-          xv[c] = (s < nl && j < K) ? sl.v[c][s] : 0.f;
-        }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const int krow = kb * 16 + c16;
-          const bool oka = (s < nl) && krow < d;
-          float xm, xd;
-          if (NET) {
-            const float eye = (krow == l0 + s) ? 1.f : 0.f;
-            xm = e * eye + (1.f - e) * sl.nt[kb][s];
-            xd = -(gam * e * (sl.nt[kb][s] - eye) + (1.f - e) * sl.dn[kb][s]);
-          } else {
-            xm = sl.nt[kb][s];
-            xd = -sl.dn[kb][s];
-          }
-          xm = oka ? xm : 0.f;
-          xd = (oka && j < K) ? xd : 0.f;
-#pragma unroll
-          for (int c = 0; c < CT; ++c)
-            acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm, xq[c], acc[kb][c], 0, 0, 0);
-#pragma unroll
-          for (int c = 0; c < CT; ++c)
-            acc[kb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd, xv[c], acc[kb][c], 0, 0, 0);
-        }
-      }
-    };
-    // the next iteration's operands are requested before the current one is multiplied (its KB*CT*8 MFMAs cover
-    // the round trip); (jr, lb) advance as counters (no division)
-    auto advance = [&](int& jr, int& lb) { lb += 16; if (lb >= nlb * 16) { lb = 0; ++jr; } };
-    Slot cur, nxt;
-    int cjr = 0, clb = 0;
-    load(cjr, clb, cur);
-    while (cjr < npair) {
-      int njr = cjr, nlb2 = clb;
-      advance(njr, nlb2);
-      const bool more = njr < npair;
-      if (more) load(njr, nlb2, nxt);
-      consume(cjr, clb, cur);
-      if (more) cur = nxt;
-      cjr = njr; clb = nlb2;
-    }
-    // D: lane holds k = kb*16 + 4*g4 + r (r = 0..3) of batch column mcol[c]
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-        if (mcol[c] < B) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int k = kb * 16 + 4 * g4 + r;
-            if (k < d) a.target[((size_t)i * B + mcol[c]) * d + k] = acc[kb][c][r];
-          }
-        }
-  }
-}
-
-// Wide form, A operand staged through LDS.  Same work split as socm_target_wide_kernel (row pair x 8 waves x CT=2
-// column tiles, all KB k-blocks per wave), but the pair matrices are fetched ONCE per workgroup: threads 0..255 each
+// Wide form for 16 < d <= 64 and B >= 256 (the MFMA-bound regime, e.g. d = 64, K = 400, B = 512: 676 GFLOP), A operand
+// staged through LDS: a workgroup owns a row and 8 x CT x 16 batch columns; its 8 waves split the COLUMNS, each wave keeps
+// all KB k-blocks x CT=2 column tiles of the output in registers and walks the (pair, l-block) iterations in order.  The
+// pair matrices are fetched ONCE per workgroup: threads 0..255 each
 // own one 16-byte piece (row k, four l) of net and dnet, keep three iterations of them in flight in registers,
 // form M / -dM/ds (zero padding, NET blend) once and write them to a three-stage LDS ring; the eight waves read their
 // MFMA A fragments from there (ds_read_b128).  One barrier per iteration.  The B fragments (q, v: different for every
@@ -1816,120 +1685,6 @@ __device__ __forceinline__ void bwd_lds_epilogue(const TargetBwdArgs& a, int64_t
 // in LDS, so the consumer needs no predicates.
 constexpr int kBwdStride = 20;
 
-template <bool NET, int LB>               // LB = ceil(d / 16) l-blocks (2..4)
-__global__ __launch_bounds__(256, 2) void socm_target_bwd_lds_kernel(const TargetBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ts[2][3][64][kBwdStride];   // [stage][G, q, v][column][batch row]
-  const int d = a.d, K = a.K, B = a.B;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t np = (int64_t)(K + 1) * (K + 2) / 2;
-  const int64_t p = blockIdx.x;
-  const int64_t pe = np - 1 - p;
-  int r = (int)((sqrtf(8.f * (float)pe + 1.f) - 1.f) * 0.5f);
-  while ((int64_t)(r + 1) * (r + 2) / 2 <= pe) ++r;
-  while ((int64_t)r * (r + 1) / 2 > pe) --r;
-  r = __builtin_amdgcn_readfirstlane(r);     // (came through the float unit: pin it -- and every pointer derived from it -- to scalar registers)
-  const int i = K - r;
-  const int j = i + (int)(p - pair_row_offset(i, K));
-  const bool last = (j == K);
-  const int c16 = lane & 15, g4 = lane >> 4;
-  const int kb = wave * 16;
-  const bool wave_on = kb < d;
-  // loader role (waves 0..2): tensor `wave`, rows 4*rg .. 4*rg+3 of the chunk, columns 4*pc .. 4*pc+3
-  const int rg = lane & 3, pc = lane >> 2;
-  const bool loader = wave < 3;
-  const bool piece_on = 4 * pc < d;
-  const bool tensor_zero = (wave == 2) && last;            // the terminal pair has no v operand
-  const float* src = wave == 0 ? a.G + (size_t)i * B * d
-                   : wave == 1 ? (last ? a.gT : a.q + (size_t)j * B * d)
-                               : a.v + (size_t)(last ? 0 : j) * B * d;
-  f32x4 pr[2][4];                         // chunks c+1 and c+2 in flight (slot = chunk & 1): pr[slot][row][column]
-  auto gload = [&](int m0, int sl) {
-    if (piece_on) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) pr[sl][s] = load4<true>(src, min(m0 + 4 * rg + s, B - 1) * d + 4 * pc, 0);
-    }
-  };
-  auto stage = [&](int m0, int st, int sl) {   // rows past the batch, columns past d and (terminal pair) v are zeroed here
-    float* col = &Ts[st][loader ? wave : 0][4 * pc][4 * rg];
-    if (!piece_on || tensor_zero) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(col + s * kBwdStride) = z;
-    } else if (m0 + 16 <= B) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        *reinterpret_cast<f32x4*>(col + s * kBwdStride) = f32x4{pr[sl][0][s], pr[sl][1][s], pr[sl][2][s], pr[sl][3][s]};
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        f32x4 t;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) t[rr] = (m0 + 4 * rg + rr < B) ? pr[sl][rr][s] : 0.f;
-        *reinterpret_cast<f32x4*>(col + s * kBwdStride) = t;
-      }
-    }
-  };
-  f32x4 accq[LB], accv[LB];
-#pragma unroll
-  for (int b = 0; b < LB; ++b) { accq[b] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const int nch = (B + 15) >> 4;
-  if (loader) {
-    gload(0, 0);
-    if (nch > 1) gload(16, 1);
-    stage(0, 0, 0);
-    if (nch > 2) gload(32, 0);
-  }
-  // Chunk loop, unrolled by two so that the register slots are static.  Two copies (waves with / without a k-block of
-  // their own): with the MFMAs behind a branch inside ONE loop the accumulators travel between VGPRs and AccVGPRs on
-  // every trip (64 moves per chunk).  A chunk is staged two trips after its loads were issued (one trip is shorter than a
-  // round trip to L2: the loader waves -- which also multiply -- then stall in front of their own MFMAs).
-  auto chunk_loop = [&](auto with_mfma) {
-    for (int c0 = 0; c0 < nch; c0 += 2) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = c0 + h;             // c & 1 == h
-        if (c < nch) {
-          __syncthreads();                // stage h visible; everyone is done reading stage 1-h
-          if constexpr (decltype(with_mfma)::value) {
-            // The loader work sits BETWEEN this wave's MFMAs: beside the MFMA streams of the other workgroups' waves on
-            // this SIMD an instruction outside one's own stream gets one issue slot per MFMA (see socm_target_lds4_kernel).
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(&Ts[h][0][kb + c16][4 * g4]);
-            f32x4 qb[LB], vb[LB];
-#pragma unroll
-            for (int b = 0; b < LB; ++b) {
-              qb[b] = *reinterpret_cast<const f32x4*>(&Ts[h][1][b * 16 + c16][4 * g4]);
-              vb[b] = *reinterpret_cast<const f32x4*>(&Ts[h][2][b * 16 + c16][4 * g4]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-              for (int b = 0; b < LB; ++b)
-                accq[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[u], qb[b][u], accq[b], 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-              if (u == 0 && loader && c + 1 < nch) stage((c + 1) * 16, 1 - h, 1 - h);
-              if (u == 1 && loader && c + 3 < nch) gload((c + 3) * 16, 1 - h);
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int b = 0; b < LB; ++b)
-                accv[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[u], vb[b][u], accv[b], 0, 0, 0);
-            }
-          } else if (loader && c + 1 < nch) {
-            stage((c + 1) * 16, 1 - h, 1 - h);
-            if (c + 3 < nch) gload((c + 3) * 16, 1 - h);
-          }
-        }
-      }
-    }
-  };
-  if (!wave_on) {
-    chunk_loop(std::false_type{});
-    return;
-  }
-  chunk_loop(std::true_type{});
-  bwd_lds_epilogue<NET, LB>(a, p, accq, accv, kb, wave, lane);
-}
-
 // Two rows per workgroup: the pairs (i0, j) and (i0 + 1, j) share q_j and v_j.  At d = 64 every pair of the one-row kernel
 // pulls 3 x 128 KiB of operand rows out of L2 / the memory side (31 GB per launch at the configs[4] slice, 5 TB/s while it
 // runs); with two G tiles against one (q, v) tile that is 2 x 128 + 256 KiB per two pairs (-33 %), 10 instead of 18 fragment
@@ -2002,7 +1757,7 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_lds2_kernel(const Targ
   if (nch > 1) gload(16, 1);
   stage(0, 0, 0);
   if (nch > 2) gload(32, 0);
-  // chunk loop (see socm_target_bwd_lds_kernel: unrolled by two for static register slots, loader work between the MFMA groups,
+  // chunk loop (unrolled by two for static register slots, loader work between the MFMA groups,
   // one copy for waves without a k-block of their own)
   auto chunk_loop = [&](auto with_mfma) {
     for (int c0 = 0; c0 < nch; c0 += 2) {
@@ -2367,8 +2122,7 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
   a.ts = ts; a.states = states; a.noises = noises; a.controls = controls; a.frac = frac;
   a.v = v; a.q = q; a.gT = gT; a.vT = vT; a.qT = qT; a.gTT = gTT;
   const size_t tile_lds = (size_t)4 * 64 * (pb->d + 1) * sizeof(float);
-  static const bool prep_valu = getenv("SOCMX_PREP_VALU") != nullptr;             // A/B switch: LDS-tile VALU form
-  if (pb->d % 4 == 0 && pb->d <= 64 && !vT && !qT && !prep_valu) {
+  if (pb->d % 4 == 0 && pb->d <= 64 && !vT && !qT) {
     const int64_t tiles = ((int64_t)K * B + 15) / 16;
     const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 3) / 4, 1024);
     if (const int err = launch(socm_prep_mfma_kernel, dim3(blocks), dim3(256), 0, stream, a)) return err;
@@ -2402,30 +2156,20 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   bool launched = false;
   int lerr = 0;
   if (d > 16 && d <= 64 && B >= 256) {                 // wide form: all k-blocks and 8 x 2 batch tiles per workgroup
-    dim3 wgrid((K + 2) / 2, (B + 16 * 2 * kTargetWaves - 1) / (16 * 2 * kTargetWaves));
+    const dim3 wgrid(K + 1, (B + 16 * 2 * kTargetWaves - 1) / (16 * 2 * kTargetWaves));
     const dim3 wblk(64 * kTargetWaves);
-    static const bool use_regs = getenv("SOCMX_TARGET_WIDE_REGS") != nullptr;   // A/B switch: register-only form
-    if (!use_regs) {
-      wgrid.x = K + 1;
-      const bool al4 = d % 4 == 0;
+    const bool al4 = d % 4 == 0;
 #define SOCMX_LDS_LAUNCH(NETV, KBV) \
   lerr = al4 ? launch(socm_target_lds4_kernel<NETV, KBV>, wgrid, dim3(64 * (kTargetWaves + kStageWaves)), 0, st0, a) \
              : launch(socm_target_lds_kernel<NETV, KBV>, wgrid, wblk, 0, st0, a)
-      if (delta) {
-        if (d <= 32) SOCMX_LDS_LAUNCH(true, 2);
-        else         SOCMX_LDS_LAUNCH(true, 4);
-      } else {
-        if (d <= 32) SOCMX_LDS_LAUNCH(false, 2);
-        else         SOCMX_LDS_LAUNCH(false, 4);
-      }
-#undef SOCMX_LDS_LAUNCH
-    } else if (delta) {
-      if (d <= 32) lerr = launch(socm_target_wide_kernel<true, 2, 2>, wgrid, wblk, 0, st0, a);
-      else         lerr = launch(socm_target_wide_kernel<true, 4, 2>, wgrid, wblk, 0, st0, a);
+    if (delta) {
+      if (d <= 32) SOCMX_LDS_LAUNCH(true, 2);
+      else         SOCMX_LDS_LAUNCH(true, 4);
     } else {
-      if (d <= 32) lerr = launch(socm_target_wide_kernel<false, 2, 2>, wgrid, wblk, 0, st0, a);
-      else         lerr = launch(socm_target_wide_kernel<false, 4, 2>, wgrid, wblk, 0, st0, a);
+      if (d <= 32) SOCMX_LDS_LAUNCH(false, 2);
+      else         SOCMX_LDS_LAUNCH(false, 4);
     }
+#undef SOCMX_LDS_LAUNCH
     launched = true;
   }
   const int ct = B > 32 ? 4 : (B > 16 ? 2 : 1);        // 16-column batch tiles per wave
@@ -2448,8 +2192,7 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   if (lerr) return lerr;
   const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
   if (lds > 160 * 1024) return SOCMX_E_LDS;
-  static const bool residual_valu = getenv("SOCMX_RESIDUAL_VALU") != nullptr;     // A/B switch: thread-per-row form
-  if (d % 4 == 0 && d <= 64 && !residual_valu) {
+  if (d % 4 == 0 && d <= 64) {
     const int64_t tiles = ((int64_t)(K + 1) * B + 15) / 16;
     const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 3) / 4, 1024);
     return launch(socm_residual_mfma_kernel, dim3(blocks), dim3(256), 0, stream, a);
@@ -2486,21 +2229,14 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
   a.d = d; a.K = K; a.B = B; a.G = G; a.q = q; a.v = v; a.gT = gT; a.gout = gout; a.gM = gM; a.gdM = gdM;
   a.net = net; a.dnet = dnet; a.delta = delta; a.gamma = gamma; a.ggamma_part = ggamma_part;
   const int64_t np = socmx_num_pairs(K);
-  static const bool bwd_regs = getenv("SOCMX_TARGET_BWD_REGS") != nullptr;       // A/B switch: register-only form
-  if (d > 16 && d <= 64 && d % 4 == 0 && !bwd_regs) {
+  if (d > 16 && d <= 64 && d % 4 == 0) {
     // (reads of whole 16-byte pieces stay inside the rows because d % 4 == 0)
-    dim3 lgrid((unsigned)np);
     const int lb = (d + 15) / 16;
-    static const bool one_row = getenv("SOCMX_BWD_ONE_ROW") != nullptr;           // A/B switch: one pair per workgroup
-    if (!one_row) {
-      const int64_t r2n = (K + 2) / 2;
-      lgrid = dim3((unsigned)(r2n * (K + 2 - r2n)));                                // items (row pair, j)
-    }
+    const int64_t r2n = (K + 2) / 2;
+    const dim3 lgrid((unsigned)(r2n * (K + 2 - r2n)));                              // items (row pair, j)
 #define SOCMX_BWD_LDS(LBV) \
-  return one_row ? (net ? launch(socm_target_bwd_lds_kernel<true, LBV>, lgrid, dim3(256), 0, stream, a) \
-                        : launch(socm_target_bwd_lds_kernel<false, LBV>, lgrid, dim3(256), 0, stream, a)) \
-                 : (net ? launch(socm_target_bwd_lds2_kernel<true, LBV>, lgrid, dim3(256), 0, stream, a) \
-                        : launch(socm_target_bwd_lds2_kernel<false, LBV>, lgrid, dim3(256), 0, stream, a))
+  return net ? launch(socm_target_bwd_lds2_kernel<true, LBV>, lgrid, dim3(256), 0, stream, a) \
+             : launch(socm_target_bwd_lds2_kernel<false, LBV>, lgrid, dim3(256), 0, stream, a)
     if (lb == 2) { SOCMX_BWD_LDS(2); }
     if (lb == 3) { SOCMX_BWD_LDS(3); }
     SOCMX_BWD_LDS(4);
@@ -2517,8 +2253,7 @@ static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, co
   }
   // two pairs per wave pay off once a wave has enough 16-row chunks to stream (B = 1,024: 0.40 -> 0.36 ms at d = 10, K = 200);
   // at a training batch of 128 the halved wave count costs more than the shared fragments save (58 -> 61 us)
-  static const bool one_row_small = getenv("SOCMX_BWD_ONE_ROW") != nullptr;      // A/B switch: one pair per wave
-  if (!one_row_small && B >= 512) {
+  if (B >= 512) {
     const int64_t r2n = (K + 2) / 2, nitems = r2n * (K + 2 - r2n);                // items (row pair, j): two pairs per wave
     dim3 grid2((unsigned)((nitems + 3) / 4), (d + 15) / 16, (d + 15) / 16);
     return net ? launch(socm_target_bwd_mfma2_kernel<true>, grid2, dim3(256), 0, stream, a, nitems)

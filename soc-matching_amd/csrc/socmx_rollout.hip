@@ -1025,9 +1025,8 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   if (const int err = ensure_max_lds(kern)) return err;
   // Few row tiles (a training batch: B / 16 workgroups on a 256-CU chip): claim the CU's whole LDS, so that no workgroup
   // of a kernel running beside the rollout on another stream (the pair-grid network's GEMMs) is placed on the same CU
-  // and takes MFMA issue slots from this latency-bound chain.  (SOCMX_SHARE_CU=1 switches it off for A/B runs.)
-  static const bool share_cu = getenv("SOCMX_SHARE_CU") != nullptr;
-  const size_t launch_lds = (!share_cu && blocks <= 128) ? (size_t)kMaxLdsBytes : lds_bytes;
+  // and takes MFMA issue slots from this latency-bound chain.
+  const size_t launch_lds = blocks <= 128 ? (size_t)kMaxLdsBytes : lds_bytes;
   return launch(kern, dim3(blocks), dim3(nw * 64), launch_lds, stream, a);
 }
 

@@ -239,7 +239,6 @@ struct TileArgs {
   const float* x;         // (N, d) rows
   const float* ts;        // time of row r = ts[r / rows_per_t]
   const float* gout;      // (N, d)  d objective / d nabla_V
-  int dbg;                // developer switch (SOCMX_K2_DBG): bit 0 = no exports
   float* ws;              // workspace: T_N tensors, tensor t at ws + 16 * ntiles * prefix(t), each [tile][width][16]
   int64_t N;
   int rows_per_t;
@@ -267,7 +266,7 @@ __device__ __forceinline__ void export4_block(float* slab_block, uint32_t lane_o
 
 struct EpiCtx {
   float* lds;
-  float* ws;               // workspace base (nullptr: developer switch SOCMX_K2_DBG=1, no exports -- timing only)
+  float* ws;               // workspace base
   const float* bias_lds;
   int64_t tile_rows;       // 16 * ntiles
   int tile;                // first 16-row tile of this workgroup (row r of the LDS tiles belongs to tile + r / 16)
@@ -592,7 +591,7 @@ __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a
     slabG[e] = v;
   }
   unet_load_biases(a.packed, u, t, lds, tid, nthr);
-  EpiCtx ctx{lds, (a.dbg & 1) ? nullptr : a.ws, lds + t.bias, tile_rows, tile};
+  EpiCtx ctx{lds, a.ws, lds + t.bias, tile_rows, tile};
   // first ring of stage 0 (GEMM 1 = down_0 of the forward image)
   Pre carry;
   {
@@ -872,6 +871,12 @@ struct MDesc {
   int x, hh1, hh2, gout, gz2, m1, m2, bias, scratch, lds_floats;
   // slab tensors [tile][unit][16]: X, H1, H2, GOUT, GZ2, GZ1 -- prefix = sum of widths before
   int pre[6], wid[6];
+  // WIDE form (the (d*d)-wide tile does not fit LDS -- BASELINE configs[4]: d = 64, 4096 outputs): the last layer's outputs
+  // leave the forward kernel straight from the accumulators, the backward kernel reads g_net / g_dnet rows from HBM as
+  // the MFMA B operand (split-K over the waves) and the last layer's weight gradient has its own kernel
+  // (mnet_wgrad_wide_kernel); no GOUT tile, no GOUT slab.  Needs d % 4 == 0 (16-byte pieces of a row) and h1p <= 128.
+  int wide;
+  int lds_fwd_floats;      // LDS of the forward kernel (wide: without the backward kernel's tiles and combine scratch)
 };
 enum { MT_X = 0, MT_H1, MT_H2, MT_GOUT, MT_GZ2, MT_GZ1, MT_N };
 
@@ -911,7 +916,39 @@ inline MDesc make_mdesc(int d, int h0, int h1, int nwaves) {
   }
   m.scratch = o; o += need;
   m.lds_floats = o;
-  const int wid[6] = {16, m.h0p, m.h1p, m.d2p, m.h1p, m.h0p};
+  m.lds_fwd_floats = m.lds_floats;
+  m.wide = 0;
+  if ((size_t)m.lds_floats * sizeof(float) > (size_t)160 * 1024 && d % 4 == 0 && m.h1p <= 128) {
+    // wide layout: x | hh1 | hh2 | gz2 | m1 | m2 | bias (L0, L1, then L2: forward only) | scratch
+    m.wide = 1;
+    o = 0;
+    m.x = o; o += 32 * m.sx;
+    m.hh1 = o; o += 32 * m.s1;
+    m.hh2 = o; o += 32 * m.s2;
+    m.gout = -1;
+    m.gz2 = o; o += 32 * m.s2;
+    m.m1 = o; o += m.h0p;
+    m.m2 = o; o += m.h1p;
+    m.bias = o;
+    // small-stage split-K scratch as above, without the (d*d)-wide stage
+    int need_small = 0;
+    const int outs_w[4] = {m.h0p, m.h1p, m.h1p, m.h0p};
+    for (int i = 0; i < 4; ++i) {
+      const int nblk = outs_w[i] >> 4;
+      if (nblk >= kSimds || nblk >= nwaves) continue;
+      const int n = (nwaves / nblk) * 32 * outs_w[i];
+      need_small = n > need_small ? n : need_small;
+    }
+    // forward: all three biases + small scratch; backward: two biases + the split-K combine of the wide stage
+    // (four waves' 2 x (h1p / 16) accumulator quads: 4 x 2 x NOB x 256 floats)
+    m.lds_fwd_floats = m.bias + boff + need_small;
+    const int nob_t = (m.h1p >> 4) <= 2 ? 2 : ((m.h1p >> 4) <= 4 ? 4 : 8);   // the kernel's NOB instantiation
+    const int combine = 4 * 2 * nob_t * 256;
+    const int need_b = combine > need_small ? combine : need_small;
+    m.scratch = m.bias + m.L[0].out_pad + m.L[1].out_pad;      // (backward; the forward kernel places it behind L2's bias)
+    m.lds_floats = m.scratch + need_b;
+  }
+  const int wid[6] = {16, m.h0p, m.h1p, m.wide ? 0 : m.d2p, m.h1p, m.h0p};
   int pre = 0;
   for (int t = 0; t < 6; ++t) { m.wid[t] = wid[t]; m.pre[t] = pre; pre += wid[t]; }
   return m;
@@ -945,9 +982,16 @@ struct MEpi {
   __device__ __forceinline__ void fin(f32x4 vq, f32x4 tq, int r, int n0) const {
     if (kind == ME_OUT) {
       if (p0 + r < Np) {
+        if ((d2 & 3) == 0) {           // rows are whole 16-byte pieces: one store per quad
+          if (n0 < d2) {
+            *reinterpret_cast<f32x4*>(net + (size_t)(p0 + r) * d2 + n0) = vq;
+            *reinterpret_cast<f32x4*>(dnet + (size_t)(p0 + r) * d2 + n0) = tq;
+          }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (n0 + i < d2) { net[(size_t)(p0 + r) * d2 + n0 + i] = vq[i]; dnet[(size_t)(p0 + r) * d2 + n0 + i] = tq[i]; }
+          for (int i = 0; i < 4; ++i)
+            if (n0 + i < d2) { net[(size_t)(p0 + r) * d2 + n0 + i] = vq[i]; dnet[(size_t)(p0 + r) * d2 + n0 + i] = tq[i]; }
+        }
       }
       return;
     }
@@ -1043,7 +1087,8 @@ __device__ __forceinline__ void m_stage(const float* __restrict__ Wp, const Laye
 
 // F1, F2 (both kernels): H1 = relu-pair(L0 X), H2 = relu-pair(L1 H1); `ws` non-null: export X, H1, H2 slabs
 template <int NW>
-__device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int tile, int64_t tile_rows) {
+__device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int tile, int64_t tile_rows, int nbias = 3,
+                                                 int scratch_off = -1) {
   const MDesc& m = a.m;
   const int tid = threadIdx.x, nthr = NW * 64;
   const int64_t p0 = (int64_t)tile * 16;
@@ -1059,7 +1104,7 @@ __device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int
     }
     X[r * m.sx + c] = v;
   }
-  for (int l = 0; l < 3; ++l)
+  for (int l = 0; l < nbias; ++l)
     for (int e = tid; e < m.L[l].out_pad; e += nthr) lds[m.bias + m.L[l].b_lds + e] = a.packed[m.L[l].b_off + e];
   __syncthreads();
   if (a.ws) {
@@ -1069,7 +1114,7 @@ __device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int
       sl[e] = X[(h * 16 + r16) * m.sx + c];
     }
   }
-  float* scratch = lds + m.scratch;
+  float* scratch = lds + (scratch_off >= 0 ? scratch_off : m.scratch);
   MEpi e1{ME_RELU, lds, lds + m.bias + m.L[0].b_lds, m.hh1, m.s1, m.m1, m.h0p,
           a.ws ? a.ws + (size_t)tile_rows * m.pre[MT_H1] + (size_t)(2 * tile) * m.h0p * 16 : nullptr, m.h0p,
           nullptr, nullptr, 0, 0, 0};
@@ -1084,10 +1129,12 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void mnet_forward_kernel(const MArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile = blockIdx.x;
-  m_forward_hidden<NW>(a, lds, tile, 0);
   const MDesc& m = a.m;
+  // (wide form: the forward kernel's split-K scratch sits behind all three biases)
+  const int sc = m.wide ? m.bias + m.bias_floats : m.scratch;
+  m_forward_hidden<NW>(a, lds, tile, 0, 3, sc);
   MEpi e3{ME_OUT, lds, lds + m.bias + m.L[2].b_lds, -1, 0, 0, 0, nullptr, 0, a.net, a.dnet, m.d2, (int64_t)tile * 16, a.Np};
-  m_stage<NW>(a.packed, m.L[2], lds, m.hh2, m.s2, lds + m.scratch, e3);
+  m_stage<NW>(a.packed, m.L[2], lds, m.hh2, m.s2, lds + sc, e3);
 }
 
 template <int NW>
@@ -1116,6 +1163,250 @@ __global__ __launch_bounds__(NW * 64) void mnet_backward_kernel(const MArgs a) {
   MEpi b2{ME_MASK, lds, nullptr, -1, 0, m.m1, m.h0p,
           a.ws + (size_t)tile_rows * m.pre[MT_GZ1] + (size_t)(2 * tile) * m.h0p * 16, m.h0p, nullptr, nullptr, 0, 0, 0};
   m_stage<NW>(a.packedT, m.LT[1], lds, m.gz2, m.s2, scratch, b2);
+}
+
+// ---- WIDE form (d*d outputs do not fit an LDS tile: BASELINE configs[4], d = 64) -----------------------------------------
+// Backward tile kernel: F1, F2 recomputed as above, then  (g_h2, g_t2) = L2^T (g_net, g_dnet)  with the reduction over the
+// d*d outputs SPLIT OVER THE WAVES: wave w multiplies chunks [w KC / NW, (w+1) KC / NW) of all NOB = h1p / 16 output
+// blocks for the value and the tangent rows (2 NOB accumulators).  The B operand is not an LDS tile: lane (row, g) reads
+// g_net[p0 + row][16 kc + 4 g .. + 3] -- one 16-byte piece of the row-major gradient, the same (g, i) indexing the LDS
+// fragments have -- so every byte of g_net / g_dnet is read from HBM once, by one wave.  The A fragments (L2^T, fragment
+// order) stream from L2.  Three chunks (8 A + 2 B requests each) in flight, asm loads with written-out wait counts (see
+// wgrad_body).  Combine: waves 4..7 park their quads in LDS, waves 0..3 add them to their own and park the sums, then wave
+// j reduces block j's four partials and runs the masked epilogue (gz2 tile + GZ2 slab).  Then L1^T as above.
+template <int NW, int NOB>
+__global__ __launch_bounds__(NW * 64) void mnet_backward_wide_kernel(const MArgs a) {
+  static_assert(NW == 8, "the combine below is written for eight waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MDesc& m = a.m;
+  const int tile = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile_rows = (int64_t)a.ntiles * 32;
+  const int64_t p0 = (int64_t)tile * 16;
+  m_forward_hidden<NW>(a, lds, tile, tile_rows, 2);
+  const int row = lane & 15, g = lane >> 4;
+  const int KC = m.d2p >> 4;                              // chunks of the reduction (d2p = d2: d % 4 == 0)
+  const int kc0 = (wave * KC) / NW, kc1 = ((wave + 1) * KC) / NW;
+  f32x4 acc[2][NOB];
+#pragma unroll
+  for (int j = 0; j < NOB; ++j) { acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (kc1 > kc0) {
+    const bool rowok = p0 + row < a.Np;
+    const int64_t prow = min(p0 + row, a.Np - 1);
+    const float* bv = a.gnet + (size_t)prow * m.d2 + 4 * g;
+    const float* bt = a.gdnet + (size_t)prow * m.d2 + 4 * g;
+    const f32x4* wl = reinterpret_cast<const f32x4*>(a.packedT + m.LT[0].w_off) + lane;   // fragment (block j, chunk kc): (j KC + kc) 64
+    constexpr int PD = 3, NL = NOB + 2;
+    const int nobm1 = (m.h1p >> 4) - 1;
+    f32x4 fa[PD][NOB], fb[PD][2];
+    auto load = [&](int kc, int sl) {
+      const int k = min(kc, kc1 - 1);
+#pragma unroll
+      for (int j = 0; j < NOB; ++j)      // (blocks past h1p / 16 re-read the last one: their accumulators are never used)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[sl][j]) : "v"(wl + (size_t)(min(j, nobm1) * KC + k) * 64) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][0]) : "v"(bv + (size_t)k * 16) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][1]) : "v"(bt + (size_t)k * 16) : "memory");
+    };
+    auto wait_slot = [&](int sl) {                 // the two younger chunks may stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+#pragma unroll
+      for (int j = 0; j < NOB; ++j) asm volatile("" : "+v"(fa[sl][j]));
+      asm volatile("" : "+v"(fb[sl][0]), "+v"(fb[sl][1]));
+    };
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl) load(kc0 + sl, sl);
+    for (int kc = kc0; kc < kc1; kc += PD) {
+#pragma unroll
+      for (int sl = 0; sl < PD; ++sl) {
+        wait_slot(sl);
+        if (kc + sl < kc1) {
+          f32x4 bq[2] = {fb[sl][0], fb[sl][1]};
+          if (!rowok) { bq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; bq[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NOB; ++j) {
+              acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][j][i], bq[0][i], acc[0][j], 0, 0, 0);
+              acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl][j][i], bq[1][i], acc[1][j], 0, 0, 0);
+            }
+        }
+        load(kc + sl + PD, sl);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // combine the eight waves' partial sums (LDS quads: [slot 0..3][h][block j][lane])
+  float* sc = lds + m.scratch;
+  const int nob = m.h1p >> 4;
+  auto slot = [&](int w4, int h, int j) { return sc + ((size_t)((w4 * 2 + h) * NOB + j) * 64 + lane) * 4; };
+  if (wave >= 4) {
+#pragma unroll
+    for (int j = 0; j < NOB; ++j) {
+      *reinterpret_cast<f32x4*>(slot(wave - 4, 0, j)) = acc[0][j];
+      *reinterpret_cast<f32x4*>(slot(wave - 4, 1, j)) = acc[1][j];
+    }
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int j = 0; j < NOB; ++j) { acc[0][j] += lds4(slot(wave, 0, j)); acc[1][j] += lds4(slot(wave, 1, j)); }
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int j = 0; j < NOB; ++j) {
+      *reinterpret_cast<f32x4*>(slot(wave, 0, j)) = acc[0][j];
+      *reinterpret_cast<f32x4*>(slot(wave, 1, j)) = acc[1][j];
+    }
+  }
+  __syncthreads();
+  MEpi b1{ME_MASK, lds, nullptr, m.gz2, m.s2, m.m2, m.h1p,
+          a.ws + (size_t)tile_rows * m.pre[MT_GZ2] + (size_t)(2 * tile) * m.h1p * 16, m.h1p, nullptr, nullptr, 0, 0, 0};
+  for (int j = wave; j < nob; j += NW) {                 // (NOB <= 8 = NW: at most one block per wave)
+    f32x4 vq = f32x4{0.f, 0.f, 0.f, 0.f}, tq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) {
+      vq += lds4(sc + ((size_t)((w4 * 2 + 0) * NOB + j) * 64 + lane) * 4);
+      tq += lds4(sc + ((size_t)((w4 * 2 + 1) * NOB + j) * 64 + lane) * 4);
+    }
+    b1.fin(vq, tq, row, j * 16 + 4 * g);
+  }
+  __syncthreads();
+  MEpi b2{ME_MASK, lds, nullptr, -1, 0, m.m1, m.h0p,
+          a.ws + (size_t)tile_rows * m.pre[MT_GZ1] + (size_t)(2 * tile) * m.h0p * 16, m.h0p, nullptr, nullptr, 0, 0, 0};
+  m_stage<NW>(a.packedT, m.LT[1], lds, m.gz2, m.s2, sc, b2);
+}
+
+// Weight / bias gradient of the WIDE last layer:  dW2[n][c] = sum_p g_net[p][n] h2[p][c] + g_dnet[p][n] t2[p][c],
+// db2[n] = sum_p g_net[p][n]  (4096 x 128 outputs, 2 x 80,601 rows at BASELINE configs[4]: 169 GFLOP).
+//   D (16 n x 16 c) += A (16 n x 4 p) . B (4 p x 16 c):  B = the H2 slab the tile kernel exported ([16-row tile][unit c][16 rows]:
+//   lane (c, g) reads rows 4g..4g+3 with one 16-byte load -- value tile 2t, tangent tile 2t+1), A = g^T, which in the
+//   row-major (Np, d*d) gradient is 4 floats from 4 DIFFERENT rows per lane: the 16 x 64 tile of g_net (and of g_dnet) is
+//   loaded in 4 x 4 register blocks (16-byte pieces of four consecutive rows), transposed in registers and parked in LDS as
+//   T[n][16 rows] (20-float stride: conflict-free 16-byte column writes and fragment reads -- the layout of
+//   socm_target_bwd_lds2_kernel), double-buffered, one barrier per 16 pairs.
+// Workgroup (4 waves) = 64 outputs n x all h1p inputs c x one slab of pair tiles; wave w owns c-blocks {NCB w .. NCB w + NCB - 1}
+// x 4 n-blocks; waves 0 / 1 load the g_net / g_dnet tiles.  Workgroups reading one slab are numbered onto one XCD (their
+// H2 tiles hit that L2).  Partials go to the cells kernel C adds up.
+struct MWgradWideArgs {
+  const float *gnet, *gdnet;
+  const float* h2slab;       // [2 ntiles][h1p][16]
+  float* part;               // (S, slab_floats)
+  int64_t Np, slab_floats;
+  int d2, h1p, ntiles, S, NG, IB;
+  int cell_off, bias_off;    // float offsets of layer 2's cells / bias partial inside a slab of partials
+};
+
+template <int NCB>
+__global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float T[2][2][64][20];   // [stage][g_net, g_dnet][n][pair row]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int ng = q % a.NG;
+  const int slab = (q / a.NG) * 8 + xcd;
+  if (slab >= a.S) return;
+  const int t0 = (int)(((int64_t)slab * a.ntiles) / a.S), t1 = (int)(((int64_t)(slab + 1) * a.ntiles) / a.S);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int n0 = ng * 64;
+  // loader (waves 0, 1): lane (rg, pc) owns rows 4 rg .. + 3, columns n0 + 4 pc .. + 3 of its tensor's tile
+  const int rg = lane & 3, pc = lane >> 2;
+  const float* src = wave == 0 ? a.gnet : a.gdnet;
+  const bool colok = n0 + 4 * pc < a.d2;
+  const int ncol = colok ? n0 + 4 * pc : 0;
+  f32x4 lr[4];
+  auto tile_load = [&](int t) {
+    const int64_t p0 = (int64_t)min(t, t1 - 1) * 16 + 4 * rg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t pr = min(p0 + i, a.Np - 1);
+      lr[i] = *reinterpret_cast<const f32x4*>(src + (size_t)pr * a.d2 + ncol);
+    }
+  };
+  auto tile_park = [&](int t, int st) {
+    const int64_t p0 = (int64_t)t * 16 + 4 * rg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f32x4 col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) col[i] = (colok && p0 + i < a.Np) ? lr[i][e] : 0.f;
+      *reinterpret_cast<f32x4*>(&T[st][wave][4 * pc + e][4 * rg]) = col;
+    }
+  };
+  // B operand: H2 slab, value tile 2t (with g_net), tangent tile 2t + 1 (with g_dnet)
+  const int cb0 = wave * NCB;
+  const float* hb = a.h2slab + (size_t)c16 * 16 + 4 * g4;
+  auto bload = [&](int t, f32x4 (&b)[2][NCB]) {
+    const int tc = min(t, t1 - 1);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int k = 0; k < NCB; ++k) {
+        const int cb = min(cb0 + k, a.IB - 1);
+        b[x][k] = *reinterpret_cast<const f32x4*>(hb + ((size_t)(2 * tc + x) * a.h1p + cb * 16) * 16);
+      }
+  };
+  f32x4 acc[4][NCB];
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) acc[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (t0 < t1) {
+    f32x4 bcur[2][NCB], bnext[2][NCB];
+    if (wave < 2) { tile_load(t0); tile_park(t0, 0); tile_load(t0 + 1); }
+    bload(t0, bcur);
+    bload(t0 + 1, bnext);
+    for (int t = t0; t < t1; ++t) {
+      const int st = (t - t0) & 1;
+      __syncthreads();                                   // T[st] holds tile t; everyone is done with T[st ^ 1]
+      f32x4 af[2][4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[x][j] = lds4(&T[st][x][j * 16 + c16][4 * g4]);
+      if (wave < 2 && t + 1 < t1) tile_park(t + 1, st ^ 1);        // (loaded one iteration ago)
+      if (wave < 2) tile_load(t + 2);
+      f32x4 bnext2[2][NCB];
+      bload(t + 2, bnext2);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < NCB; ++k)
+              acc[j][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x][j][i], bcur[x][k][i], acc[j][k], 0, 0, 0);
+      if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bsum[j] += (af[0][j][0] + af[0][j][1]) + (af[0][j][2] + af[0][j][3]);
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) { bcur[x][k] = bnext[x][k]; bnext[x][k] = bnext2[x][k]; }
+    }
+  }
+  float* out = a.part + (size_t)slab * a.slab_floats;
+  const int OB = a.d2 >> 4;                                // d2 % 16 == 0 in the wide form
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+      const int ob = ng * 4 + j, ib = cb0 + k;
+      if (ob < OB && ib < a.IB)
+        *reinterpret_cast<f32x4*>(out + a.cell_off + ((size_t)ob * a.IB + ib) * 256 + lane * 4) = acc[j][k];
+    }
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float b = bsum[j];
+      b += __shfl_xor(b, 16, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (ng * 4 + j < OB && lane < 16) out[a.bias_off + (ng * 4 + j) * 16 + lane] = b;
+    }
+  }
 }
 
 struct MPackArgs {
@@ -1235,12 +1526,11 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   p.slab_floats = off;
   p.n_items = items;
   // Slabs of row tiles for kernel B (one wave per (block group, slab), four slabs per workgroup).  Measured on MI355X
-  // (tools/k2_prof.sh, SOCMX_K2_S sweep): the slab GROUPS must divide evenly over the 8 XCDs -- kernel B numbers them onto
+  // (tools/k2_prof.sh, a sweep of S): the slab GROUPS must divide evenly over the 8 XCDs -- kernel B numbers them onto
   // XCDs -- so S is a multiple of 32; 64 is within 5 % of the best for 400 ... 13,000 tiles, and more slabs only grow
   // kernel C's reduction.  Small inputs: at least 4 tiles per slab.
   (void)items;
   int S = 64;
-  { const char* e = getenv("SOCMX_K2_S"); if (e) S = atoi(e); }       // developer switch
   if (S > p.ntiles / 4) S = p.ntiles / 4 >= 32 ? 32 : p.ntiles / 4;
   p.S = S < 1 ? 1 : (S > 128 ? 128 : S);
   p.part_floats = (int64_t)p.S * p.slab_floats;
@@ -1297,7 +1587,6 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   for (int si = 0; si < kBwdStages; ++si) ta.prog.st[si] = k2_stage_desc(p.u, p.bd, p.lay, si);
   ta.packed = packed; ta.packedT = packedT; ta.x = x; ta.ts = ts; ta.gout = gout; ta.ws = workspace;
   ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles;
-  { const char* e = getenv("SOCMX_K2_DBG"); ta.dbg = e ? atoi(e) : 0; }
   const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
   void (*kern)(const TileArgs) = unet_bwd_tile_kernel<kK2Waves, void>;
   if (p.variant == 1) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<16, 256, 128, 64, 16>>;
@@ -1368,7 +1657,7 @@ extern "C" int socmx_mnet_forward_f32(const float* packed, int32_t d, const int3
   if (const int rc = mnet_plan(d, hdims, a.m)) return rc;
   a.packed = packed; a.packedT = packed + a.m.total_floats; a.t = t; a.s = s; a.Np = Np;
   a.ntiles = (int)((Np + 15) / 16); a.net = net; a.dnet = dnet; a.ws = nullptr;
-  const size_t lds_bytes = (size_t)a.m.lds_floats * sizeof(float);
+  const size_t lds_bytes = (size_t)a.m.lds_fwd_floats * sizeof(float);
   if (const int err = ensure_max_lds(mnet_forward_kernel<kK2Waves>)) return err;
   return launch(mnet_forward_kernel<kK2Waves>, dim3(a.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a);
 }
@@ -1404,7 +1693,8 @@ static int mnet_bwd_plan(int32_t d, const int32_t hdims[2], int64_t Np, MnetBwdP
   p.total_bias = off - p.total_cells_floats;
   p.slab_floats = off;
   const int nt16 = 2 * p.ntiles;
-  int S = 64;
+  // (wide form: the last layer's partials are 2 MB per slab at d = 64 -- 32 slabs keep kernel C's reduction at 70 MB)
+  int S = p.m.wide ? 32 : 64;
   if (S > nt16 / 4) S = nt16 / 4 >= 32 ? 32 : nt16 / 4;
   p.S = S < 1 ? 1 : S;
   p.part_floats = (int64_t)p.S * p.slab_floats;
@@ -1430,8 +1720,29 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
   a.m = p.m; a.packed = packed; a.packedT = packed + p.m.total_floats; a.t = t; a.s = s; a.Np = Np; a.ntiles = p.ntiles;
   a.gnet = gnet; a.gdnet = gdnet; a.ws = workspace;
   const size_t lds_bytes = (size_t)p.m.lds_floats * sizeof(float);
-  if (const int err = ensure_max_lds(mnet_backward_kernel<kK2Waves>)) return err;
-  if (const int err = launch(mnet_backward_kernel<kK2Waves>, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a)) return err;
+  const int nlay_b = p.m.wide ? 2 : 3;                    // layers whose weight gradient kernel B forms from the slabs
+  if (p.m.wide) {
+    void (*kern)(const MArgs) = mnet_backward_wide_kernel<kK2Waves, 8>;
+    const int nob = p.m.h1p >> 4;
+    if (nob <= 2) kern = mnet_backward_wide_kernel<kK2Waves, 2>;
+    else if (nob <= 4) kern = mnet_backward_wide_kernel<kK2Waves, 4>;
+    if (const int err = ensure_max_lds(kern)) return err;
+    if (const int err = launch(kern, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a)) return err;
+    // the last layer's weight / bias gradient partials (its own kernel: A operand transposed through LDS)
+    MWgradWideArgs ga;
+    ga.gnet = gnet; ga.gdnet = gdnet;
+    ga.h2slab = workspace + (size_t)p.ntiles * 32 * p.m.pre[MT_H2];
+    ga.part = workspace + p.ws_floats;
+    ga.Np = Np; ga.slab_floats = p.slab_floats; ga.d2 = p.m.d2; ga.h1p = p.m.h1p; ga.ntiles = p.ntiles; ga.S = p.S;
+    ga.NG = (p.m.d2 + 63) / 64; ga.IB = p.IB[2]; ga.cell_off = p.w_cell_off[2]; ga.bias_off = p.b_part_off[2];
+    const unsigned wgrid = (unsigned)(ga.NG * 8 * ((p.S + 7) / 8));
+    const int err = ga.IB > 4 ? launch(mnet_wgrad_wide_kernel<2>, dim3(wgrid), dim3(256), 0, stream, ga)
+                              : launch(mnet_wgrad_wide_kernel<1>, dim3(wgrid), dim3(256), 0, stream, ga);
+    if (err) return err;
+  } else {
+    if (const int err = ensure_max_lds(mnet_backward_kernel<kK2Waves>)) return err;
+    if (const int err = launch(mnet_backward_kernel<kK2Waves>, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a)) return err;
+  }
   // weight / bias gradient partials: kernel B over the 2 ntiles slab tiles (value, tangent alternating)
   WgradArgs wa{};
   wa.S = p.S; wa.ntiles = 2 * p.ntiles; wa.slab_floats = p.slab_floats; wa.bias_even_tiles = 1;
@@ -1439,7 +1750,7 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
   const int gt[3] = {MT_GZ1, MT_GZ2, MT_GOUT}, at[3] = {MT_X, MT_H1, MT_H2};
   wa.n_items = 0;
   for (int l = 0; l < 9; ++l) {
-    if (l < 3) {
+    if (l < nlay_b) {
       wa.gt_off[l] = p.m.pre[gt[l]]; wa.at_off[l] = p.m.pre[at[l]]; wa.gW[l] = p.m.wid[gt[l]]; wa.aW[l] = p.m.wid[at[l]];
       wa.OB[l] = p.OB[l]; wa.IB[l] = p.IB[l]; wa.w_cell_off[l] = p.w_cell_off[l]; wa.b_part_off[l] = p.b_part_off[l];
       wa.item0[l] = wa.n_items;

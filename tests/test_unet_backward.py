@@ -91,7 +91,10 @@ def test_unet_backward_zero_gradient_rows_contribute_nothing():
 
 @pytest.mark.parametrize("name,extra", [("tiny_double_well_d10", {}), ("tiny_ou_linear_d6", {}), ("tiny_ou_linear_d20", {}),
                                         ("cfg1_ou_quadratic_easy_d2_K50", {}), ("cfg3_double_well_d10_K200", {}),
-                                        ("ouq20_ou_quadratic_easy_d20_K12", {})])
+                                        ("ouq20_ou_quadratic_easy_d20_K12", {}),
+                                        # d = 64: the WIDE form (4096 outputs: last layer straight to HBM, split-K backward
+                                        # from the row-major gradients, its own weight-gradient kernel) -- 231 pairs / 10 pairs
+                                        ("cfg5_ou_linear_d64_K20", {}), ("cfg5_ou_linear_d64_B256_K3", {})])
 def test_pair_network_kernels_vs_library_autograd(name, extra):
     """K3: socmx_mnet_forward_f32 / _backward_f32 (SigmoidMLP.sigmoid_layers and its s-tangent on the pair grid) against
     the library path of the same module (torch GEMMs + analytic tangent, itself pinned by the reference's jacrev fixtures):
@@ -123,3 +126,54 @@ def test_pair_network_kernels_vs_library_autograd(name, extra):
         e = float(((a - b) ** 2).sum()) ** 0.5
         n_ = float((b ** 2).sum()) ** 0.5
         assert e <= 2e-4 * n_ + 1e-6 * sc(b), (k, e, n_)
+
+
+@pytest.mark.parametrize("d,hdims,K", [(28, (128, 128), 9), (32, (128, 128), 30), (36, (64, 32), 12), (64, (128, 128), 45),
+                                       (64, (16, 16), 7), (40, (128, 64), 20), (48, (48, 80), 17)])
+def test_wide_pair_network_kernels_vs_fp64(d, hdims, K):
+    """The WIDE pair-grid-network kernels (d*d outputs beyond an LDS tile; d % 4 == 0) on random modules of several hidden
+    widths and ragged pair counts, against the same module evaluated in fp64 by torch (values, s-tangents and all six
+    parameter gradients for random upstream gradients), and additivity of the gradients over the pairs."""
+    from socmx import loss as L, nets
+    torch.manual_seed(d * 100 + K)
+    M = nets.SigmoidMLP(dim=d, hdims=hdims, gamma=torch.nn.Parameter(torch.tensor([1.0])), scaling_factor=0.5).to(DEV)
+    ts = torch.linspace(0, 1, K + 1).to(DEV)
+    t_vec, s_vec, _, _ = L.pair_times(ts, 1.0, K)
+    Np = t_vec.shape[0]
+    assert nets.pair_net_supported(M, Np)
+    g = torch.Generator().manual_seed(2)
+    gn = torch.randn(Np, d, d, generator=g).to(DEV)
+    gd = torch.randn(Np, d, d, generator=g).to(DEV)
+    net, dnet = M.forward_with_ds(t_vec, s_vec, raw=True)
+    assert type(net.grad_fn).__name__ == "_PairNetHipBackward"
+    torch.autograd.backward([net, dnet], [gn, gd])
+    got = [p.grad.double().cpu().clone() for p in M.sigmoid_layers.parameters()]
+    # fp64 reference of the same module on the CPU
+    import copy
+    M64 = copy.deepcopy(M).double().cpu()
+    M64.fused_pair_net = False
+    for p_ in M64.parameters():
+        p_.grad = None
+    n64, d64 = M64.forward_with_ds(t_vec.double().cpu(), s_vec.double().cpu(), raw=True)
+    torch.autograd.backward([n64, d64], [gn.double().cpu(), gd.double().cpu()])
+    sc = lambda x: max(1.0, float(x.abs().max()))
+    np.testing.assert_allclose(net.detach().cpu().numpy(), n64.detach().numpy(), rtol=1e-5, atol=2e-6 * sc(n64))
+    np.testing.assert_allclose(dnet.detach().cpu().numpy(), d64.detach().numpy(), rtol=1e-5, atol=2e-6 * sc(d64))
+    for (k, p_), a in zip(M64.sigmoid_layers.named_parameters(), got):
+        b = p_.grad
+        e = float(((a - b) ** 2).sum()) ** 0.5
+        n_ = float((b ** 2).sum()) ** 0.5
+        assert e <= 1e-5 * n_ + 1e-6 * sc(b), (k, e, n_)
+    # additivity over the pairs: the first h pairs + the rest (other tile / slab decomposition)
+    h = Np // 3
+    c = lambda x: x.detach().to(torch.float32).contiguous()
+    params = [c(p_) for l in (0, 2, 4) for p_ in (M.sigmoid_layers[l].weight, M.sigmoid_layers[l].bias)]
+    parts = []
+    for sl in (slice(0, h), slice(h, Np)):
+        _, _, packed = nets.pair_net_forward(d, hdims, params, c(t_vec[sl]), c(s_vec[sl]))
+        parts.append(nets.pair_net_backward(d, hdims, [p_.shape for p_ in params], packed, c(t_vec[sl]), c(s_vec[sl]),
+                                            c(gn[sl]), c(gd[sl])))
+    for a, b1, b2 in zip(got, parts[0], parts[1]):
+        ref = b1.double().cpu() + b2.double().cpu()
+        e = float(((a - ref) ** 2).sum()) ** 0.5
+        assert e <= 1e-5 * float((ref ** 2).sum()) ** 0.5 + 1e-6, e
