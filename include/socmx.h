@@ -153,20 +153,27 @@ int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d
  * (the exp(-gamma (s-t)) blend of models.py:263-275 is applied inside socmx_socm_target_*_net_f32).  Forward tangent and
  * value share every weight fragment (two MFMA column tiles per fragment).  The backward takes g_net, g_dnet
  * = d objective / d (net, dnet) (what socmx_socm_target_bwd_net_f32 writes) and returns the parameter gradients as one flat
- * buffer [W0 (h0,2) | b0 | W1 (h1,h0) | b1 | W2 (d*d,h1) | b2] (torch layouts); the forward is recomputed tile by tile.
+ * buffer [W0 (h0,n_in) | b0 | W1 (h1,h0) | b1 | W2 (d*d,h1) | b2] (torch layouts); the forward is recomputed tile by tile.
  * packed: socmx_mnet_packed_floats floats, rebuilt by socmx_mnet_pack_f32 whenever the weights changed.
- * SOCMX_E_LDS when the (d*d)-wide tile does not fit (d > 22 with 128-wide hidden layers): callers keep library autograd.
+ * n_in = 2: SigmoidMLP; n_in = 3: TwoBoundarySigmoidMLP.sigmoid_layers (models.py:278-310: Linear(3,h0) ...), whose third
+ * input z[p] is the stopped / running flag of models.py:313-336 -- both evaluations of the stopping-time loss are ONE call
+ * on 2 Np rows (z = 0 on the first Np, 1 on the rest).  z may be NULL when n_in = 2.
+ * d*d outputs beyond an LDS tile (d > 26 with 128-wide hidden layers; BASELINE configs[4]: d = 64) take the WIDE kernels:
+ * the last layer's outputs leave the forward kernel from the accumulators, the backward reads g_net / g_dnet from HBM as
+ * MFMA operands (split-K over the waves) and forms the last layer's weight gradient in its own kernel; this needs
+ * d % 4 == 0 and h1 <= 128, otherwise SOCMX_E_LDS (callers keep library autograd).
  */
 size_t socmx_mnet_packed_floats(int32_t d, const int32_t hdims_M[2]);
-int socmx_mnet_pack_f32(int32_t d, const int32_t hdims_M[2], const float* w0, const float* b0, const float* w1,
-                        const float* b1, const float* w2, const float* b2, float* packed, socmx_stream_t stream);
+int socmx_mnet_pack_f32(int32_t d, const int32_t hdims_M[2], int32_t n_in, const float* w0, const float* b0,
+                        const float* w1, const float* b1, const float* w2, const float* b2, float* packed,
+                        socmx_stream_t stream);
 int socmx_mnet_forward_f32(const float* packed, int32_t d, const int32_t hdims_M[2], const float* t, const float* s,
-                           int64_t Np, float* net, float* dnet, socmx_stream_t stream);
-int socmx_mnet_backward_sizes(int32_t d, const int32_t hdims_M[2], int64_t Np, int64_t* workspace_floats,
+                           const float* z, int64_t Np, float* net, float* dnet, socmx_stream_t stream);
+int socmx_mnet_backward_sizes(int32_t d, const int32_t hdims_M[2], int32_t n_in, int64_t Np, int64_t* workspace_floats,
                               int64_t* grad_floats);
-int socmx_mnet_backward_f32(const float* packed, int32_t d, const int32_t hdims_M[2], const float* t, const float* s,
-                            int64_t Np, const float* g_net, const float* g_dnet, float* workspace, float* grads,
-                            socmx_stream_t stream);
+int socmx_mnet_backward_f32(const float* packed, int32_t d, const int32_t hdims_M[2], int32_t n_in, const float* t,
+                            const float* s, const float* z, int64_t Np, const float* g_net, const float* g_dnet,
+                            float* workspace, float* grads, socmx_stream_t stream);
 
 /* ---- rollout ------------------------------------------------------------ */
 
@@ -335,22 +342,28 @@ int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* 
 
 /*
  * Stopping-time SOCM target (method.py:484-507, 548-564, 597-613, 649-660, 692-701 with models.py:278-393
- * TwoBoundarySigmoidMLP): the pair matrices depend on the SAMPLE through its stopping time,
- *     M[p,m]     =      w I +  c0 N0[p] +  c1 N1[p]
- *     dM/ds[p,m] = ok ( dw I + dc0 N0[p] + c0 dN0[p] + dc1 N1[p] + c1 dN1[p] )        (ok = 0 where nan_to_num zeroes it)
+ * TwoBoundarySigmoidMLP): the pair matrices depend on the SAMPLE through its stopping time tau_m (method.py:525-530),
+ *     M[p,m]     =              w I +  c0 N0[p] +  c1 N1[p]
+ *     dM/ds[p,m] = nan_to_num( dw I + dc0 N0[p] + c0 dN0[p] + dc1 N1[p] + c1 dN1[p] )      (entry-wise: method.py:553-555)
  *     target[i,m] = sum_{j>=i} ( M[p,m] qx[j,m] - dM/ds[p,m] vx[j,m] ),  qx = q | nabla_g at j = K,  vx = v | 0.
- * coef (8, Np, B) = the scalar gate fields [w, c0, c1, ok dw, ok dc0, ok dc1, ok c0, ok c1]; N0, N1, dN0, dN1
- * (Np, d, d) = the two network evaluations and their s-tangents; q, v (K,B,d) built with the per-sample fractional time
- * steps (socmx_socm_prep_f32 with `frac`).  The (Np, B, d, d) tensors of the reference are never formed; d <= 4.
- * The backward returns d obj / d coef (8, Np, B) and d obj / d (N0, N1, dN0, dN1) from gtarget = d obj / d target.
+ * The scalar gates (w, c0, c1) = (factor1 | exp_gamma3, fun_gamma2(factor1), 1 - exp_gamma3) of models.py:341-392 and their
+ * s-derivatives are formed per (pair, sample) INSIDE the kernels from pair_t, pair_s (Np,) = the pair grid of
+ * method.py:533-547, tau (B,), gammas (3,) = (gamma, gamma2, gamma3) in device memory and T_model = the model's own T
+ * (models.py:287: 1.0 whatever cfg.method.T is) -- neither the reference's (Np, B, d, d) tensors nor (Np, B) gate fields
+ * exist.  N0, N1, dN0, dN1 (Np, d, d) = the two network evaluations and their s-tangents (socmx_mnet_forward_f32, n_in = 3);
+ * q, v (K,B,d) built with the per-sample fractional time steps (socmx_socm_prep_f32 with `frac`).  d <= 16.
+ * The backward returns d obj / d (N0, N1, dN0, dN1) and ggamma_part (Np, 3): per-pair partial sums of
+ * d obj / d (gamma, gamma2, gamma3) (the caller adds the Np rows), from gtarget = d obj / d target; deterministic.
  */
-int socmx_socm_stopping_target_fwd_f32(int32_t d, int32_t K, int32_t B, const float* coef, const float* N0,
+int socmx_socm_stopping_target_fwd_f32(int32_t d, int32_t K, int32_t B, const float* pair_t, const float* pair_s,
+                                       const float* tau, const float* gammas, float T_model, const float* N0,
                                        const float* N1, const float* dN0, const float* dN1, const float* q,
                                        const float* v, const float* gT, float* target, socmx_stream_t stream);
-int socmx_socm_stopping_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* coef, const float* N0,
+int socmx_socm_stopping_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* pair_t, const float* pair_s,
+                                       const float* tau, const float* gammas, float T_model, const float* N0,
                                        const float* N1, const float* dN0, const float* dN1, const float* q,
-                                       const float* v, const float* gT, const float* gtarget, float* gcoef,
-                                       float* gN0, float* gN1, float* gdN0, float* gdN1, socmx_stream_t stream);
+                                       const float* v, const float* gT, const float* gtarget, float* gN0, float* gN1,
+                                       float* gdN0, float* gdN1, float* ggamma_part, socmx_stream_t stream);
 
 /*
  * The scalar bookkeeping of one training iteration (main.py:313-322, 325-345, 354-359 with compute_EMA, utils.py:389-396) on

@@ -169,7 +169,7 @@ __host__ __device__ inline UnetProgram make_unet_program(const UnetDesc& u, cons
 }
 
 // first eight GEMM-1 fragments wave `w` consumes in a stage whose GEMM 1 is layer Lg
-__host__ __device__ constexpr bool first_fragment_numbers(const LayerDesc& Lg, int NW, int w, unsigned short (&pf)[8]) {
+__host__ __device__ __attribute__((always_inline)) constexpr bool first_fragment_numbers(const LayerDesc& Lg, int NW, int w, unsigned short (&pf)[8]) {
   const int NBLK = Lg.out_pad >> 4, KC = Lg.in_pad >> 4;
   int blk = 0, bstride = 0, nb = 1, kc0 = 0, kc1 = 1;
   bool ok = false;
@@ -186,6 +186,7 @@ __host__ __device__ constexpr bool first_fragment_numbers(const LayerDesc& Lg, i
     ok = part < parts && kc1 > kc0;
     if (!ok) { kc0 = 0; kc1 = 1; }
   }
+#pragma unroll
   for (int f = 0; f < 8; ++f) {
     int kc = kc0 + f / nb; if (kc > kc1 - 1) kc = kc1 - 1;
     int b = blk + (f % nb) * bstride; if (b > NBLK - 1) b = NBLK - 1;
@@ -254,6 +255,8 @@ __device__ __forceinline__ void relu4_keep_nan(f32x4& v) {
 // all threads: copy the padded biases of the nine layers from the packed image into LDS (once per kernel)
 __device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, const UnetDesc& u, const TileLayout& t,
                                                  float* lds, int tid, int nthr) {
+  // (unrolled: a runtime index into u.L[] would put the whole descriptor into scratch memory)
+#pragma unroll
   for (int l = 0; l < 9; ++l)
     for (int e = tid; e < u.L[l].out_pad; e += nthr) lds[t.bias + u.L[l].b_lds + e] = Wp[u.L[l].b_off + e];
 }

@@ -546,19 +546,28 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
 template <class NET> struct K2RowTiles { static constexpr int value = 2; };
 template <> struct K2RowTiles<void> { static constexpr int value = 1; };
 
+template <int NW, class NET> struct K2Const {
+  static constexpr UnetDesc u = NET::desc();
+  static constexpr BwdLayout lay = make_bwd_layout(NET::desc(), NW, K2RowTiles<NET>::value);
+  __device__ static const UnetDesc& desc(const UnetDesc&) { return u; }
+  __device__ static const BwdLayout& layout(const BwdLayout&) { return lay; }
+};
+template <int NW> struct K2Const<NW, void> {
+  __device__ static const UnetDesc& desc(const UnetDesc& x) { return x; }
+  __device__ static const BwdLayout& layout(const BwdLayout& x) { return x; }
+};
+
 template <int NW, class NET>
 __global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool kStatic = !std::is_same<NET, void>::value;
-  UnetDesc u;
-  BwdLayout lay;
-  if constexpr (kStatic) {
-    constexpr UnetDesc uc = NET::desc();
-    constexpr BwdLayout lc = make_bwd_layout(uc, NW, K2RowTiles<NET>::value);
-    u = uc; lay = lc;
-  } else {
-    u = a.u; lay = a.lay;
-  }
+  // constexpr instantiations: the descriptors are constants in the code object (a local copy whose address is handed on
+  // lives in scratch memory); the descriptor-driven one copies them from the kernel arguments
+  UnetDesc u_arg;
+  BwdLayout lay_arg;
+  if constexpr (!kStatic) { u_arg = a.u; lay_arg = a.lay; }
+  const UnetDesc& u = K2Const<NW, NET>::desc(u_arg);
+  const BwdLayout& lay = K2Const<NW, NET>::layout(lay_arg);
   const TileLayout& t = lay.t;
   const int tid = threadIdx.x, nthr = NW * 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -960,6 +969,7 @@ struct MArgs {
   const float* packed;     // forward image
   const float* packedT;    // transposed image (backward kernel)
   const float *t, *s;      // (Np,) pair times
+  const float* z;          // (Np,) third network input (TwoBoundarySigmoidMLP's stopped / running flag), or nullptr
   int64_t Np;
   int ntiles;              // 16-pair tiles (= workgroups); slab tiles = 2 ntiles (value, tangent alternating)
   float *net, *dnet;       // forward kernel outputs (Np, d2)
@@ -1098,7 +1108,7 @@ __device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int
     float v = 0.f;
     if (r < 16) {
       const int64_t p = min(p0 + r, a.Np - 1);
-      v = c == 0 ? a.t[p] : (c == 1 ? a.s[p] : 0.f);
+      v = c == 0 ? a.t[p] : (c == 1 ? a.s[p] : ((c == 2 && a.z) ? a.z[p] : 0.f));
     } else {
       v = c == 1 ? 1.f : 0.f;                          // d [t, s] / d s
     }
@@ -1411,14 +1421,14 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
 
 struct MPackArgs {
   MDesc m;
-  int d, h0, h1;
+  int d, h0, h1, n_in;
   const float *w0, *b0, *w1, *b1, *w2, *b2;   // torch layouts: (h0,2) (h0,) (h1,h0) (h1,) (d2,h1) (d2,)
   float *packed, *packedT;
 };
 
 __global__ void mnet_pack_kernel(const MPackArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int fin[3] = {2, a.h0, a.h1}, fout[3] = {a.h0, a.h1, a.d * a.d};
+  const int fin[3] = {a.n_in, a.h0, a.h1}, fout[3] = {a.h0, a.h1, a.d * a.d};
   const float* W[3] = {a.w0, a.w1, a.w2};
   const float* Bv[3] = {a.b0, a.b1, a.b2};
   if (idx < a.m.total_floats) {
@@ -1636,13 +1646,14 @@ extern "C" size_t socmx_mnet_packed_floats(int32_t d, const int32_t hdims[2]) {
   return (size_t)m.total_floats + (size_t)m.totalT_floats;
 }
 
-extern "C" int socmx_mnet_pack_f32(int32_t d, const int32_t hdims[2], const float* w0, const float* b0, const float* w1,
-                                   const float* b1, const float* w2, const float* b2, float* packed,
+extern "C" int socmx_mnet_pack_f32(int32_t d, const int32_t hdims[2], int32_t n_in, const float* w0, const float* b0,
+                                   const float* w1, const float* b1, const float* w2, const float* b2, float* packed,
                                    socmx_stream_t stream) {
   if (!w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !packed) return SOCMX_E_NULL;
+  if (n_in != 2 && n_in != 3) return SOCMX_E_DIM;
   MPackArgs a;
   if (const int rc = mnet_plan(d, hdims, a.m)) return rc;
-  a.d = d; a.h0 = hdims[0]; a.h1 = hdims[1];
+  a.d = d; a.h0 = hdims[0]; a.h1 = hdims[1]; a.n_in = n_in;
   a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
   a.packed = packed; a.packedT = packed + a.m.total_floats;
   const int n = a.m.total_floats + a.m.totalT_floats;
@@ -1650,12 +1661,13 @@ extern "C" int socmx_mnet_pack_f32(int32_t d, const int32_t hdims[2], const floa
 }
 
 extern "C" int socmx_mnet_forward_f32(const float* packed, int32_t d, const int32_t hdims[2], const float* t,
-                                      const float* s, int64_t Np, float* net, float* dnet, socmx_stream_t stream) {
+                                      const float* s, const float* z, int64_t Np, float* net, float* dnet,
+                                      socmx_stream_t stream) {
   if (!packed || !t || !s || !net || !dnet) return SOCMX_E_NULL;
   if (Np < 1 || Np > ((int64_t)1 << 30)) return SOCMX_E_DIM;
   MArgs a{};
   if (const int rc = mnet_plan(d, hdims, a.m)) return rc;
-  a.packed = packed; a.packedT = packed + a.m.total_floats; a.t = t; a.s = s; a.Np = Np;
+  a.packed = packed; a.packedT = packed + a.m.total_floats; a.t = t; a.s = s; a.z = z; a.Np = Np;
   a.ntiles = (int)((Np + 15) / 16); a.net = net; a.dnet = dnet; a.ws = nullptr;
   const size_t lds_bytes = (size_t)a.m.lds_fwd_floats * sizeof(float);
   if (const int err = ensure_max_lds(mnet_forward_kernel<kK2Waves>)) return err;
@@ -1670,14 +1682,14 @@ struct MnetBwdPlan {
   int64_t ws_floats, slab_floats, part_floats, gw_off[3], gb_off[3], grad_floats;
 };
 
-static int mnet_bwd_plan(int32_t d, const int32_t hdims[2], int64_t Np, MnetBwdPlan& p) {
+static int mnet_bwd_plan(int32_t d, const int32_t hdims[2], int32_t n_in, int64_t Np, MnetBwdPlan& p) {
   if (const int rc = mnet_plan(d, hdims, p.m)) return rc;
-  if (Np < 1 || Np > ((int64_t)1 << 30)) return SOCMX_E_DIM;
+  if (Np < 1 || Np > ((int64_t)1 << 30) || (n_in != 2 && n_in != 3)) return SOCMX_E_DIM;
   p.ntiles = (int)((Np + 15) / 16);
   int wsum = 0;
   for (int t = 0; t < MT_N; ++t) wsum += p.m.wid[t];
   p.ws_floats = (int64_t)p.ntiles * 32 * wsum;
-  const int fin[3] = {2, hdims[0], hdims[1]}, fout[3] = {hdims[0], hdims[1], d * d};
+  const int fin[3] = {n_in, hdims[0], hdims[1]}, fout[3] = {hdims[0], hdims[1], d * d};
   int off = 0;
   int64_t goff = 0;
   for (int l = 0; l < 3; ++l) {
@@ -1701,23 +1713,24 @@ static int mnet_bwd_plan(int32_t d, const int32_t hdims[2], int64_t Np, MnetBwdP
   return 0;
 }
 
-extern "C" int socmx_mnet_backward_sizes(int32_t d, const int32_t hdims[2], int64_t Np, int64_t* workspace_floats,
-                                         int64_t* grad_floats) {
+extern "C" int socmx_mnet_backward_sizes(int32_t d, const int32_t hdims[2], int32_t n_in, int64_t Np,
+                                         int64_t* workspace_floats, int64_t* grad_floats) {
   MnetBwdPlan p;
-  if (const int rc = mnet_bwd_plan(d, hdims, Np, p)) return rc;
+  if (const int rc = mnet_bwd_plan(d, hdims, n_in, Np, p)) return rc;
   if (workspace_floats) *workspace_floats = p.ws_floats + p.part_floats;
   if (grad_floats) *grad_floats = p.grad_floats;
   return 0;
 }
 
-extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int32_t hdims[2], const float* t,
-                                       const float* s, int64_t Np, const float* gnet, const float* gdnet,
-                                       float* workspace, float* grads, socmx_stream_t stream) {
-  if (!packed || !t || !s || !gnet || !gdnet || !workspace || !grads) return SOCMX_E_NULL;
+extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int32_t hdims[2], int32_t n_in,
+                                       const float* t, const float* s, const float* z, int64_t Np, const float* gnet,
+                                       const float* gdnet, float* workspace, float* grads, socmx_stream_t stream) {
+  if (!packed || !t || !s || !gnet || !gdnet || !workspace || !grads || (n_in == 3 && !z)) return SOCMX_E_NULL;
   MnetBwdPlan p;
-  if (const int rc = mnet_bwd_plan(d, hdims, Np, p)) return rc;
+  if (const int rc = mnet_bwd_plan(d, hdims, n_in, Np, p)) return rc;
   MArgs a{};
-  a.m = p.m; a.packed = packed; a.packedT = packed + p.m.total_floats; a.t = t; a.s = s; a.Np = Np; a.ntiles = p.ntiles;
+  a.m = p.m; a.packed = packed; a.packedT = packed + p.m.total_floats; a.t = t; a.s = s; a.z = z; a.Np = Np;
+  a.ntiles = p.ntiles;
   a.gnet = gnet; a.gdnet = gdnet; a.ws = workspace;
   const size_t lds_bytes = (size_t)p.m.lds_floats * sizeof(float);
   const int nlay_b = p.m.wide ? 2 : 3;                    // layers whose weight gradient kernel B forms from the slabs

@@ -62,12 +62,12 @@ PROTOTYPES = {
     "socmx_unet_backward_f32": (C.c_int, [_fp, _fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, C.c_int32, C.c_int64,
                                           _fp, _fp, _fp, _fp]),
     "socmx_mnet_packed_floats": (C.c_size_t, [C.c_int32, C.POINTER(C.c_int32)]),
-    "socmx_mnet_pack_f32": (C.c_int, [C.c_int32, C.POINTER(C.c_int32)] + [_fp] * 8),
-    "socmx_mnet_forward_f32": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, C.c_int64, _fp, _fp, _fp]),
-    "socmx_mnet_backward_sizes": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64),
+    "socmx_mnet_pack_f32": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32] + [_fp] * 8),
+    "socmx_mnet_forward_f32": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp]),
+    "socmx_mnet_backward_sizes": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.POINTER(C.c_int64),
                                             C.POINTER(C.c_int64)]),
-    "socmx_mnet_backward_f32": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp,
-                                          _fp]),
+    "socmx_mnet_backward_f32": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _fp, _fp, _fp, C.c_int64, _fp,
+                                          _fp, _fp, _fp, _fp]),
     "socmx_rollout_f32": (C.c_int, [C.POINTER(Problem), _fp, C.POINTER(C.c_int32), _fp, _fp, C.c_int32,
                                     C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
                                     _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
@@ -90,8 +90,10 @@ PROTOTYPES = {
                                             _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp]),
     "socmx_socm_target_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
                                             _fp]),
-    "socmx_socm_stopping_target_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_fp] * 10),
-    "socmx_socm_stopping_target_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_fp] * 15),
+    "socmx_socm_stopping_target_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, C.c_float]
+                                           + [_fp] * 9),
+    "socmx_socm_stopping_target_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, C.c_float]
+                                           + [_fp] * 14),
     "socmx_iteration_scalars_f32": (C.c_int, [C.c_int32] + [_fp] * 8 + [C.c_double, C.c_double, _fp, _fp, _fp]),
     "socmx_adam_step_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_double, C.c_float, C.c_float,
                                       C.c_float, C.c_float, _fp, _fp, _fp]),

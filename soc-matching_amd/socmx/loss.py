@@ -225,43 +225,49 @@ class _TargetResidualNetHip(torch.autograd.Function):
 
 
 class _StoppingTargetHip(torch.autograd.Function):
-    """target (Kp,B,d) of the stopping-time SOCM loss from the gate fields and the two network evaluations
-    (socmx_socm_stopping_target_{fwd,bwd}_f32): the per-sample (Np,B,d,d) matrices are formed in registers."""
+    """target (Kp,B,d) of the stopping-time SOCM loss from the two network evaluations, the pair grid, the samples' stopping
+    times and (gamma, gamma2, gamma3) (socmx_socm_stopping_target_{fwd,bwd}_f32): the gates of models.py:341-392, their
+    s-derivatives and -- backward -- their derivatives in the three gammas are formed per (pair, sample) inside the kernels."""
 
     @staticmethod
-    def forward(ctx, coef, N0, N1, dN0, dN1, ops, K):
+    def forward(ctx, gamma, gamma2, gamma3, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops, K, T_model):
         L = _lib.lib()
         B, d = ops["gT"].shape
         c = lambda t: t.detach().to(torch.float32).contiguous()
-        coef, N0, N1, dN0, dN1 = map(c, (coef, N0, N1, dN0, dN1))
-        target = torch.empty(K + 1, B, d, dtype=torch.float32, device=coef.device)
-        with _lib.on_device(coef.device):
+        N0, N1, dN0, dN1, t_vec, s_vec, tau = map(c, (N0, N1, dN0, dN1, t_vec, s_vec, tau))
+        gam = torch.cat([c(gamma).reshape(1), c(gamma2).reshape(1), c(gamma3).reshape(1)])
+        target = torch.empty(K + 1, B, d, dtype=torch.float32, device=N0.device)
+        with _lib.on_device(N0.device):
             _lib.check(L.socmx_socm_stopping_target_fwd_f32(
-                d, K, B, _lib.ptr(coef), _lib.ptr(N0), _lib.ptr(N1), _lib.ptr(dN0), _lib.ptr(dN1), _lib.ptr(ops["q"]),
-                _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]), _lib.ptr(target), _lib.stream_ptr(coef.device)),
-                "socmx_socm_stopping_target_fwd_f32")
-        ctx.save_for_backward(coef, N0, N1, dN0, dN1, ops["q"], ops["v"], ops["gT"])
-        ctx.K = K
+                d, K, B, _lib.ptr(t_vec), _lib.ptr(s_vec), _lib.ptr(tau), _lib.ptr(gam), float(T_model), _lib.ptr(N0),
+                _lib.ptr(N1), _lib.ptr(dN0), _lib.ptr(dN1), _lib.ptr(ops["q"]), _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]),
+                _lib.ptr(target), _lib.stream_ptr(N0.device)), "socmx_socm_stopping_target_fwd_f32")
+        ctx.save_for_backward(gam, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops["q"], ops["v"], ops["gT"])
+        ctx.meta = (K, float(T_model), gamma.shape, gamma2.shape, gamma3.shape)
         return target
 
     @staticmethod
     def backward(ctx, gtarget):
         L = _lib.lib()
-        coef, N0, N1, dN0, dN1, q, v, gT = ctx.saved_tensors
+        gam, N0, N1, dN0, dN1, t_vec, s_vec, tau, q, v, gT = ctx.saved_tensors
+        K, T_model, sh, sh2, sh3 = ctx.meta
         B, d = gT.shape
         gtarget = gtarget.detach().to(torch.float32).contiguous()
-        gcoef = torch.empty_like(coef)
         gN0, gN1, gdN0, gdN1 = (torch.empty_like(N0) for _ in range(4))
-        with _lib.on_device(coef.device):
+        part = torch.empty(N0.shape[0], 3, dtype=torch.float32, device=N0.device)
+        with _lib.on_device(N0.device):
             _lib.check(L.socmx_socm_stopping_target_bwd_f32(
-                d, ctx.K, B, _lib.ptr(coef), _lib.ptr(N0), _lib.ptr(N1), _lib.ptr(dN0), _lib.ptr(dN1), _lib.ptr(q),
-                _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gtarget), _lib.ptr(gcoef), _lib.ptr(gN0), _lib.ptr(gN1),
-                _lib.ptr(gdN0), _lib.ptr(gdN1), _lib.stream_ptr(coef.device)), "socmx_socm_stopping_target_bwd_f32")
-        return gcoef, gN0, gN1, gdN0, gdN1, None, None
+                d, K, B, _lib.ptr(t_vec), _lib.ptr(s_vec), _lib.ptr(tau), _lib.ptr(gam), T_model, _lib.ptr(N0), _lib.ptr(N1),
+                _lib.ptr(dN0), _lib.ptr(dN1), _lib.ptr(q), _lib.ptr(v), _lib.ptr(gT), _lib.ptr(gtarget), _lib.ptr(gN0),
+                _lib.ptr(gN1), _lib.ptr(gdN0), _lib.ptr(gdN1), _lib.ptr(part), _lib.stream_ptr(N0.device)),
+                "socmx_socm_stopping_target_bwd_f32")
+        gg = part.sum(0)
+        return (gg[0].reshape(sh), gg[1].reshape(sh2), gg[2].reshape(sh3), gN0, gN1, gdN0, gdN1, None, None, None, None, None,
+                None)
 
 
-def stopping_target_hip(coef, N0, N1, dN0, dN1, ops, K):
-    return _StoppingTargetHip.apply(coef, N0, N1, dN0, dN1, ops, K)
+def stopping_target_hip(gamma, gamma2, gamma3, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops, K, T_model):
+    return _StoppingTargetHip.apply(gamma, gamma2, gamma3, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops, K, T_model)
 
 
 def socm_objective_net(pb, ts, lmbd, K, states, noises, controls, net, dnet, gamma, delta, nablaV, w, inv_norm):

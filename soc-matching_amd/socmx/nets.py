@@ -301,9 +301,10 @@ def unet_forward_hip(net, tx):
     return out
 
 
-def pair_net_forward(d, hdims, params, t, s, packed=None):
+def pair_net_forward(d, hdims, params, t, s, packed=None, z=None):
     """(net, dnet, packed): socmx_mnet_pack_f32 + socmx_mnet_forward_f32 on plain fp32 tensors; `packed` may be a
-    caller-owned buffer (hipGraph mode keeps the image for the deferred backward)."""
+    caller-owned buffer (hipGraph mode keeps the image for the deferred backward).  `z` (Np,): the third network input of
+    TwoBoundarySigmoidMLP (params[0] is then (h0, 3))."""
     L = _lib.lib()
     dev = t.device
     h2 = _lib.i2(hdims)
@@ -312,27 +313,31 @@ def pair_net_forward(d, hdims, params, t, s, packed=None):
     Np = t.shape[0]
     net = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
     dnet = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+    n_in = int(params[0].shape[1])
+    assert (n_in == 3) == (z is not None)
     with _lib.on_device(dev):
-        _lib.check(L.socmx_mnet_pack_f32(d, h2, *[_lib.ptr(p) for p in params], _lib.ptr(packed), _lib.stream_ptr(dev)),
-                   "socmx_mnet_pack_f32")
-        _lib.check(L.socmx_mnet_forward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(net),
+        _lib.check(L.socmx_mnet_pack_f32(d, h2, n_in, *[_lib.ptr(p) for p in params], _lib.ptr(packed),
+                                         _lib.stream_ptr(dev)), "socmx_mnet_pack_f32")
+        _lib.check(L.socmx_mnet_forward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), _lib.ptr(z), Np, _lib.ptr(net),
                                             _lib.ptr(dnet), _lib.stream_ptr(dev)), "socmx_mnet_forward_f32")
     return net, dnet, packed
 
 
-def pair_net_backward(d, hdims, shapes, packed, t, s, g_net, g_dnet, out=None):
+def pair_net_backward(d, hdims, shapes, packed, t, s, g_net, g_dnet, out=None, z=None):
     """Parameter gradients [W0, b0, W1, b1, W2, b2] (views of one flat buffer -- `out` when given): socmx_mnet_backward_f32."""
     L = _lib.lib()
     dev = t.device
     Np = t.shape[0]
     h2 = _lib.i2(hdims)
+    n_in = int(shapes[0][1])
     ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
-    _lib.check(L.socmx_mnet_backward_sizes(d, h2, Np, _lib.C.byref(ws), _lib.C.byref(ng)), "socmx_mnet_backward_sizes")
+    _lib.check(L.socmx_mnet_backward_sizes(d, h2, n_in, Np, _lib.C.byref(ws), _lib.C.byref(ng)), "socmx_mnet_backward_sizes")
     work = torch.empty(ws.value, dtype=torch.float32, device=dev)
     flat = torch.empty(ng.value, dtype=torch.float32, device=dev) if out is None else out[:ng.value]
     with _lib.on_device(dev):
-        _lib.check(L.socmx_mnet_backward_f32(_lib.ptr(packed), d, h2, _lib.ptr(t), _lib.ptr(s), Np, _lib.ptr(g_net),
-                                             _lib.ptr(g_dnet), _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
+        _lib.check(L.socmx_mnet_backward_f32(_lib.ptr(packed), d, h2, n_in, _lib.ptr(t), _lib.ptr(s), _lib.ptr(z), Np,
+                                             _lib.ptr(g_net), _lib.ptr(g_dnet), _lib.ptr(work), _lib.ptr(flat),
+                                             _lib.stream_ptr(dev)),
                    "socmx_mnet_backward_f32")
     grads, off = [], 0
     for shp in shapes:
@@ -343,32 +348,36 @@ def pair_net_backward(d, hdims, shapes, packed, t, s, g_net, g_dnet, out=None):
 
 
 class _PairNetHip(torch.autograd.Function):
-    """(net, d net / d s) of SigmoidMLP.sigmoid_layers on the pair grid: socmx_mnet_forward_f32 / socmx_mnet_backward_f32
-    (value and forward tangent share every weight fragment; the backward recomputes the forward in LDS)."""
+    """(net, d net / d s) of SigmoidMLP.sigmoid_layers (or, with a third input z, TwoBoundarySigmoidMLP.sigmoid_layers) on the
+    pair grid: socmx_mnet_forward_f32 / socmx_mnet_backward_f32 (value and forward tangent share every weight fragment; the
+    backward recomputes the forward in LDS)."""
 
     @staticmethod
-    def forward(ctx, t, s, d, hdims, w0, b0, w1, b1, w2, b2):
+    def forward(ctx, t, s, z, d, hdims, w0, b0, w1, b1, w2, b2):
         c = lambda x: x.detach().to(torch.float32).contiguous()
         t, s = c(t), c(s)
+        z = None if z is None else c(z)
         params = [c(p) for p in (w0, b0, w1, b1, w2, b2)]
-        net, dnet, packed = pair_net_forward(d, hdims, params, t, s)
-        ctx.save_for_backward(packed, t, s)
+        net, dnet, packed = pair_net_forward(d, hdims, params, t, s, z=z)
+        ctx.save_for_backward(packed, t, s, *([] if z is None else [z]))
         ctx.meta = (d, tuple(hdims), [p.shape for p in params])
         return net, dnet
 
     @staticmethod
     def backward(ctx, g_net, g_dnet):
-        packed, t, s = ctx.saved_tensors
+        packed, t, s, *rest = ctx.saved_tensors
         d, hdims, shapes = ctx.meta
         c = lambda x: x.detach().to(torch.float32).contiguous()
-        grads = pair_net_backward(d, hdims, shapes, packed, t, s, c(g_net), c(g_dnet))
-        return (None, None, None, None) + tuple(grads)
+        grads = pair_net_backward(d, hdims, shapes, packed, t, s, c(g_net), c(g_dnet), z=rest[0] if rest else None)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def pair_net_supported(mlp, n_pairs):
     L = _lib.lib()
     ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
-    return L.socmx_mnet_backward_sizes(mlp.dim, _lib.i2(mlp.hdims), int(n_pairs), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
+    n_in = int(mlp.sigmoid_layers[0].weight.shape[1])
+    return L.socmx_mnet_backward_sizes(mlp.dim, _lib.i2(mlp.hdims), n_in, int(n_pairs), _lib.C.byref(ws),
+                                       _lib.C.byref(ng)) == 0
 
 
 class SigmoidMLP(nn.Module):
@@ -402,8 +411,8 @@ class SigmoidMLP(nn.Module):
         if (raw and t.is_cuda and t.dtype == torch.float32 and getattr(self, "fused_pair_net", True)
                 and pair_net_supported(self, t.shape[0])):
             # hand-written tile kernels (csrc/socmx_unet_bwd.hip, K3): no library GEMM, value + tangent in one pass
-            return _PairNetHip.apply(t, s, self.dim, tuple(self.hdims), l0.weight, l0.bias, l2.weight, l2.bias, l4.weight,
-                                     l4.bias)
+            return _PairNetHip.apply(t, s, None, self.dim, tuple(self.hdims), l0.weight, l0.bias, l2.weight, l2.bias,
+                                     l4.weight, l4.bias)
         sk = t.is_cuda and t.shape[0] >= 8192 and torch.is_grad_enabled()
         lin = (lambda x, w, b: _LinearSplitK.apply(x, w, b)) if sk else (lambda x, w, b: torch.addmm(b, x, w.T))
         if sk:      # fused Linear+ReLU (the ReLU mask of the tangent path is h > 0, same set as a > 0)
@@ -467,6 +476,34 @@ class TwoBoundarySigmoidMLP(nn.Module):
             t2 = (h2 > 0).to(h2.dtype) * (t1 @ l2.weight.T)
             out.append((net, (t2 @ l4.weight.T).reshape(-1, d, d)))
         return out[0][0], out[1][0], out[0][1], out[1][1]
+
+    def nets_with_ds_hip(self, t, s, grid=None):
+        """The same four (N,d,d) tensors from ONE launch of the pair-grid-network kernel on 2 N rows (third input 0 on the
+        first N, 1 on the rest): socmx_mnet_forward_f32 / socmx_mnet_backward_f32 with n_in = 3.  `grid`: a dict the
+        caller keeps per time grid (the doubled inputs are built once)."""
+        N = t.shape[0]
+        key = (t.data_ptr(), s.data_ptr(), N)
+        if grid is None or grid.get("key") != key:
+            c = lambda x: x.detach().to(torch.float32).contiguous()
+            built = dict(key=key, t2=torch.cat([c(t), c(t)]), s2=torch.cat([c(s), c(s)]),
+                         z=torch.cat([torch.zeros_like(t, dtype=torch.float32), torch.ones_like(t, dtype=torch.float32)]))
+            if grid is not None:
+                grid.clear()
+                grid.update(built)
+            else:
+                grid = built
+        l0, l2, l4 = self.sigmoid_layers[0], self.sigmoid_layers[2], self.sigmoid_layers[4]
+        hd = (l0.weight.shape[0], l2.weight.shape[0])
+        net, dnet = _PairNetHip.apply(grid["t2"], grid["s2"], grid["z"], self.dim, hd, l0.weight, l0.bias, l2.weight, l2.bias,
+                                      l4.weight, l4.bias)
+        return net[:N], net[N:], dnet[:N], dnet[N:]
+
+    def hip_supported(self, n_pairs):
+        l0, l2 = self.sigmoid_layers[0], self.sigmoid_layers[2]
+        L = _lib.lib()
+        ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
+        return L.socmx_mnet_backward_sizes(self.dim, _lib.i2((l0.weight.shape[0], l2.weight.shape[0])), 3, 2 * int(n_pairs),
+                                           _lib.C.byref(ws), _lib.C.byref(ng)) == 0
 
     def forward(self, t, s, stopping_timestep_values):
         tau = stopping_timestep_values                       # (N, B)

@@ -69,6 +69,7 @@ class SOC_Solver(nn.Module):
         st.pop("_side_streams", None)
         st.pop("_pair_grid_cache", None)
         st.pop("_pending_M", None)
+        st.pop("_stop_grid", None)
         return st
 
     def _side_stream(self, device, which=0):
@@ -122,30 +123,24 @@ class SOC_Solver(nn.Module):
     #      loss with dt -> fractional time steps, never forming the reference's (Kp,Kp,B,d,d) tensors.
     def _socm_stopping_objective(self, pb, ts, t_vec, s_vec, ii, jj, states, noises, controls, stop_indicators,
                                  frac, nabla_V, weight):
-        if self.shard is not None:
-            raise NotImplementedError("stopping-time SOCM is single-process only")
         sde = self.neural_sde
         K = self.num_steps
         Kp, B, d = states.shape
         tau = ((sde.Phi(states) > 0).to(torch.int).sum(dim=0) - 1) / (Kp - 1)            # method.py:525-530
         tau_vec = tau.unsqueeze(0).expand(t_vec.shape[0], B)
-        if states.is_cuda and d <= 4 and getattr(self, "fused_stopping", True):
-            # HIP path: the gates are (Np,B) scalar fields (torch: differentiable w.r.t. gamma, gamma2, gamma3; their
-            # s-derivatives by forward mode), the (Np,B,d,d) matrices are formed per (pair, sample) inside
-            # socmx_socm_stopping_target_*_f32.  nan_to_num(dM/ds) (method.py:553-555): an entry of dM/ds is NaN exactly
-            # when one of the gate derivatives is (every entry contains all three) -> `ok` zeroes the whole matrix.
+        if states.is_cuda and d <= 16 and getattr(self, "fused_stopping", True):
+            # HIP path: the two network evaluations and their s-tangents from one launch of the pair-grid-network kernel
+            # (n_in = 3), the gates (models.py:341-392), their s-derivatives and the (Np,B,d,d) matrices formed per
+            # (pair, sample) inside socmx_socm_stopping_target_*_f32; nan_to_num(dM/ds) (method.py:553-555) entry-wise there
             M = sde.M
-            (w, c0, c1), (dw, dc0, dc1) = torch.func.jvp(lambda s_: M.gates(t_vec, s_, tau_vec), (s_vec,),
-                                                         (torch.ones_like(s_vec),))
-            ok = torch.isfinite(dw) & torch.isfinite(dc0) & torch.isfinite(dc1)
-            z = torch.zeros_like(w)
-            keep = lambda x: torch.where(ok, x, z)
-            coef = torch.stack([w, c0, c1, keep(dw), keep(dc0), keep(dc1), keep(c0), keep(c1)])
-            N0, N1, dN0, dN1 = M.nets_with_ds(t_vec, s_vec)
+            if M.hip_supported(t_vec.shape[0]):
+                N0, N1, dN0, dN1 = M.nets_with_ds_hip(t_vec, s_vec, self.__dict__.setdefault("_stop_grid", {}))
+            else:
+                N0, N1, dN0, dN1 = M.nets_with_ds(t_vec, s_vec)
             ops = L.socm_operands_hip(pb, ts, self.lmbd, states, noises, controls, frac=frac)
-            target = L.stopping_target_hip(coef, N0, N1, dN0, dN1, ops, K)
+            target = L.stopping_target_hip(M.gamma, M.gamma2, M.gamma3, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops, K, M.T)
             r = stop_indicators.unsqueeze(2) * ((nabla_V - target) @ pb.sigma)
-            return torch.sum(r * r * weight.reshape(1, -1, 1)) / torch.sum(stop_indicators)
+            return torch.sum(r * r * weight.reshape(1, -1, 1)) / self._stop_normaliser(stop_indicators)
         # dM/ds as a forward-mode tangent (the reference: functorch.jacrev over the batch-summed output)
         M_all, dM_all = torch.func.jvp(lambda s_: sde.M(t_vec, s_, tau_vec), (s_vec,), (torch.ones_like(s_vec),))
         dM_all = torch.nan_to_num(dM_all)                                                   # method.py:553-555
@@ -157,7 +152,15 @@ class SOC_Solver(nn.Module):
         contrib = torch.einsum("pmkl,pml->pmk", M_all, qx) - torch.einsum("pmkl,pml->pmk", dM_all, vx)
         target = torch.zeros(Kp, B, d, device=states.device, dtype=contrib.dtype).index_add(0, ii, contrib)
         r = stop_indicators.unsqueeze(2) * ((nabla_V - target) @ pb.sigma)
-        return torch.sum(r * r * weight.reshape(1, -1, 1)) / torch.sum(stop_indicators)
+        return torch.sum(r * r * weight.reshape(1, -1, 1)) / self._stop_normaliser(stop_indicators)
+
+    def _stop_normaliser(self, stop_indicators):
+        """sum of the stop indicators (method.py:713-715) -- over the GLOBAL batch when this rank holds a shard (one scalar
+        all-reduce: the normaliser scales every gradient, so it is needed before the backward pass)."""
+        den = torch.sum(stop_indicators.to(torch.float32))
+        if self.shard is not None:
+            den = self.shard.allreduce_flat_(den.reshape(1)).reshape(())
+        return den
 
     # ---- method.py:223-906 -------------------------------------------------------------------
     def loss(self, batch_size, compute_L2_error=False, optimal_control=None, compute_control_objective=False,

@@ -279,6 +279,12 @@ FIXTURES = [
     # d = 2 with the stopping-time loss: per-sample 2 x 2 pair matrices (TwoBoundarySigmoidMLP), off-diagonal terms
     ("tiny_molecular_dynamics_d2_stopping", "molecular_dynamics", 2, 20, 16, TINY, 1.0, 6,
      dict(T=2.0, lmbd=2.0, use_stopping_time=True)),
+    # d = 5 and d = 10 with stopping times: the entry-wise (8- and 16-wide) instantiations of the stopping-time kernels, B = 66
+    # rows (two 64-sample blocks, ragged)
+    ("tiny_molecular_dynamics_d5_stopping", "molecular_dynamics", 5, 14, 66, TINY, 1.0, 11,
+     dict(T=1.2, lmbd=2.0, use_stopping_time=True)),
+    ("tiny_molecular_dynamics_d10_stopping", "molecular_dynamics", 10, 8, 12, TINY, 1.5, 12,
+     dict(T=1.5, lmbd=1.0, use_stopping_time=True)),
     # default architecture at the BASELINE configs, small batch (weights dominate the size)
     ("cfg1_ou_quadratic_easy_d2_K50", "OU_quadratic_easy", 2, 50, 8, DEFAULT, 2.0, 0,
      dict(with_pairs=False)),

@@ -574,11 +574,14 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("name", ["tiny_molecular_dynamics_d1_stopping", "tiny_molecular_dynamics_d2_stopping"])
+@pytest.mark.parametrize("name", ["tiny_molecular_dynamics_d1_stopping", "tiny_molecular_dynamics_d2_stopping",
+                                  "tiny_molecular_dynamics_d5_stopping", "tiny_molecular_dynamics_d10_stopping"])
 def test_stopping_time_socm_loss_on_gpu_vs_golden(name, fused):
-    """a7': SOCM with per-sample pair matrices (TwoBoundarySigmoidMLP, models.py:278-393).  fused = the HIP contraction
-    (socmx_socm_stopping_target_*_f32: gates as (Np,B) fields, matrices in registers); otherwise the torch restatement
-    that materialises (Np,B,d,d).  Objective and the gradients of gamma, gamma2, the M network and nabla_V against the
+    """a7': SOCM with per-sample pair matrices (TwoBoundarySigmoidMLP, models.py:278-393).  fused = the device path: both
+    network evaluations + s-tangents from the pair-grid-network kernel (n_in = 3), the gates, their s-derivatives and their
+    derivatives in gamma / gamma2 / gamma3 formed per (pair, sample) inside socmx_socm_stopping_target_*_f32 (d = 1, 2: the
+    register instantiations; d = 5, 10: the 8- and 16-wide ones, two sample blocks); otherwise the torch restatement that
+    materialises (Np,B,d,d).  Objective and the gradients of gamma, gamma2, gamma3, the M network and nabla_V against the
     reference-generated fixture."""
     from SOC_matching.method import SOC_Solver
     sde, aux = build_sde(name, DEV)
@@ -594,6 +597,9 @@ def test_stopping_time_socm_loss_on_gpu_vs_golden(name, fused):
     out[0].backward()
     np.testing.assert_allclose(_np(sde.gamma.grad), z["grad_gamma"], rtol=5e-3, atol=1e-6)
     np.testing.assert_allclose(_np(sde.gamma2.grad), z["grad_gamma2"], rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(_np(sde.gamma3.grad), z["grad_gamma3"], rtol=5e-3, atol=1e-5)
+    if fused:
+        assert type(out[0].grad_fn).__name__ != "NoneType" and sde.M.hip_supported((aux["K"] + 1) * (aux["K"] + 2) // 2)
 
     def relnorm(pairs):
         num = sum(float(((_np(p.grad) - g) ** 2).sum()) for p, g in pairs)

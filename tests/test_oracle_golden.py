@@ -92,9 +92,10 @@ def test_socm_loss_default_arch(name):
     assert (num / den) ** 0.5 < 1e-3
 
 
-@pytest.mark.parametrize("name", ["tiny_molecular_dynamics_d1_stopping", "tiny_molecular_dynamics_d2_stopping"])
+@pytest.mark.parametrize("name", ["tiny_molecular_dynamics_d1_stopping", "tiny_molecular_dynamics_d2_stopping",
+                                  "tiny_molecular_dynamics_d5_stopping", "tiny_molecular_dynamics_d10_stopping"])
 def test_socm_loss_stopping_time(name):
-    torch.set_num_threads(1)
+    torch.set_num_threads(4 if "d5" in name else 1)
     pb, vp, mp, gamma, aux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"), requires_grad=True)
     z = aux["z"]
     obj, wm, ws = O.socm_loss_stopping(pb, vp, mp, gamma, aux["gamma2"], aux["gamma3"], aux["x0"], aux["ts"],
