@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 120 /* 0.1.2: + socmx_shard_stats_f32; socmx_adam_step_f32 sums are deterministic (scratch layout) */
+#define SOCMX_VERSION 130 /* 0.1.3: mnet n_in / z, wide pair-net kernels, in-kernel stopping gates, baseline-loss kernels */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -339,6 +339,35 @@ int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* 
                                   const float* v, const float* gT, const float* gout, const float* net,
                                   const float* dnet, const float* delta, const float* gamma, float* g_net,
                                   float* g_dnet, float* g_gamma_part, socmx_stream_t stream);
+
+/*
+ * The reference's OTHER losses on the same rollout buffers, one launch per family member.
+ * Matching family (method.py:289-478, 722-749: SOCM_const_M, SOCM_exp, SOCM_adjoint) -- the least-squares target:
+ *   kind 0  target[i] = sum_{j>=i}^{K-1} q_j + nabla_g(X_K)                                        (M = I)
+ *   kind 1  target[i] = sum_{j>=i} e^{-gamma (t_j - t_i)} (q_j + gamma v_j) + e^{-gamma (T - t_i)} nabla_g(X_K)
+ *           and dtarget = d target / d gamma (gamma (1,) in device memory; method.py:371-478 trains it)
+ *   kind 2  the costate recursion a_K = nabla_g(X_K), a_i = a_{i+1} + dt ((nabla_f_i + nabla_f_{i+1}) / 2
+ *           + ((nabla_b_i + nabla_b_{i+1}) / 2)^T a_{i+1}) with the constant step dt = T / K (method.py:722-749): all K steps
+ *           inside one kernel (d <= 64)
+ * q, v (K,B,d), gT (B,d) from socmx_socm_prep_f32; states (K+1,B,d) for kind 2; unused pointers may be NULL.
+ * socmx_socm_residual_f32 then gives objective = sum w |sigma^T (nabla_V - target)|^2 inv_norm (ADDED to objective[0]) and
+ * G = d objective / d nabla_V for ANY target in HBM (method.py:702-720's form, shared by the three).
+ * Girsanov family (method.py:751-856: cross_entropy, variance, log-variance, moment): c (K,B) with
+ *   c[i,m] = stop[i,m] ( dt (-<l,u>/lmbd + |l|^2/(2 lmbd) - [with_f] f(X_i)/lmbd) - sqrt(dt/lmbd) <l,eps> ),  l = -sigma^T nabla_V,
+ * dt = frac[i,m] or ts[i+1]-ts[i]; the per-sample totals sum_i c[i,m] and the B-long loss formulas stay with the caller;
+ * the backward writes G (K+1,B,d) = d obj / d nabla_V from gtotal (B,) = d obj / d total_m.
+ */
+int socmx_matching_target_f32(int32_t kind, const socmx_problem* problem, int32_t K, int32_t B, const float* ts, float T,
+                              float dt, const float* gamma, const float* q, const float* v, const float* gT,
+                              const float* states, float* target, float* dtarget, socmx_stream_t stream);
+int socmx_socm_residual_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* target, const float* nablaV,
+                            const float* w, float inv_norm, float* G, float* objective, socmx_stream_t stream);
+int socmx_girsanov_fwd_f32(const socmx_problem* problem, int32_t K, int32_t B, float lmbd, int32_t with_f, const float* ts,
+                           const float* nablaV, const float* noises, const float* controls, const float* states,
+                           const float* frac, const float* stop, float* c, socmx_stream_t stream);
+int socmx_girsanov_bwd_f32(const socmx_problem* problem, int32_t K, int32_t B, float lmbd, const float* ts,
+                           const float* nablaV, const float* noises, const float* controls, const float* frac,
+                           const float* stop, const float* gtotal, float* G, socmx_stream_t stream);
 
 /*
  * Stopping-time SOCM target (method.py:484-507, 548-564, 597-613, 649-660, 692-701 with models.py:278-393

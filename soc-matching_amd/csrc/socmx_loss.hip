@@ -2139,6 +2139,19 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
   return launch(socm_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
 }
 
+static int launch_residual(const TargetArgs& a, socmx_stream_t stream) {
+  const int d = a.d, K = a.K, B = a.B;
+  const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
+  if (lds > 160 * 1024) return SOCMX_E_LDS;
+  if (d % 4 == 0 && d <= 64) {
+    const int64_t tiles = ((int64_t)(K + 1) * B + 15) / 16;
+    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 3) / 4, 1024);
+    return launch(socm_residual_mfma_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  }
+  if (const int err = ensure_max_lds(socm_residual_kernel)) return err;
+  return launch(socm_residual_kernel, dim3(K + 1, (B + 63) / 64), dim3(64), lds, stream, a);
+}
+
 static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all, const float* dM_all,
                              const float* delta, const float* gamma, const float* q, const float* v,
                              const float* gT, const float* nablaV, const float* w, float inv_norm, float* target,
@@ -2190,15 +2203,21 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   }
 #undef SOCMX_TARGET_LAUNCH
   if (lerr) return lerr;
-  const size_t lds = (size_t)2 * 64 * (d + 1) * sizeof(float);
-  if (lds > 160 * 1024) return SOCMX_E_LDS;
-  if (d % 4 == 0 && d <= 64) {
-    const int64_t tiles = ((int64_t)(K + 1) * B + 15) / 16;
-    const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 3) / 4, 1024);
-    return launch(socm_residual_mfma_kernel, dim3(blocks), dim3(256), 0, stream, a);
-  }
-  if (const int err = ensure_max_lds(socm_residual_kernel)) return err;
-  return launch(socm_residual_kernel, dim3(K + 1, (B + 63) / 64), dim3(64), lds, stream, a);
+  return launch_residual(a, stream);
+}
+
+// objective = sum w |sigma^T (nabla_V - target)|^2 inv_norm and G = d objective / d nabla_V from a target that is already in
+// HBM: the residual kernels of the SOCM loss, for the matching-family baselines (socmx_matching_target_f32) whose targets
+// come from other kernels (method.py:289-478, 722-749 end in the same least-squares form as method.py:702-720)
+extern "C" int socmx_socm_residual_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* target,
+                                       const float* nablaV, const float* w, float inv_norm, float* G, float* objective,
+                                       socmx_stream_t stream) {
+  if (!pb || !target || !nablaV || !w || !G || !objective || !pb->sigma) return SOCMX_E_NULL;
+  if (pb->d < 1 || pb->d > 1024 || K < 1 || B < 1) return SOCMX_E_DIM;
+  TargetArgs a{};
+  a.d = pb->d; a.K = K; a.B = B; a.inv_norm = inv_norm; a.sigma = pb->sigma; a.nablaV = nablaV; a.w = w;
+  a.target = const_cast<float*>(target); a.G = G; a.objective = objective;
+  return launch_residual(a, stream);
 }
 
 extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all,

@@ -84,6 +84,11 @@ PROTOTYPES = {
     "socmx_weights_stats_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp]),
     "socmx_shard_stats_f32": (C.c_int, [C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "socmx_num_pairs": (C.c_int64, [C.c_int32]),
+    "socmx_matching_target_f32": (C.c_int, [C.c_int32, C.POINTER(Problem), C.c_int32, C.c_int32, _fp, C.c_float, C.c_float,
+                                            _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_socm_residual_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp]),
+    "socmx_girsanov_fwd_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, C.c_float, C.c_int32] + [_fp] * 9),
+    "socmx_girsanov_bwd_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, C.c_float] + [_fp] * 9),
     "socmx_socm_prep_f32": (C.c_int, [C.POINTER(Problem), _fp, C.c_int32, C.c_int32, C.c_float,
                                       _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "socmx_socm_target_fwd_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, _fp,

@@ -196,10 +196,11 @@ class SOC_Solver(nn.Module):
             t_vec, s_vec, ii, jj, delta = self._pair_grid(ts, K)    # built on this stream the first time: before fork
             fork = torch.cuda.Event()
             fork.record()                       # after the previous optimizer step, before the rollout launch
-        # SOCM on the GPU: the rollout kernel hands over nabla_V at all (K+1) B trajectory rows (it evaluates the network
-        # there anyway) and socmx_unet_backward_f32 produces the parameter gradients -- no library forward/backward
+        # Every loss that does not differentiate through the rollout: the rollout kernel hands over nabla_V at all (K+1) B
+        # trajectory rows (it evaluates the network there anyway) and socmx_unet_backward_f32 produces the parameter
+        # gradients -- no library forward/backward
         from . import nets as _nets
-        fused_V = (algorithm == "SOCM" and detach and R._eligible_for_hip(sde, state0, detach) and getattr(self, "fused_nabla_V", True)
+        fused_V = (detach and R._eligible_for_hip(sde, state0, detach) and getattr(self, "fused_nabla_V", True)
                    and _nets.unet_backward_supported(sde.nabla_V, Kp * B))
         rolled = R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0,
                                            key=getattr(self, "philox_key", None), want_nabla_v=fused_V)

@@ -12,6 +12,13 @@ import torch.multiprocessing as mp
 from test_host_cpu import build_sde
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, name, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,7 +48,7 @@ def _worker(rank, world, port, name, ret):
 @pytest.mark.parametrize("name", ["tiny_ou_linear_d5_B20", "tiny_double_well_d10"])
 def test_sharded_step_equals_single_process(name):
     world = 2
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, port, name, ret), nprocs=world, join=True)
@@ -127,7 +134,7 @@ def test_sharded_trainer_steps_equal_the_reference_training_run(name):
     shifted weight sums), Adam with the reference's groups, EMA normaliser -- reproduces the reference's own training run on
     the same noise, both ranks end with identical parameters, and exactly one collective is issued per iteration."""
     world = 2
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_train_worker, args=(world, port, name, ret), nprocs=world, join=True)

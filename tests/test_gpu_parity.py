@@ -26,7 +26,7 @@ def _np(t):
 def test_library_is_loaded_and_reports_gfx950():
     from socmx import _lib
     L = _lib.lib()
-    assert L.socmx_version() == 120
+    assert L.socmx_version() == 130
     buf = (b" " * 512)
     import ctypes
     b = ctypes.create_string_buffer(512)
@@ -1006,10 +1006,18 @@ OTHER_ALGS = ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-
 
 @pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10"])
 @pytest.mark.parametrize("alg", OTHER_ALGS)
-def test_other_losses_on_gpu_match_reference(name, alg):
+def test_other_losses_on_gpu_match_reference(name, alg, monkeypatch):
     """Row f4 on the GPU: the reference's eight other losses on the HIP rollout's buffers (rel_entropy differentiates
-    through the eager rollout) against the reference-generated `alg.*` fixtures: objective and nabla_V gradients."""
+    through the eager rollout) against the reference-generated `alg.*` fixtures: objective and nabla_V gradients.  Seven of
+    them run on the fused kernels of csrc/socmx_baselines.hip (matching family: target scan / costate recursion + the SOCM
+    residual kernel; Girsanov family: integrand kernel + its backward) with nabla_V's values from the rollout and its
+    parameter gradients from socmx_unet_backward_f32 -- the test counts the launches so that a silent torch path fails."""
     from SOC_matching.method import SOC_Solver
+    from socmx import baselines, nets
+    calls = []
+    for cls, tag in ((baselines._MatchingHip, "matching"), (baselines._GirsanovHip, "girsanov"), (nets.UnetOnTrajectory, "unet")):
+        orig = cls.apply
+        monkeypatch.setattr(cls, "apply", staticmethod(lambda *a, _o=orig, _t=tag: (calls.append(_t), _o(*a))[1]))
     sde, aux = build_sde(name, DEV)
     z = aux["z"]
     solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"],
@@ -1032,6 +1040,9 @@ def test_other_losses_on_gpu_match_reference(name, alg):
         np.testing.assert_allclose(_np(solver.gamma.grad), z[f"alg.{alg}.grad_gamma"], rtol=2e-3, atol=1e-6)
     if alg == "moment":
         np.testing.assert_allclose(_np(solver.y0.grad), z[f"alg.{alg}.grad_y0"], rtol=2e-3)
+    if alg != "rel_entropy":
+        family = "matching" if alg.startswith("SOCM") else "girsanov"
+        assert calls.count(family) == 1 and calls.count("unet") == 1, calls
 
 
 _RCCL_CHILD = r"""
@@ -1117,7 +1128,10 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gpath = str(tmp_path / "grads.npz")
-    port = str(29600 + os.getpid() % 300)
+    import socket
+    with socket.socket() as sk:                      # a free port (a fixed one can still sit in TIME_WAIT from the previous case)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     res = subprocess.run([sys.executable, "-c", _RCCL_CHILD, root, port, name, gpath], capture_output=True, text=True,
                          timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
