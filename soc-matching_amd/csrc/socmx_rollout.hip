@@ -123,9 +123,10 @@ __device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, float&
 }
 
 struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
-typedef StaticNet<16, 256, 128, 64, 16> DefaultNet;  // arch.hdims = [256,128,64], d <= 15: the reference default
-typedef StaticNet<80, 256, 128, 64, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
-typedef StaticNet<32, 256, 128, 64, 32> Wide32Net;   // ... and at 16 <= d <= 31 (soc.yaml's default d = 20)
+// (SOCMX_H*P: the reference's default arch.hdims = [256,128,64] unless this is a variant build, see socmx_unet.h)
+typedef StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16> DefaultNet;  // d <= 15
+typedef StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
+typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... and at 16 <= d <= 31 (soc.yaml's default d = 20)
 
 template <int NW, bool STOPPING, bool PROF, class NET, bool FAST>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
@@ -873,9 +874,12 @@ static bool dims_ok(int d, const int32_t h[3]) {
 extern "C" int socmx_version(void) { return SOCMX_VERSION; }
 
 extern "C" int socmx_capabilities(char* buf, int cap) {
+#define SOCMX_STR2(x) #x
+#define SOCMX_STR(x) SOCMX_STR2(x)
   static const char msg[] =
-      "socmx 0.1.0; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network; "
-      "Philox4x32-10 noise; kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target";
+      "socmx 0.1.3; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network; "
+      "Philox4x32-10 noise; static_hdims=" SOCMX_STR(SOCMX_H0P) "," SOCMX_STR(SOCMX_H1P) "," SOCMX_STR(SOCMX_H2P) "; "
+      "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target";
   const int need = (int)sizeof(msg);
   if (buf && cap > 0) {
     const int n = need < cap ? need : cap;
@@ -996,8 +1000,8 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   // the reference's default architecture runs the fully specialised instantiation (SOCMX_GENERIC=1 forces the
   // table-driven one, for A/B runs and tests)
   static const bool force_generic = getenv("SOCMX_GENERIC") != nullptr;
-  const bool is_default = !force_generic && nw == 8 && a.u.in0p == 16 && a.u.hp[0] == 256 && a.u.hp[1] == 128 &&
-                          a.u.hp[2] == 64 && a.u.outp == 16;
+  const bool is_default = !force_generic && nw == 8 && a.u.in0p == 16 && a.u.hp[0] == SOCMX_H0P && a.u.hp[1] == SOCMX_H1P &&
+                          a.u.hp[2] == SOCMX_H2P && a.u.outp == 16;
   // sigma = I and d <= 15: the SDE step runs in 16-lane groups with one barrier per step (FAST)
   static const bool force_slow = getenv("SOCMX_NOFAST") != nullptr;
   const bool fast = !force_slow && a.sigma_identity && d <= 15;
@@ -1012,10 +1016,10 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
       else kern = stopping ? rollout_kernel<NWV, true, false, NETV, false> : rollout_kernel<NWV, false, false, NETV, false>; \
     }                                                                                                           \
   } while (0)
-  const bool is_wide64 = !force_generic && nw == 8 && a.u.in0p == 80 && a.u.hp[0] == 256 && a.u.hp[1] == 128 &&
-                         a.u.hp[2] == 64 && a.u.outp == 64;
-  const bool is_wide32 = !force_generic && nw == 8 && a.u.in0p == 32 && a.u.hp[0] == 256 && a.u.hp[1] == 128 &&
-                         a.u.hp[2] == 64 && a.u.outp == 32;
+  const bool is_wide64 = !force_generic && nw == 8 && a.u.in0p == 80 && a.u.hp[0] == SOCMX_H0P && a.u.hp[1] == SOCMX_H1P &&
+                         a.u.hp[2] == SOCMX_H2P && a.u.outp == 64;
+  const bool is_wide32 = !force_generic && nw == 8 && a.u.in0p == 32 && a.u.hp[0] == SOCMX_H0P && a.u.hp[1] == SOCMX_H1P &&
+                         a.u.hp[2] == SOCMX_H2P && a.u.outp == 32;
   if (is_default) SOCMX_PICK(8, DefaultNet);
   else if (is_wide64) SOCMX_PICK(8, Wide64Net);
   else if (is_wide32) SOCMX_PICK(8, Wide32Net);

@@ -18,6 +18,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Padded hidden widths of the constexpr-specialised kernel instantiations (StaticNet<..., H0P, H1P, H2P, ...>).  The shipped
+// library is built for the reference's default arch.hdims = [256, 128, 64] (configs/soc.yaml:33-35); a VARIANT library for
+// another architecture is the same sources compiled with -DSOCMX_H0P=.. -DSOCMX_H1P=.. -DSOCMX_H2P=.. (csrc/Makefile
+// VARIANT=h0_h1_h2; socmx/_lib.py builds and loads it at first use when backend.specialize_arch is on).
+#ifndef SOCMX_H0P
+#define SOCMX_H0P 256
+#define SOCMX_H1P 128
+#define SOCMX_H2P 64
+#endif
+
 namespace socmx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1479,7 +1479,7 @@ static bool k2_dims_ok(int d, const int32_t h[3]) {
 // which instantiation of kernel A: 0 = descriptor-driven, 1..3 = the constexpr ones (default hidden widths)
 static int k2_variant(const UnetDesc& u) {
   static const bool force_generic = getenv("SOCMX_GENERIC") != nullptr;
-  if (force_generic || u.hp[0] != 256 || u.hp[1] != 128 || u.hp[2] != 64) return 0;
+  if (force_generic || u.hp[0] != SOCMX_H0P || u.hp[1] != SOCMX_H1P || u.hp[2] != SOCMX_H2P) return 0;
   if (u.in0p == 16 && u.outp == 16) return 1;
   if (u.in0p == 32 && u.outp == 32) return 2;
   if (u.in0p == 80 && u.outp == 64) return 3;
@@ -1511,6 +1511,11 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   p.variant = k2_variant(p.u);
   p.rt = p.variant ? 2 : 1;
   p.lay = make_bwd_layout(p.u, kK2Waves, p.rt);
+  if (p.variant && (size_t)p.lay.floats * sizeof(float) > (size_t)kLdsBytesPerCU) {
+    // (a variant build with wide layers: two row tiles per workgroup do not fit -- the descriptor-driven form with one)
+    p.variant = 0; p.rt = 1;
+    p.lay = make_bwd_layout(p.u, kK2Waves, p.rt);
+  }
   if ((size_t)p.lay.floats * sizeof(float) > (size_t)kLdsBytesPerCU) return SOCMX_E_LDS;
   if ((N + 15) / 16 > (int64_t)1 << 27) return SOCMX_E_DIM;
   p.ntiles = (int)((N + 16 * p.rt - 1) / (16 * p.rt)) * p.rt;     // 16-row tiles, whole workgroups (padding tiles: zero gradient)
@@ -1599,9 +1604,9 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles;
   const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
   void (*kern)(const TileArgs) = unet_bwd_tile_kernel<kK2Waves, void>;
-  if (p.variant == 1) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<16, 256, 128, 64, 16>>;
-  else if (p.variant == 2) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<32, 256, 128, 64, 32>>;
-  else if (p.variant == 3) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<80, 256, 128, 64, 64>>;
+  if (p.variant == 1) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>>;
+  else if (p.variant == 2) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32>>;
+  else if (p.variant == 3) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64>>;
   if (const int err = ensure_max_lds(kern)) return err;
   if (const int err = launch(kern, dim3(p.ntiles / p.rt), dim3(kK2Waves * 64), lds_bytes, stream, ta)) return err;
   // ---- kernel B ----

@@ -44,6 +44,14 @@ def run(cfg):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl" if cfg.method.use_gpu else "gloo")
         shard = Shard()
+    if cfg.method.use_gpu and bool((cfg.get("backend", {}) or {}).get("specialize_arch", True)):
+        # arch.hdims other than [256,128,64]: build (once, rank 0) / load the kernel variant with these widths as constants
+        from socmx import _lib as _socmx_lib
+        _socmx_lib.set_specialize(True)
+        if world > 1:
+            if rank == 0:
+                _socmx_lib.variant(list(cfg.arch.hdims))
+            dist.barrier()
     log = print if rank == 0 else (lambda *a, **k: None)
     log(cfg)
     torch.manual_seed(cfg.method.seed)          # every rank builds the same problem and the same initial weights

@@ -146,6 +146,83 @@ def lib():
     return _lib
 
 
+# ---- architecture variants ---------------------------------------------------------------------------------------------
+# libsocmx.so carries constexpr-specialised rollout / control-network-backward kernels for the reference's default
+# arch.hdims = [256,128,64] (configs/soc.yaml:33-35) and a descriptor-driven form for everything else (~1.6x slower per
+# step).  A VARIANT library is the same sources compiled with another architecture's padded widths as the constexpr ones
+# (csrc/Makefile VARIANT=h0_h1_h2, ~2.5 min of hipcc): `variant(hdims)` loads it -- building it first when asked to --
+# and the calls that depend on the architecture (rollout, control-network forward / backward) go through it.
+_variants = {}
+DEFAULT_HDIMS = (256, 128, 64)
+
+
+def _pad16(v):
+    return (int(v) + 15) // 16 * 16
+
+
+def specialize_enabled():
+    """Build missing variants at first use?  Off by default (a first use would cost minutes); main.py turns it on from the
+    `backend.specialize_arch` config key, `SOCMX_SPECIALIZE=1` does from the environment.  An existing variant library is
+    always used."""
+    return os.environ.get("SOCMX_SPECIALIZE", "0") not in ("", "0") or _specialize_flag[0]
+
+
+_specialize_flag = [False]
+
+
+def set_specialize(on=True):
+    _specialize_flag[0] = bool(on)
+
+
+def variant_path(hdims):
+    hp = tuple(_pad16(h) for h in hdims)
+    return os.path.join(_HERE, "libsocmx_%d_%d_%d.so" % hp)
+
+
+def build_variant(hdims, quiet=False):
+    """`make -C csrc VARIANT=h0_h1_h2` (hipcc; cross-compiles without a GPU).  Returns the library path."""
+    import subprocess
+    hp = tuple(_pad16(h) for h in hdims)
+    csrc = os.path.join(os.path.dirname(_HERE), "csrc")
+    if not quiet:
+        print(f"socmx: compiling kernels specialised for arch.hdims -> {list(hp)} (one-time, a few minutes) ...", flush=True)
+    res = subprocess.run(["make", "-C", csrc, "-j8", "VARIANT=%d_%d_%d" % hp], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise SocmxError("building the architecture variant failed:\n" + res.stdout[-2000:] + res.stderr[-2000:])
+    return variant_path(hdims)
+
+
+def variant(hdims):
+    """The library whose constexpr kernels match `hdims` (padded to multiples of 16): the default library for the default
+    architecture, an existing variant library, a freshly built one when `specialize_enabled()`, else the default library
+    (whose descriptor-driven kernels take any architecture)."""
+    hp = tuple(_pad16(h) for h in hdims)
+    if hp == DEFAULT_HDIMS:
+        return lib()
+    if hp in _variants:
+        return _variants[hp]
+    path = variant_path(hdims)
+    if not os.path.exists(path) and specialize_enabled():
+        build_variant(hdims)
+    if os.path.exists(path):
+        base = lib()                                      # (also makes torch's HIP runtime the one in this process)
+        handle = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.socmx_version() != base.socmx_version():
+            raise SocmxError(f"{path} is a stale build (version {handle.socmx_version()} != {base.socmx_version()}): "
+                             "delete it or rebuild with make VARIANT=...")
+        buf = C.create_string_buffer(512)
+        handle.socmx_capabilities(buf, 512)
+        assert ("static_hdims=%d,%d,%d" % hp).encode() in buf.value, buf.value
+        _variants[hp] = handle
+    else:
+        _variants[hp] = lib()
+    return _variants[hp]
+
+
 _STATUS_TEXT = {-1: "null pointer", -2: "bad dimension", -3: "unknown problem kind", -4: "workspace too small",
                 -5: "does not fit in 160 KiB of LDS (d too large for this setting / these hidden widths)"}
 

@@ -172,6 +172,11 @@ class FullyConnectedUNet(nn.Module):
         return _linear(self.up_0, o1, sk) + _linear(self.res_0, x, sk)
 
     # ---- HIP side ---------------------------------------------------------------
+    def hip_lib(self):
+        """The library handle for the calls that depend on the architecture (rollout, forward, backward): the default
+        library or the variant compiled for these hidden widths (socmx._lib.variant)."""
+        return _lib.variant(self.hdims)
+
     def c_struct(self):
         s = _lib.Unet(d=self.dim, hdims=_lib.i3(self.hdims))
         keep = []
@@ -221,7 +226,7 @@ class FullyConnectedUNet(nn.Module):
 
 def unet_backward_supported(net, n_rows):
     """True when socmx_unet_backward_f32 takes this architecture (its 16-row tiles must fit 160 KiB of LDS)."""
-    L = _lib.lib()
+    L = net.hip_lib()
     ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
     return L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
 
@@ -230,7 +235,7 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=No
     """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
     x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
     `net.parameters()` order (views of one flat buffer)."""
-    L = _lib.lib()
+    L = net.hip_lib()
     dev = x.device
     N, d = x.shape
     assert d == net.dim and gout.shape == (N, d)
@@ -291,7 +296,7 @@ def unet_on_trajectory(net, values, states, ts):
 
 def unet_forward_hip(net, tx):
     """nabla_V rows through the fused MFMA kernel (no autograd): socmx_unet_forward_f32."""
-    L = _lib.lib()
+    L = net.hip_lib()
     tx = tx.detach().to(torch.float32).contiguous()
     out = torch.empty(tx.shape[0], net.dim, dtype=torch.float32, device=tx.device)
     with _lib.on_device(tx.device):

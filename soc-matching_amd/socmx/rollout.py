@@ -148,6 +148,7 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
         _lib.check(status, "socmx_rollout_control_f32")
         return states, noises, stop, frac, lpd, lps, ltw, controls
     net = sde.nabla_V
+    L = net.hip_lib()              # (the default library, or the variant compiled for this architecture)
     with _lib.on_device(dev):
         head = (pb.c_struct(), _lib.ptr(net.packed()), _lib.i3(net.hdims), _lib.ptr(x0c), _lib.ptr(tc), B, K,
                 float(lmbd))

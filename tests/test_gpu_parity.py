@@ -1270,3 +1270,50 @@ def test_optimal_control_objective_burst_is_fused():
     costs = torch.cat(costs)
     np.testing.assert_allclose(m.item(), costs.mean().item(), rtol=1e-4)
     np.testing.assert_allclose(e.item(), (costs.std() / np.sqrt(costs.numel() - 1)).item(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("hdims", [[128, 64, 32], [120, 50, 30]])
+def test_architecture_variant_library_matches_the_generic_kernels(hdims):
+    """arch.hdims other than the reference default: a variant library (the same sources compiled with these padded widths as
+    the constexpr ones, csrc/Makefile VARIANT=128_64_32 -- prebuilt in the authoring container, it travels with the tree)
+    serves the rollout, the network forward and the control-network backward; results must equal the descriptor-driven
+    kernels of the default library (same arithmetic, other instantiation) and the oracle's network."""
+    from socmx import _lib, nets, rollout as R
+    from SOC_matching.experiment_settings.double_well import DoubleWell
+    path = _lib.variant_path(hdims)
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not built (make -C soc-matching_amd/csrc VARIANT=128_64_32)")
+    torch.manual_seed(3)
+    d, K, B = 10, 12, 37
+    kappa, nu = torch.ones(d, device=DEV), torch.ones(d, device=DEV)
+    sde = DoubleWell(device=DEV, dim=d, hdims=hdims, hdims_M=[16, 16], lmbd=1.0, kappa=kappa, nu=nu,
+                     sigma=torch.eye(d, device=DEV), gamma=2.0, scaling_factor_nabla_V=1.0, scaling_factor_M=0.1)
+    sde.initialize_models()
+    net = sde.nabla_V
+    L_var = net.hip_lib()
+    assert L_var is not _lib.lib()
+    buf = __import__("ctypes").create_string_buffer(512)
+    L_var.socmx_capabilities(buf, 512)
+    assert b"static_hdims=128,64,32" in buf.value
+    ts = torch.linspace(0, 1, K + 1, device=DEV)
+    x0 = 0.3 * torch.randn(B, d, device=DEV)
+    noise = torch.randn(K, B, d, device=DEV)
+    got = R.stochastic_trajectories(sde, x0, ts, 1.0, noise_in=noise, want_nabla_v=True)
+    x = torch.randn(200, d, device=DEV)
+    gout = torch.randn(200, d, device=DEV)
+    tgrid = torch.linspace(0, 1, 200, device=DEV)
+    g_var = nets.unet_backward_hip(net, x, tgrid, 1, gout)
+    # the same calls through the default library (descriptor-driven kernels)
+    net.hip_lib = lambda: _lib.lib()
+    want = R.stochastic_trajectories(sde, x0, ts, 1.0, noise_in=noise, want_nabla_v=True)
+    g_def = nets.unet_backward_hip(net, x, tgrid, 1, gout)
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-5, atol=2e-6)
+    for a, b in zip(g_var, g_def):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=1e-4, atol=1e-5 * max(1.0, float(b.abs().max())))
+    # and against the oracle's network on the trajectory rows
+    vp = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    tx = torch.cat([ts.reshape(-1, 1, 1).expand(K + 1, B, 1), got[0]], -1).reshape(-1, d + 1).cpu()
+    with torch.no_grad():
+        ref = O.unet_forward(vp, tx).reshape(K + 1, B, d).numpy()
+    np.testing.assert_allclose(_np(got[8]), ref, rtol=1e-4, atol=1e-5)
