@@ -1135,6 +1135,108 @@ __device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int
   m_stage<NW>(a.packed, m.L[1], lds, m.hh1, m.s1, scratch, e2);
 }
 
+// F3 of the WIDE form: net / dnet = L2 (h2 | t2) for the 16 pairs of the tile, d2p / 16 output blocks of 16 units.  Wave w
+// owns blocks w, w + NW, ... in groups of four; a group is eight chunks (h1p = 128; fewer for narrower layers) of four weight
+// fragments and 32 MFMAs (4 blocks x value / tangent tile x 4 k-steps).  The fragments stream from L2 through a ring of
+// three chunks whose requests are asm statements with written-out waits and run on ACROSS the group boundaries (the generic
+// stage restarts its ring for every group of blocks: a full L2 round trip per 256 MFMAs); the activation quads come from
+// LDS; every accumulator quad leaves with one 16-byte store.
+template <int NW>
+__device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* lds, int tile) {
+  // (h1p = 128, i.e. eight chunks per block -- the caller checks: narrower last layers take the generic stage)
+  constexpr int KC = 8, PD = 4;
+  const MDesc& m = a.m;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = lane & 15, g = lane >> 4;
+  const LayerDesc& L = m.L[2];
+  const int NBLK = L.out_pad >> 4;
+  const int cnt = wave < NBLK ? (NBLK - wave + NW - 1) / NW : 0;       // blocks of this wave
+  const int ngroups = (cnt + 3) >> 2;
+  if (ngroups == 0) return;
+  const float* xv = lds + m.hh2 + row * m.s2 + 4 * g;                   // value rows; tangent rows 16 s2 further
+  const float* xt = xv + 16 * m.s2;
+  const float* bias = lds + m.bias + L.b_lds + 4 * g;
+  const int64_t p = (int64_t)tile * 16 + row;
+  const bool rowok = p < a.Np;
+  float* orow_n = a.net + (size_t)min(p, a.Np - 1) * m.d2 + 4 * g;
+  float* orow_d = a.dnet + (size_t)min(p, a.Np - 1) * m.d2 + 4 * g;
+  auto blk_of = [&](int grp, int j) { return min(wave + NW * (4 * grp + j), NBLK - 1); };
+  // ring of four chunks (4 fragments each); chunk c of a group sits in slot c & 3.  Requests carry their chunk as an
+  // immediate offset from a per-(group, block) base: no address arithmetic inside the group.
+  f32x4 fr[PD][4];
+  // (scalar base + 32-bit lane offset: eight offset registers instead of sixteen pointer registers keep the kernel at two
+  //  workgroups per CU)
+  const float* wbase = a.packed + L.w_off;
+#define SOCMX_GLD(dst, voff, off) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #off : "=v"(dst) : "v"(voff), "s"(wbase) : "memory")
+  unsigned cur[4], nxt[4];                               // byte offsets of (block, chunk 0, this lane)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cur[j] = (unsigned)(blk_of(0, j) * KC) * 1024u + (unsigned)lane * 16u;
+  // (chunk after chunk: the waits below count whole chunks)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) SOCMX_GLD(fr[0][j], cur[j], 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) SOCMX_GLD(fr[1][j], cur[j], 1024);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) SOCMX_GLD(fr[2][j], cur[j], 2048);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) SOCMX_GLD(fr[3][j], cur[j], 3072);
+  f32x4 acc[2][4];
+  for (int grp = 0; grp < ngroups; ++grp) {
+    const int gn = min(grp + 1, ngroups - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][j] = lds4(bias + blk_of(grp, j) * 16);
+      acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      nxt[j] = (unsigned)(blk_of(gn, j) * KC) * 1024u + (unsigned)lane * 16u;
+    }
+    auto chunk = [&](const int c) {                       // c = 0..7, constant after unrolling
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // the three younger chunks (12 requests) may stay in flight
+#pragma unroll
+      for (int q = 0; q < PD; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(fr[q][j]));
+      const f32x4 bv = lds4(xv + c * 16), bt = lds4(xt + c * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float w = fr[c & 3][j][i];
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv[i], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bt[i], acc[1][j], 0, 0, 0);
+        }
+      // refill the slot: chunk c + 4 of this group (c < 4) or chunk c - 4 of the next one
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c == 0) SOCMX_GLD(fr[0][j], cur[j] + 4096u, 0);           // (+ 4 KiB: immediate offsets stay below 4096)
+        else if (c == 1) SOCMX_GLD(fr[1][j], cur[j] + 4096u, 1024);
+        else if (c == 2) SOCMX_GLD(fr[2][j], cur[j] + 4096u, 2048);
+        else if (c == 3) SOCMX_GLD(fr[3][j], cur[j] + 4096u, 3072);
+        else if (c == 4) SOCMX_GLD(fr[0][j], nxt[j], 0);
+        else if (c == 5) SOCMX_GLD(fr[1][j], nxt[j], 1024);
+        else if (c == 6) SOCMX_GLD(fr[2][j], nxt[j], 2048);
+        else SOCMX_GLD(fr[3][j], nxt[j], 3072);
+      }
+    };
+    chunk(0); chunk(1); chunk(2); chunk(3); chunk(4); chunk(5); chunk(6); chunk(7);
+    if (rowok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = wave + NW * (4 * grp + j);
+        if (b < NBLK && b * 16 + 4 * g < m.d2) {
+          *reinterpret_cast<f32x4*>(orow_n + b * 16) = acc[0][j];
+          *reinterpret_cast<f32x4*>(orow_d + b * 16) = acc[1][j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+  }
+#undef SOCMX_GLD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void mnet_forward_kernel(const MArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1143,6 +1245,10 @@ __global__ __launch_bounds__(NW * 64) void mnet_forward_kernel(const MArgs a) {
   // (wide form: the forward kernel's split-K scratch sits behind all three biases)
   const int sc = m.wide ? m.bias + m.bias_floats : m.scratch;
   m_forward_hidden<NW>(a, lds, tile, 0, 3, sc);
+  if (m.wide && m.h1p == 128) {                   // (d % 4 == 0: whole 16-byte quads; eight chunks per block)
+    m_wide_out_stage<NW>(a, lds, tile);
+    return;
+  }
   MEpi e3{ME_OUT, lds, lds + m.bias + m.L[2].b_lds, -1, 0, 0, 0, nullptr, 0, a.net, a.dnet, m.d2, (int64_t)tile * 16, a.Np};
   m_stage<NW>(a.packed, m.L[2], lds, m.hh2, m.s2, lds + sc, e3);
 }
@@ -1319,43 +1425,17 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
   const int t0 = (int)(((int64_t)slab * a.ntiles) / a.S), t1 = (int)(((int64_t)(slab + 1) * a.ntiles) / a.S);
   const int c16 = lane & 15, g4 = lane >> 4;
   const int n0 = ng * 64;
-  // loader (waves 0, 1): lane (rg, pc) owns rows 4 rg .. + 3, columns n0 + 4 pc .. + 3 of its tensor's tile
+  // Loader duty, the same for every wave (equal instruction counts: nobody waits at the barrier for a loader): wave (x = w & 1:
+  // g_net | g_dnet, h = w >> 1), lane (rg, pc) owns rows 4 rg + 2 h, + 1 and columns n0 + 4 pc .. + 3 of tensor x's 16 x 64 tile:
+  // two 16-byte loads, transposed in registers, four 8-byte LDS writes T[x][4 pc + e][4 rg + 2 h .. + 1].
+  const int lx = wave & 1, lh = wave >> 1;
   const int rg = lane & 3, pc = lane >> 2;
-  const float* src = wave == 0 ? a.gnet : a.gdnet;
+  const float* src = lx == 0 ? a.gnet : a.gdnet;
   const bool colok = n0 + 4 * pc < a.d2;
   const int ncol = colok ? n0 + 4 * pc : 0;
-  f32x4 lr[4];
-  auto tile_load = [&](int t) {
-    const int64_t p0 = (int64_t)min(t, t1 - 1) * 16 + 4 * rg;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t pr = min(p0 + i, a.Np - 1);
-      lr[i] = *reinterpret_cast<const f32x4*>(src + (size_t)pr * a.d2 + ncol);
-    }
-  };
-  auto tile_park = [&](int t, int st) {
-    const int64_t p0 = (int64_t)t * 16 + 4 * rg;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      f32x4 col;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) col[i] = (colok && p0 + i < a.Np) ? lr[i][e] : 0.f;
-      *reinterpret_cast<f32x4*>(&T[st][wave][4 * pc + e][4 * rg]) = col;
-    }
-  };
   // B operand: H2 slab, value tile 2t (with g_net), tangent tile 2t + 1 (with g_dnet)
   const int cb0 = wave * NCB;
   const float* hb = a.h2slab + (size_t)c16 * 16 + 4 * g4;
-  auto bload = [&](int t, f32x4 (&b)[2][NCB]) {
-    const int tc = min(t, t1 - 1);
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int k = 0; k < NCB; ++k) {
-        const int cb = min(cb0 + k, a.IB - 1);
-        b[x][k] = *reinterpret_cast<const f32x4*>(hb + ((size_t)(2 * tc + x) * a.h1p + cb * 16) * 16);
-      }
-  };
   f32x4 acc[4][NCB];
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1363,11 +1443,55 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
 #pragma unroll
     for (int k = 0; k < NCB; ++k) acc[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (t0 < t1) {
-    f32x4 bcur[2][NCB], bnext[2][NCB];
-    if (wave < 2) { tile_load(t0); tile_park(t0, 0); tile_load(t0 + 1); }
-    bload(t0, bcur);
-    bload(t0 + 1, bnext);
-    for (int t = t0; t < t1; ++t) {
+    // Requests are asm statements and the one wait per iteration is written out (vmcnt(6): the six requests of the previous
+    // iteration may stay in flight): written as plain loads the compiler waited for every request right behind its issue
+    // (vmcnt(0) in front of the MFMAs) -- the kernel ran at 58 % MFMA-busy.  Tile x is requested in iteration x - 3, parked
+    // in LDS in iteration x - 1, multiplied in iteration x; the H2 fragments are requested two iterations ahead.
+    f32x4 tl[2][2];                  // [tile slot][row]
+    f32x4 bq[3][2][NCB];             // [slot][value | tangent][c-block]
+    // (slots are plain ints, constant at every call site: after inlining each switch leaves one asm statement with a fixed
+    //  register -- a generic lambda may not name captured variables in asm operands)
+#define SOCMX_GLD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+    auto tile_load = [&](int t, int sl) {
+      const int64_t p0 = (int64_t)min(t, t1 - 1) * 16 + 4 * rg + 2 * lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float* ptr = src + (size_t)min(p0 + i, a.Np - 1) * a.d2 + ncol;
+        if (sl == 0) SOCMX_GLD(tl[0][i], ptr); else SOCMX_GLD(tl[1][i], ptr);
+      }
+    };
+    auto tile_park = [&](int t, int sl, int st) {
+      const int64_t p0 = (int64_t)t * 16 + 4 * rg + 2 * lh;
+      const bool ok0 = colok && p0 < a.Np, ok1 = colok && p0 + 1 < a.Np;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float2 col;
+        col.x = ok0 ? (sl == 0 ? tl[0][0][e] : tl[1][0][e]) : 0.f;
+        col.y = ok1 ? (sl == 0 ? tl[0][1][e] : tl[1][1][e]) : 0.f;
+        *reinterpret_cast<float2*>(&T[st][lx][4 * pc + e][4 * rg + 2 * lh]) = col;
+      }
+    };
+    auto bload = [&](int t, int sl) {
+      const int tc = min(t, t1 - 1);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) {
+          const int cb = min(cb0 + k, a.IB - 1);
+          const float* ptr = hb + ((size_t)(2 * tc + x) * a.h1p + cb * 16) * 16;
+          if (sl == 0) SOCMX_GLD(bq[0][x][k], ptr); else if (sl == 1) SOCMX_GLD(bq[1][x][k], ptr); else SOCMX_GLD(bq[2][x][k], ptr);
+        }
+    };
+#undef SOCMX_GLD
+    // prologue: tile t0 straight into T[0]; then the two request groups the loop expects to find in flight
+    tile_load(t0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(tl[0][0]), "+v"(tl[0][1]));
+    tile_park(t0, 0, 0);
+    tile_load(t0 + 1, 1); bload(t0, 0);
+    tile_load(t0 + 2, 0); bload(t0 + 1, 1);
+    auto iter = [&](int t, const int TS /* slot of tile t + 1 (= of tile t + 3) */, const int BS /* slot of B(t) */,
+                    const int bnx /* of B(t + 2) */) {
       const int st = (t - t0) & 1;
       __syncthreads();                                   // T[st] holds tile t; everyone is done with T[st ^ 1]
       f32x4 af[2][4];
@@ -1375,10 +1499,23 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int j = 0; j < 4; ++j) af[x][j] = lds4(&T[st][x][j * 16 + c16][4 * g4]);
-      if (wave < 2 && t + 1 < t1) tile_park(t + 1, st ^ 1);        // (loaded one iteration ago)
-      if (wave < 2) tile_load(t + 2);
-      f32x4 bnext2[2][NCB];
-      bload(t + 2, bnext2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 2 * NCB) : "memory");    // the group requested two iterations ago is here
+      // (the wait covers every register of the older groups: tell the compiler all of them changed)
+      asm volatile("" : "+v"(tl[0][0]), "+v"(tl[0][1]), "+v"(tl[1][0]), "+v"(tl[1][1]));
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int k = 0; k < NCB; ++k) asm volatile("" : "+v"(bq[sl][x][k]));
+      f32x4 bcur[2][NCB];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) bcur[x][k] = BS == 0 ? bq[0][x][k] : (BS == 1 ? bq[1][x][k] : bq[2][x][k]);
+      if (t + 1 < t1) tile_park(t + 1, TS, st ^ 1);
+      tile_load(t + 3, TS);
+      bload(t + 2, bnx);
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -1392,11 +1529,17 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
 #pragma unroll
         for (int j = 0; j < 4; ++j) bsum[j] += (af[0][j][0] + af[0][j][1]) + (af[0][j][2] + af[0][j][3]);
       }
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int k = 0; k < NCB; ++k) { bcur[x][k] = bnext[x][k]; bnext[x][k] = bnext2[x][k]; }
+    };
+    // relative iteration r = t - t0: tile t + 1 sits in slot (r + 1) & 1, B(t) in slot r % 3 -- six static cases
+    for (int t = t0; t < t1; t += 6) {
+      iter(t, 1, 0, 2);
+      if (t + 1 < t1) iter(t + 1, 0, 1, 0);
+      if (t + 2 < t1) iter(t + 2, 1, 2, 1);
+      if (t + 3 < t1) iter(t + 3, 0, 0, 2);
+      if (t + 4 < t1) iter(t + 4, 1, 1, 0);
+      if (t + 5 < t1) iter(t + 5, 0, 2, 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   float* out = a.part + (size_t)slab * a.slab_floats;
   const int OB = a.d2 >> 4;                                // d2 % 16 == 0 in the wide form

@@ -94,14 +94,18 @@ def target_residual_torch(pb, K, M_all, dM_all, q, v, gT, nablaV, w, inv_norm):
     return objective, tgt
 
 
-def socm_operands_hip(pb, ts, lmbd, states, noises, controls, frac=None):
-    """socmx_socm_prep_f32: v, q (K,B,d) and gT (B,d), batch-major (read by the forward and the backward kernels)."""
+def socm_operands_hip(pb, ts, lmbd, states, noises, controls, frac=None, out=None):
+    """socmx_socm_prep_f32: v, q (K,B,d) and gT (B,d), batch-major (read by the forward and the backward kernels).
+    `out`: a dict of caller-owned v / q / gT buffers (hipGraph mode keeps them for the deferred contraction backward)."""
     L = _lib.lib()
     K, B, d = noises.shape
     dev = states.device
     f32 = dict(dtype=torch.float32, device=dev)
-    v, q = torch.empty(K, B, d, **f32), torch.empty(K, B, d, **f32)
-    gT = torch.empty(B, d, **f32)
+    if out is not None:
+        v, q, gT = out["v"], out["q"], out["gT"]
+    else:
+        v, q = torch.empty(K, B, d, **f32), torch.empty(K, B, d, **f32)
+        gT = torch.empty(B, d, **f32)
     tsc = ts.detach().to(**f32).contiguous()
     with _lib.on_device(dev):
         _lib.check(L.socmx_socm_prep_f32(
@@ -158,12 +162,14 @@ class _TargetResidualHip(torch.autograd.Function):
         return gM, gdM, gV, None, None, None, None, None, None
 
 
-def target_fwd_net(pb, K, net, dnet, delta, gam, ops, nablaV, w, inv_norm):
-    """socmx_socm_target_fwd_net_f32 on plain tensors: (objective (1,), G = d obj / d nablaV, target)."""
+def target_fwd_net(pb, K, net, dnet, delta, gam, ops, nablaV, w, inv_norm, G=None):
+    """socmx_socm_target_fwd_net_f32 on plain tensors: (objective (1,), G = d obj / d nablaV, target); `G` may be a
+    caller-owned buffer."""
     L = _lib.lib()
     dev = net.device
     B, d = ops["gT"].shape
-    G = torch.empty_like(nablaV)
+    if G is None:
+        G = torch.empty_like(nablaV)
     target = torch.empty_like(nablaV)
     obj = torch.zeros(1, dtype=torch.float32, device=dev)
     with _lib.on_device(dev):

@@ -306,7 +306,7 @@ def unet_forward_hip(net, tx):
     return out
 
 
-def pair_net_forward(d, hdims, params, t, s, packed=None, z=None):
+def pair_net_forward(d, hdims, params, t, s, packed=None, z=None, out=None):
     """(net, dnet, packed): socmx_mnet_pack_f32 + socmx_mnet_forward_f32 on plain fp32 tensors; `packed` may be a
     caller-owned buffer (hipGraph mode keeps the image for the deferred backward).  `z` (Np,): the third network input of
     TwoBoundarySigmoidMLP (params[0] is then (h0, 3))."""
@@ -316,8 +316,11 @@ def pair_net_forward(d, hdims, params, t, s, packed=None, z=None):
     if packed is None:
         packed = torch.empty(L.socmx_mnet_packed_floats(d, h2), dtype=torch.float32, device=dev)
     Np = t.shape[0]
-    net = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
-    dnet = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+    if out is not None:                       # caller-owned (net, dnet) buffers
+        net, dnet = out
+    else:
+        net = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
+        dnet = torch.empty(Np, d, d, dtype=torch.float32, device=dev)
     n_in = int(params[0].shape[1])
     assert (n_in == 3) == (z is not None)
     with _lib.on_device(dev):

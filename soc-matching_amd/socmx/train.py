@@ -252,13 +252,15 @@ class Trainer:
                                 gn.reshape(()), ema_gn.reshape(()), gne.reshape(()), norm_before] + extra)
 
     # ---- the iteration without autograd (plain SOCM, every network on the hand-written kernels) -----------------------
-    # rollout (+ nabla_V values) -> weights -> operands -> contraction forward (objective, G) -> contraction backward
-    # (g_net, g_dnet, g_gamma into PERSISTENT buffers) -> control-network backward -> Adam(nabla_V).  The pair-grid
-    # network's backward + its Adam groups for iteration n run at the START of iteration n+1 on the second stream, beside
-    # that iteration's rollout, followed by its forward for iteration n+1 -- the schedule of the eager two-stream path
-    # (_finish_M_on_side_stream), but expressible inside ONE captured graph because nothing of it lives in an autograd
-    # graph: the buffers that cross the iteration boundary (g_net, g_dnet, g_gamma, the packed weight image the
-    # backward recomputes from) are owned by the Trainer.
+    # main stream: rollout (+ nabla_V values) -> weights -> operands -> contraction forward (objective, G) -> control-network
+    # backward from G -> Adam(nabla_V).  Everything that only serves the pair-grid network -- the contraction BACKWARD
+    # (d obj / d (net, dnet, gamma)), that network's backward and its Adam groups for iteration n -- runs at the START of
+    # iteration n+1 on the second stream, beside that iteration's rollout, followed by the network's forward for iteration
+    # n+1: the critical path of an iteration is rollout + contraction forward + control-network backward.  This is
+    # expressible inside ONE captured graph because nothing of it lives in an autograd graph: the buffers that cross the
+    # iteration boundary (G, q, v, gT, net, dnet, gamma and 1/normaliser of iteration n; g_net, g_dnet, g_gamma; the packed
+    # weight image the backward recomputes from) are owned by the Trainer, at fixed addresses -- the second stream consumes
+    # iteration n's values before the main stream, behind the join, overwrites them with iteration n+1's.
     def _manual_ok(self, loss_kwargs):
         from . import nets
         solver, sde = self.solver, self.solver.neural_sde
@@ -282,6 +284,14 @@ class Trainer:
         layers = [sde.M.sigmoid_layers[i] for i in (0, 2, 4)]
         params = [p for l in layers for p in (l.weight, l.bias)]
         shard = self.solver.shard
+        # the contraction backward of iteration n (d obj / d (net, dnet, gamma): it feeds this network only, the control
+        # network's gradient came from the forward kernels' G) runs HERE, on the second stream beside rollout n + 1, from the
+        # operands iteration n left in the Trainer's buffers
+        from . import loss as L
+        solver = self.solver
+        _, _, part = L.target_bwd_net(solver.dim, solver.num_steps, D["q"].shape[1], D["G"], D, D["gout"], D["net"], D["dnet"],
+                                      D["delta"], D["gam"], g_net=D["g_net"], g_dnet=D["g_dnet"])
+        torch.sum(part, dim=0, keepdim=True, out=D["g_gamma"])
         if shard is None:
             grads = nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
                                            D["g_net"], D["g_dnet"])
@@ -338,9 +348,18 @@ class Trainer:
             from . import _lib
             D["packed"] = torch.empty(_lib.lib().socmx_mnet_packed_floats(d, _lib.i2(M.hdims)), dtype=torch.float32,
                                       device=dev)
-            D["g_net"] = torch.zeros(Np, d, d, dtype=torch.float32, device=dev)
-            D["g_dnet"] = torch.zeros(Np, d, d, dtype=torch.float32, device=dev)
-            D["g_gamma"] = torch.zeros(1, dtype=torch.float32, device=dev)
+            f32 = dict(dtype=torch.float32, device=dev)
+            D["g_net"] = torch.zeros(Np, d, d, **f32)
+            D["g_dnet"] = torch.zeros(Np, d, d, **f32)
+            D["g_gamma"] = torch.zeros(1, **f32)
+            # what the DEFERRED contraction backward reads one iteration later (fixed addresses: a replayed graph's second
+            # stream consumes the previous replay's values before this replay's main stream overwrites them behind the join)
+            D["net"], D["dnet"] = torch.empty(Np, d, d, **f32), torch.empty(Np, d, d, **f32)
+            D["q"], D["v"] = torch.empty(K, B, d, **f32), torch.empty(K, B, d, **f32)
+            D["gT"] = torch.empty(B, d, **f32)
+            D["G"] = torch.empty(Kp, B, d, **f32)
+            D["gout"], D["gam"] = torch.ones(1, **f32), torch.ones(1, **f32)
+            D["delta"] = delta
             # the telemetry EMA of the control-network gradient as one flat buffer, in parameters() order (= the order of
             # socmx_unet_backward_f32's output); D["ema_grad"] (shared with the autograd body / the eager mirrors) = its views
             vp = list(sde.nabla_V.parameters())
@@ -355,7 +374,8 @@ class Trainer:
         def m_branch():
             if self._m_pending:
                 self._m_update(t_vec, s_vec)
-            net, dnet, _ = nets.pair_net_forward(d, M.hdims, mparams, t_vec, s_vec, packed=D["packed"])
+            net, dnet, _ = nets.pair_net_forward(d, M.hdims, mparams, t_vec, s_vec, packed=D["packed"],
+                                                 out=(D["net"], D["dnet"]))
             return net, dnet
 
         main = torch.cuda.current_stream(dev)
@@ -378,12 +398,13 @@ class Trainer:
             dnet.record_stream(main)
         weight, stats = L.weights_and_stats(lpd, lps, ltw)
         w_mean, w_std = L.mean_std_from_stats(stats)
-        ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls)
-        gam = sde.gamma.detach().to(torch.float32).reshape(1).contiguous()
-        obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B_global))
-        gout = (1.0 / D["norm"]).reshape(1)                               # d loss / d objective  (main.py:313-320)
-        _, _, part = L.target_bwd_net(d, K, B, G, ops, gout, net, dnet, delta, gam, g_net=D["g_net"], g_dnet=D["g_dnet"])
-        torch.sum(part, dim=0, keepdim=True, out=D["g_gamma"])
+        ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls, out=D)
+        gam = D["gam"]
+        gam.copy_(sde.gamma.detach().reshape(1))
+        obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B_global), G=D["G"])
+        gout = D["gout"]
+        torch.reciprocal(D["norm1"], out=gout)                            # d loss / d objective  (main.py:313-320)
+        # (the contraction BACKWARD -- gradients of the pair-grid network and gamma only -- is deferred: _m_update)
         from . import _lib
         Lh, f = _lib.lib(), _lib.ptr
         want_l2 = bool(loss_kwargs and loss_kwargs.get("compute_L2_error"))
