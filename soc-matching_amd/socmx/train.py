@@ -592,7 +592,11 @@ class Trainer:
                 vals.record_stream(torch.cuda.current_stream(dev))
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # (sharded: the process group's watchdog thread polls its events with hipEventQuery while this thread
+                #  captures -- under the default "global" error mode that invalidates the capture now and then; the
+                #  collectives themselves are enqueued by this thread)
+                mode = "thread_local" if solver.shard is not None else "global"
+                with torch.cuda.graph(g, capture_error_mode=mode):
                     static_vals = body()
                 self._graphs[key] = entry = (g, static_vals)
                 g.replay()                                   # capture does not execute: this replay IS the iteration
