@@ -70,7 +70,7 @@ def build(device, setting=SETTING, d=D, num_steps=NUM_STEPS, gamma=GAMMA, batch=
     return cfg, ts, x0, sde, solver
 
 
-def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_dist, row0):
+def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_dist, row0, dist_graph=False):
     """Rollout and full-iteration timings of another BASELINE configuration (driver-timed secondary entries: the
     headline `value` stays configs[2])."""
     from socmx import rollout
@@ -107,14 +107,15 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
     it_ms_eager, info = time_iterations(False)
     it_ms, mode = it_ms_eager, "eager (two HIP streams)"
     it_ms_graph = None
-    try:          # (sharded: the RCCL all-reduces are captured inside the graph; an RCCL build that cannot capture keeps eager)
-        it_ms_graph, info_g = time_iterations(True)
-        if it_ms_graph < it_ms:
-            it_ms, mode, info = it_ms_graph, "hipGraph replay", info_g
-    except Exception as e:  # noqa: BLE001
-        if not use_dist:
-            raise
-        mode += f" (hipGraph capture with RCCL failed: {type(e).__name__})"
+    if world == 1 or dist_graph:
+        try:      # (sharded: the RCCL all-reduces are captured inside the graph; an RCCL build that cannot capture keeps eager)
+            it_ms_graph, info_g = time_iterations(True)
+            if it_ms_graph < it_ms:
+                it_ms, mode, info = it_ms_graph, "hipGraph replay", info_g
+        except Exception as e:  # noqa: BLE001
+            if not use_dist:
+                raise
+            mode += f" (hipGraph capture with RCCL failed: {type(e).__name__})"
     fl = flops_per_traj_step(d, HDIMS) * B * K
     out = {"workload": label, "rollout_ms": roll_ms, "trajectory_steps_per_s": B * K / (roll_ms * 1e-3),
            "socm_ms_per_iter": it_ms, "socm_iters_per_sec": 1e3 / it_ms, "iteration_mode": mode,
@@ -184,7 +185,9 @@ def cpu_baseline(budget_s=12.0):
                     f"(dispatch-bound: no multi-thread leg)")
     torch.set_num_threads(1)
     best = dict(value=n * B * K / el, unit="trajectory-steps/s", cores=used, kind="port",
-                sample=f"{n} rollouts of double_well d=10 K=200 B=128 (oracle eager torch-CPU, {el:.1f} s, {note})",
+                sample=f"{n} rollouts of double_well d=10 K=200 B=128 (oracle eager torch-CPU, {el:.1f} s, {note}; the oracle "
+                       f"'port' costs 0.86x the reference's own rollout on the same CPU: tests/golden/calibrate_cpu_baseline.py, "
+                       f"BASELINE.md section 4)",
                 ms_per_rollout=1e3 * el / n, host_cpus=ncpu)
     return best
 
@@ -208,7 +211,7 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
            str(args.warmup)]
-    for flag in ("no_cpu_baseline", "no_burst", "no_secondary"):
+    for flag in ("no_cpu_baseline", "no_burst", "no_secondary", "dist_graph"):
         if getattr(args, flag):
             cmd.append("--" + flag.replace("_", "-"))
     if args.force_dist or args.spawn:
@@ -227,6 +230,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and take the sharded code path even at world_size 1")
     ap.add_argument("--spawn", action="store_true", help="take the launcher path even for --gpus 1 (one child rank under "
                     "torch.distributed.run; implies --force-dist in the child)")
+    ap.add_argument("--dist-graph", action="store_true", help="world size > 1: also time the iteration as a replayed hipGraph "
+                    "with its RCCL all-reduces captured inside (validated at world size 1 here; off by default so that a "
+                    "multi-GPU run never depends on a capture this builder could not try on more than one GPU)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
@@ -318,14 +324,15 @@ def main():
     it_elapsed_eager, last_loss = time_iterations(False)
     it_elapsed, it_mode = it_elapsed_eager, "eager (two HIP streams)"
     it_elapsed_graph = None
-    try:          # (sharded: the iteration's RCCL all-reduces are captured inside the graph)
-        it_elapsed_graph, last_loss_g = time_iterations(True)
-        if it_elapsed_graph < it_elapsed:
-            it_elapsed, it_mode, last_loss = it_elapsed_graph, "hipGraph replay", last_loss_g
-    except Exception as e:  # noqa: BLE001
-        if not use_dist:
-            raise
-        it_mode += f" (hipGraph capture with RCCL failed: {type(e).__name__}: {str(e)[:200]})"
+    if world == 1 or args.dist_graph:
+        try:      # (sharded: the iteration's RCCL all-reduces are captured inside the graph)
+            it_elapsed_graph, last_loss_g = time_iterations(True)
+            if it_elapsed_graph < it_elapsed:
+                it_elapsed, it_mode, last_loss = it_elapsed_graph, "hipGraph replay", last_loss_g
+        except Exception as e:  # noqa: BLE001
+            if not use_dist:
+                raise
+            it_mode += f" (hipGraph capture with RCCL failed: {type(e).__name__}: {str(e)[:200]})"
 
     # (after the iteration leg: its 2 GB of buffers and the empty_cache() would otherwise cost the next leg its warm
     #  allocator state)
@@ -357,10 +364,11 @@ def main():
     if not args.no_secondary:
         n2 = max(3, args.steps // 5)
         secondary.append(secondary_config(device, "OU_quadratic_easy d=2 num_steps=50 batch=128 SOCM (BASELINE configs[1])",
-                                          "OU_quadratic_easy", 2, 50, 128, 2.0, 4 * n2, 3, use_dist, rank * 128))
+                                          "OU_quadratic_easy", 2, 50, 128, 2.0, 4 * n2, 3, use_dist, rank * 128,
+                                          args.dist_graph))
         secondary.append(secondary_config(device, "OU_linear d=64 num_steps=400 batch=512/GPU SOCM (one GPU's slice of "
                                           "BASELINE configs[4])", "OU_linear", 64, 400, 512, 2.0, n2, 2, use_dist,
-                                          rank * 512))
+                                          rank * 512, args.dist_graph))
 
     if rank == 0:
         flops = flops_per_traj_step(d, HDIMS) * B * K

@@ -13,7 +13,7 @@ CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-burst"
 # the counter passes see the headline configuration only (the secondary configurations launch the same kernel template with
 # other shapes; their dispatches would be averaged into the per-launch traffic that bench.py reads back)
 PMC_CMD="$CMD --no-secondary"
-KERNELS="rollout_kernel|rollout_ctrl|socm_|stopping_|colsum|weights_stats|unet_bwd|unet_wgrad"
+KERNELS="rollout_kernel|rollout_ctrl|socm_|stopping_|colsum|weights_stats|unet_bwd|unet_wgrad|mnet_"
 # kernel_stats.csv: the headline configuration alone, so that the rollout kernel's AVERAGE is the number bench.py reports as
 # roofline.kernel_ms; kernel_stats_full.csv: the whole default command (secondary configurations included)
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o $RND -- $PMC_CMD > $OUT/trace_bench.log 2>&1
@@ -27,7 +27,16 @@ python3 bench.py > $R/bench.json 2> $R/bench.err
 # the fused control-network backward alone (cfg3 and the cfg5 slice), the iteration in both modes, the stage-chain floor
 for c in cfg3 cfg5r; do bash tools/k2_prof.sh $c > $R/k2_$c.txt 2>&1; done
 for c in cfg2 cfg3; do for m in eager graph; do bash tools/iter_prof.sh $c $m > $R/iter_${c}_$m.txt 2>&1; done; done
-bash tools/iter_prof.sh cfg5r eager > $R/iter_cfg5r_eager.txt 2>&1
+for m in eager graph; do bash tools/iter_prof.sh cfg5r $m > $R/iter_cfg5r_$m.txt 2>&1; done
+bash tools/iter_prof.sh md graph > $R/iter_md_graph.txt 2>&1
+# the pair-grid network's kernels alone at d = 64 (wide form) and d = 10, kernel averages + SQ counters
+bash tools/prof_any.sh k3_cfg5r tools/k3_bench.py cfg5r > $R/k3_cfg5r.txt 2>&1
+python3 tools/k3_bench.py cfg3 >> $R/k3_cfg5r.txt 2>&1
+bash tools/pmc_any.sh "mnet_" k3 python3 tools/k3_bench.py cfg5r > $R/k3_cfg5r_pmc.txt 2>&1
+# non-default architectures: variant library vs descriptor-driven kernels (the variants are prebuilt in-tree)
+for h in "128 64 32" "512 256 128"; do python3 tools/arch_bench.py $h 2>&1 | grep hdims >> $R/arch_variants.txt; done
+# the sharded code path on one GPU: launcher + RCCL at world size 1 (collectives inside the captured graph)
+python3 bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline --no-burst > $R/bench_sharded_world1.json 2> $R/bench_sharded_world1.err
 # the d = 64 contraction kernels alone (with the forward kernel's in-kernel cycle counters) and the two issue micro-benchmarks
 # their schedule is built on
 (hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -DSOCMX_CONTRACTION_PROF -o /tmp/cb tools/ubench/contraction_bench.hip 2>/dev/null && /tmp/cb 64 400 512 5) > $R/contraction_cfg5r.txt 2>&1
@@ -36,5 +45,5 @@ bash tools/iter_prof.sh cfg5r eager > $R/iter_cfg5r_eager.txt 2>&1
 python3 tools/iter_bench.py md eager > $R/iter_md.txt 2>&1; python3 tools/iter_bench.py md graph >> $R/iter_md.txt 2>&1
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o stage_chain stage_chain.hip 2>/dev/null && ./stage_chain) > $R/stage_chain.txt 2>&1
 python3 tools/quick_bench.py cfg3 cfg2 ouq20 cfg5r burst 2>&1 | grep -E "parity|rollout|iteration" > $R/quick.txt
-rm -rf $OUT gpurun_out/k2prof gpurun_out/iterprof
+rm -rf $OUT gpurun_out/k2prof gpurun_out/iterprof gpurun_out/prof gpurun_out/pmc_k3
 ls -la $R
