@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the SOC-matching hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[2], the one the target is quoted on):
@@ -13,7 +13,7 @@ One JSON line on rank 0:
   value            trajectory-steps/s = N*B*num_steps*steps / t   (a "step" = one full rollout call
                    producing the reference's 8-tuple, SURVEY 8(d) metric 1), inputs resident in HBM
   socm_iters_per_sec  secondary metric: 1/time_per_iteration of a full SOCM iteration (rollout + loss
-                   + backward + gradient all-reduce + Adam), timed like main.py:280,351-352
+                   + backward + ONE flat gradient all-reduce + Adam), timed like main.py:280,351-352
   roofline         dominant kernel = socmx rollout_kernel; algorithmic flops (and bytes) per launch
                    over its HIP-event duration, against the fp32 MFMA peak (157.3 TF) / HBM (8 TB/s)
   cpu_baseline     the oracle's eager rollout (oracle/socm_oracle.py, "port") timed on this host
@@ -255,7 +255,19 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # (RCCL prints a version banner to STDOUT when its communicator comes up: keep stdout for the one JSON line)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize(device)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from socmx import _lib, rollout, dist as sdist
     from socmx.train import Trainer, make_optimizer

@@ -15,8 +15,9 @@ Two executions of the same math:
   * CUDA tensors -> HIP kernels through `libsocmx.so` (csrc/socmx_loss.hip) wrapped in
     `torch.autograd.Function`s; missing library raises.
   * CPU tensors  -> plain torch (BASELINE config 0 plumbing; gloo tests).
-The network GEMMs (nabla_V on the Kp*B trajectory rows, the M network on the Np
-pairs) are library GEMMs via torch autograd in both cases.
+On the GPU neither network is a library GEMM: nabla_V's values on the Kp*B trajectory rows
+come from the rollout kernel and its gradients from socmx_unet_backward_f32, the M network on
+the Np pairs runs on socmx_mnet_* (socmx/nets.py); the CPU path uses torch autograd.
 """
 import math
 

@@ -3,16 +3,19 @@
 Same constructor, same `.loss(...)` keyword surface and 8-tuple return
 `(objective, norm_sqd_diff, ctrl_loss_mean, ctrl_loss_std_err, trajectory,
 mean(w), std(w), stop_indicators)` (method.py:223-236, 897-906), same
-`.control_objective` (method.py:185-221).  `algorithm="SOCM"` without stopping times runs on
-the HIP loss kernels; the stopping-time variant
-(molecular_dynamics, per-sample TwoBoundarySigmoidMLP) and the other eight losses of
-method.py:264-478, 722-856 (row f4, `socmx.baselines`) are torch restatements on the same
-fused-rollout buffers (`rel_entropy` differentiates through the eager rollout instead).
+`.control_objective` (method.py:185-221).  On CUDA tensors `algorithm="SOCM"` runs on the HIP
+loss kernels, with stopping times (molecular_dynamics, per-sample
+TwoBoundarySigmoidMLP) on csrc/socmx_stopping.hip, and seven of the other eight losses of
+method.py:264-478, 722-856 (row f4, `socmx.baselines`) on csrc/socmx_baselines.hip -- all on the
+fused rollout's buffers, with nabla_V's values from the rollout kernel and its parameter gradients
+from socmx_unet_backward_f32 (`rel_entropy` differentiates through the eager rollout instead).
+CPU tensors take torch restatements of the same formulas.
 
 Data parallelism: when `self.shard` is set (see socmx.dist), `batch_size` is the
 GLOBAL batch; this rank simulates rows [row0, row0+B_local) and divides by the
 global (K+1)*B so that summing gradients over ranks reproduces the single-GPU
-gradient; mean/std of w are combined across ranks.
+gradient; mean/std of w are combined across ranks (by the Trainer inside its one flat
+all-reduce; by an all_gather when `.loss()` is called directly).
 """
 import numpy as np
 import torch

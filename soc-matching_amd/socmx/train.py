@@ -380,18 +380,22 @@ class Trainer:
 
         main = torch.cuda.current_stream(dev)
         side = solver._side_stream(dev) if Np >= 4096 else None
+        state0 = solver.x0.repeat(B, 1)
+        noise_in, solver.noise_in = solver.noise_in, None
         if side is not None:
             fork = torch.cuda.Event()
             fork.record(main)
+        else:
+            net, dnet = m_branch()
+        # The rollout is enqueued BEFORE the second stream's branch: its few workgroups claim whole CUs (exclusive LDS), and
+        # behind a chip-filling kernel that keeps refilling every CU with small workgroups they wait for CUs to drain (the
+        # d = 64 rollout took 13.0 instead of 7.3 ms behind the deferred contraction backward)
+        (states, noises, stop, frac, lpd, lps, ltw, controls, nabla_v) = R.stochastic_trajectories(
+            sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0)
+        if side is not None:
             with torch.cuda.stream(side):
                 side.wait_event(fork)
                 net, dnet = m_branch()
-        else:
-            net, dnet = m_branch()
-        state0 = solver.x0.repeat(B, 1)
-        noise_in, solver.noise_in = solver.noise_in, None
-        (states, noises, stop, frac, lpd, lps, ltw, controls, nabla_v) = R.stochastic_trajectories(
-            sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0)
         if side is not None:
             main.wait_stream(side)
             net.record_stream(main)
