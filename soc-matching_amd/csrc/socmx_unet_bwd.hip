@@ -1170,7 +1170,7 @@ __device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* ld
   const float* wbase = a.packed + L.w_off;
 #define SOCMX_GLD(dst, voff, off) \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #off : "=v"(dst) : "v"(voff), "s"(wbase) : "memory")
-  unsigned cur[4], nxt[4];                               // byte offsets of (block, chunk 0, this lane)
+  unsigned cur[4];                                       // byte offsets of (block, chunk 0, this lane)
 #pragma unroll
   for (int j = 0; j < 4; ++j) cur[j] = (unsigned)(blk_of(0, j) * KC) * 1024u + (unsigned)lane * 16u;
   // (chunk after chunk: the waits below count whole chunks)
@@ -1189,7 +1189,6 @@ __device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* ld
     for (int j = 0; j < 4; ++j) {
       acc[0][j] = lds4(bias + blk_of(grp, j) * 16);
       acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      nxt[j] = (unsigned)(blk_of(gn, j) * KC) * 1024u + (unsigned)lane * 16u;
     }
     auto chunk = [&](const int c) {                       // c = 0..7, constant after unrolling
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // the three younger chunks (12 requests) may stay in flight
@@ -1213,13 +1212,18 @@ __device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* ld
         else if (c == 1) SOCMX_GLD(fr[1][j], cur[j] + 4096u, 1024);
         else if (c == 2) SOCMX_GLD(fr[2][j], cur[j] + 4096u, 2048);
         else if (c == 3) SOCMX_GLD(fr[3][j], cur[j] + 4096u, 3072);
-        else if (c == 4) SOCMX_GLD(fr[0][j], nxt[j], 0);
-        else if (c == 5) SOCMX_GLD(fr[1][j], nxt[j], 1024);
-        else if (c == 6) SOCMX_GLD(fr[2][j], nxt[j], 2048);
-        else SOCMX_GLD(fr[3][j], nxt[j], 3072);
+        else if (c == 4) SOCMX_GLD(fr[0][j], cur[j], 0);              // (cur = the NEXT group's offsets from here on)
+        else if (c == 5) SOCMX_GLD(fr[1][j], cur[j], 1024);
+        else if (c == 6) SOCMX_GLD(fr[2][j], cur[j], 2048);
+        else SOCMX_GLD(fr[3][j], cur[j], 3072);
       }
     };
-    chunk(0); chunk(1); chunk(2); chunk(3); chunk(4); chunk(5); chunk(6); chunk(7);
+    chunk(0); chunk(1); chunk(2); chunk(3);
+    // this group's last refill from `cur` is out: the registers take the next group's offsets (two workgroups per CU need
+    // the kernel under 128 VGPRs)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = (unsigned)(blk_of(gn, j) * KC) * 1024u + (unsigned)lane * 16u;
+    chunk(4); chunk(5); chunk(6); chunk(7);
     if (rowok) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1230,15 +1234,13 @@ __device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* ld
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
   }
 #undef SOCMX_GLD
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void mnet_forward_kernel(const MArgs a) {
+__global__ __launch_bounds__(NW * 64) void mnet_forward_kernel(const MArgs a) {   // (one workgroup per CU measured faster than two at 128 VGPRs: 1.72 vs 1.89 ms)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile = blockIdx.x;
   const MDesc& m = a.m;
