@@ -543,7 +543,16 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
 // NET = StaticNet<...> (constexpr descriptors) or void (descriptors from the kernel arguments: any architecture)
 // constexpr instantiations: two 16-row tiles per workgroup; the descriptor-driven one: one (smaller LDS: more
 // architectures fit; it is the fallback for non-default widths)
-template <class NET> struct K2RowTiles { static constexpr int value = 2; };
+// Kernel A's constexpr instantiations: FOUR waves (one per SIMD) on ONE 16-row tile, two workgroups per CU (77 KiB of LDS, 170
+// VGPRs each).  Round 2 ran eight waves on two tiles, one workgroup per CU -- every weight fragment fed two column tiles, but
+// nothing covered a workgroup's eleven barriers and ring restarts; two independent four-wave workgroups do (their stalls
+// interleave), at twice the fragment traffic from L2 (32 B/clk/CU: still half of what the L1 sustains): 260 -> 220 us at
+// cfg3, 1.88 -> 1.73 ms at the configs[4] slice.  (Two EIGHT-wave workgroups on one tile each spilled at 128 VGPRs.)
+#ifndef SOCMX_K2A_WAVES
+#define SOCMX_K2A_WAVES 4        /* waves per workgroup ... */
+#define SOCMX_K2A_RT 1           /* ... and 16-row tiles per workgroup */
+#endif
+template <class NET> struct K2RowTiles { static constexpr int value = SOCMX_K2A_RT; };
 template <> struct K2RowTiles<void> { static constexpr int value = 1; };
 
 template <int NW, class NET> struct K2Const {
@@ -1654,8 +1663,8 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   p.u = make_unet_desc(d, h);
   p.bd = make_bwd_desc(p.u);
   p.variant = k2_variant(p.u);
-  p.rt = p.variant ? 2 : 1;
-  p.lay = make_bwd_layout(p.u, kK2Waves, p.rt);
+  p.rt = p.variant ? SOCMX_K2A_RT : 1;
+  p.lay = make_bwd_layout(p.u, p.variant ? SOCMX_K2A_WAVES : kK2Waves, p.rt);
   if (p.variant && (size_t)p.lay.floats * sizeof(float) > (size_t)kLdsBytesPerCU) {
     // (a variant build with wide layers: two row tiles per workgroup do not fit -- the descriptor-driven form with one)
     p.variant = 0; p.rt = 1;
@@ -1749,11 +1758,12 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles;
   const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
   void (*kern)(const TileArgs) = unet_bwd_tile_kernel<kK2Waves, void>;
-  if (p.variant == 1) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>>;
-  else if (p.variant == 2) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32>>;
-  else if (p.variant == 3) kern = unet_bwd_tile_kernel<kK2Waves, StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64>>;
+  if (p.variant == 1) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>>;
+  else if (p.variant == 2) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32>>;
+  else if (p.variant == 3) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64>>;
   if (const int err = ensure_max_lds(kern)) return err;
-  if (const int err = launch(kern, dim3(p.ntiles / p.rt), dim3(kK2Waves * 64), lds_bytes, stream, ta)) return err;
+  const int nwa = p.variant ? SOCMX_K2A_WAVES : kK2Waves;
+  if (const int err = launch(kern, dim3(p.ntiles / p.rt), dim3(nwa * 64), lds_bytes, stream, ta)) return err;
   // ---- kernel B ----
   WgradArgs wa;
   wa.n_items = 0; wa.S = p.S; wa.ntiles = p.ntiles; wa.slab_floats = p.slab_floats; wa.bias_even_tiles = 0;

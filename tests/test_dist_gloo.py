@@ -33,9 +33,11 @@ def _worker(rank, world, port, name, ret):
     B = aux["B"]
     Bl, row0 = solver.shard.local_rows(B)
     solver.noise_in = aux["noise"][:, row0:row0 + Bl].contiguous()
-    out = solver.loss(B, algorithm="SOCM", use_warm_start=False)
+    out = solver.loss(B, algorithm="SOCM", use_warm_start=False, use_stopping_time=aux["stopping"])
     out[0].backward()
     params = list(sde.nabla_V.parameters()) + list(sde.M.sigmoid_layers.parameters()) + [sde.gamma]
+    if aux["stopping"]:
+        params.append(sde.gamma2)
     (obj,) = solver.shard.allreduce_gradients(params, extra=[out[0].detach()])
     if rank == 0:
         ret["objective"] = float(obj)
@@ -45,7 +47,7 @@ def _worker(rank, world, port, name, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["tiny_ou_linear_d5_B20", "tiny_double_well_d10"])
+@pytest.mark.parametrize("name", ["tiny_ou_linear_d5_B20", "tiny_double_well_d10", "tiny_molecular_dynamics_d2_stopping"])
 def test_sharded_step_equals_single_process(name):
     world = 2
     port = _free_port()
@@ -60,6 +62,8 @@ def test_sharded_step_equals_single_process(name):
     sde, aux = build_sde(name)
     names = ["grad_nablaV." + k for k, _ in sde.nabla_V.named_parameters()] + \
             ["grad_M.sigmoid_layers." + k for k, _ in sde.M.sigmoid_layers.named_parameters()] + ["grad_gamma"]
+    if name.endswith("_stopping"):        # (the stopping-time loss's normaliser sum(stop_indicators) is all-reduced before the backward)
+        names.append("grad_gamma2")
     for g, n in zip(ret["grads"], names):
         np.testing.assert_allclose(g, z[n], rtol=1e-3, atol=1e-5 * max(1.0, np.abs(z[n]).max()), err_msg=n)
 
