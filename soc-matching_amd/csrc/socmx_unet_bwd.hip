@@ -894,6 +894,7 @@ struct MDesc {
   // the MFMA B operand (split-K over the waves) and the last layer's weight gradient has its own kernel
   // (mnet_wgrad_wide_kernel); no GOUT tile, no GOUT slab.  Needs d % 4 == 0 (16-byte pieces of a row) and h1p <= 128.
   int wide;
+  int wscratch;            // wide backward kernel: float offset of the split-K combine scratch (aliases the forward tiles)
   int lds_fwd_floats;      // LDS of the forward kernel (wide: without the backward kernel's tiles and combine scratch)
 };
 enum { MT_X = 0, MT_H1, MT_H2, MT_GOUT, MT_GZ2, MT_GZ1, MT_N };
@@ -937,13 +938,19 @@ inline MDesc make_mdesc(int d, int h0, int h1, int nwaves) {
   m.lds_fwd_floats = m.lds_floats;
   m.wide = 0;
   if ((size_t)m.lds_floats * sizeof(float) > (size_t)160 * 1024 && d % 4 == 0 && m.h1p <= 128) {
-    // wide layout: x | hh1 | hh2 | gz2 | m1 | m2 | bias (L0, L1, then L2: forward only) | scratch
+    // wide layout: [x | hh1 | hh2] | gz2 | m1 | m2 | bias (L0, L1, then L2: forward only) | small scratch.  The backward
+    // kernel's split-K combine of the wide stage ALIASES the bracketed forward tiles (dead by then): wscratch = 0.
     m.wide = 1;
     o = 0;
     m.x = o; o += 32 * m.sx;
     m.hh1 = o; o += 32 * m.s1;
     m.hh2 = o; o += 32 * m.s2;
     m.gout = -1;
+    // one half of the combine: four waves' quads of half the output blocks, value and tangent
+    const int nob_t = (m.h1p >> 4) <= 2 ? 2 : ((m.h1p >> 4) <= 4 ? 4 : 8);   // the kernel's NOB instantiation
+    const int combine_half = 4 * 2 * (nob_t / 2) * 256;
+    m.wscratch = 0;
+    if (combine_half > o) o = combine_half;
     m.gz2 = o; o += 32 * m.s2;
     m.m1 = o; o += m.h0p;
     m.m2 = o; o += m.h1p;
@@ -957,14 +964,10 @@ inline MDesc make_mdesc(int d, int h0, int h1, int nwaves) {
       const int n = (nwaves / nblk) * 32 * outs_w[i];
       need_small = n > need_small ? n : need_small;
     }
-    // forward: all three biases + small scratch; backward: two biases + the split-K combine of the wide stage
-    // (four waves' 2 x (h1p / 16) accumulator quads: 4 x 2 x NOB x 256 floats)
+    // forward: all three biases + small scratch; backward: two biases + small scratch
     m.lds_fwd_floats = m.bias + boff + need_small;
-    const int nob_t = (m.h1p >> 4) <= 2 ? 2 : ((m.h1p >> 4) <= 4 ? 4 : 8);   // the kernel's NOB instantiation
-    const int combine = 4 * 2 * nob_t * 256;
-    const int need_b = combine > need_small ? combine : need_small;
     m.scratch = m.bias + m.L[0].out_pad + m.L[1].out_pad;      // (backward; the forward kernel places it behind L2's bias)
-    m.lds_floats = m.scratch + need_b;
+    m.lds_floats = m.scratch + need_small;
   }
   const int wid[6] = {16, m.h0p, m.h1p, m.wide ? 0 : m.d2p, m.h1p, m.h0p};
   int pre = 0;
@@ -1294,16 +1297,16 @@ __global__ __launch_bounds__(NW * 64) void mnet_backward_kernel(const MArgs a) {
 
 // ---- WIDE form (d*d outputs do not fit an LDS tile: BASELINE configs[4], d = 64) -----------------------------------------
 // Backward tile kernel: F1, F2 recomputed as above, then  (g_h2, g_t2) = L2^T (g_net, g_dnet)  with the reduction over the
-// d*d outputs SPLIT OVER THE WAVES: wave w multiplies chunks [w KC / NW, (w+1) KC / NW) of all NOB = h1p / 16 output
+// d*d outputs SPLIT OVER THE (four) WAVES: wave w multiplies chunks [w KC / NW, (w+1) KC / NW) of all NOB = h1p / 16 output
 // blocks for the value and the tangent rows (2 NOB accumulators).  The B operand is not an LDS tile: lane (row, g) reads
 // g_net[p0 + row][16 kc + 4 g .. + 3] -- one 16-byte piece of the row-major gradient, the same (g, i) indexing the LDS
 // fragments have -- so every byte of g_net / g_dnet is read from HBM once, by one wave.  The A fragments (L2^T, fragment
 // order) stream from L2.  Three chunks (8 A + 2 B requests each) in flight, asm loads with written-out wait counts (see
-// wgrad_body).  Combine: waves 4..7 park their quads in LDS, waves 0..3 add them to their own and park the sums, then wave
-// j reduces block j's four partials and runs the masked epilogue (gz2 tile + GZ2 slab).  Then L1^T as above.
+// wgrad_body).  Four waves per workgroup, two workgroups per CU (their prologues, combines and barriers interleave); the
+// combine and the masked epilogue are described in the kernel.  Then L1^T as above.
 template <int NW, int NOB>
 __global__ __launch_bounds__(NW * 64) void mnet_backward_wide_kernel(const MArgs a) {
-  static_assert(NW == 8, "the combine below is written for eight waves");
+  static_assert(NW == 4, "the combine below is written for four waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const MDesc& m = a.m;
   const int tile = blockIdx.x, lane = threadIdx.x & 63;
@@ -1362,46 +1365,45 @@ __global__ __launch_bounds__(NW * 64) void mnet_backward_wide_kernel(const MArgs
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  // combine the eight waves' partial sums (LDS quads: [slot 0..3][h][block j][lane])
-  float* sc = lds + m.scratch;
+  // Combine the four waves' partial sums in two halves of the output blocks, through an LDS scratch that ALIASES the dead
+  // forward tiles (X, H1, H2: exported as slabs, only their ReLU masks are needed from here on) -- 2 x (h1p / 32) x 4 KiB per
+  // half: the whole kernel stays under 80 KiB of LDS = two workgroups per CU.  Per half: every wave parks its quads of the
+  // half's blocks, barrier, wave w reduces block(s) w, w + 4 of the half (four partials per tile) and runs the masked
+  // epilogue (gz2 tile + GZ2 slab), barrier.
+  float* sc = lds + m.wscratch;
   const int nob = m.h1p >> 4;
-  auto slot = [&](int w4, int h, int j) { return sc + ((size_t)((w4 * 2 + h) * NOB + j) * 64 + lane) * 4; };
-  if (wave >= 4) {
-#pragma unroll
-    for (int j = 0; j < NOB; ++j) {
-      *reinterpret_cast<f32x4*>(slot(wave - 4, 0, j)) = acc[0][j];
-      *reinterpret_cast<f32x4*>(slot(wave - 4, 1, j)) = acc[1][j];
-    }
-  }
-  __syncthreads();
-  if (wave < 4) {
-#pragma unroll
-    for (int j = 0; j < NOB; ++j) { acc[0][j] += lds4(slot(wave, 0, j)); acc[1][j] += lds4(slot(wave, 1, j)); }
-  }
-  __syncthreads();
-  if (wave < 4) {
-#pragma unroll
-    for (int j = 0; j < NOB; ++j) {
-      *reinterpret_cast<f32x4*>(slot(wave, 0, j)) = acc[0][j];
-      *reinterpret_cast<f32x4*>(slot(wave, 1, j)) = acc[1][j];
-    }
-  }
-  __syncthreads();
+  constexpr int HB = NOB / 2 > 0 ? NOB / 2 : 1;           // blocks per half
   MEpi b1{ME_MASK, lds, nullptr, m.gz2, m.s2, m.m2, m.h1p,
           a.ws + (size_t)tile_rows * m.pre[MT_GZ2] + (size_t)(2 * tile) * m.h1p * 16, m.h1p, nullptr, nullptr, 0, 0, 0};
-  for (int j = wave; j < nob; j += NW) {                 // (NOB <= 8 = NW: at most one block per wave)
-    f32x4 vq = f32x4{0.f, 0.f, 0.f, 0.f}, tq = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                        // (everyone is done with the forward tiles)
 #pragma unroll
-    for (int w4 = 0; w4 < 4; ++w4) {
-      vq += lds4(sc + ((size_t)((w4 * 2 + 0) * NOB + j) * 64 + lane) * 4);
-      tq += lds4(sc + ((size_t)((w4 * 2 + 1) * NOB + j) * 64 + lane) * 4);
+  for (int half = 0; half < (NOB + HB - 1) / HB; ++half) {
+#pragma unroll
+    for (int jj = 0; jj < HB; ++jj) {
+      const int j = half * HB + jj;
+      if (j < NOB) {
+        *reinterpret_cast<f32x4*>(sc + ((size_t)((wave * 2 + 0) * HB + jj) * 64 + lane) * 4) = acc[0][j];
+        *reinterpret_cast<f32x4*>(sc + ((size_t)((wave * 2 + 1) * HB + jj) * 64 + lane) * 4) = acc[1][j];
+      }
     }
-    b1.fin(vq, tq, row, j * 16 + 4 * g);
+    __syncthreads();
+    for (int jj = wave; jj < HB; jj += NW) {
+      const int j = half * HB + jj;
+      if (j < nob) {
+        f32x4 vq = f32x4{0.f, 0.f, 0.f, 0.f}, tq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w4 = 0; w4 < NW; ++w4) {
+          vq += lds4(sc + ((size_t)((w4 * 2 + 0) * HB + jj) * 64 + lane) * 4);
+          tq += lds4(sc + ((size_t)((w4 * 2 + 1) * HB + jj) * 64 + lane) * 4);
+        }
+        b1.fin(vq, tq, row, j * 16 + 4 * g);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   MEpi b2{ME_MASK, lds, nullptr, -1, 0, m.m1, m.h0p,
           a.ws + (size_t)tile_rows * m.pre[MT_GZ1] + (size_t)(2 * tile) * m.h0p * 16, m.h0p, nullptr, nullptr, 0, 0, 0};
-  m_stage<NW>(a.packedT, m.LT[1], lds, m.gz2, m.s2, sc, b2);
+  m_stage<NW>(a.packedT, m.LT[1], lds, m.gz2, m.s2, lds + m.scratch, b2);
 }
 
 // Weight / bias gradient of the WIDE last layer:  dW2[n][c] = sum_p g_net[p][n] h2[p][c] + g_dnet[p][n] t2[p][c],
@@ -1792,10 +1794,13 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
 }
 
 // ---- K3: the pair-grid network ---------------------------------------------------------------------------------------
+static const int kK3WideWaves = 4;   // the WIDE pair-net kernels: four waves per workgroup, two workgroups per CU
+
 static int mnet_plan(int32_t d, const int32_t hdims[2], MDesc& m) {
   if (!hdims) return SOCMX_E_NULL;
   if (d < 1 || d > 1024 || hdims[0] < 1 || hdims[0] > 4096 || hdims[1] < 1 || hdims[1] > 4096) return SOCMX_E_DIM;
   m = make_mdesc(d, hdims[0], hdims[1], kK2Waves);
+  if (m.wide) m = make_mdesc(d, hdims[0], hdims[1], kK3WideWaves);      // (the small-stage scratch depends on the wave count)
   if ((size_t)m.lds_floats * sizeof(float) > (size_t)kLdsBytesPerCU) return SOCMX_E_LDS;
   return 0;
 }
@@ -1830,6 +1835,10 @@ extern "C" int socmx_mnet_forward_f32(const float* packed, int32_t d, const int3
   a.packed = packed; a.packedT = packed + a.m.total_floats; a.t = t; a.s = s; a.z = z; a.Np = Np;
   a.ntiles = (int)((Np + 15) / 16); a.net = net; a.dnet = dnet; a.ws = nullptr;
   const size_t lds_bytes = (size_t)a.m.lds_fwd_floats * sizeof(float);
+  if (a.m.wide) {
+    if (const int err = ensure_max_lds(mnet_forward_kernel<kK3WideWaves>)) return err;
+    return launch(mnet_forward_kernel<kK3WideWaves>, dim3(a.ntiles), dim3(kK3WideWaves * 64), lds_bytes, stream, a);
+  }
   if (const int err = ensure_max_lds(mnet_forward_kernel<kK2Waves>)) return err;
   return launch(mnet_forward_kernel<kK2Waves>, dim3(a.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a);
 }
@@ -1895,12 +1904,12 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
   const size_t lds_bytes = (size_t)p.m.lds_floats * sizeof(float);
   const int nlay_b = p.m.wide ? 2 : 3;                    // layers whose weight gradient kernel B forms from the slabs
   if (p.m.wide) {
-    void (*kern)(const MArgs) = mnet_backward_wide_kernel<kK2Waves, 8>;
+    void (*kern)(const MArgs) = mnet_backward_wide_kernel<kK3WideWaves, 8>;
     const int nob = p.m.h1p >> 4;
-    if (nob <= 2) kern = mnet_backward_wide_kernel<kK2Waves, 2>;
-    else if (nob <= 4) kern = mnet_backward_wide_kernel<kK2Waves, 4>;
+    if (nob <= 2) kern = mnet_backward_wide_kernel<kK3WideWaves, 2>;
+    else if (nob <= 4) kern = mnet_backward_wide_kernel<kK3WideWaves, 4>;
     if (const int err = ensure_max_lds(kern)) return err;
-    if (const int err = launch(kern, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a)) return err;
+    if (const int err = launch(kern, dim3(p.ntiles), dim3(kK3WideWaves * 64), lds_bytes, stream, a)) return err;
     // the last layer's weight / bias gradient partials (its own kernel: A operand transposed through LDS)
     MWgradWideArgs ga;
     ga.gnet = gnet; ga.gdnet = gdnet;
