@@ -70,7 +70,7 @@ def build(device, setting=SETTING, d=D, num_steps=NUM_STEPS, gamma=GAMMA, batch=
     return cfg, ts, x0, sde, solver
 
 
-def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_dist, row0, dist_graph=False):
+def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_dist, row0, defer_graph=False):
     """Rollout and full-iteration timings of another BASELINE configuration (driver-timed secondary entries: the
     headline `value` stays configs[2])."""
     from socmx import rollout
@@ -105,27 +105,29 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
         trainer.join()
         return 1e3 * (time.perf_counter() - t0) / steps, info
     it_ms_eager, info = time_iterations(False)
-    it_ms, mode = it_ms_eager, "eager (two HIP streams)"
-    it_ms_graph = None
-    if world == 1 or dist_graph:
-        try:      # (sharded: the RCCL all-reduces are captured inside the graph; an RCCL build that cannot capture keeps eager)
-            it_ms_graph, info_g = time_iterations(True)
-            if it_ms_graph < it_ms:
-                it_ms, mode, info = it_ms_graph, "hipGraph replay", info_g
-        except Exception as e:  # noqa: BLE001
-            if not use_dist:
-                raise
-            mode += f" (hipGraph capture with RCCL failed: {type(e).__name__})"
     fl = flops_per_traj_step(d, HDIMS) * B * K
     out = {"workload": label, "rollout_ms": roll_ms, "trajectory_steps_per_s": B * K / (roll_ms * 1e-3),
-           "socm_ms_per_iter": it_ms, "socm_iters_per_sec": 1e3 / it_ms, "iteration_mode": mode,
-           "socm_ms_per_iter_eager": it_ms_eager, "socm_ms_per_iter_graph": it_ms_graph, "last_loss": float(info["loss"]),
+           "socm_ms_per_iter": it_ms_eager, "socm_iters_per_sec": 1e3 / it_ms_eager,
+           "iteration_mode": "eager (two HIP streams)" if not use_dist else "eager (one flat all-reduce per iteration)",
+           "socm_ms_per_iter_eager": it_ms_eager, "socm_ms_per_iter_graph": None, "last_loss": float(info["loss"]),
            "rollout_roofline": {"bound": "mfma", "achieved": fl / (roll_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": fl / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                                 "active_workgroups": (B + 15) // 16}}
+
+    def graph_leg():
+        """The same iterations replayed as ONE captured hipGraph (sharded: with the RCCL all-reduces captured inside)."""
+        it_ms_graph, info_g = time_iterations(True)
+        out["socm_ms_per_iter_graph"] = it_ms_graph
+        if it_ms_graph < out["socm_ms_per_iter"]:
+            out.update(socm_ms_per_iter=it_ms_graph, socm_iters_per_sec=1e3 / it_ms_graph, iteration_mode="hipGraph replay",
+                       last_loss=float(info_g["loss"]))
+
+    if defer_graph:           # world > 1: the caller runs every graph leg at the end, under its watchdog
+        return out, graph_leg
+    graph_leg()
     del opt, solver, sde
     torch.cuda.empty_cache()
-    return out
+    return out, None
 
 
 def cpu_baseline(budget_s=12.0):
@@ -211,7 +213,7 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
            str(args.warmup)]
-    for flag in ("no_cpu_baseline", "no_burst", "no_secondary", "dist_graph"):
+    for flag in ("no_cpu_baseline", "no_burst", "no_secondary", "no_dist_graph", "defer_graph"):
         if getattr(args, flag):
             cmd.append("--" + flag.replace("_", "-"))
     if args.force_dist or args.spawn:
@@ -230,9 +232,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and take the sharded code path even at world_size 1")
     ap.add_argument("--spawn", action="store_true", help="take the launcher path even for --gpus 1 (one child rank under "
                     "torch.distributed.run; implies --force-dist in the child)")
-    ap.add_argument("--dist-graph", action="store_true", help="world size > 1: also time the iteration as a replayed hipGraph "
-                    "with its RCCL all-reduces captured inside (validated at world size 1 here; off by default so that a "
-                    "multi-GPU run never depends on a capture this builder could not try on more than one GPU)")
+    ap.add_argument("--defer-graph", action="store_true", help="take the multi-GPU ordering of the hipGraph legs (last, under the "
+                    "watchdog) at any world size: how that path is exercised on one GPU")
+    ap.add_argument("--no-dist-graph", action="store_true", help="world size > 1: skip the hipGraph legs (the iteration "
+                    "replayed with its RCCL all-reduces captured inside).  They run LAST, after every eager number is in the "
+                    "line, under a watchdog that prints the line and exits if they do not finish -- this builder could "
+                    "validate the capture at world size 1 only")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
@@ -334,17 +339,15 @@ def main():
     # captured hipGraph (Trainer(hip_graph=True); sharded: with its all-reduces inside): same arithmetic, no host work between
     # the launches
     it_elapsed_eager, last_loss = time_iterations(False)
-    it_elapsed, it_mode = it_elapsed_eager, "eager (two HIP streams)"
+    it_elapsed = it_elapsed_eager
+    it_mode = "eager (two HIP streams)" if not use_dist else "eager (one flat all-reduce per iteration)"
     it_elapsed_graph = None
-    if world == 1 or args.dist_graph:
-        try:      # (sharded: the iteration's RCCL all-reduces are captured inside the graph)
-            it_elapsed_graph, last_loss_g = time_iterations(True)
-            if it_elapsed_graph < it_elapsed:
-                it_elapsed, it_mode, last_loss = it_elapsed_graph, "hipGraph replay", last_loss_g
-        except Exception as e:  # noqa: BLE001
-            if not use_dist:
-                raise
-            it_mode += f" (hipGraph capture with RCCL failed: {type(e).__name__}: {str(e)[:200]})"
+    defer_graph = world > 1 or args.defer_graph  # multi-GPU: every hipGraph leg runs at the end, under the watchdog
+    graph_legs = []
+    if not defer_graph:
+        it_elapsed_graph, last_loss_g = time_iterations(True)
+        if it_elapsed_graph < it_elapsed:
+            it_elapsed, it_mode, last_loss = it_elapsed_graph, "hipGraph replay", last_loss_g
 
     # (after the iteration leg: its 2 GB of buffers and the empty_cache() would otherwise cost the next leg its warm
     #  allocator state)
@@ -375,12 +378,14 @@ def main():
     secondary = []
     if not args.no_secondary:
         n2 = max(3, args.steps // 5)
-        secondary.append(secondary_config(device, "OU_quadratic_easy d=2 num_steps=50 batch=128 SOCM (BASELINE configs[1])",
-                                          "OU_quadratic_easy", 2, 50, 128, 2.0, 4 * n2, 3, use_dist, rank * 128,
-                                          args.dist_graph))
-        secondary.append(secondary_config(device, "OU_linear d=64 num_steps=400 batch=512/GPU SOCM (one GPU's slice of "
-                                          "BASELINE configs[4])", "OU_linear", 64, 400, 512, 2.0, n2, 2, use_dist,
-                                          rank * 512, args.dist_graph))
+        for spec in (("OU_quadratic_easy d=2 num_steps=50 batch=128 SOCM (BASELINE configs[1])",
+                      "OU_quadratic_easy", 2, 50, 128, 2.0, 4 * n2, 3, use_dist, rank * 128),
+                     ("OU_linear d=64 num_steps=400 batch=512/GPU SOCM (one GPU's slice of BASELINE configs[4])",
+                      "OU_linear", 64, 400, 512, 2.0, n2, 2, use_dist, rank * 512)):
+            entry, leg = secondary_config(device, *spec, defer_graph=defer_graph)
+            secondary.append(entry)
+            if leg is not None:
+                graph_legs.append(leg)
 
     if rank == 0:
         flops = flops_per_traj_step(d, HDIMS) * B * K
@@ -432,6 +437,42 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 figure
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+    else:
+        line = None
+    if defer_graph and not args.no_dist_graph:
+        # Multi-GPU hipGraph legs (the iteration replayed with its RCCL all-reduces captured inside), LAST and under a watchdog:
+        # every eager number is already in the line; if a capture or a replay does not come back, every rank prints /
+        # exits on its own timer and the run still delivers its line.
+        import threading
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if line is not None:
+                line["dist_graph"] = "hipGraph legs did not finish within 300 s: eager numbers reported"
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(300.0, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            g_elapsed, g_loss = time_iterations(True)
+            for leg in graph_legs:
+                leg()
+            if line is not None:
+                line["socm_ms_per_iter_graph"] = 1e3 * g_elapsed / it_steps
+                if g_elapsed < it_elapsed:
+                    line.update(socm_iters_per_sec=it_steps / g_elapsed, socm_ms_per_iter=1e3 * g_elapsed / it_steps,
+                                socm_iteration_mode="hipGraph replay (RCCL all-reduces captured)", socm_last_loss=g_loss)
+                line["dist_graph"] = "ok"
+        except Exception as e:  # noqa: BLE001
+            if line is not None:
+                line["dist_graph"] = f"hipGraph capture with RCCL failed: {type(e).__name__}: {str(e)[:200]}"
+        finished.set()
+        timer.cancel()
+    if line is not None:
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
