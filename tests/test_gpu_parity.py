@@ -644,6 +644,10 @@ def test_solver_pickles_after_hip_calls(tmp_path):
      "method.num_iterations=12", "method.compute_control_objective_every=5"],
     ["method.setting=molecular_dynamics", "method.d=1", "method.num_steps=30", "method.use_stopping_time=True",
      "method.T=2.0", "method.lmbd=2.0", "backend.hip_graph=True", "method.num_iterations=10"],
+    # non-default hidden widths through the architecture VARIANT library (backend.specialize_arch: built at first use; the
+    # 128_64_32 variant is prebuilt by __graft_entry__.build(), so nothing compiles here)
+    ["method.setting=double_well", "method.d=3", "method.num_steps=40", "method.delta_t_optimal=0.02",
+     "method.delta_x_optimal=0.02", "arch.hdims=[128,64,32]", "backend.specialize_arch=True", "backend.hip_graph=True"],
 ])
 def test_main_trains_on_the_gpu(tmp_path, overrides):
     """The reference's entry point end to end on the GPU (main.py:33-481 flow): normalisation-constant burst,
@@ -654,7 +658,7 @@ def test_main_trains_on_the_gpu(tmp_path, overrides):
     cmd = [sys.executable, os.path.join(root, "soc-matching_amd", "main.py"), "method.use_gpu=True",
            "method.num_iterations=6", "arch.hdims=[32,16,8]", "arch.hdims_M=[16,16]", "method.n_samples_control=256",
            "+method.n_batches_normalization=2", "optim.batch_size=32", "method.gamma=2.0",
-           "method.compute_control_objective_every=3"] + overrides
+           "method.compute_control_objective_every=3", "backend.specialize_arch=False"] + overrides
     res = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "nan" not in res.stdout.lower(), res.stdout[-3000:]
