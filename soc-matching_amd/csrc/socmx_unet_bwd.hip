@@ -1701,7 +1701,10 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   // XCDs -- so S is a multiple of 32; 64 is within 5 % of the best for 400 ... 13,000 tiles, and more slabs only grow
   // kernel C's reduction.  Small inputs: at least 4 tiles per slab.
   (void)items;
-  int S = 64;
+#ifndef SOCMX_K2_SLABS
+#define SOCMX_K2_SLABS 64
+#endif
+  int S = SOCMX_K2_SLABS;
   if (S > p.ntiles / 4) S = p.ntiles / 4 >= 32 ? 32 : p.ntiles / 4;
   p.S = S < 1 ? 1 : (S > 128 ? 128 : S);
   p.part_floats = (int64_t)p.S * p.slab_floats;
