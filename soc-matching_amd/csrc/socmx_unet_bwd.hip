@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <cstring>
 
 #include "../../include/socmx.h"
 #include "socmx_unet.h"
@@ -648,23 +650,40 @@ struct WgItem {
   int variant;             // index into the (NOB, NIB) instantiations
 };
 
+// Cost-balanced placement of kernel B's waves (control network).  A wave is one (block group, slab of row tiles); the chip
+// holds 2 waves per SIMD of this kernel (173 VGPRs), i.e. 256 per XCD, and a uniform "every group x S slabs" grid neither
+// fills a whole number of such rounds nor gives a (4, 4) group (64 MFMAs per tile) more waves than a (2, 2) one (16).
+// Instead every XCD x owns the x-th eighth of the row tiles (its L2 then holds what the groups re-read) and runs
+// `nslots` waves on it: group i gets n[i] of them, n[i] proportional to its cost per tile (largest-remainder by a
+// greedy pass on the host, wgrad_make_schedule), so that ONE full round of equal-length waves covers the work.
+// Group i is therefore cut into S_i = 8 n[i] slabs, and kernel C adds S_i partials for its cells.
+constexpr int kWgSlots = 256;            // wave slots per XCD: one full round of the chip
+constexpr int kWgMaxItems = 255;         // block groups the table can describe (more: the uniform grid)
+struct WgSched {
+  int nslots;                            // 0: uniform grid (S slabs for every group); else kWgSlots
+  uint8_t item[kWgSlots];                // wave slot -> block group (255: idle)
+  uint8_t k[kWgSlots];                   // ... -> which of the group's n slabs inside the XCD's eighth
+  uint8_t n[kWgMaxItems + 1];            // per block group: slabs per XCD
+};
+
 struct WgradArgs {
   // per forward layer: tensors, block counts, first item; block groups (<= 4 x 4 blocks) are numbered ig-fastest
   int gt_off[9], at_off[9], gW[9], aW[9], OB[9], IB[9], w_cell_off[9], b_part_off[9], item0[10];
   int n_items;
-  int S;                   // slabs
+  int S;                   // slabs (uniform grid; with a schedule: the largest S_i, which sizes `part`)
   int ntiles;
   int64_t slab_floats;     // floats per slab of partials
   const float* ws;
   float* part;             // (S, slab_floats)
   int bias_even_tiles;     // 1: only even 16-row tiles count towards the bias gradients (pair network: the odd tiles hold
                            //    the forward TANGENT rows, which pass through the weights but not the biases)
+  WgSched sched;
 };
 
 template <int NOB, int NIB>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it, int slab, int lane) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it, int slab, int S, int lane) {
   const int c = lane & 15, g = lane >> 4;
-  const int t0 = (int)(((int64_t)slab * a.ntiles) / a.S), t1 = (int)(((int64_t)(slab + 1) * a.ntiles) / a.S);
+  const int t0 = (int)(((int64_t)slab * a.ntiles) / S), t1 = (int)(((int64_t)(slab + 1) * a.ntiles) / S);
   const int64_t tile_rows = (int64_t)a.ntiles * 16;
   // lane (c, g) reads rows 4g .. 4g+3 of unit (block * 16 + c): one 16-byte load; MFMA number s of a tile takes component s
   // from every lane, i.e. k-slot g carries row 4g + s -- the same permutation for both operands
@@ -685,11 +704,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
 #pragma unroll
     for (int k = 0; k < NIB; ++k) acc[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // Three tiles of operands in flight.  The loads are asm statements and the waits are written out: with `if (t < t1) load`
+  // PD (three or more) tiles of operands in flight.  The loads are asm statements and the waits are written out: with `if (t < t1) load`
   // in the loop the compiler's wait-count insertion falls back to (nearly) vmcnt(0) in front of every tile's MFMAs, i.e. one
   // tile in flight (the socm_target_lds4_kernel story, socmx_loss.hip).  Requests past the slab's last tile re-read it, so
-  // that "two younger tiles may stay in flight" is the same number on every trip.
-  constexpr int PD = 3, NL = NOB + NIB;
+  // that "PD - 1 younger tiles may stay in flight" is the same number on every trip.
+  // (narrow block groups have few MFMAs per tile to hide the load latency behind: more tiles in flight for them)
+  constexpr int PD = NOB * NIB >= 16 ? 3 : NOB * NIB >= 8 ? 4 : NOB * NIB >= 4 ? 6 : 8, NL = NOB + NIB;
   f32x4 ga[PD][NOB], ab[PD][NIB];
   auto load = [&](int t, int s) {
     const int tc = min(t, t1 - 1);
@@ -700,8 +720,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
     for (int k = 0; k < NIB; ++k)
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ab[s][k]) : "v"(abase + (size_t)tc * astep + io[k]) : "memory");
   };
-  auto wait_slot = [&](int s) {                 // the two younger tiles may stay in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+  auto wait_slot = [&](int s) {                 // the PD - 1 younger tiles may stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NL) : "memory");
 #pragma unroll
     for (int j = 0; j < NOB; ++j) asm volatile("" : "+v"(ga[s][j]));
 #pragma unroll
@@ -757,9 +777,20 @@ __global__ __launch_bounds__(256, 2) void unet_wgrad_kernel(const WgradArgs a) {
   // that read one slab of row tiles are numbered onto ONE XCD, so a tile's operands cross the fabric once and the
   // other groups' re-reads hit that L2.  (Speed only: any placement is correct.)
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int item = q % a.n_items;
-  const int slab = ((q / a.n_items) * 8 + xcd) * 4 + wave;
-  if (slab >= a.S) return;
+  int item, slab, S;
+  if (a.sched.nslots) {
+    const int ws = q * 4 + wave;
+    item = a.sched.item[ws];
+    if (item == 255) return;
+    const int n = a.sched.n[item];
+    S = 8 * n;
+    slab = xcd * n + a.sched.k[ws];
+  } else {
+    item = q % a.n_items;
+    slab = ((q / a.n_items) * 8 + xcd) * 4 + wave;
+    S = a.S;
+    if (slab >= S) return;
+  }
   int l = 8;
   while (l > 0 && item < a.item0[l]) --l;
   WgItem it;
@@ -779,13 +810,13 @@ __global__ __launch_bounds__(256, 2) void unet_wgrad_kernel(const WgradArgs a) {
                  (vo == 4 && vi == 1) ? 4 : (vo == 1 && vi == 4) ? 5 : (vo == 1 && vi == 1) ? 6 : (vo == 2) ? 1 : 2;
   }
   switch (it.variant) {
-    case 0: wgrad_body<4, 4>(a, it, slab, lane); break;
-    case 1: wgrad_body<4, 2>(a, it, slab, lane); break;
-    case 2: wgrad_body<2, 4>(a, it, slab, lane); break;
-    case 3: wgrad_body<2, 2>(a, it, slab, lane); break;
-    case 4: wgrad_body<4, 1>(a, it, slab, lane); break;
-    case 5: wgrad_body<1, 4>(a, it, slab, lane); break;
-    default: wgrad_body<1, 1>(a, it, slab, lane); break;
+    case 0: wgrad_body<4, 4>(a, it, slab, S, lane); break;
+    case 1: wgrad_body<4, 2>(a, it, slab, S, lane); break;
+    case 2: wgrad_body<2, 4>(a, it, slab, S, lane); break;
+    case 3: wgrad_body<2, 2>(a, it, slab, S, lane); break;
+    case 4: wgrad_body<4, 1>(a, it, slab, S, lane); break;
+    case 5: wgrad_body<1, 4>(a, it, slab, S, lane); break;
+    default: wgrad_body<1, 1>(a, it, slab, S, lane); break;
   }
 }
 
@@ -802,42 +833,65 @@ struct FinishArgs {
   int64_t slab_floats;
   const float* part;
   float* grads;
+  int scheduled;           // 1: block group i of kernel B's schedule wrote 8 n[i] partials (else S for every cell)
+  int item0[10];
+  uint8_t n[kWgMaxItems + 1];
 };
 
+__device__ __forceinline__ int finish_partials(const FinishArgs& a, int l, int ob, int ib) {
+  if (!a.scheduled) return a.S;
+  return 8 * a.n[a.item0[l] + (ob >> 2) * ((a.IB[l] + 3) >> 2) + (ib >> 2)];
+}
+
+// 64 x 4 threads: thread (x, y) adds quarter y of the partials of four consecutive floats (one lane's 16 bytes of a cell, or four
+// bias units) in four independent chains; the quarters meet in LDS and are added in a fixed order.  (One thread per float
+// over all S partials was a chain of S / 4 dependent round trips: 20 us for 38 MB.)
 __global__ __launch_bounds__(256) void unet_wgrad_finish_kernel(const FinishArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  __shared__ f32x4 quarter[4][64];
+  const int xl = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int idx = (blockIdx.x * 64 + xl) * 4;
+  const int total = a.total_cells_floats + a.total_bias;           // both multiples of 16
+  int l = 8, S = 0, o = 0, i = 0;
+  bool cells = false;
   if (idx < a.total_cells_floats) {
-    int l = 8;
+    cells = true;
     while (l > 0 && idx < a.w_cell_off[l]) --l;
     const int rel = idx - a.w_cell_off[l];
-    const int cell = rel >> 8, lane = (rel >> 2) & 63, rr = rel & 3;
+    const int cell = rel >> 8, lane = (rel >> 2) & 63;
     const int ob = cell / a.IB[l], ib = cell - ob * a.IB[l];
-    const int o = ob * 16 + 4 * (lane >> 4) + rr, i = ib * 16 + (lane & 15);
-    if (o < a.fout[l] && i < a.fin[l]) {
-      // four independent chains (loads in flight), combined in a fixed order
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int p = 0;
-      for (; p + 3 < a.S; p += 4) {
-        s0 += a.part[(size_t)p * a.slab_floats + idx];
-        s1 += a.part[(size_t)(p + 1) * a.slab_floats + idx];
-        s2 += a.part[(size_t)(p + 2) * a.slab_floats + idx];
-        s3 += a.part[(size_t)(p + 3) * a.slab_floats + idx];
-      }
-      for (; p < a.S; ++p) s0 += a.part[(size_t)p * a.slab_floats + idx];
-      a.grads[a.gw_off[l] + (int64_t)o * a.fin[l] + i] = (s0 + s1) + (s2 + s3);
-    }
-    return;
+    o = ob * 16 + 4 * (lane >> 4); i = ib * 16 + (lane & 15);
+    S = finish_partials(a, l, ob, ib);
+  } else if (idx < total) {
+    while (l > 0 && idx < a.b_part_off[l]) --l;
+    o = idx - a.b_part_off[l];
+    S = finish_partials(a, l, o >> 4, 0);
   }
-  const int b = idx - a.total_cells_floats;
-  if (b < a.total_bias) {
-    int l = 8;
-    while (l > 0 && a.total_cells_floats + b < a.b_part_off[l]) --l;
-    const int o = a.total_cells_floats + b - a.b_part_off[l];
-    if (o < a.fout[l]) {
-      float s = 0.f;
-      for (int p = 0; p < a.S; ++p) s += a.part[(size_t)p * a.slab_floats + a.b_part_off[l] + o];
-      a.grads[a.gb_off[l] + o] = s;
+  f32x4 s0{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  {
+    const int p1 = ((y + 1) * S) >> 2;
+    int p = (y * S) >> 2;
+    const float* src = a.part + idx;
+    for (; p + 3 < p1; p += 4) {
+      s0 += *reinterpret_cast<const f32x4*>(src + (size_t)p * a.slab_floats);
+      s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(p + 1) * a.slab_floats);
+      s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(p + 2) * a.slab_floats);
+      s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(p + 3) * a.slab_floats);
     }
+    for (; p < p1; ++p) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)p * a.slab_floats);
+  }
+  quarter[y][xl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (y != 0 || S == 0) return;
+  const f32x4 v = (quarter[0][xl] + quarter[1][xl]) + (quarter[2][xl] + quarter[3][xl]);
+  if (cells) {
+    if (i < a.fin[l])
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        if (o + rr < a.fout[l]) a.grads[a.gw_off[l] + (int64_t)(o + rr) * a.fin[l] + i] = v[rr];
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      if (o + rr < a.fout[l]) a.grads[a.gb_off[l] + o + rr] = v[rr];
   }
 }
 
@@ -1642,7 +1696,57 @@ static int k2_variant(const UnetDesc& u) {
   return 0;
 }
 
+// Fills `sc` for the block groups of `OB x IB` (9 layers, numbered like kernel B numbers them) and returns the largest
+// S_i; nslots = 0 (uniform grid) when the table cannot describe the net.  Cost of a group per row tile = the MFMAs of the
+// instantiation that runs it (clamped blocks are computed twice) + its loads' share of the issue slots.
+static int wgrad_make_schedule(const int OB[9], const int IB[9], int ntiles, WgSched& sc) {
+  sc.nslots = 0;
+  float cost[kWgMaxItems];
+  int ni = 0;
+  for (int l = 0; l < 9; ++l)
+    for (int og = 0; og < (OB[l] + 3) / 4; ++og)
+      for (int ig = 0; ig < (IB[l] + 3) / 4; ++ig) {
+        if (ni >= kWgMaxItems) return 0;
+        const int nob = std::min(4, OB[l] - 4 * og), nib = std::min(4, IB[l] - 4 * ig);
+        int vo = nob > 2 ? 4 : (nob > 1 ? 2 : 1), vi = nib > 2 ? 4 : (nib > 1 ? 2 : 1);
+        if (vo == 2 && vi == 1) vi = 2;
+        if (vo == 1 && vi == 2) vo = 2;
+        cost[ni++] = (float)(vo * vi) + 0.125f * (float)(vo + vi);
+      }
+  if (ntiles < 64 * 8) return 0;               // (small inputs: the uniform grid with few slabs)
+  // n[i] by largest remainder: the next wave goes to the group whose waves are longest
+  int n[kWgMaxItems];
+  for (int i = 0; i < ni; ++i) n[i] = 1;
+  for (int left = kWgSlots - ni; left > 0; --left) {
+    int arg = -1;
+    float worst = 0.f;
+    for (int i = 0; i < ni; ++i)
+      if (n[i] < 31 && cost[i] / (float)n[i] > worst) { worst = cost[i] / (float)n[i]; arg = i; }
+    if (arg < 0) break;
+    ++n[arg];
+  }
+  // Slot order: slab index first, groups inside it by falling wave length -- the four waves of a workgroup are then
+  // different groups on (nearly) the same row tiles, which they re-read from L2 while they walk in step.  (Measured, cfg3 /
+  // d = 64 slice: 96.8 / 763 us; group-major order 98.7 / 761; a second round of half-length waves 97.5 / 768 and kernel C
+  // twice as long; the uniform grid 112.7 / 943.)
+  int order[kWgMaxItems];
+  for (int i = 0; i < ni; ++i) order[i] = i;
+  std::sort(order, order + ni, [&](int x, int y) {
+    const float cx = cost[x] / (float)n[x], cy = cost[y] / (float)n[y];
+    return cx != cy ? cx > cy : x < y;
+  });
+  int ws = 0, smax = 0;
+  for (int i = 0; i < ni; ++i) { sc.n[i] = (uint8_t)n[i]; smax = std::max(smax, 8 * n[i]); }
+  for (int k = 0; k < 32; ++k)
+    for (int oi = 0; oi < ni; ++oi)
+      if (k < n[order[oi]]) { sc.item[ws] = (uint8_t)order[oi]; sc.k[ws] = (uint8_t)k; ++ws; }
+  for (; ws < kWgSlots; ++ws) { sc.item[ws] = 255; sc.k[ws] = 0; }
+  sc.nslots = kWgSlots;
+  return smax;
+}
+
 struct K2Plan {
+  WgSched sched;
   int variant, rt;
   UnetDesc u;
   BwdDesc bd;
@@ -1707,6 +1811,8 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   int S = SOCMX_K2_SLABS;
   if (S > p.ntiles / 4) S = p.ntiles / 4 >= 32 ? 32 : p.ntiles / 4;
   p.S = S < 1 ? 1 : (S > 128 ? 128 : S);
+  // (large inputs: the cost-balanced schedule, WgSched; its largest per-group slab count sizes the partials)
+  if (const int smax = wgrad_make_schedule(p.OB, p.IB, p.ntiles, p.sched)) p.S = smax;
   p.part_floats = (int64_t)p.S * p.slab_floats;
   return 0;
 }
@@ -1782,10 +1888,15 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
     wa.n_items += ((p.OB[l] + 3) / 4) * ((p.IB[l] + 3) / 4);
   }
   wa.item0[9] = wa.n_items;
+  wa.sched = p.sched;
   const int slab_groups = (((p.S + 3) / 4) + 7) & ~7;       // padded to a multiple of the XCD count
-  if (const int err = launch(unet_wgrad_kernel, dim3(wa.n_items * slab_groups), dim3(256), 0, stream, wa)) return err;
+  const unsigned wgrid = p.sched.nslots ? 8u * (unsigned)(p.sched.nslots / 4) : (unsigned)(wa.n_items * slab_groups);
+  if (const int err = launch(unet_wgrad_kernel, dim3(wgrid), dim3(256), 0, stream, wa)) return err;
   // ---- kernel C ----
   FinishArgs fa;
+  fa.scheduled = p.sched.nslots != 0;
+  std::memcpy(fa.item0, wa.item0, sizeof(fa.item0));
+  std::memcpy(fa.n, p.sched.n, sizeof(fa.n));
   for (int l = 0; l < 9; ++l) {
     fa.w_cell_off[l] = p.w_cell_off[l]; fa.b_part_off[l] = p.b_part_off[l]; fa.OB[l] = p.OB[l]; fa.IB[l] = p.IB[l];
     fa.fin[l] = p.fin[l]; fa.fout[l] = p.fout[l]; fa.gw_off[l] = p.gw_off[l]; fa.gb_off[l] = p.gb_off[l];
@@ -1946,6 +2057,7 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
     }
   }
   wa.item0[9] = wa.n_items;
+  wa.sched.nslots = 0;                                      // (uniform grid: the wide form's last layer has its own kernel)
   const int slab_groups = (((p.S + 3) / 4) + 7) & ~7;
   if (const int err = launch(unet_wgrad_kernel, dim3(wa.n_items * slab_groups), dim3(256), 0, stream, wa)) return err;
   FinishArgs fa{};
