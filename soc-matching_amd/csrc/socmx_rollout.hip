@@ -786,6 +786,150 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
 }
 
 // ---- nabla_V on arbitrary rows (method.py:272-278): same tile code, rows from HBM ----------
+// ---- small batches: 4-row tiles ----------------------------------------------------------------------------------------
+// The same fused step (sigma = I, d <= 15: the FAST form above) on a 4-row tile: the control network runs on
+// v_mfma_f32_4x4x1_16b_f32 (socmx_unet.h, unet_tile_forward_static4) from the same packed image.  B / 4 workgroups instead
+// of B / 16 -- a training batch of 128 rows works on 32 CUs instead of 8 -- and half the MFMA time per step and tile.
+// Wave 0 integrates (thread = (row r, component i), 64 threads), wave 1 draws the next step's noise.
+template <int NW, bool STOPPING, class NET>
+__global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(NET::outp == 16 && NW >= 2, "4-row tile: d <= 15, at least two waves");
+  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+  constexpr TileLayout tl = NET::layout4(NW);
+  constexpr UnetDesc ud = NET::desc();
+  const int tid = threadIdx.x;
+  constexpr int nthr = NW * 64;
+  const int d = a.d, B = a.B, K = a.K, kind = a.kind;
+  const int tile_row0 = blockIdx.x * 4;
+  float* X0 = lds + tl.x0;
+  const int ds = socmx_sde_stride(d);
+  const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
+  const bool is_quad = kind == SOCMX_OU_QUADRATIC;
+  float* A_l = lds + a.lds_mats;                        // (d, ds)   OU only
+  float* P_l = A_l + (is_ou ? d * ds : 0);              // (d, ds)   OU_quadratic only
+  float* NZ = P_l + (is_quad ? d * ds : 0);             // (2, 4, 16) double-buffered noise of steps k, k + 1
+  for (float* z = lds + tid; z < NZ + 128; z += nthr) *z = 0.f;       // (tiles' padding columns stay zero for good)
+  __syncthreads();
+  for (int e = tid; e < d * d; e += nthr) {
+    const int r = e / d, c = e - r * d;
+    if (is_ou) A_l[r * ds + c] = a.A[e];
+    if (is_quad) P_l[r * ds + c] = a.P[e];
+  }
+  unet_load_biases(a.packed, ud, tl, lds, tid, nthr);
+  Pre carry = unet_carry_init_static<NW, NET>(a.packed);
+
+  const bool act = tid < 64;
+  const int r = (tid >> 4) & 3, i = tid & 15;
+  const int ic = min(i, d - 1);
+  const bool lane_ok = act && i < d;
+  const int grow = tile_row0 + r;
+  const bool traj = a.states != nullptr;          // costs-only launches (evaluation bursts) pass no trajectory buffers
+  const bool store = lane_ok && grow < B && traj;
+  const bool store0 = act && i == 0 && grow < B && traj;
+  const size_t rowoff = (size_t)grow * d + i;
+  auto gsum = [](float v) { return row16_sum(v); };
+  float x = lane_ok ? a.x0[(size_t)min(grow, B - 1) * d + i] : 0.f;
+  const float kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
+  float stop = 1.f, lpd = 0.f, lps = 0.f;
+  if (store) a.states[rowoff] = x;
+  if (store0) a.stop_ind[grow] = 1.f;
+  if (act) {
+    if (i < 15) X0[r * tl.s0 + 1 + i] = x;   // columns 1..15; lanes i >= d hold x = 0
+    if (i == 0) X0[r * tl.s0] = a.ts[0];
+  }
+  const bool producer = tid >= 64 && tid < 128;
+  const int pgrow = tile_row0 + r;
+  auto draw = [&](int k) -> float {
+    if (i >= d || k >= K) return 0.f;
+    if (a.noise_in) return a.noise_in[((size_t)k * B + min(pgrow, B - 1)) * d + i];
+    return philox_normal(key_seed, key_offset, (uint32_t)(a.row0 + pgrow), (uint32_t)k, i);
+  };
+  if (producer) NZ[r * 16 + i] = draw(0);
+  for (int k = 0; k < K; ++k) {
+    const float t0 = a.ts[k], t1 = a.ts[k + 1];
+    const float dt = t1 - t0;                 // utils.py:38
+    const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
+    __syncthreads();
+    float gv = 0.f;                           // nabla_V[r][i] of this thread
+    unet_tile_forward_static4<NW, NET>(a.packed, lds, carry, &gv);           // last stage -> register, no barrier
+    if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
+    if (act) {
+      const float u = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
+      const float eps = NZ[(k & 1) * 64 + r * 16 + i];                  // drawn during the previous step
+      float bi;
+      if (is_ou) {                                                      // b = A x
+        bi = 0.f;
+        for (int j = 0; j < d; ++j) bi += A_l[ic * ds + j] * __shfl(x, j, 16);
+        if (!lane_ok) bi = 0.f;
+      } else {
+        bi = -2.f * kap * (x * x - 1.f) * 2.f * x;                      // double_well.py:44-48
+      }
+      const float upd = (bi + u) * dt + sq_ldt * eps;                   // utils.py:45-47
+      const float xn = x + stop * upd;                                  // utils.py:48
+      float xe = xn, step = dt, stop_new = 1.f;
+      if (STOPPING) {                                                   // utils.py:42-44, 49-75; Phi = -x_0
+        const float phi_b = -__shfl(x, 0, 16), phi_a = -__shfl(xn, 0, 16);
+        const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
+        const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
+        const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
+        xe = js * (x + fr * stop * upd) + (1.f - js) * xn;
+        step = js * (fr * fr) * dt + ns * dt;                           // step_fraction squared (utils.py:70-72)
+        stop_new = (-__shfl(xe, 0, 16) > 0.f) ? 1.f : 0.f;
+      }
+      float f = 0.f;                                                    // f at the NEW state, OLD time (utils.py:92-96)
+      if (kind == SOCMX_OU_QUADRATIC) {
+        float px = 0.f;
+        for (int j = 0; j < d; ++j) px += P_l[ic * ds + j] * __shfl(xe, j, 16);
+        f = gsum(lane_ok ? xe * px : 0.f);
+      } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
+        f = 1.f;
+      }
+      const float uu = gsum(u * u), ue = gsum(u * eps);
+      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
+      lps = lps + sqrtf(step / a.lmbd) * (-ue);
+      if (store) {
+        a.controls[(size_t)k * B * d + rowoff] = u;
+        a.noises[(size_t)k * B * d + rowoff] = eps;
+        a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
+      }
+      if (store0) {
+        a.frac[(size_t)k * B + grow] = step;
+        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? stop_new : 1.f;
+      }
+      x = lane_ok ? xe : 0.f;
+      if (STOPPING) stop = stop_new;
+      if (i < 15) X0[r * tl.s0 + 1 + i] = x;                            // next step's network input [t, x, 0..]
+      if (i == 0) X0[r * tl.s0] = t1;
+    }
+    if (producer) NZ[((k + 1) & 1) * 64 + r * 16 + i] = draw(k + 1);
+  }
+  if (a.nabla_v) {                        // nabla_V(T, X_K): X0 already holds [t_K, x_K] (written at the end of the last step)
+    __syncthreads();
+    float gv = 0.f;
+    unet_tile_forward_static4<NW, NET>(a.packed, lds, carry, &gv);
+    if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
+  }
+  if (act) {                                                            // terminal cost (utils.py:101)
+    float gval = 0.f;
+    if (kind == SOCMX_OU_QUADRATIC) {
+      float qx = 0.f;
+      for (int j = 0; j < d; ++j) qx += a.Q[ic * d + j] * __shfl(x, j, 16);
+      gval = gsum(lane_ok ? x * qx : 0.f);
+    } else if (kind == SOCMX_OU_LINEAR) {
+      gval = gsum(lane_ok ? a.omega[ic] * x : 0.f);
+    } else if (kind == SOCMX_DOUBLE_WELL) {
+      const float q = x * x - 1.f;
+      gval = gsum(lane_ok ? a.nu[ic] * (q * q) : 0.f);
+    }
+    if (i == 0 && grow < B) {
+      a.lpd[grow] = lpd;
+      a.lps[grow] = lps;
+      a.ltw[grow] = -gval / a.lmbd;
+    }
+  }
+}
+
 struct ForwardArgs {
   UnetDesc u;
   TileLayout t;
@@ -1026,6 +1170,20 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   else if (nw == 4) SOCMX_PICK(4, DynamicNet);
   else SOCMX_PICK(8, DynamicNet);
 #undef SOCMX_PICK
+  // Small batches (at most 64 tiles of 16 rows: a quarter of the CUs), default widths, sigma = I, d <= 15: 4-row tiles,
+  // B / 4 workgroups (rollout4_kernel).  SOCMX_TILE_ROWS=16 / 4 (developer A/B switch, read once) forces one form.
+  static const int force_rows = [] { const char* e = getenv("SOCMX_TILE_ROWS"); return e ? atoi(e) : 0; }();
+  if (is_default && fast && !prof && force_rows != 16 && (blocks <= 64 || force_rows == 4)) {
+    constexpr TileLayout t4 = DefaultNet::layout4(8);
+    a.lds_mats = (t4.floats + 3) & ~3;
+    const size_t floats4 = (size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 128;
+    void (*k4)(const RolloutArgs) = stopping ? rollout4_kernel<8, true, DefaultNet> : rollout4_kernel<8, false, DefaultNet>;
+    if (const int err = ensure_max_lds(k4)) return err;
+    const int blocks4 = (B + 3) / 4;
+    // (one workgroup per CU while there are CUs left: the whole LDS)
+    const size_t lds4 = blocks4 <= 256 ? (size_t)kMaxLdsBytes : floats4 * sizeof(float);
+    return launch(k4, dim3(blocks4), dim3(8 * 64), lds4, stream, a);
+  }
   if (const int err = ensure_max_lds(kern)) return err;
   // Few row tiles (a training batch: B / 16 workgroups on a 256-CU chip): claim the CU's whole LDS, so that no workgroup
   // of a kernel running beside the rollout on another stream (the pair-grid network's GEMMs) is placed on the same CU

@@ -105,18 +105,19 @@ struct TileLayout {
   int floats;                                // total
 };
 
-__host__ __device__ constexpr TileLayout make_tile_layout(const UnetDesc& u, int nwaves) {
+// (rows = 4: the small-batch tile of the 4x4x1 kernels below -- same strides, a quarter of the rows)
+__host__ __device__ constexpr TileLayout make_tile_layout(const UnetDesc& u, int nwaves, int rows = 16) {
   TileLayout t{};
   t.s0 = u.in0p + 4; t.s1 = u.hp[0] + 4; t.s2 = u.hp[1] + 4; t.s3 = u.hp[2] + 4; t.sg = u.outp + 4;
   int off = 0;
-  t.x0 = off; off += 16 * t.s0;
-  t.r1 = off; off += 16 * t.s1;
-  t.r2 = off; off += 16 * t.s2;
-  t.r3 = off; off += 16 * t.s3;
-  t.o2 = off; off += 16 * t.s2;
-  t.o1 = off; off += 16 * t.s1;
-  t.gv = off; off += 16 * t.sg;
-  t.scratch = off; off += 2 * 16 * 16 * nwaves;  // split-K partials: 2 GEMMs x (parts*out_pad <= 16*nwaves) x 16 rows
+  t.x0 = off; off += rows * t.s0;
+  t.r1 = off; off += rows * t.s1;
+  t.r2 = off; off += rows * t.s2;
+  t.r3 = off; off += rows * t.s3;
+  t.o2 = off; off += rows * t.s2;
+  t.o1 = off; off += rows * t.s1;
+  t.gv = off; off += rows * t.sg;
+  t.scratch = off; off += 2 * rows * 16 * nwaves;  // split-K partials: 2 GEMMs x (parts*out_pad <= 16*nwaves) x rows
   t.bias = off; off += u.bias_floats;
   t.floats = off;
   return t;
@@ -271,14 +272,44 @@ __device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, c
     for (int e = tid; e < u.L[l].out_pad; e += nthr) lds[t.bias + u.L[l].b_lds + e] = Wp[u.L[l].b_off + e];
 }
 
-template <int NB>
+// R4: the 4-row tile.  The SAME weight fragment feeds v_mfma_f32_4x4x1_16b_f32: its 16 blocks are lane quads, block
+// (l >> 2) = (k-group kg = l >> 4, neuron group ng = (l >> 2) & 3); lane l's A value is W[16 nb + (l & 15)][16 kc + 4 kg + i]
+// as before, its B value x[row l & 3][16 kc + 4 kg + i], and D = neurons 4 ng .. 4 ng + 3 of row (l & 3), summed over
+// k-group kg's inputs only -- the four k-groups' partial sums are added across lanes when a GEMM ends (kg_sum).
+// 16 cycles per instruction (half the 16x16x4 rate per MAC), a quarter of the rows: half the time per tile.
+template <int NB, bool R4 = false>
 __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NB], const f32x4 (&a)[NB], const f32x4 bx) {
   // k-step outer, block inner: consecutive MFMAs hit different accumulators (the dependent-accumulator latency
   // of v_mfma_f32_16x16x4_f32 is 40 cycles against a 32-cycle issue interval)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], bx[i], acc[j], 0, 0, 0);
+    for (int j = 0; j < NB; ++j) {
+      if constexpr (R4) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][i], bx[i], acc[j], 0, 0, 0);
+      else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], bx[i], acc[j], 0, 0, 0);
+    }
+}
+
+// sum over the four k-groups (lanes l, l ^ 16, l ^ 32, l ^ 48) of a 4-row accumulator; every lane ends with the total.
+// gfx950's row / half swaps (v_permlane16_swap: odd rows of the first register <-> even rows of the second;
+// v_permlane32_swap: upper half of the first <-> lower half of the second): VALU only, where a ds_bpermute pair per
+// register would queue behind the stage's LDS traffic.  Inline asm: with both operands of
+// __builtin_amdgcn_permlane16_swap the same value, this compiler folds the result pair into one register (a + a).  The
+// leading s_nop covers the MFMA -> VALU wait states of the accumulator (not inserted in front of inline asm).
+__device__ __forceinline__ f32x4 kg_sum(const f32x4 v) {
+  float a = v[0], b = v[1], c = v[2], d = v[3], t0, t1, t2, t3;
+  asm volatile(
+      "s_nop 7\n\t"
+      "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\t"
+      "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %7\n\t"
+      "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+      "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %7"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+  return f32x4{a, b, c, d};
 }
 
 // Weight fragments come straight from L2 into VGPRs (each is used by exactly one MFMA group of one
@@ -306,7 +337,7 @@ struct GemmPlan {
   int kc0, kc1;
 };
 
-template <int NB>
+template <int NB, bool R4 = false>
 __device__ __forceinline__ GemmPlan<NB> make_plan(const float* __restrict__ Wp, const LayerDesc& L, int blk0, int bstride,
                                                   const float* X, int S, int lane, int kc0, int kc1) {
   GemmPlan<NB> p;
@@ -314,7 +345,7 @@ __device__ __forceinline__ GemmPlan<NB> make_plan(const float* __restrict__ Wp, 
   const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + L.w_off) + lane;
 #pragma unroll
   for (int j = 0; j < NB; ++j) p.wb[j] = wl + (size_t)((blk0 + j * bstride) * KC) * 64;
-  p.xrow = X + (lane & 15) * S + 4 * (lane >> 4);
+  p.xrow = X + (R4 ? (lane & 3) : (lane & 15)) * S + 4 * (lane >> 4);
   p.kc0 = kc0; p.kc1 = kc1;
   return p;
 }
@@ -340,7 +371,7 @@ __device__ __forceinline__ void ring_fill(Ring<NB>& r, const GemmPlan<NB>& p, co
 // PINNED (the constexpr-specialised stages, fully unrolled): refill loads fenced by scheduling barriers and skipped
 // past the end of the GEMM.  The table-driven stages keep rolled loops with runtime bounds, where the fences and the
 // extra branch cost more than they give (3.78 -> 4.00 ms on cfg3): they re-request the last chunk instead.
-template <int NB, bool PINNED = false>
+template <int NB, bool PINNED = false, bool R4 = false>
 __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const GemmPlan<NB>& p) {
   constexpr int PD = Ring<NB>::PD;
   const int last = p.kc1 - 1;
@@ -352,7 +383,7 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
 #pragma unroll
     for (int s = 0; s < PD; ++s) {
       const f32x4 bx_next2 = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 2, last) * 16);
-      mfma_chunk<NB>(acc, r.slot[s], bx);
+      mfma_chunk<NB, R4>(acc, r.slot[s], bx);
       // Refill the slot just consumed with chunk kc+s+PD (nothing to fetch past the end of the GEMM).  The scheduling
       // barriers keep the loads HERE: left alone, the scheduler sinks them towards their use and the ring that
       // should hold PD chunks in flight ends up ~2 deep (s_waitcnt vmcnt(2..3) in front of the MFMAs).
@@ -377,7 +408,7 @@ __device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const Ge
   for (int s = 0; s < PD - 1; ++s) {
     if (kc + s < p.kc1) {
       const f32x4 bx_next2 = *reinterpret_cast<const f32x4*>(p.xrow + min(kc + s + 2, last) * 16);
-      mfma_chunk<NB>(acc, r.slot[s], bx);
+      mfma_chunk<NB, R4>(acc, r.slot[s], bx);
       bx = bx_next;
       bx_next = bx_next2;
     }
@@ -602,6 +633,7 @@ struct StaticNet {
   static constexpr int in0p = IN0P, outp = OUTP;
   __host__ __device__ static constexpr UnetDesc desc() { return make_unet_desc_padded(0, IN0P, H0P, H1P, H2P, OUTP); }
   __host__ __device__ static constexpr TileLayout layout(int nw) { return make_tile_layout(desc(), nw); }
+  __host__ __device__ static constexpr TileLayout layout4(int nw) { return make_tile_layout(desc(), nw, 4); }   // 4-row tile
 };
 
 template <int NW, class NET, int SI, typename Hook>
@@ -784,6 +816,172 @@ __device__ __forceinline__ Pre unet_carry_init_static(const float* __restrict__ 
 #pragma unroll
   for (int f = 0; f < 8; ++f) w.pf[f] = w0.pf[f];
   return prefetch_fragments(Wp, sd.Ln, w, lane);
+}
+
+// ---- the 4-row tile (small batches) ---------------------------------------------------------------------------------
+// A training batch of 128 rows is 8 tiles of 16 rows: 8 of 256 CUs work, each through a chain of 2,700 dependent-stage
+// MFMAs per step.  With v_mfma_f32_4x4x1_16b_f32 (see mfma_chunk) the same weight image multiplies a 4-row tile: four
+// times the workgroups, each with half the MFMA time per step.  Constexpr-specialised networks only, every stage either
+// `uniform` (each active wave owns NBc whole neuron blocks) or `slim_split` (one or two blocks, K split over the waves) --
+// which is what the default architecture's six stages are.
+template <int NB, int NW>
+__device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, const float* bias_lds, const LayerDesc& L1,
+                                              const float* X1, int S1, bool has2, const LayerDesc& L2, const float* X2,
+                                              int S2, float* Y, int SY, int blk0, int lane, const Pre& pre) {
+  const int j = lane & 3, ng = (lane >> 2) & 3, kg = lane >> 4;
+  const GemmPlan<NB> p1 = make_plan<NB, true>(Wp, L1, blk0, NW, X1, S1, lane, 0, L1.in_pad >> 4);
+  const GemmPlan<NB> p2 = make_plan<NB, true>(Wp, L2, blk0, NW, X2, S2, lane, 0, L2.in_pad >> 4);
+  Ring<NB> r1, r2;
+  ring_fill<NB, true>(r1, p1, pre);
+  if (has2) ring_fill<NB, false>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
+  // the biases ride in k-group 0's accumulators (the other groups start from zero: kg_sum adds the four)
+  f32x4 acc[NB], acc2[NB];
+  const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_lds + L1.b_lds + (blk0 + b * NW) * 16 + 4 * ng);
+    acc[b] = kg == 0 ? b1 : zero;
+    acc2[b] = zero;
+    if (has2) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(bias_lds + L2.b_lds + (blk0 + b * NW) * 16 + 4 * ng);
+      acc2[b] = kg == 0 ? b2 : zero;
+    }
+  }
+  gemm_run<NB, true, true>(acc, r1, p1);
+  if (has2) gemm_run<NB, true, true>(acc2, r2, p2);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    f32x4 v = kg_sum(acc[b]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = relu_keep_nan(v[c]);
+    if (has2) v += kg_sum(acc2[b]);
+    if (kg == 0) *reinterpret_cast<f32x4*>(Y + j * SY + (blk0 + b * NW) * 16 + 4 * ng) = v;
+  }
+}
+
+template <int NW, class NET, int SI>
+__device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp, float* lds, Pre& c, int wave,
+                                                   float* to_reg = nullptr) {
+  constexpr UnetDesc u = NET::desc();
+  constexpr TileLayout t = NET::layout4(NW);
+  constexpr StageDesc sd = unet_stage_desc(u, t, SI);
+  constexpr int NBLK = sd.L1.out_pad >> 4;
+  constexpr WaveWork wref = wave_work_of(sd, NW, 0);
+  constexpr StageDesc sdn = unet_stage_desc(u, t, (SI + 1) % 6);
+  constexpr int NBLKn = sdn.L1.out_pad >> 4, KCn = sdn.L1.in_pad >> 4;
+  constexpr WaveWork wrefn = wave_work_of(sdn, NW, 0);
+  constexpr bool uniform_next = !wrefn.split && ((NBLKn >= NW && NBLKn % NW == 0 && NBLKn / NW <= 4 && NBLKn / NW != 3) ||
+                                                 (NBLKn < NW));
+  constexpr int KC1 = sd.L1.in_pad >> 4, KC2 = sd.L2.in_pad >> 4;
+  constexpr int PARTS = (NBLK <= 2 && NW % NBLK == 0) ? NW / NBLK : 1;
+  constexpr bool slim_split = wref.split && NBLK <= 2 && NW % NBLK == 0 && KC1 % PARTS == 0 && (KC1 / PARTS) + 1 <= 8 &&
+                              (!sd.has2 || KC2 <= PARTS);
+  constexpr int KC2n = sdn.L2.in_pad >> 4;
+  constexpr int PARTSn = (NBLKn <= 2 && NW % NBLKn == 0) ? NW / NBLKn : 1;
+  constexpr bool slim_split_next = wrefn.split && NBLKn <= 2 && NW % NBLKn == 0 && KCn % PARTSn == 0 &&
+                                   (KCn / PARTSn) + 1 <= 8 && (!sdn.has2 || KC2n <= PARTSn);
+  constexpr bool uniform = !wref.split && ((NBLK >= NW && NBLK % NW == 0 && NBLK / NW <= 4 && NBLK / NW != 3) ||
+                                           (NBLK < NW));
+  static_assert(uniform || slim_split, "4-row tile: this architecture needs the 16-row kernels");
+  static_assert(uniform_next || slim_split_next, "4-row tile: this architecture needs the 16-row kernels");
+  const int lane = threadIdx.x & 63;
+  // (settle the fragments the previous stage requested before this stage issues loads of its own, see unet_stage)
+  asm volatile("" : "+v"(c.f[0]), "+v"(c.f[1]), "+v"(c.f[2]), "+v"(c.f[3]));
+  asm volatile("" : "+v"(c.f[4]), "+v"(c.f[5]), "+v"(c.f[6]), "+v"(c.f[7]));
+  // first ring of the next stage's GEMM 1 (requested before this stage's closing barrier)
+  auto prefetch_next = [&]() {
+    if constexpr (uniform_next) {
+      constexpr int nbn = NBLKn >= NW ? NBLKn / NW : 1;
+      const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + sdn.L1.w_off) + lane;
+      const int wb = min(wave, NBLKn - 1) * KCn;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int kc = (f / nbn) < KCn ? (f / nbn) : KCn - 1;
+        const int boff = ((f % nbn) * NW) * KCn;
+        c.f[f] = wl[(size_t)(wb + boff + kc) * 64];
+      }
+    } else {
+      constexpr int CPWn = KCn / PARTSn;
+      const int bn = wave % NBLKn, pn = wave / NBLKn;
+      const f32x4* w1 = reinterpret_cast<const f32x4*>(Wp + sdn.L1.w_off) + lane;
+#pragma unroll
+      for (int f = 0; f < CPWn; ++f) c.f[f] = w1[(size_t)(bn * KCn + pn * CPWn + f) * 64];
+      if (sdn.has2 && pn < KC2n)
+        c.f[CPWn] = (reinterpret_cast<const f32x4*>(Wp + sdn.L2.w_off) + lane)[(size_t)(bn * KC2n + pn) * 64];
+    }
+  };
+  if constexpr (uniform) {
+    constexpr int NBc = NBLK >= NW ? NBLK / NW : 1;
+    constexpr int nact = NBLK >= NW ? NW : NBLK;
+    if (wave < nact)
+      stage_direct4<NBc, NW>(Wp, lds + t.bias, sd.L1, lds + sd.x1, sd.s1, sd.has2 != 0, sd.L2, lds + sd.x2, sd.s2,
+                             lds + sd.y, sd.sy, wave, lane, c);
+    prefetch_next();
+    __syncthreads();
+  } else {
+    constexpr int CPW = KC1 / PARTS;
+    static_assert(NBLK * 64 <= NW * 64, "the combine needs one thread per output element");
+    const int j = lane & 3, ng = (lane >> 2) & 3, kg = lane >> 4;
+    const int blk = wave % NBLK, part = wave / NBLK;
+    float* P1 = lds + t.scratch;                       // [NBLK][PARTS][4 rows][16]  (NBLK PARTS = NW)
+    float* P2 = P1 + NW * 64;                          // [NBLK][KC2][4 rows][16]
+    {
+      const float* xrow = lds + sd.x1 + j * sd.s1 + 4 * kg + part * (CPW * 16);
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int f = 0; f < CPW; ++f) {
+        const f32x4 a1[1] = {c.f[f]};
+        mfma_chunk<1, true>(acc, a1, *reinterpret_cast<const f32x4*>(xrow + f * 16));
+      }
+      const f32x4 v = kg_sum(acc[0]);
+      if (kg == 0) *reinterpret_cast<f32x4*>(P1 + ((blk * PARTS + part) * 4 + j) * 16 + 4 * ng) = v;
+    }
+    if (sd.has2 && part < KC2) {
+      const float* xrow = lds + sd.x2 + j * sd.s2 + 4 * kg + part * 16;
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      const f32x4 a2[1] = {c.f[CPW]};
+      mfma_chunk<1, true>(acc, a2, *reinterpret_cast<const f32x4*>(xrow));
+      const f32x4 v = kg_sum(acc[0]);
+      if (kg == 0) *reinterpret_cast<f32x4*>(P2 + ((blk * KC2 + part) * 4 + j) * 16 + 4 * ng) = v;
+    }
+    prefetch_next();
+    __syncthreads();
+    const float* bias_lds = lds + t.bias;
+    const int e = threadIdx.x & 63, eb = threadIdx.x >> 6;    // element (r, n) = (e >> 4, e & 15) of block eb
+    float v = 0.f;
+    if (eb < NBLK) {                                   // bias, ReLU, residual
+      const int n = eb * 16 + (e & 15);
+      v = bias_lds[sd.L1.b_lds + n];
+#pragma unroll
+      for (int p = 0; p < PARTS; ++p) v += P1[(eb * PARTS + p) * 64 + e];
+      v = relu_keep_nan(v);
+      if (sd.has2) {
+        float v2 = bias_lds[sd.L2.b_lds + n];
+#pragma unroll
+        for (int p = 0; p < KC2; ++p) v2 += P2[(eb * KC2 + p) * 64 + e];
+        v += v2;
+      }
+    }
+    if (to_reg) {                                      // (16-wide outputs only: thread tid < 64 holds element tid)
+      *to_reg = v;                                     // the caller synchronises before LDS is reused
+    } else {
+      if (eb < NBLK) (lds + sd.y)[(e >> 4) * sd.sy + eb * 16 + (e & 15)] = v;
+      __syncthreads();
+    }
+  }
+}
+
+// X0 (4 rows of [t, x, 0-pad]) -> nabla_V; gv_reg (output width 16): thread tid < 64 gets nabla_V[tid >> 4][tid & 15]
+template <int NW, class NET>
+__device__ __forceinline__ void unet_tile_forward_static4(const float* __restrict__ Wp, float* lds, Pre& c,
+                                                          float* gv_reg = nullptr) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unet_stage_static4<NW, NET, 0>(Wp, lds, c, wave);
+  unet_stage_static4<NW, NET, 1>(Wp, lds, c, wave);
+  unet_stage_static4<NW, NET, 2>(Wp, lds, c, wave);
+  unet_stage_static4<NW, NET, 3>(Wp, lds, c, wave);
+  unet_stage_static4<NW, NET, 4>(Wp, lds, c, wave);
+  unet_stage_static4<NW, NET, 5>(Wp, lds, c, wave, NET::outp == 16 ? gv_reg : nullptr);
 }
 
 #endif  // __HIPCC__
