@@ -35,6 +35,13 @@ import torch.distributed as dist
 SETTING, D, NUM_STEPS, BATCH_PER_GPU, GAMMA = "double_well", 10, 200, 128, 6.0
 HDIMS, HDIMS_M = [256, 128, 64], [128, 128]
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+ROLLOUT_KERNEL_TAG = "rollout4_kernel"   # the headline workload (d = 10, B = 128) runs the 4-row small-batch kernel
+
+
+def rollout_workgroups(d, B):
+    """Workgroups of one rollout launch (csrc/socmx_rollout.hip, rollout_launch): 4-row tiles for sigma = I, d <= 15 and at
+    most 64 tiles of 16 rows, else 16-row tiles."""
+    return (B + 3) // 4 if (d <= 15 and (B + 15) // 16 <= 64) else (B + 15) // 16
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -112,7 +119,7 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
            "socm_ms_per_iter_eager": it_ms_eager, "socm_ms_per_iter_graph": None, "last_loss": float(info["loss"]),
            "rollout_roofline": {"bound": "mfma", "achieved": fl / (roll_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": fl / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                                "active_workgroups": (B + 15) // 16}}
+                                "active_workgroups": rollout_workgroups(d, B)}}
 
     def graph_leg():
         """The same iterations replayed as ONE captured hipGraph (sharded: with the RCCL all-reduces captured inside)."""
@@ -399,7 +406,7 @@ def main():
             try:
                 pm = json.load(open(path))
                 for kname, v in pm.items():
-                    if "rollout_kernel" in kname and "StaticNet<16" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    if ROLLOUT_KERNEL_TAG in kname and "StaticNet<16" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                         traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
                         traffic_src = (os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                        "passes of this command; FETCH_SIZE doubled per the gfx950 note)")
@@ -419,16 +426,17 @@ def main():
             "socm_iters_timed": it_steps, "socm_last_loss": last_loss, "socm_iteration_mode": it_mode,
             "socm_ms_per_iter_eager": 1e3 * it_elapsed_eager / it_steps,
             "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps,
-            "roofline": {"bound": "mfma", "kernel": "socmx::rollout_kernel<8,false,false,StaticNet<16,256,128,64,16>,true>",
+            "roofline": {"bound": "mfma", "kernel": "socmx::rollout4_kernel<8,false,StaticNet<16,256,128,64,16>>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "B=128 gives 8 row tiles: at most 8 of 256 CUs can work (frac <= 0.031 by construction); "
-                                 "see roofline_full_chip for the same kernel with 4096 workgroups",
+                         "note": "B=128 is 32 tiles of 4 rows (the small-batch kernel, v_mfma_f32_4x4x1_16b_f32 at half the "
+                                 "16x16x4 rate per MAC): 32 of 256 CUs work, frac <= 32/256/2 = 0.0625 by construction; "
+                                 "see roofline_full_chip for the 16-row kernel with 4096 workgroups",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": byts,
                          "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,
                          "hbm_frac": byts / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                         "active_workgroups": (B + 15) // 16, "cus": 256},
+                         "active_workgroups": rollout_workgroups(d, B), "cus": 256},
         }
         if burst is not None:
             line["roofline_full_chip"] = burst

@@ -1321,3 +1321,55 @@ def test_architecture_variant_library_matches_the_generic_kernels(hdims):
     with torch.no_grad():
         ref = O.unet_forward(vp, tx).reshape(K + 1, B, d).numpy()
     np.testing.assert_allclose(_np(got[8]), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_both_rollout_tile_shapes_pass_the_reference_fixtures():
+    """Small batches run the 4-row kernel (rollout4_kernel, v_mfma_f32_4x4x1_16b_f32), larger ones the 16-row kernel; every
+    fixture above has a small batch.  The developer switch SOCMX_TILE_ROWS=16 (read once per process) sends the same
+    fixtures through the 16-row kernel, SOCMX_TILE_ROWS=4 through the 4-row one wherever it applies, and the rollout must
+    agree with the oracle and the reference-generated states either way."""
+    import subprocess, sys
+    for rows in ("16", "4"):
+        env = dict(os.environ, SOCMX_TILE_ROWS=rows)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                            "test_rollout_kernel_vs_oracle_and_golden or test_rollout_hands_over_nabla_V or "
+                            "test_keyed_rollout"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (rows, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_four_row_and_sixteen_row_rollouts_agree_row_by_row():
+    """The same Philox rows through both tile shapes: B = 1024 (64 tiles of 16 rows: 4-row kernel) against the same rows
+    inside a B = 2048 launch (16-row kernel).  A row's trajectory does not depend on which kernel integrates it beyond
+    fp32 summation order in the network (k-groups are added last on the 4-row tile)."""
+    from SOC_matching import utils
+    sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+    ts = aux["ts"][:41]
+    torch.manual_seed(5)
+    x0 = torch.randn(2048, aux["x0"].shape[-1], device=DEV) * 0.5
+    small = utils.stochastic_trajectories(sde, x0[:1024], ts, aux["lmbd"], seed=11, offset=3)
+    big = utils.stochastic_trajectories(sde, x0, ts, aux["lmbd"], seed=11, offset=3)
+    torch.cuda.synchronize()
+    assert torch.equal(small[1], big[1][:, :1024])                      # the noise is keyed by (row, step): identical
+    np.testing.assert_allclose(_np(small[0]), _np(big[0][:, :1024]), rtol=0, atol=5e-4)
+    for i in (4, 5, 6):                                                 # lpd, lps, ltw
+        np.testing.assert_allclose(_np(small[i]), _np(big[i][:1024]), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(_np(small[7]), _np(big[7][:, :1024]), rtol=0, atol=5e-4)
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 18])
+def test_four_row_rollout_ragged_batches(B):
+    """4-row tiles (default widths, d <= 15, small batch): every tail size gives the oracle's rows."""
+    from SOC_matching import utils
+    name = "cfg1_ou_quadratic_easy_d2_K50"
+    sde, aux = build_sde(name, DEV)
+    pb, vp, mp, gamma, oaux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    K, d = 12, aux["d"]
+    ts = aux["ts"][: K + 1]
+    g = torch.Generator().manual_seed(100 + B)
+    noise = torch.randn(K, B, d, generator=g)
+    x0 = 0.3 * torch.randn(B, d, generator=g)
+    with torch.no_grad():
+        want = O.stochastic_trajectories(pb, vp, x0, oaux["ts"][: K + 1], aux["lmbd"], noise)
+    got = utils.stochastic_trajectories(sde, x0.to(DEV), ts, aux["lmbd"], noise_in=noise.to(DEV))
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(_np(a), b.numpy(), rtol=1e-4, atol=1e-4)

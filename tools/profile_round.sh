@@ -13,14 +13,14 @@ CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-burst"
 # the counter passes see the headline configuration only (the secondary configurations launch the same kernel template with
 # other shapes; their dispatches would be averaged into the per-launch traffic that bench.py reads back)
 PMC_CMD="$CMD --no-secondary"
-KERNELS="rollout_kernel|rollout_ctrl|socm_|stopping_|colsum|weights_stats|unet_bwd|unet_wgrad|mnet_"
+KERNELS="rollout_kernel|rollout4_kernel|rollout_ctrl|socm_|stopping_|colsum|weights_stats|unet_bwd|unet_wgrad|mnet_"
 # kernel_stats.csv: the headline configuration alone, so that the rollout kernel's AVERAGE is the number bench.py reports as
 # roofline.kernel_ms; kernel_stats_full.csv: the whole default command (secondary configurations included)
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o $RND -- $PMC_CMD > $OUT/trace_bench.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_full -o $RND -- $CMD > $OUT/trace_full.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KERNELS" -f csv -d $OUT/pmc_fetch -o $RND -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KERNELS" -f csv -d $OUT/pmc_write -o $RND -- $PMC_CMD > $OUT/pmc_write.log 2>&1
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-include-regex "rollout_kernel|unet_bwd|unet_wgrad_kernel" -f csv -d $OUT/pmc_sq -o $RND -- $PMC_CMD > $OUT/pmc_sq.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-include-regex "rollout_kernel|rollout4_kernel|unet_bwd|unet_wgrad_kernel" -f csv -d $OUT/pmc_sq -o $RND -- $PMC_CMD > $OUT/pmc_sq.log 2>&1
 python3 tools/summarize_profile.py $OUT $R > $R/summarize.log 2>&1
 f=$(find $OUT/trace_full -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/kernel_stats_full.csv
 python3 bench.py > $R/bench.json 2> $R/bench.err
