@@ -930,6 +930,219 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
   }
 }
 
+// sum over the 64 lanes of a wave; every lane ends with the total (row sums by DPP, rows by the gfx950 swaps of kg_sum)
+__device__ __forceinline__ float wave64_sum(float v) {
+  float a = row16_sum(v), t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %1\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_add_f32 %0, %0, %1"
+      : "+v"(a), "=&v"(t));
+  return a;
+}
+
+constexpr int kRow4Stride = 68;   // floats per row vector of the general 4-row step (d <= 64, 16-byte aligned rows)
+
+// y_i = sum_j M[i][j] v_j for lane i (row-major M with row stride ds in LDS, v a zero-padded row vector in LDS)
+__device__ __forceinline__ float matvec_rows(const float* M, int ds, int ic, const float* v, int d) {
+  float s0 = 0.f, s1 = 0.f;
+  const float* m = M + ic * ds;
+  for (int j = 0; j < d; j += 4) {                      // (columns d .. d+3 of M's rows: the next row or the zero pad, times 0)
+    const f32x4 x = *reinterpret_cast<const f32x4*>(v + j);
+    s0 += m[j] * x[0] + m[j + 2] * x[2];
+    s1 += m[j + 1] * x[1] + m[j + 3] * x[3];
+  }
+  return s0 + s1;
+}
+// y_i = sum_j M[j][i] v_j (the transpose's rows: lane i walks column i)
+__device__ __forceinline__ float matvec_cols(const float* M, int ds, int ic, const float* v, int d) {
+  float s0 = 0.f, s1 = 0.f;
+  const float* m = M + ic;
+  for (int j = 0; j < d; j += 4) {                      // (rows d .. d+3 are zero: the matrices are stored with padded rows)
+    const f32x4 x = *reinterpret_cast<const f32x4*>(v + j);
+    s0 += m[j * ds] * x[0] + m[(j + 2) * ds] * x[2];
+    s1 += m[(j + 1) * ds] * x[1] + m[(j + 3) * ds] * x[3];
+  }
+  return s0 + s1;
+}
+
+// The general step (any sigma, d <= 64) on a 4-row tile: wave r < 4 owns row r, lane i component i -- the matrix
+// products are 64-term dot products per lane with the row vectors broadcast from LDS (4 rows are no MFMA tile), row sums
+// are wave sums, and nothing inside the step needs a workgroup barrier.  Waves 4..7 draw the next step's noise.
+template <int NW, bool STOPPING, class NET>
+__global__ __launch_bounds__(NW * 64) void rollout4g_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(NW == 8, "four integrating waves, four noise waves");
+  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+  constexpr TileLayout tl = NET::layout4(NW);
+  constexpr UnetDesc ud = NET::desc();
+  constexpr int RS = kRow4Stride;
+  const int tid = threadIdx.x;
+  constexpr int nthr = NW * 64;
+  const int d = a.d, B = a.B, K = a.K, kind = a.kind;
+  const int tile_row0 = blockIdx.x * 4;
+  float* X0 = lds + tl.x0;
+  const float* GV = lds + tl.gv;
+  const int ds = socmx_sde_stride(d), dp = (d + 3) & ~3;
+  const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
+  const bool is_quad = kind == SOCMX_OU_QUADRATIC;
+  const bool sid = a.sigma_identity != 0;
+  float* sig = lds + a.lds_mats;                        // (dp, ds)  dense sigma only
+  float* A_l = sig + (sid ? 0 : dp * ds);               // (dp, ds)  OU only
+  float* P_l = A_l + (is_ou ? dp * ds : 0);             // (dp, ds)  OU_quadratic only
+  const int mats4 = (sid ? 0 : 1) + (is_ou ? 1 : 0) + (is_quad ? 1 : 0);
+  float* XS = sig + ((mats4 * dp * ds + 3) & ~3);       // (4, RS) row vectors, 16-byte aligned: state ...
+  float* XN = XS + 4 * RS;                              // ... state at the end of the step (x' P x)
+  float* U = XN + 4 * RS;                               // ... control
+  float* E0 = U + 4 * RS;                               // ... noise of the even steps
+  float* E1 = E0 + 4 * RS;                              // ... and of the odd ones (drawn one step ahead)
+  for (float* z = lds + tid; z < E1 + 4 * RS; z += nthr) *z = 0.f;
+  __syncthreads();
+  for (int e = tid; e < d * d; e += nthr) {
+    const int r = e / d, c = e - r * d;
+    if (!sid) sig[r * ds + c] = a.sigma[e];
+    if (is_ou) A_l[r * ds + c] = a.A[e];
+    if (is_quad) P_l[r * ds + c] = a.P[e];
+  }
+  unet_load_biases(a.packed, ud, tl, lds, tid, nthr);
+  Pre carry = unet_carry_init_static<NW, NET>(a.packed);
+
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = tid & 63;
+  const bool act = wave < 4;
+  const int r = wave & 3;
+  const int ic = min(i, d - 1);
+  const bool lane_ok = act && i < d;
+  const int grow = tile_row0 + r;
+  const bool traj = a.states != nullptr;          // costs-only launches (evaluation bursts) pass no trajectory buffers
+  const bool store = lane_ok && grow < B && traj;
+  const bool store0 = act && i == 0 && grow < B && traj;
+  const size_t rowoff = (size_t)grow * d + i;
+  float x = lane_ok ? a.x0[(size_t)min(grow, B - 1) * d + i] : 0.f;
+  const float kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
+  float stop = 1.f, lpd = 0.f, lps = 0.f;
+  if (store) a.states[rowoff] = x;
+  if (store0) a.stop_ind[grow] = 1.f;
+  if (lane_ok) { X0[r * tl.s0 + 1 + i] = x; XS[r * RS + i] = x; }
+  if (act && i == 0) X0[r * tl.s0] = a.ts[0];
+  // noise: lane p of wave 4 + r draws the Box-Muller pair (2p, 2p + 1) of row r (the 16-row kernel's draws)
+  const bool producer = !act && i < ((d + 1) >> 1);
+  auto draw = [&](int k, float* Eb) {
+    if (!producer || k >= K) return;
+    float z0, z1;
+    const int c0 = 2 * i;
+    if (a.noise_in) {
+      const float* src = a.noise_in + ((size_t)k * B + min(grow, B - 1)) * d;
+      z0 = src[c0];
+      z1 = c0 + 1 < d ? src[c0 + 1] : 0.f;
+    } else {
+      philox_normal2(key_seed, key_offset, (uint32_t)(a.row0 + grow), (uint32_t)k, i >> 1, i & 1, z0, z1);
+    }
+    Eb[r * RS + c0] = z0;
+    if (c0 + 1 < d) Eb[r * RS + c0 + 1] = z1;
+    if (grow < B && traj) {
+      float* dst = a.noises + ((size_t)k * B + grow) * d;
+      dst[c0] = z0;
+      if (c0 + 1 < d) dst[c0 + 1] = z1;
+    }
+  };
+  draw(0, E0);
+  for (int k = 0; k < K; ++k) {
+    const float t0 = a.ts[k], t1 = a.ts[k + 1];
+    const float dt = t1 - t0;                 // utils.py:38
+    const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
+    __syncthreads();
+    unet_tile_forward_static4<NW, NET>(a.packed, lds, carry);                // GV = nabla_V(t, x); ends behind a barrier
+    const float* E = (k & 1) ? E1 : E0;
+    float* En = (k & 1) ? E0 : E1;
+    if (act) {
+      const float gv = GV[r * tl.sg + ic];
+      if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
+      // u = -sigma^T nabla_V (method.py:68-72)
+      float u = sid ? -gv : -matvec_cols(sig, ds, ic, GV + r * tl.sg, d);
+      if (!lane_ok) u = 0.f;
+      const float eps = E[r * RS + ic];                                  // drawn during the previous step (0 past d)
+      float su = u, se = lane_ok ? eps : 0.f;
+      if (!sid) {
+        U[r * RS + i] = u;                                               // (lanes >= d write the zero pad)
+        __builtin_amdgcn_wave_barrier();
+        su = matvec_rows(sig, ds, ic, U + r * RS, d);
+        se = matvec_rows(sig, ds, ic, E + r * RS, d);
+      }
+      float bi;
+      if (is_ou) bi = matvec_rows(A_l, ds, ic, XS + r * RS, d);          // b = A x
+      else bi = -2.f * kap * (x * x - 1.f) * 2.f * x;                    // double_well.py:44-48
+      const float upd = lane_ok ? (bi + su) * dt + sq_ldt * se : 0.f;    // utils.py:45-47
+      const float xn = x + stop * upd;                                   // utils.py:48
+      float xe = xn, step = dt, stop_new = 1.f;
+      if (STOPPING) {                                                    // utils.py:42-44, 49-75; Phi = -x_0
+        const float phi_b = -__shfl(x, 0, 64), phi_a = -__shfl(xn, 0, 64);
+        const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
+        const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
+        const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
+        xe = js * (x + fr * stop * upd) + (1.f - js) * xn;
+        step = js * (fr * fr) * dt + ns * dt;                            // step_fraction squared (utils.py:70-72)
+        stop_new = (-__shfl(xe, 0, 64) > 0.f) ? 1.f : 0.f;
+      }
+      float f = 0.f;                                                     // f at the NEW state, OLD time (utils.py:92-96)
+      if (is_quad) {
+        XN[r * RS + i] = lane_ok ? xe : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const float px = matvec_rows(P_l, ds, ic, XN + r * RS, d);
+        f = wave64_sum(lane_ok ? xe * px : 0.f);
+      } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
+        f = 1.f;
+      }
+      const float uu = wave64_sum(u * u), ue = wave64_sum(lane_ok ? u * eps : 0.f);
+      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
+      lps = lps + sqrtf(step / a.lmbd) * (-ue);
+      if (store) {
+        a.controls[(size_t)k * B * d + rowoff] = u;
+        a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
+      }
+      if (store0) {
+        a.frac[(size_t)k * B + grow] = step;
+        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? stop_new : 1.f;
+      }
+      x = lane_ok ? xe : 0.f;
+      if (STOPPING) stop = stop_new;
+      if (lane_ok) { X0[r * tl.s0 + 1 + i] = x; XS[r * RS + i] = x; }    // next step's network input [t, x, 0..]
+      if (i == 0) X0[r * tl.s0] = t1;
+    } else {
+      draw(k + 1, En);
+    }
+  }
+  if (a.nabla_v) {                        // nabla_V(T, X_K): X0 already holds [t_K, x_K] (written at the end of the last step)
+    __syncthreads();
+    unet_tile_forward_static4<NW, NET>(a.packed, lds, carry);
+    if (store) a.nabla_v[(size_t)K * B * d + rowoff] = GV[r * tl.sg + ic];
+  }
+  if (act) {                                                            // terminal cost (utils.py:101)
+    float part = 0.f;
+    if (kind == SOCMX_OU_QUADRATIC) {
+      float qx = 0.f;
+      for (int j = 0; j < d; ++j) qx += a.Q[ic * d + j] * XS[r * RS + j];
+      part = lane_ok ? x * qx : 0.f;
+    } else if (kind == SOCMX_OU_LINEAR) {
+      part = lane_ok ? a.omega[ic] * x : 0.f;
+    } else if (kind == SOCMX_DOUBLE_WELL) {
+      const float q = x * x - 1.f;
+      part = lane_ok ? a.nu[ic] * (q * q) : 0.f;
+    }
+    const float gval = wave64_sum(part);
+    if (i == 0 && grow < B) {
+      a.lpd[grow] = lpd;
+      a.lps[grow] = lps;
+      a.ltw[grow] = -gval / a.lmbd;
+    }
+  }
+}
+
 struct ForwardArgs {
   UnetDesc u;
   TileLayout t;
@@ -1170,14 +1383,27 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   else if (nw == 4) SOCMX_PICK(4, DynamicNet);
   else SOCMX_PICK(8, DynamicNet);
 #undef SOCMX_PICK
-  // Small batches (at most 64 tiles of 16 rows: a quarter of the CUs), default widths, sigma = I, d <= 15: 4-row tiles,
-  // B / 4 workgroups (rollout4_kernel).  SOCMX_TILE_ROWS=16 / 4 (developer A/B switch, read once) forces one form.
+  // Small batches (at most 64 tiles of 16 rows: a quarter of the CUs), the constexpr-specialised widths, d <= 64: 4-row
+  // tiles, B / 4 workgroups -- rollout4_kernel for sigma = I and d <= 15, rollout4g_kernel for everything else.
+  // SOCMX_TILE_ROWS=16 / 4 (developer A/B switch, read once) forces one form.
   static const int force_rows = [] { const char* e = getenv("SOCMX_TILE_ROWS"); return e ? atoi(e) : 0; }();
-  if (is_default && fast && !prof && force_rows != 16 && (blocks <= 64 || force_rows == 4)) {
-    constexpr TileLayout t4 = DefaultNet::layout4(8);
+  if ((is_default || is_wide32 || is_wide64) && !prof && d <= 64 && force_rows != 16 && (blocks <= 64 || force_rows == 4)) {
+    const TileLayout t4 = is_default ? DefaultNet::layout4(8) : is_wide32 ? Wide32Net::layout4(8) : Wide64Net::layout4(8);
     a.lds_mats = (t4.floats + 3) & ~3;
-    const size_t floats4 = (size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 128;
-    void (*k4)(const RolloutArgs) = stopping ? rollout4_kernel<8, true, DefaultNet> : rollout4_kernel<8, false, DefaultNet>;
+    void (*k4)(const RolloutArgs);
+    size_t floats4;
+    if (is_default && fast) {
+      floats4 = (size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 128;
+      k4 = stopping ? rollout4_kernel<8, true, DefaultNet> : rollout4_kernel<8, false, DefaultNet>;
+    } else {
+      const size_t dp = (size_t)((d + 3) & ~3);
+      const int mats4 = (a.sigma_identity ? 0 : 1) + (ou ? 1 : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? 1 : 0);
+      floats4 = (size_t)a.lds_mats + ((mats4 * dp * sds + 3) & ~(size_t)3) + 5 * 4 * kRow4Stride;
+      if (is_default) k4 = stopping ? rollout4g_kernel<8, true, DefaultNet> : rollout4g_kernel<8, false, DefaultNet>;
+      else if (is_wide32) k4 = stopping ? rollout4g_kernel<8, true, Wide32Net> : rollout4g_kernel<8, false, Wide32Net>;
+      else k4 = stopping ? rollout4g_kernel<8, true, Wide64Net> : rollout4g_kernel<8, false, Wide64Net>;
+    }
+    if (floats4 * sizeof(float) > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
     if (const int err = ensure_max_lds(k4)) return err;
     const int blocks4 = (B + 3) / 4;
     // (one workgroup per CU while there are CUs left: the whole LDS)
