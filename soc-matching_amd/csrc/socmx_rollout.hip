@@ -1234,7 +1234,8 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
 #define SOCMX_STR2(x) #x
 #define SOCMX_STR(x) SOCMX_STR2(x)
   static const char msg[] =
-      "socmx 0.1.3; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network; "
+      "socmx 0.1.3; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
+      "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches); "
       "Philox4x32-10 noise; static_hdims=" SOCMX_STR(SOCMX_H0P) "," SOCMX_STR(SOCMX_H1P) "," SOCMX_STR(SOCMX_H2P) "; "
       "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target";
   const int need = (int)sizeof(msg);
