@@ -39,9 +39,10 @@ ROLLOUT_KERNEL_TAG = "rollout4_kernel"   # the headline workload (d = 10, B = 12
 
 
 def rollout_workgroups(d, B):
-    """Workgroups of one rollout launch (csrc/socmx_rollout.hip, rollout_launch): 4-row tiles for sigma = I, d <= 15 and at
-    most 64 tiles of 16 rows, else 16-row tiles."""
-    return (B + 3) // 4 if (d <= 15 and (B + 15) // 16 <= 64) else (B + 15) // 16
+    """Workgroups of one rollout launch (csrc/socmx_rollout.hip, rollout_launch): 4-row tiles for at most 64 tiles of 16 rows
+    (16 at d >= 32), else 16-row tiles."""
+    t16 = (B + 15) // 16
+    return (B + 3) // 4 if (d <= 64 and (t16 <= 16 or (t16 <= 64 and d <= 31))) else t16
 PEAK_HBM_GBPS = 8000.0
 
 

@@ -791,6 +791,8 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
 // v_mfma_f32_4x4x1_16b_f32 (socmx_unet.h, unet_tile_forward_static4) from the same packed image.  B / 4 workgroups instead
 // of B / 16 -- a training batch of 128 rows works on 32 CUs instead of 8 -- and half the MFMA time per step and tile.
 // Wave 0 integrates (thread = (row r, component i), 64 threads), wave 1 draws the next step's noise.
+// The 4-row tiles leave ~135 KiB of the CU's LDS free: stage 4's GEMM-1 layer (up_1, 128 KiB at the default widths, a fifth of
+// the 689 KB a step streams) is copied there once and read from there every step (r4_resident_stage, socmx_unet.h).
 template <int NW, bool STOPPING, class NET>
 __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -810,6 +812,16 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
   float* P_l = A_l + (is_ou ? d * ds : 0);              // (d, ds)   OU_quadratic only
   float* NZ = P_l + (is_quad ? d * ds : 0);             // (2, 4, 16) double-buffered noise of steps k, k + 1
   for (float* z = lds + tid; z < NZ + 128; z += nthr) *z = 0.f;       // (tiles' padding columns stay zero for good)
+  // the resident layer's fragment image, 16-byte aligned behind the small state
+  constexpr int kResidentStage = r4_resident_stage<NW, NET>();
+  constexpr StageDesc sd_res = unet_stage_desc(ud, tl, 4);
+  constexpr int res_floats = r4_resident_floats<NW, NET>();
+  float* RES = lds + ((a.lds_mats + (is_ou ? d * ds : 0) + (is_quad ? d * ds : 0) + 128 + 3) & ~3);
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + sd_res.L1.w_off);
+    f32x4* dst = reinterpret_cast<f32x4*>(RES);
+    for (int e = tid; e < res_floats / 4; e += nthr) dst[e] = src[e];
+  }
   __syncthreads();
   for (int e = tid; e < d * d; e += nthr) {
     const int r = e / d, c = e - r * d;
@@ -852,7 +864,7 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
     __syncthreads();
     float gv = 0.f;                           // nabla_V[r][i] of this thread
-    unet_tile_forward_static4<NW, NET>(a.packed, lds, carry, &gv);           // last stage -> register, no barrier
+    unet_tile_forward_static4<NW, NET, kResidentStage>(a.packed, lds, carry, &gv, RES);   // last stage -> register, no barrier
     if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
     if (act) {
       const float u = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
@@ -907,7 +919,7 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
   if (a.nabla_v) {                        // nabla_V(T, X_K): X0 already holds [t_K, x_K] (written at the end of the last step)
     __syncthreads();
     float gv = 0.f;
-    unet_tile_forward_static4<NW, NET>(a.packed, lds, carry, &gv);
+    unet_tile_forward_static4<NW, NET, kResidentStage>(a.packed, lds, carry, &gv, RES);
     if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
   }
   if (act) {                                                            // terminal cost (utils.py:101)
@@ -1303,6 +1315,24 @@ extern "C" int socmx_unet_forward_f32(const float* packed, int32_t d, const int3
   return launch(kern, dim3((unsigned)blocks), dim3(nw * 64), lds_bytes, stream, a);
 }
 
+// the 4-row kernel of a constexpr-specialised architecture, if its stages fit the 4-row forms (variant builds of other
+// hidden widths may not: then the 16-row kernels run)
+template <class NET>
+static bool r4_pick(bool fast_form, bool stopping, void (**k)(const RolloutArgs)) {
+  if constexpr (r4_supported<8, NET>()) {
+    if constexpr (NET::outp == 16) {
+      if (fast_form) {
+        *k = stopping ? rollout4_kernel<8, true, NET> : rollout4_kernel<8, false, NET>;
+        return true;
+      }
+    }
+    *k = stopping ? rollout4g_kernel<8, true, NET> : rollout4g_kernel<8, false, NET>;
+    return true;
+  } else {
+    return false;
+  }
+}
+
 static int rollout_launch(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3], const float* x0,
                           const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed, uint64_t offset,
                           const uint64_t* key_dev, float* nabla_v, int64_t row0, const float* noise_in, float* states,
@@ -1384,32 +1414,38 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   else if (nw == 4) SOCMX_PICK(4, DynamicNet);
   else SOCMX_PICK(8, DynamicNet);
 #undef SOCMX_PICK
-  // Small batches (at most 64 tiles of 16 rows: a quarter of the CUs), the constexpr-specialised widths, d <= 64: 4-row
-  // tiles, B / 4 workgroups -- rollout4_kernel for sigma = I and d <= 15, rollout4g_kernel for everything else.
+  // Small batches (at most 64 tiles of 16 rows: a quarter of the CUs; 16 at d >= 32), the constexpr-specialised widths,
+  // d <= 64: 4-row tiles, B / 4 workgroups -- rollout4_kernel for sigma = I and d <= 15, rollout4g_kernel for everything else.
   // SOCMX_TILE_ROWS=16 / 4 (developer A/B switch, read once) forces one form.
   static const int force_rows = [] { const char* e = getenv("SOCMX_TILE_ROWS"); return e ? atoi(e) : 0; }();
-  if ((is_default || is_wide32 || is_wide64) && !prof && d <= 64 && force_rows != 16 && (blocks <= 64 || force_rows == 4)) {
-    const TileLayout t4 = is_default ? DefaultNet::layout4(8) : is_wide32 ? Wide32Net::layout4(8) : Wide64Net::layout4(8);
-    a.lds_mats = (t4.floats + 3) & ~3;
-    void (*k4)(const RolloutArgs);
-    size_t floats4;
-    if (is_default && fast) {
-      floats4 = (size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 128;
-      k4 = stopping ? rollout4_kernel<8, true, DefaultNet> : rollout4_kernel<8, false, DefaultNet>;
-    } else {
-      const size_t dp = (size_t)((d + 3) & ~3);
-      const int mats4 = (a.sigma_identity ? 0 : 1) + (ou ? 1 : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? 1 : 0);
-      floats4 = (size_t)a.lds_mats + ((mats4 * dp * sds + 3) & ~(size_t)3) + 5 * 4 * kRow4Stride;
-      if (is_default) k4 = stopping ? rollout4g_kernel<8, true, DefaultNet> : rollout4g_kernel<8, false, DefaultNet>;
-      else if (is_wide32) k4 = stopping ? rollout4g_kernel<8, true, Wide32Net> : rollout4g_kernel<8, false, Wide32Net>;
-      else k4 = stopping ? rollout4g_kernel<8, true, Wide64Net> : rollout4g_kernel<8, false, Wide64Net>;
+  // (d >= 32 with more than 256 rows -- one GPU's slice of BASELINE configs[4] -- keeps the 16-row tiles: there the loss side of
+  //  an iteration fills the chip for longer than the rollout runs beside it, and the 4-row form's 4x CUs at half the MFMA rate
+  //  per MAC cost more than its shorter latency gives: slice iteration 21.2 ms with 4-row tiles, 19.9 with 16-row ones)
+  const bool small4 = blocks <= 16 || (blocks <= 64 && d <= 31);
+  if ((is_default || is_wide32 || is_wide64) && !prof && d <= 64 && force_rows != 16 && (small4 || force_rows == 4)) {
+    void (*k4)(const RolloutArgs) = nullptr;
+    const bool fast4 = is_default && fast;
+    const bool have4 = is_default ? r4_pick<DefaultNet>(fast4, stopping, &k4)
+                     : is_wide32 ? r4_pick<Wide32Net>(false, stopping, &k4) : r4_pick<Wide64Net>(false, stopping, &k4);
+    if (have4) {
+      const TileLayout t4 = is_default ? DefaultNet::layout4(8) : is_wide32 ? Wide32Net::layout4(8) : Wide64Net::layout4(8);
+      a.lds_mats = (t4.floats + 3) & ~3;
+      size_t floats4;
+      if (fast4) {
+        floats4 = (((size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 128 + 3) & ~(size_t)3) +
+                  (size_t)r4_resident_floats<8, DefaultNet>();
+      } else {
+        const size_t dp = (size_t)((d + 3) & ~3);
+        const int mats4 = (a.sigma_identity ? 0 : 1) + (ou ? 1 : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? 1 : 0);
+        floats4 = (size_t)a.lds_mats + ((mats4 * dp * sds + 3) & ~(size_t)3) + 5 * 4 * kRow4Stride;
+      }
+      if (floats4 * sizeof(float) > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
+      if (const int err = ensure_max_lds(k4)) return err;
+      const int blocks4 = (B + 3) / 4;
+      // (one workgroup per CU while there are CUs left: the whole LDS)
+      const size_t lds4 = blocks4 <= 256 ? (size_t)kMaxLdsBytes : floats4 * sizeof(float);
+      return launch(k4, dim3(blocks4), dim3(8 * 64), lds4, stream, a);
     }
-    if (floats4 * sizeof(float) > (size_t)kMaxLdsBytes) return SOCMX_E_LDS;
-    if (const int err = ensure_max_lds(k4)) return err;
-    const int blocks4 = (B + 3) / 4;
-    // (one workgroup per CU while there are CUs left: the whole LDS)
-    const size_t lds4 = blocks4 <= 256 ? (size_t)kMaxLdsBytes : floats4 * sizeof(float);
-    return launch(k4, dim3(blocks4), dim3(8 * 64), lds4, stream, a);
   }
   if (const int err = ensure_max_lds(kern)) return err;
   // Few row tiles (a training batch: B / 16 workgroups on a 256-CU chip): claim the CU's whole LDS, so that no workgroup

@@ -824,16 +824,53 @@ __device__ __forceinline__ Pre unet_carry_init_static(const float* __restrict__ 
 // times the workgroups, each with half the MFMA time per step.  Constexpr-specialised networks only, every stage either
 // `uniform` (each active wave owns NBc whole neuron blocks) or `slim_split` (one or two blocks, K split over the waves) --
 // which is what the default architecture's six stages are.
-template <int NB, int NW>
+// can the 4-row stages run this architecture with NW waves?  (every stage uniform or slim_split, see unet_stage_static4)
+__host__ __device__ constexpr bool r4_stage_ok(const StageDesc& sd, int NW) {
+  const int NBLK = sd.L1.out_pad >> 4, KC1 = sd.L1.in_pad >> 4, KC2 = sd.L2.in_pad >> 4;
+  const bool split = !(NBLK >= NW || NBLK >= kSimds);
+  const int PARTS = (NBLK <= 2 && NW % NBLK == 0) ? NW / NBLK : 1;
+  const bool slim = split && NBLK <= 2 && NW % NBLK == 0 && KC1 % PARTS == 0 && (KC1 / PARTS) + 1 <= 8 && (!sd.has2 || KC2 <= PARTS);
+  const bool uniform = !split && ((NBLK >= NW && NBLK % NW == 0 && NBLK / NW <= 4 && NBLK / NW != 3) || (NBLK < NW));
+  return uniform || slim;
+}
+template <int NW, class NET>
+__host__ __device__ constexpr bool r4_supported() {
+  for (int si = 0; si < 6; ++si)
+    if (!r4_stage_ok(unet_stage_desc(NET::desc(), NET::layout4(NW), si), NW)) return false;
+  return true;
+}
+// the stage whose GEMM-1 layer the 4-row FAST kernel keeps resident in LDS (-1: none -- it must be a uniform two-GEMM stage
+// and leave room for the tiles: 132 KiB at most)
+template <int NW, class NET>
+__host__ __device__ constexpr int r4_resident_stage() {
+  const StageDesc sd = unet_stage_desc(NET::desc(), NET::layout4(NW), 4);
+  const int NBLK = sd.L1.out_pad >> 4;
+  const bool uniform = (NBLK >= NW && NBLK % NW == 0 && NBLK / NW <= 4 && NBLK / NW != 3) || (NBLK < NW && NBLK >= kSimds);
+  return (uniform && sd.has2 && sd.L1.in_pad * sd.L1.out_pad <= 33 * 1024) ? 4 : -1;
+}
+template <int NW, class NET>
+__host__ __device__ constexpr int r4_resident_floats() {
+  const StageDesc sd = unet_stage_desc(NET::desc(), NET::layout4(NW), 4);
+  return r4_resident_stage<NW, NET>() < 0 ? 0 : sd.L1.in_pad * sd.L1.out_pad;
+}
+
+// W1LDS: GEMM 1's weights are RESIDENT in LDS (w1lds: the layer's fragment image, copied once per launch) -- its fragments
+// are read where they are used and `pre` carries the first ring of GEMM 2 instead (see unet_stage_static4).
+template <int NB, int NW, bool W1LDS = false>
 __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, const float* bias_lds, const LayerDesc& L1,
                                               const float* X1, int S1, bool has2, const LayerDesc& L2, const float* X2,
-                                              int S2, float* Y, int SY, int blk0, int lane, const Pre& pre) {
+                                              int S2, float* Y, int SY, int blk0, int lane, const Pre& pre,
+                                              const float* w1lds = nullptr) {
   const int j = lane & 3, ng = (lane >> 2) & 3, kg = lane >> 4;
   const GemmPlan<NB> p1 = make_plan<NB, true>(Wp, L1, blk0, NW, X1, S1, lane, 0, L1.in_pad >> 4);
   const GemmPlan<NB> p2 = make_plan<NB, true>(Wp, L2, blk0, NW, X2, S2, lane, 0, L2.in_pad >> 4);
   Ring<NB> r1, r2;
-  ring_fill<NB, true>(r1, p1, pre);
-  if (has2) ring_fill<NB, false>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
+  if constexpr (W1LDS) {
+    ring_fill<NB, true>(r2, p2, pre);
+  } else {
+    ring_fill<NB, true>(r1, p1, pre);
+    if (has2) ring_fill<NB, false>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
+  }
   // the biases ride in k-group 0's accumulators (the other groups start from zero: kg_sum adds the four)
   f32x4 acc[NB], acc2[NB];
   const f32x4 zero{0.f, 0.f, 0.f, 0.f};
@@ -847,7 +884,19 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
       acc2[b] = kg == 0 ? b2 : zero;
     }
   }
-  gemm_run<NB, true, true>(acc, r1, p1);
+  if constexpr (W1LDS) {
+    const int KC = L1.in_pad >> 4;
+    const f32x4* wl = reinterpret_cast<const f32x4*>(w1lds) + lane;
+#pragma unroll 4
+    for (int kc = 0; kc < KC; ++kc) {
+      f32x4 a[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) a[b] = wl[((blk0 + b * NW) * KC + kc) * 64];
+      mfma_chunk<NB, true>(acc, a, *reinterpret_cast<const f32x4*>(p1.xrow + kc * 16));
+    }
+  } else {
+    gemm_run<NB, true, true>(acc, r1, p1);
+  }
   if (has2) gemm_run<NB, true, true>(acc2, r2, p2);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -859,9 +908,10 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
   }
 }
 
-template <int NW, class NET, int SI>
+// RES_SI: the stage (or -1) whose GEMM-1 layer is resident in LDS at `res_w` (a uniform two-GEMM stage)
+template <int NW, class NET, int SI, int RES_SI = -1>
 __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp, float* lds, Pre& c, int wave,
-                                                   float* to_reg = nullptr) {
+                                                   float* to_reg = nullptr, const float* res_w = nullptr) {
   constexpr UnetDesc u = NET::desc();
   constexpr TileLayout t = NET::layout4(NW);
   constexpr StageDesc sd = unet_stage_desc(u, t, SI);
@@ -889,15 +939,19 @@ __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp,
   asm volatile("" : "+v"(c.f[0]), "+v"(c.f[1]), "+v"(c.f[2]), "+v"(c.f[3]));
   asm volatile("" : "+v"(c.f[4]), "+v"(c.f[5]), "+v"(c.f[6]), "+v"(c.f[7]));
   // first ring of the next stage's GEMM 1 (requested before this stage's closing barrier)
+  constexpr bool res_here = SI == RES_SI, res_next = (SI + 1) % 6 == RES_SI;
+  static_assert(!res_here || (uniform && sd.has2), "the resident layer is GEMM 1 of a uniform two-GEMM stage");
   auto prefetch_next = [&]() {
     if constexpr (uniform_next) {
+      // (next stage's GEMM 1 resident in LDS: the first ring of its GEMM 2 instead)
       constexpr int nbn = NBLKn >= NW ? NBLKn / NW : 1;
-      const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + sdn.L1.w_off) + lane;
-      const int wb = min(wave, NBLKn - 1) * KCn;
+      constexpr int KCx = res_next ? KC2n : KCn;
+      const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + (res_next ? sdn.L2.w_off : sdn.L1.w_off)) + lane;
+      const int wb = min(wave, NBLKn - 1) * KCx;
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        const int kc = (f / nbn) < KCn ? (f / nbn) : KCn - 1;
-        const int boff = ((f % nbn) * NW) * KCn;
+        const int kc = (f / nbn) < KCx ? (f / nbn) : KCx - 1;
+        const int boff = ((f % nbn) * NW) * KCx;
         c.f[f] = wl[(size_t)(wb + boff + kc) * 64];
       }
     } else {
@@ -914,8 +968,8 @@ __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp,
     constexpr int NBc = NBLK >= NW ? NBLK / NW : 1;
     constexpr int nact = NBLK >= NW ? NW : NBLK;
     if (wave < nact)
-      stage_direct4<NBc, NW>(Wp, lds + t.bias, sd.L1, lds + sd.x1, sd.s1, sd.has2 != 0, sd.L2, lds + sd.x2, sd.s2,
-                             lds + sd.y, sd.sy, wave, lane, c);
+      stage_direct4<NBc, NW, res_here>(Wp, lds + t.bias, sd.L1, lds + sd.x1, sd.s1, sd.has2 != 0, sd.L2, lds + sd.x2, sd.s2,
+                                       lds + sd.y, sd.sy, wave, lane, c, res_w);
     prefetch_next();
     __syncthreads();
   } else {
@@ -972,16 +1026,16 @@ __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp,
 }
 
 // X0 (4 rows of [t, x, 0-pad]) -> nabla_V; gv_reg (output width 16): thread tid < 64 gets nabla_V[tid >> 4][tid & 15]
-template <int NW, class NET>
+template <int NW, class NET, int RES_SI = -1>
 __device__ __forceinline__ void unet_tile_forward_static4(const float* __restrict__ Wp, float* lds, Pre& c,
-                                                          float* gv_reg = nullptr) {
+                                                          float* gv_reg = nullptr, const float* res_w = nullptr) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unet_stage_static4<NW, NET, 0>(Wp, lds, c, wave);
-  unet_stage_static4<NW, NET, 1>(Wp, lds, c, wave);
-  unet_stage_static4<NW, NET, 2>(Wp, lds, c, wave);
-  unet_stage_static4<NW, NET, 3>(Wp, lds, c, wave);
-  unet_stage_static4<NW, NET, 4>(Wp, lds, c, wave);
-  unet_stage_static4<NW, NET, 5>(Wp, lds, c, wave, NET::outp == 16 ? gv_reg : nullptr);
+  unet_stage_static4<NW, NET, 0, RES_SI>(Wp, lds, c, wave, nullptr, res_w);
+  unet_stage_static4<NW, NET, 1, RES_SI>(Wp, lds, c, wave, nullptr, res_w);
+  unet_stage_static4<NW, NET, 2, RES_SI>(Wp, lds, c, wave, nullptr, res_w);
+  unet_stage_static4<NW, NET, 3, RES_SI>(Wp, lds, c, wave, nullptr, res_w);
+  unet_stage_static4<NW, NET, 4, RES_SI>(Wp, lds, c, wave, nullptr, res_w);
+  unet_stage_static4<NW, NET, 5, RES_SI>(Wp, lds, c, wave, NET::outp == 16 ? gv_reg : nullptr, res_w);
 }
 
 #endif  // __HIPCC__
