@@ -1317,12 +1317,16 @@ extern "C" int socmx_unet_forward_f32(const float* packed, int32_t d, const int3
 
 // the 4-row kernel of a constexpr-specialised architecture, if its stages fit the 4-row forms (variant builds of other
 // hidden widths may not: then the 16-row kernels run)
+#ifndef SOCMX_R4F_WAVES
+#define SOCMX_R4F_WAVES 8
+#endif
+constexpr int kR4FastWaves = SOCMX_R4F_WAVES;   // waves of the 4-row FAST kernel's workgroup
 template <class NET>
 static bool r4_pick(bool fast_form, bool stopping, void (**k)(const RolloutArgs)) {
   if constexpr (r4_supported<8, NET>()) {
-    if constexpr (NET::outp == 16) {
+    if constexpr (NET::outp == 16 && r4_supported<kR4FastWaves, NET>()) {
       if (fast_form) {
-        *k = stopping ? rollout4_kernel<8, true, NET> : rollout4_kernel<8, false, NET>;
+        *k = stopping ? rollout4_kernel<kR4FastWaves, true, NET> : rollout4_kernel<kR4FastWaves, false, NET>;
         return true;
       }
     }
@@ -1428,12 +1432,13 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
     const bool have4 = is_default ? r4_pick<DefaultNet>(fast4, stopping, &k4)
                      : is_wide32 ? r4_pick<Wide32Net>(false, stopping, &k4) : r4_pick<Wide64Net>(false, stopping, &k4);
     if (have4) {
-      const TileLayout t4 = is_default ? DefaultNet::layout4(8) : is_wide32 ? Wide32Net::layout4(8) : Wide64Net::layout4(8);
+      const int nw4 = fast4 ? kR4FastWaves : 8;
+      const TileLayout t4 = is_default ? DefaultNet::layout4(nw4) : is_wide32 ? Wide32Net::layout4(8) : Wide64Net::layout4(8);
       a.lds_mats = (t4.floats + 3) & ~3;
       size_t floats4;
       if (fast4) {
         floats4 = (((size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 128 + 3) & ~(size_t)3) +
-                  (size_t)r4_resident_floats<8, DefaultNet>();
+                  (size_t)r4_resident_floats<kR4FastWaves, DefaultNet>();
       } else {
         const size_t dp = (size_t)((d + 3) & ~3);
         const int mats4 = (a.sigma_identity ? 0 : 1) + (ou ? 1 : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? 1 : 0);
@@ -1444,7 +1449,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
       const int blocks4 = (B + 3) / 4;
       // (one workgroup per CU while there are CUs left: the whole LDS)
       const size_t lds4 = blocks4 <= 256 ? (size_t)kMaxLdsBytes : floats4 * sizeof(float);
-      return launch(k4, dim3(blocks4), dim3(8 * 64), lds4, stream, a);
+      return launch(k4, dim3(blocks4), dim3(nw4 * 64), lds4, stream, a);
     }
   }
   if (const int err = ensure_max_lds(kern)) return err;

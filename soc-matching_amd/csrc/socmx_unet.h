@@ -351,9 +351,9 @@ __device__ __forceinline__ GemmPlan<NB> make_plan(const float* __restrict__ Wp, 
 }
 
 // issue the loads of ring slots [from, PD); slots [0, from) are taken from `pre` (from == CP) or loaded too (from == 0)
-template <int NB, bool USE_PRE>
-__device__ __forceinline__ void ring_fill(Ring<NB>& r, const GemmPlan<NB>& p, const Pre& pre) {
-  constexpr int PD = Ring<NB>::PD, CP = USE_PRE ? Ring<NB>::CP : 0;
+template <int NB, bool USE_PRE, class RingT = Ring<NB>>
+__device__ __forceinline__ void ring_fill(RingT& r, const GemmPlan<NB>& p, const Pre& pre) {
+  constexpr int PD = RingT::PD, CP = USE_PRE ? RingT::CP : 0;
   const int last = p.kc1 - 1;
 #pragma unroll
   for (int s = 0; s < PD; ++s) {
@@ -371,9 +371,9 @@ __device__ __forceinline__ void ring_fill(Ring<NB>& r, const GemmPlan<NB>& p, co
 // PINNED (the constexpr-specialised stages, fully unrolled): refill loads fenced by scheduling barriers and skipped
 // past the end of the GEMM.  The table-driven stages keep rolled loops with runtime bounds, where the fences and the
 // extra branch cost more than they give (3.78 -> 4.00 ms on cfg3): they re-request the last chunk instead.
-template <int NB, bool PINNED = false, bool R4 = false>
-__device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], Ring<NB>& r, const GemmPlan<NB>& p) {
-  constexpr int PD = Ring<NB>::PD;
+template <int NB, bool PINNED = false, bool R4 = false, class RingT = Ring<NB>>
+__device__ __forceinline__ void gemm_run(f32x4 (&acc)[NB], RingT& r, const GemmPlan<NB>& p) {
+  constexpr int PD = RingT::PD;
   const int last = p.kc1 - 1;
   int kc = p.kc0;
   // activations (B operand) are read from LDS two chunks ahead of their MFMAs
@@ -854,6 +854,15 @@ __host__ __device__ constexpr int r4_resident_floats() {
   return r4_resident_stage<NW, NET>() < 0 ? 0 : sd.L1.in_pad * sd.L1.out_pad;
 }
 
+// the 4-row stages' ring: PF fragments in flight per wave (8; 4 in a 16-wave workgroup, whose budget is 128 VGPRs)
+template <int NB, int PF>
+struct Ring4 {
+  static constexpr int PD = PF / NB > 0 ? PF / NB : 1;
+  static constexpr int CP = PD;                                  // chunks covered by the first PF `pre` fragments
+  f32x4 slot[PD][NB];
+};
+template <int NW> struct R4Frags { static constexpr int value = NW > 8 ? 4 : 8; };
+
 // W1LDS: GEMM 1's weights are RESIDENT in LDS (w1lds: the layer's fragment image, copied once per launch) -- its fragments
 // are read where they are used and `pre` carries the first ring of GEMM 2 instead (see unet_stage_static4).
 template <int NB, int NW, bool W1LDS = false>
@@ -864,12 +873,13 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
   const int j = lane & 3, ng = (lane >> 2) & 3, kg = lane >> 4;
   const GemmPlan<NB> p1 = make_plan<NB, true>(Wp, L1, blk0, NW, X1, S1, lane, 0, L1.in_pad >> 4);
   const GemmPlan<NB> p2 = make_plan<NB, true>(Wp, L2, blk0, NW, X2, S2, lane, 0, L2.in_pad >> 4);
-  Ring<NB> r1, r2;
+  typedef Ring4<NB, R4Frags<NW>::value> RingT;
+  RingT r1, r2;
   if constexpr (W1LDS) {
-    ring_fill<NB, true>(r2, p2, pre);
+    ring_fill<NB, true, RingT>(r2, p2, pre);
   } else {
-    ring_fill<NB, true>(r1, p1, pre);
-    if (has2) ring_fill<NB, false>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
+    ring_fill<NB, true, RingT>(r1, p1, pre);
+    if (has2) ring_fill<NB, false, RingT>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
   }
   // the biases ride in k-group 0's accumulators (the other groups start from zero: kg_sum adds the four)
   f32x4 acc[NB], acc2[NB];
@@ -895,9 +905,9 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
       mfma_chunk<NB, true>(acc, a, *reinterpret_cast<const f32x4*>(p1.xrow + kc * 16));
     }
   } else {
-    gemm_run<NB, true, true>(acc, r1, p1);
+    gemm_run<NB, true, true, RingT>(acc, r1, p1);
   }
-  if (has2) gemm_run<NB, true, true>(acc2, r2, p2);
+  if (has2) gemm_run<NB, true, true, RingT>(acc2, r2, p2);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     f32x4 v = kg_sum(acc[b]);
@@ -949,7 +959,7 @@ __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp,
       const f32x4* wl = reinterpret_cast<const f32x4*>(Wp + (res_next ? sdn.L2.w_off : sdn.L1.w_off)) + lane;
       const int wb = min(wave, NBLKn - 1) * KCx;
 #pragma unroll
-      for (int f = 0; f < 8; ++f) {
+      for (int f = 0; f < R4Frags<NW>::value; ++f) {
         const int kc = (f / nbn) < KCx ? (f / nbn) : KCx - 1;
         const int boff = ((f % nbn) * NW) * KCx;
         c.f[f] = wl[(size_t)(wb + boff + kc) * 64];
