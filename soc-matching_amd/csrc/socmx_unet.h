@@ -861,7 +861,10 @@ struct Ring4 {
   static constexpr int CP = PD;                                  // chunks covered by the first PF `pre` fragments
   f32x4 slot[PD][NB];
 };
-template <int NW> struct R4Frags { static constexpr int value = NW > 8 ? 4 : 8; };
+#ifndef SOCMX_R4_FRAGS
+#define SOCMX_R4_FRAGS 4
+#endif
+template <int NW> struct R4Frags { static constexpr int value = NW > 8 ? 4 : SOCMX_R4_FRAGS; };
 
 // W1LDS: GEMM 1's weights are RESIDENT in LDS (w1lds: the layer's fragment image, copied once per launch) -- its fragments
 // are read where they are used and `pre` carries the first ring of GEMM 2 instead (see unet_stage_static4).
