@@ -1373,3 +1373,40 @@ def test_four_row_rollout_ragged_batches(B):
     got = utils.stochastic_trajectories(sde, x0.to(DEV), ts, aux["lmbd"], noise_in=noise.to(DEV))
     for a, b in zip(got, want):
         np.testing.assert_allclose(_np(a), b.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("setting,d,extra", [
+    ("molecular_dynamics", 1, ["method.use_stopping_time=True", "method.T=2.0", "method.lmbd=2.0"]),
+    ("molecular_dynamics", 6, ["method.use_stopping_time=True", "method.T=2.0", "method.lmbd=2.0"]),
+    ("molecular_dynamics", 20, ["method.use_stopping_time=True", "method.T=2.0", "method.lmbd=2.0"]),
+    ("double_well", 24, []), ("OU_linear", 16, []), ("OU_linear", 64, []), ("OU_quadratic_hard", 31, []),
+])
+def test_four_row_rollout_settings_vs_eager_path(setting, d, extra):
+    """The 4-row kernels at the DEFAULT widths for the settings / sizes no reference fixture covers in that form -- stopping
+    times in the fused (d <= 15) and the general step, the elementwise drift and the OU drift of the general step at
+    d = 16 ... 64 -- against the device-agnostic eager path (pinned by the reference fixtures on the CPU) on the same
+    injected noise; a ragged batch (21 = 5 tiles + 1 row)."""
+    import contextlib, io
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from socmx import rollout as R
+    K, B = (12 if setting.startswith("OU") else 100), 21
+    cfg = load_config([f"method.setting={setting}", f"method.d={d}", f"method.num_steps={K}", "arch.hdims=[256,128,64]"]
+                      + extra)
+    cfg.method.device = DEV
+    torch.manual_seed(4)
+    T = float(cfg.method.T)
+    ts = torch.linspace(0, T, K + 1).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)
+    lmbd = float(cfg.method.lmbd)
+    noise = torch.randn(K, B, d, generator=torch.Generator().manual_seed(8)).to(DEV)
+    state0 = x0.repeat(B, 1)
+    got = R.hip_trajectories(sde, state0, ts, lmbd, noise_in=noise)
+    with torch.no_grad():
+        want = R.eager_trajectories(sde, state0, ts, lmbd, noise_in=noise)
+    names = ["states", "noises", "stop_indicators", "fractional_timesteps", "lpd", "lps", "ltw", "controls"]
+    for n, a, b in zip(names, got, want):
+        np.testing.assert_allclose(_np(a), _np(b), rtol=2e-4, atol=2e-4, err_msg=n)
+    if setting == "molecular_dynamics":
+        assert float(got[2].min()) == 0.0, "no trajectory stopped: the stopping branch went untested"
