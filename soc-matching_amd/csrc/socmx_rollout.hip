@@ -790,13 +790,13 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
 // The same fused step (sigma = I, d <= 15: the FAST form above) on a 4-row tile: the control network runs on
 // v_mfma_f32_4x4x1_16b_f32 (socmx_unet.h, unet_tile_forward_static4) from the same packed image.  B / 4 workgroups instead
 // of B / 16 -- a training batch of 128 rows works on 32 CUs instead of 8 -- and half the MFMA time per step and tile.
-// Wave 0 integrates (thread = (row r, component i), 64 threads), wave 1 draws the next step's noise.
+// Wave 0 integrates (thread = (row r, component i), 64 threads), waves 1 and 2 prepare the next steps' noise.
 // The 4-row tiles leave ~135 KiB of the CU's LDS free: stage 4's GEMM-1 layer (up_1, 128 KiB at the default widths, a fifth of
 // the 689 KB a step streams) is copied there once and read from there every step (r4_resident_stage, socmx_unet.h).
 template <int NW, bool STOPPING, class NET>
 __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  static_assert(NET::outp == 16 && NW >= 2, "4-row tile: d <= 15, at least two waves");
+  static_assert(NET::outp == 16 && NW >= 3, "4-row tile: d <= 15, at least three waves");
   const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
   constexpr TileLayout tl = NET::layout4(NW);
   constexpr UnetDesc ud = NET::desc();
@@ -811,12 +811,13 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
   float* A_l = lds + a.lds_mats;                        // (d, ds)   OU only
   float* P_l = A_l + (is_ou ? d * ds : 0);              // (d, ds)   OU_quadratic only
   float* NZ = P_l + (is_quad ? d * ds : 0);             // (2, 4, 16) double-buffered noise of steps k, k + 1
-  for (float* z = lds + tid; z < NZ + 128; z += nthr) *z = 0.f;       // (tiles' padding columns stay zero for good)
+  uint32_t* WZ = reinterpret_cast<uint32_t*>(NZ + 128); // (2, 32, 2) Philox words of steps k + 1, k + 2 (one pair of draws each)
+  for (float* z = lds + tid; z < NZ + 256; z += nthr) *z = 0.f;       // (tiles' padding columns stay zero for good)
   // the resident layer's fragment image, 16-byte aligned behind the small state
   constexpr int kResidentStage = r4_resident_stage<NW, NET>();
   constexpr StageDesc sd_res = unet_stage_desc(ud, tl, 4);
   constexpr int res_floats = r4_resident_floats<NW, NET>();
-  float* RES = lds + ((a.lds_mats + (is_ou ? d * ds : 0) + (is_quad ? d * ds : 0) + 128 + 3) & ~3);
+  float* RES = lds + ((a.lds_mats + (is_ou ? d * ds : 0) + (is_quad ? d * ds : 0) + 256 + 3) & ~3);
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + sd_res.L1.w_off);
     f32x4* dst = reinterpret_cast<f32x4*>(RES);
@@ -850,14 +851,39 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
     if (i < 15) X0[r * tl.s0 + 1 + i] = x;   // columns 1..15; lanes i >= d hold x = 0
     if (i == 0) X0[r * tl.s0] = a.ts[0];
   }
-  const bool producer = tid >= 64 && tid < 128;
-  const int pgrow = tile_row0 + r;
-  auto draw = [&](int k) -> float {
-    if (i >= d || k >= K) return 0.f;
-    if (a.noise_in) return a.noise_in[((size_t)k * B + min(pgrow, B - 1)) * d + i];
-    return philox_normal(key_seed, key_offset, (uint32_t)(a.row0 + pgrow), (uint32_t)k, i);
+  // Noise, one step ahead and in two halves on two otherwise idle waves: Philox4x32-10 and Box-Muller are ~1.1k cycles each
+  // for a thread, a chain of dependent integer multiplies and a log / sqrt / sincos -- in one piece on one wave they outlast
+  // the integrating wave's step (1.4k cycles) and every wave waits for them at the barrier.  Wave 1 computes the counter
+  // block's words of step k + 2, wave 2 turns the words of step k + 1 (from the previous step's phase) into draws; thread
+  // p < 32 of either owns the pair of draws (2q, 2q + 1) of row p >> 3, q = p & 7.  (Injected noise: wave 2 fetches it.)
+  const int pp = tid & 63, prow = (pp >> 3) & 3, pq = pp & 7;
+  const bool w_words = tid >= 64 && tid < 96 && !a.noise_in, w_draws = tid >= 128 && tid < 160;
+  const int pgrow = tile_row0 + prow;
+  auto words = [&](int k) {
+    if (!w_words || k >= K) return;
+    uint32_t wa, wb;
+    philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + pgrow), (uint32_t)k, pq >> 1, pq & 1, wa, wb);
+    WZ[((k & 1) * 32 + pp) * 2] = wa;
+    WZ[((k & 1) * 32 + pp) * 2 + 1] = wb;
   };
-  if (producer) NZ[r * 16 + i] = draw(0);
+  auto draws = [&](int k) {
+    if (!w_draws || k >= K) return;
+    float z0 = 0.f, z1 = 0.f;
+    const int c0 = 2 * pq;
+    if (a.noise_in) {
+      const float* src = a.noise_in + ((size_t)k * B + min(pgrow, B - 1)) * d;
+      if (c0 < d) z0 = src[c0];
+      if (c0 + 1 < d) z1 = src[c0 + 1];
+    } else {
+      box_muller_pair(WZ[((k & 1) * 32 + pp) * 2], WZ[((k & 1) * 32 + pp) * 2 + 1], z0, z1);
+    }
+    NZ[(k & 1) * 64 + prow * 16 + c0] = c0 < d ? z0 : 0.f;
+    NZ[(k & 1) * 64 + prow * 16 + c0 + 1] = c0 + 1 < d ? z1 : 0.f;
+  };
+  words(0);
+  __syncthreads();
+  draws(0);
+  words(1);
   for (int k = 0; k < K; ++k) {
     const float t0 = a.ts[k], t1 = a.ts[k + 1];
     const float dt = t1 - t0;                 // utils.py:38
@@ -914,7 +940,8 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
       if (i < 15) X0[r * tl.s0 + 1 + i] = x;                            // next step's network input [t, x, 0..]
       if (i == 0) X0[r * tl.s0] = t1;
     }
-    if (producer) NZ[((k + 1) & 1) * 64 + r * 16 + i] = draw(k + 1);
+    words(k + 2);
+    draws(k + 1);
   }
   if (a.nabla_v) {                        // nabla_V(T, X_K): X0 already holds [t_K, x_K] (written at the end of the last step)
     __syncthreads();
@@ -1437,7 +1464,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
       a.lds_mats = (t4.floats + 3) & ~3;
       size_t floats4;
       if (fast4) {
-        floats4 = (((size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 128 + 3) & ~(size_t)3) +
+        floats4 = (((size_t)a.lds_mats + (ou ? d * sds : 0) + (pb->kind == SOCMX_OU_QUADRATIC ? d * sds : 0) + 256 + 3) & ~(size_t)3) +
                   (size_t)r4_resident_floats<kR4FastWaves, DefaultNet>();
       } else {
         const size_t dp = (size_t)((d + 3) & ~3);
