@@ -651,13 +651,14 @@ struct WgItem {
 };
 
 // Cost-balanced placement of kernel B's waves (control network).  A wave is one (block group, slab of row tiles); the chip
-// holds 2 waves per SIMD of this kernel (173 VGPRs), i.e. 256 per XCD, and a uniform "every group x S slabs" grid neither
+// holds 3 waves per SIMD of this kernel (144 VGPRs: scalar bases + immediate block offsets, two tiles in flight for the
+// (4, 4) groups), i.e. 384 per XCD, and a uniform "every group x S slabs" grid neither
 // fills a whole number of such rounds nor gives a (4, 4) group (64 MFMAs per tile) more waves than a (2, 2) one (16).
 // Instead every XCD x owns the x-th eighth of the row tiles (its L2 then holds what the groups re-read) and runs
 // `nslots` waves on it: group i gets n[i] of them, n[i] proportional to its cost per tile (largest-remainder by a
 // greedy pass on the host, wgrad_make_schedule), so that ONE full round of equal-length waves covers the work.
 // Group i is therefore cut into S_i = 8 n[i] slabs, and kernel C adds S_i partials for its cells.
-constexpr int kWgSlots = 256;            // wave slots per XCD: one full round of the chip
+constexpr int kWgSlots = 384;            // wave slots per XCD: one full round of the chip at three waves per SIMD
 constexpr int kWgMaxItems = 255;         // block groups the table can describe (more: the uniform grid)
 struct WgSched {
   int nslots;                            // 0: uniform grid (S slabs for every group); else kWgSlots
@@ -680,22 +681,33 @@ struct WgradArgs {
   WgSched sched;
 };
 
+#ifndef SOCMX_K2B_PD44
+#define SOCMX_K2B_PD44 2     // tiles in flight per wave of a (4, 4) block group (three waves per SIMD)
+#endif
+// N asm loads of consecutive 1-KiB blocks: scalar base, 32-bit lane offset, the block as an immediate offset
+template <int J, int N>
+struct WgLoad {
+  __device__ static __forceinline__ void run(f32x4 (&dst)[N], unsigned voff, const float* base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[J]) : "v"(voff), "s"(base), "n"(J * 1024) : "memory");
+    if constexpr (J + 1 < N) WgLoad<J + 1, N>::run(dst, voff, base);
+  }
+};
+
 template <int NOB, int NIB>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it, int slab, int S, int lane) {
   const int c = lane & 15, g = lane >> 4;
   const int t0 = (int)(((int64_t)slab * a.ntiles) / S), t1 = (int)(((int64_t)(slab + 1) * a.ntiles) / S);
   const int64_t tile_rows = (int64_t)a.ntiles * 16;
   // lane (c, g) reads rows 4g .. 4g+3 of unit (block * 16 + c): one 16-byte load; MFMA number s of a tile takes component s
-  // from every lane, i.e. k-slot g carries row 4g + s -- the same permutation for both operands
-  const float* gbase = a.ws + (size_t)tile_rows * it.gt_off + (size_t)(it.ob0 * 16 + c) * 16 + 4 * g;
-  const float* abase = a.ws + (size_t)tile_rows * it.at_off + (size_t)(it.ib0 * 16 + c) * 16 + 4 * g;
+  // from every lane, i.e. k-slot g carries row 4g + s -- the same permutation for both operands.
+  // Addresses: a wave-uniform base per operand and tile (SGPR pair) + one 32-bit lane offset + the block as an IMMEDIATE
+  // (blocks are 1 KiB apart): two address VGPRs instead of a 64-bit pointer per load -- 173 -> 16x VGPRs, i.e. three waves
+  // per SIMD.  Blocks past the group (instantiations wider than the group) read the neighbouring blocks of the workspace --
+  // in bounds: the partials follow the tiles in the same allocation -- and their products are never stored.
+  const float* gbase = a.ws + (size_t)tile_rows * it.gt_off + (size_t)it.ob0 * 256;
+  const float* abase = a.ws + (size_t)tile_rows * it.at_off + (size_t)it.ib0 * 256;
+  const unsigned lane_off = (unsigned)(c * 16 + 4 * g) * 4u;
   const size_t gstep = (size_t)it.gW * 16, astep = (size_t)it.aW * 16;
-  // block indices past the group (variants wider than the group) are clamped: computed twice, stored once
-  int oo[NOB], io[NIB];
-#pragma unroll
-  for (int j = 0; j < NOB; ++j) oo[j] = min(j, it.nob - 1) * 256;
-#pragma unroll
-  for (int j = 0; j < NIB; ++j) io[j] = min(j, it.nib - 1) * 256;
   f32x4 acc[NOB][NIB];
   float bsum[NOB];
 #pragma unroll
@@ -709,16 +721,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
   // tile in flight (the socm_target_lds4_kernel story, socmx_loss.hip).  Requests past the slab's last tile re-read it, so
   // that "PD - 1 younger tiles may stay in flight" is the same number on every trip.
   // (narrow block groups have few MFMAs per tile to hide the load latency behind: more tiles in flight for them)
-  constexpr int PD = NOB * NIB >= 16 ? 3 : NOB * NIB >= 8 ? 4 : NOB * NIB >= 4 ? 6 : 8, NL = NOB + NIB;
+  constexpr int PD = NOB * NIB >= 16 ? SOCMX_K2B_PD44 : NOB * NIB >= 8 ? 4 : NOB * NIB >= 4 ? 6 : 8, NL = NOB + NIB;
   f32x4 ga[PD][NOB], ab[PD][NIB];
   auto load = [&](int t, int s) {
     const int tc = min(t, t1 - 1);
-#pragma unroll
-    for (int j = 0; j < NOB; ++j)
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ga[s][j]) : "v"(gbase + (size_t)tc * gstep + oo[j]) : "memory");
-#pragma unroll
-    for (int k = 0; k < NIB; ++k)
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ab[s][k]) : "v"(abase + (size_t)tc * astep + io[k]) : "memory");
+    WgLoad<0, NOB>::run(ga[s], lane_off, gbase + (size_t)tc * gstep);
+    WgLoad<0, NIB>::run(ab[s], lane_off, abase + (size_t)tc * astep);
   };
   auto wait_slot = [&](int s) {                 // the PD - 1 younger tiles may stay in flight
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NL) : "memory");
@@ -770,7 +778,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgItem& it,
   }
 }
 
-__global__ __launch_bounds__(256, 2) void unet_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 3) void unet_wgrad_kernel(const WgradArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2): all block groups
