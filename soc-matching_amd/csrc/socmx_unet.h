@@ -105,10 +105,18 @@ struct TileLayout {
   int floats;                                // total
 };
 
-// (rows = 4: the small-batch tile of the 4x4x1 kernels below -- same strides, a quarter of the rows)
+__host__ __device__ constexpr int r4_stride(int width) { return width + ((16 - width % 64) + 64) % 64; }   // = 16 (mod 64)
+// (rows = 4: the small-batch tile of the 4x4x1 kernels below)
 __host__ __device__ constexpr TileLayout make_tile_layout(const UnetDesc& u, int nwaves, int rows = 16) {
   TileLayout t{};
   t.s0 = u.in0p + 4; t.s1 = u.hp[0] + 4; t.s2 = u.hp[1] + 4; t.s3 = u.hp[2] + 4; t.sg = u.outp + 4;
+  if (rows == 4) {
+    // 4-row tile: a ds_read_b128 of the activation operand touches (row l & 3, k-group l >> 4), 16 bytes each -- row strides
+    // of 16 (mod 64) dwords put the 4 x 4 chunks on 64 distinct banks (width + 4 left rows one chunk apart: row j + 1,
+    // k-group g on the banks of row j, k-group g + 1 -- 2.0k conflict cycles per step, SQ_LDS_BANK_CONFLICT)
+    t.s0 = r4_stride(u.in0p); t.s1 = r4_stride(u.hp[0]); t.s2 = r4_stride(u.hp[1]); t.s3 = r4_stride(u.hp[2]);
+    t.sg = r4_stride(u.outp);
+  }
   int off = 0;
   t.x0 = off; off += rows * t.s0;
   t.r1 = off; off += rows * t.s1;
