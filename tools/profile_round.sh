@@ -43,6 +43,12 @@ python3 bench.py --gpus 1 --spawn --defer-graph --steps 20 --warmup 5 --no-cpu-b
 (hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -DSOCMX_CONTRACTION_PROF -o /tmp/cb tools/ubench/contraction_bench.hip 2>/dev/null && /tmp/cb 64 400 512 5) > $R/contraction_cfg5r.txt 2>&1
 (hipcc -O3 --offload-arch=gfx950 -o /tmp/mi tools/ubench/mfma_issue.hip 2>/dev/null && /tmp/mi) > $R/mfma_issue.txt 2>&1
 (hipcc -O3 --offload-arch=gfx950 -o /tmp/ov tools/ubench/mfma_valu_overlap.hip 2>/dev/null && /tmp/ov) > $R/mfma_valu_overlap.txt 2>&1
+# the 4-row tile's building blocks: lane mapping + k-group sum against the CPU, the 4x4x1 issue rate, the per-CU weight stream
+(hipcc -O3 --offload-arch=gfx950 -o /tmp/r4c tools/ubench/r4_check.hip 2>/dev/null && timeout 60 /tmp/r4c) > $R/r4_check.txt 2>&1
+(hipcc -O3 --offload-arch=gfx950 -o /tmp/m44 tools/ubench/mfma4x4.hip 2>/dev/null && timeout 60 /tmp/m44) > $R/mfma4x4.txt 2>&1
+(hipcc -O3 --offload-arch=gfx950 -o /tmp/l2r tools/ubench/l2ring.hip 2>/dev/null && timeout 60 /tmp/l2r) > $R/l2ring.txt 2>&1
+# SQ counters of the 4-row rollout kernel alone
+bash tools/pmc_any.sh "rollout4_kernel" r4 python3 tools/quick_bench.py cfg3 > $R/rollout4_pmc.txt 2>&1
 python3 tools/iter_bench.py md eager > $R/iter_md.txt 2>&1; python3 tools/iter_bench.py md graph >> $R/iter_md.txt 2>&1
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o stage_chain stage_chain.hip 2>/dev/null && ./stage_chain) > $R/stage_chain.txt 2>&1
 python3 tools/quick_bench.py cfg3 cfg2 ouq20 cfg5r burst 2>&1 | grep -E "parity|rollout|iteration" > $R/quick.txt
