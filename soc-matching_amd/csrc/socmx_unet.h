@@ -298,27 +298,29 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NB], const f32x4 (&a)[NB
     }
 }
 
-// sum over the four k-groups (lanes l, l ^ 16, l ^ 32, l ^ 48) of a 4-row accumulator; every lane ends with the total.
-// gfx950's row / half swaps (v_permlane16_swap: odd rows of the first register <-> even rows of the second;
-// v_permlane32_swap: upper half of the first <-> lower half of the second): VALU only, where a ds_bpermute pair per
-// register would queue behind the stage's LDS traffic.  Inline asm: with both operands of
-// __builtin_amdgcn_permlane16_swap the same value, this compiler folds the result pair into one register (a + a).  The
-// leading s_nop covers the MFMA -> VALU wait states of the accumulator (not inserted in front of inline asm).
-__device__ __forceinline__ f32x4 kg_sum(const f32x4 v) {
-  float a = v[0], b = v[1], c = v[2], d = v[3], t0, t1, t2, t3;
+// Sum over the four k-groups (lanes l, l ^ 16, l ^ 32, l ^ 48) of a 4-row accumulator as a butterfly that also SCATTERS:
+// gfx950's v_permlane32_swap (upper half of the first register <-> lower half of the second) pairs components (0, 1) and
+// (2, 3), one add each folds k-groups g and g + 2; v_permlane16_swap (odd rows of the first <-> even rows of the second)
+// and one more add fold the rest -- six VALU instructions for the four registers, and lane l is left with the TOTAL of
+// ONE component: kg_comp(l) = {0, 2, 1, 3}[l >> 4], i.e. neuron 4 ng + kg_comp of row l & 3 (every total exactly once
+// over the wave: the stage writes one float per lane).  Inline asm: with both operands of the swap builtins the same value
+// this compiler folds the result pair into one register; the leading s_nop covers the MFMA -> VALU wait states of the
+// accumulator (not inserted in front of inline asm).  Checked against the CPU by tools/ubench/r4_check.hip.
+__device__ __forceinline__ float kg_reduce(const f32x4 v) {
+  float a = v[0], b = v[1], c = v[2], d = v[3];
   asm volatile(
       "s_nop 7\n\t"
-      "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_permlane32_swap_b32 %2, %3\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_add_f32 %2, %2, %3\n\t"
       "s_nop 1\n\t"
-      "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\t"
-      "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %7\n\t"
-      "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
-      "s_nop 1\n\t"
-      "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
-      "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %7"
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
-  return f32x4{a, b, c, d};
+      "v_permlane16_swap_b32 %0, %2\n\t"
+      "v_add_f32 %0, %0, %2"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  return a;
 }
+__device__ __forceinline__ int kg_comp(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }   // {0, 2, 1, 3}[lane >> 4]
 
 // Weight fragments come straight from L2 into VGPRs (each is used by exactly one MFMA group of one
 // wave, so an LDS round trip would be pure overhead).  L2 latency is ~500-1000 cycles while one chunk is
@@ -919,13 +921,12 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
     gemm_run<NB, true, true, RingT>(acc, r1, p1);
   }
   if (has2) gemm_run<NB, true, true, RingT>(acc2, r2, p2);
+  const int comp = kg_comp(lane);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    f32x4 v = kg_sum(acc[b]);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = relu_keep_nan(v[c]);
-    if (has2) v += kg_sum(acc2[b]);
-    if (kg == 0) *reinterpret_cast<f32x4*>(Y + j * SY + (blk0 + b * NW) * 16 + 4 * ng) = v;
+    float v = relu_keep_nan(kg_reduce(acc[b]));
+    if (has2) v += kg_reduce(acc2[b]);
+    Y[j * SY + (blk0 + b * NW) * 16 + 4 * ng + comp] = v;                  // one float per lane, 64 banks
   }
 }
 
@@ -1008,16 +1009,14 @@ __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp,
         const f32x4 a1[1] = {c.f[f]};
         mfma_chunk<1, true>(acc, a1, *reinterpret_cast<const f32x4*>(xrow + f * 16));
       }
-      const f32x4 v = kg_sum(acc[0]);
-      if (kg == 0) *reinterpret_cast<f32x4*>(P1 + ((blk * PARTS + part) * 4 + j) * 16 + 4 * ng) = v;
+      P1[((blk * PARTS + part) * 4 + j) * 16 + 4 * ng + kg_comp(lane)] = kg_reduce(acc[0]);
     }
     if (sd.has2 && part < KC2) {
       const float* xrow = lds + sd.x2 + j * sd.s2 + 4 * kg + part * 16;
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       const f32x4 a2[1] = {c.f[CPW]};
       mfma_chunk<1, true>(acc, a2, *reinterpret_cast<const f32x4*>(xrow));
-      const f32x4 v = kg_sum(acc[0]);
-      if (kg == 0) *reinterpret_cast<f32x4*>(P2 + ((blk * KC2 + part) * 4 + j) * 16 + 4 * ng) = v;
+      P2[((blk * KC2 + part) * 4 + j) * 16 + 4 * ng + kg_comp(lane)] = kg_reduce(acc[0]);
     }
     prefetch_next();
     __syncthreads();

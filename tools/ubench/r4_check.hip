@@ -4,21 +4,21 @@
 #include <cstdio>
 #include <cmath>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 kg_sum(const f32x4 v) {
-  float a = v[0], b = v[1], c = v[2], d = v[3], t0, t1, t2, t3;
+__device__ __forceinline__ float kg_reduce(const f32x4 v) {      // the butterfly of socmx_unet.h: lane l keeps component {0,2,1,3}[l >> 4]
+  float a = v[0], b = v[1], c = v[2], d = v[3];
   asm volatile(
       "s_nop 7\n\t"
-      "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_permlane32_swap_b32 %2, %3\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_add_f32 %2, %2, %3\n\t"
       "s_nop 1\n\t"
-      "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\t"
-      "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %7\n\t"
-      "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
-      "s_nop 1\n\t"
-      "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
-      "v_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %7"
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
-  return f32x4{a, b, c, d};
+      "v_permlane16_swap_b32 %0, %2\n\t"
+      "v_add_f32 %0, %0, %2"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  return a;
 }
+__device__ __forceinline__ int kg_comp(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }
 __global__ void k(const float* W /*16x16*/, const float* X /*4x16*/, float* Y /*4x16*/, float* S /*64*/, float* R /*64x4 raw*/) {
   const int l = threadIdx.x;
   f32x4 w, x;
@@ -26,9 +26,8 @@ __global__ void k(const float* W /*16x16*/, const float* X /*4x16*/, float* Y /*
   f32x4 acc = {0, 0, 0, 0};
   for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x[i], acc, 0, 0, 0);
   for (int i = 0; i < 4; ++i) R[l * 4 + i] = acc[i];
-  const f32x4 t = kg_sum(acc);
-  S[l] = kg_sum(f32x4{(float)l, 0.f, 0.f, 0.f})[0];
-  if ((l >> 4) == 0) for (int i = 0; i < 4; ++i) Y[(l & 3) * 16 + 4 * ((l >> 2) & 3) + i] = t[i];
+  Y[(l & 3) * 16 + 4 * ((l >> 2) & 3) + kg_comp(l)] = kg_reduce(acc);
+  S[l] = kg_reduce(f32x4{(float)l, 100.f + l, 200.f + l, 300.f + l});
 }
 int main() {
   float hW[256], hX[64], hY[64], hS[64], hR[256], *W, *X, *Y, *S, *R;
@@ -44,7 +43,14 @@ int main() {
     err = fmax(err, fabs(s - hY[r * 16 + n]));
   }
   printf("max |Y - ref| = %.3e\n", err);
-  printf("kg_sum(lane): "); for (int l = 0; l < 64; l += 5) printf("%d:%g ", l, hS[l]); printf("\n");
+  // lane l keeps component c = {0,2,1,3}[l >> 4] of (l, 100 + l, 200 + l, 300 + l) summed over l, l^16, l^32, l^48
+  int bad = 0;
+  for (int l = 0; l < 64; ++l) {
+    const int c = ((l >> 4) & 1) * 2 + (l >> 5);
+    const float want = 4.f * (100.f * c + (l & 15)) + 96.f;
+    if (hS[l] != want) ++bad;
+  }
+  printf("kg_reduce on lane ids: %d of 64 lanes wrong\n", bad);
   // raw check: lane l reg i should be sum over its kg of W[4ng+i][4kg+m] x[j][4kg+m]
   double e2 = 0;
   for (int l = 0; l < 64; ++l) for (int i = 0; i < 4; ++i) {
