@@ -883,7 +883,7 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
                                               const float* X1, int S1, bool has2, const LayerDesc& L2, const float* X2,
                                               int S2, float* Y, int SY, int blk0, int lane, const Pre& pre,
                                               const float* w1lds = nullptr) {
-  const int j = lane & 3, ng = (lane >> 2) & 3, kg = lane >> 4;
+  const int j = lane & 3, ng = (lane >> 2) & 3;
   const GemmPlan<NB> p1 = make_plan<NB, true>(Wp, L1, blk0, NW, X1, S1, lane, 0, L1.in_pad >> 4);
   const GemmPlan<NB> p2 = make_plan<NB, true>(Wp, L2, blk0, NW, X2, S2, lane, 0, L2.in_pad >> 4);
   typedef Ring4<NB, R4Frags<NW>::value> RingT;
@@ -894,18 +894,18 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
     ring_fill<NB, true, RingT>(r1, p1, pre);
     if (has2) ring_fill<NB, false, RingT>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
   }
-  // the biases ride in k-group 0's accumulators (the other groups start from zero: kg_sum adds the four)
+  // accumulators start from zero; a lane's ONE bias value (of the neuron whose total kg_reduce leaves it with) is read here
+  // and added behind the reduction -- nothing between the barrier and the first MFMA waits for it
   f32x4 acc[NB], acc2[NB];
+  float bias1[NB], bias2[NB];
   const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+  const int comp = kg_comp(lane);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_lds + L1.b_lds + (blk0 + b * NW) * 16 + 4 * ng);
-    acc[b] = kg == 0 ? b1 : zero;
+    acc[b] = zero;
     acc2[b] = zero;
-    if (has2) {
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(bias_lds + L2.b_lds + (blk0 + b * NW) * 16 + 4 * ng);
-      acc2[b] = kg == 0 ? b2 : zero;
-    }
+    bias1[b] = bias_lds[L1.b_lds + (blk0 + b * NW) * 16 + 4 * ng + comp];
+    bias2[b] = has2 ? bias_lds[L2.b_lds + (blk0 + b * NW) * 16 + 4 * ng + comp] : 0.f;
   }
   if constexpr (W1LDS) {
     const int KC = L1.in_pad >> 4;
@@ -921,11 +921,10 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
     gemm_run<NB, true, true, RingT>(acc, r1, p1);
   }
   if (has2) gemm_run<NB, true, true, RingT>(acc2, r2, p2);
-  const int comp = kg_comp(lane);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    float v = relu_keep_nan(kg_reduce(acc[b]));
-    if (has2) v += kg_reduce(acc2[b]);
+    float v = relu_keep_nan(kg_reduce(acc[b]) + bias1[b]);
+    if (has2) v += kg_reduce(acc2[b]) + bias2[b];
     Y[j * SY + (blk0 + b * NW) * 16 + 4 * ng + comp] = v;                  // one float per lane, 64 banks
   }
 }
