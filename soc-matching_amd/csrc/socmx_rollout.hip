@@ -884,8 +884,12 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
   __syncthreads();
   draws(0);
   words(1);
+  // (the time grid one step ahead: a scalar load at the top of a step would be waited for at the step's first LDS wait)
+  float t_cur = a.ts[0], t_nxt = a.ts[1];
   for (int k = 0; k < K; ++k) {
-    const float t0 = a.ts[k], t1 = a.ts[k + 1];
+    const float t0 = t_cur, t1 = t_nxt;
+    t_cur = t_nxt;
+    t_nxt = a.ts[min(k + 2, K)];
     const float dt = t1 - t0;                 // utils.py:38
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
     __syncthreads();
