@@ -892,6 +892,9 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
     t_nxt = a.ts[min(k + 2, K)];
     const float dt = t1 - t0;                 // utils.py:38
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
+    // (without a stopping time the step is dt for every row: its quotient and root are formed here, off the chain that follows
+    //  the network -- an IEEE division and a square root are ~25 dependent instructions)
+    const float dt_over_lmbd = dt / a.lmbd, sqrt_dt_over_lmbd = sqrtf(dt_over_lmbd);
     __syncthreads();
     float gv = 0.f;                           // nabla_V[r][i] of this thread
     unet_tile_forward_static4<NW, NET, kResidentStage>(a.packed, lds, carry, &gv, RES);   // last stage -> register, no barrier
@@ -928,8 +931,10 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
         f = 1.f;
       }
       const float uu = gsum(u * u), ue = gsum(u * eps);
-      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
-      lps = lps + sqrtf(step / a.lmbd) * (-ue);
+      const float sol = STOPPING ? step / a.lmbd : dt_over_lmbd;
+      const float ssol = STOPPING ? sqrtf(sol) : sqrt_dt_over_lmbd;
+      lpd = lpd + sol * (-f - 0.5f * uu);
+      lps = lps + ssol * (-ue);
       if (store) {
         a.controls[(size_t)k * B * d + rowoff] = u;
         a.noises[(size_t)k * B * d + rowoff] = eps;

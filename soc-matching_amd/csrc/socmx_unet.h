@@ -1024,14 +1024,23 @@ __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp,
     float v = 0.f;
     if (eb < NBLK) {                                   // bias, ReLU, residual
       const int n = eb * 16 + (e & 15);
-      v = bias_lds[sd.L1.b_lds + n];
+      // every operand is requested before the first add (one LDS round trip on the chain that ends the step, not one per
+      // pair of partials), then a fixed-order tree
+      float q1[PARTS], q2[KC2 > 0 ? KC2 : 1];
+      const float b1 = bias_lds[sd.L1.b_lds + n], b2 = sd.has2 ? bias_lds[sd.L2.b_lds + n] : 0.f;
 #pragma unroll
-      for (int p = 0; p < PARTS; ++p) v += P1[(eb * PARTS + p) * 64 + e];
-      v = relu_keep_nan(v);
+      for (int p = 0; p < PARTS; ++p) q1[p] = P1[(eb * PARTS + p) * 64 + e];
+#pragma unroll
+      for (int p = 0; p < KC2; ++p) q2[p] = sd.has2 ? P2[(eb * KC2 + p) * 64 + e] : 0.f;
+#pragma unroll
+      for (int w = 1; w < PARTS; w *= 2)
+#pragma unroll
+        for (int p = 0; p + w < PARTS; p += 2 * w) q1[p] += q1[p + w];
+      v = relu_keep_nan(q1[0] + b1);
       if (sd.has2) {
-        float v2 = bias_lds[sd.L2.b_lds + n];
+        float v2 = b2;
 #pragma unroll
-        for (int p = 0; p < KC2; ++p) v2 += P2[(eb * KC2 + p) * 64 + e];
+        for (int p = 0; p < KC2; ++p) v2 += q2[p];
         v += v2;
       }
     }
