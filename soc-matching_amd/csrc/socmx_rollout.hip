@@ -1100,10 +1100,14 @@ __global__ __launch_bounds__(NW * 64) void rollout4g_kernel(const RolloutArgs a)
     }
   };
   draw(0, E0);
+  float t_cur = a.ts[0], t_nxt = a.ts[1];     // (the time grid one step ahead, see rollout4_kernel)
   for (int k = 0; k < K; ++k) {
-    const float t0 = a.ts[k], t1 = a.ts[k + 1];
+    const float t0 = t_cur, t1 = t_nxt;
+    t_cur = t_nxt;
+    t_nxt = a.ts[min(k + 2, K)];
     const float dt = t1 - t0;                 // utils.py:38
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
+    const float dt_over_lmbd = dt / a.lmbd, sqrt_dt_over_lmbd = sqrtf(dt_over_lmbd);   // (off the post-network chain, see rollout4_kernel)
     __syncthreads();
     unet_tile_forward_static4<NW, NET>(a.packed, lds, carry);                // GV = nabla_V(t, x); ends behind a barrier
     const float* E = (k & 1) ? E1 : E0;
@@ -1147,8 +1151,10 @@ __global__ __launch_bounds__(NW * 64) void rollout4g_kernel(const RolloutArgs a)
         f = 1.f;
       }
       const float uu = wave64_sum(u * u), ue = wave64_sum(lane_ok ? u * eps : 0.f);
-      lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
-      lps = lps + sqrtf(step / a.lmbd) * (-ue);
+      const float sol = STOPPING ? step / a.lmbd : dt_over_lmbd;
+      const float ssol = STOPPING ? sqrtf(sol) : sqrt_dt_over_lmbd;
+      lpd = lpd + sol * (-f - 0.5f * uu);
+      lps = lps + ssol * (-ue);
       if (store) {
         a.controls[(size_t)k * B * d + rowoff] = u;
         a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
