@@ -978,7 +978,7 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
   }
 }
 
-// sum over the 64 lanes of a wave; every lane ends with the total (row sums by DPP, rows by the gfx950 swaps of kg_sum)
+// sum over the 64 lanes of a wave; every lane ends with the total (row sums by DPP, rows by the gfx950 row / half swaps, cf. kg_reduce)
 __device__ __forceinline__ float wave64_sum(float v) {
   float a = row16_sum(v), t;
   asm volatile(

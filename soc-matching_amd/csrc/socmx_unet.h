@@ -283,7 +283,7 @@ __device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, c
 // R4: the 4-row tile.  The SAME weight fragment feeds v_mfma_f32_4x4x1_16b_f32: its 16 blocks are lane quads, block
 // (l >> 2) = (k-group kg = l >> 4, neuron group ng = (l >> 2) & 3); lane l's A value is W[16 nb + (l & 15)][16 kc + 4 kg + i]
 // as before, its B value x[row l & 3][16 kc + 4 kg + i], and D = neurons 4 ng .. 4 ng + 3 of row (l & 3), summed over
-// k-group kg's inputs only -- the four k-groups' partial sums are added across lanes when a GEMM ends (kg_sum).
+// k-group kg's inputs only -- the four k-groups' partial sums are added across lanes when a GEMM ends (kg_reduce).
 // 16 cycles per instruction (half the 16x16x4 rate per MAC), a quarter of the rows: half the time per tile.
 template <int NB, bool R4 = false>
 __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NB], const f32x4 (&a)[NB], const f32x4 bx) {

@@ -1808,10 +1808,9 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   p.total_bias = off - p.total_cells_floats;
   p.slab_floats = off;
   p.n_items = items;
-  // Slabs of row tiles for kernel B (one wave per (block group, slab), four slabs per workgroup).  Measured on MI355X
-  // (tools/k2_prof.sh, a sweep of S): the slab GROUPS must divide evenly over the 8 XCDs -- kernel B numbers them onto
-  // XCDs -- so S is a multiple of 32; 64 is within 5 % of the best for 400 ... 13,000 tiles, and more slabs only grow
-  // kernel C's reduction.  Small inputs: at least 4 tiles per slab.
+  // Slabs of row tiles for kernel B's UNIFORM grid (small inputs, and nets the wave schedule's table cannot describe): one
+  // wave per (block group, slab), four slabs per workgroup; the slab GROUPS must divide evenly over the 8 XCDs -- kernel B
+  // numbers them onto XCDs -- so S is a multiple of 32; at least 4 tiles per slab.
   (void)items;
 #ifndef SOCMX_K2_SLABS
 #define SOCMX_K2_SLABS 64
