@@ -1410,3 +1410,25 @@ def test_four_row_rollout_settings_vs_eager_path(setting, d, extra):
         np.testing.assert_allclose(_np(a), _np(b), rtol=2e-4, atol=2e-4, err_msg=n)
     if setting == "molecular_dynamics":
         assert float(got[2].min()) == 0.0, "no trajectory stopped: the stopping branch went untested"
+
+
+@pytest.mark.parametrize("d", [1, 7, 15, 20, 33])
+def test_philox_noise_does_not_depend_on_the_tile_shape(d):
+    """The device generator is keyed by (seed, offset, global row, step, dim / 4): the 4-row kernels (fused step: two noise
+    waves, one Box-Muller pair per thread; general step: one pair per lane) must draw exactly the 16-row kernels' values,
+    for odd and even d, below and above 16, and for a row offset."""
+    from SOC_matching.experiment_settings.OU_quadratic import OU_Quadratic
+    from socmx import rollout as R
+    torch.manual_seed(3)
+    eye = torch.eye(d, device=DEV)
+    sde = OU_Quadratic(device=DEV, dim=d, lmbd=1.0, A=-0.2 * eye, P=0.1 * eye, Q=0.1 * eye, sigma=eye, T=1.0)
+    sde.initialize_models()
+    sde.to(DEV)
+    K = 5
+    ts = torch.linspace(0, 1.0, K + 1).to(DEV)
+    x0 = 0.1 * torch.randn(2048, d, device=DEV)
+    small = R.hip_trajectories(sde, x0[512:768], ts, 1.0, seed=99, offset=5, row0=512)      # 64 tiles of 4 rows
+    big = R.hip_trajectories(sde, x0, ts, 1.0, seed=99, offset=5)                           # 128 tiles of 16 rows
+    torch.cuda.synchronize()
+    assert torch.equal(small[1], big[1][:, 512:768])
+    assert float(small[1].abs().max()) > 0.5 and not torch.isnan(small[1]).any()
