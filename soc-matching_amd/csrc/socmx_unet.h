@@ -194,6 +194,10 @@ __host__ __device__ __attribute__((always_inline)) constexpr bool first_fragment
   bool ok = false;
   if (NBLK >= NW || NBLK >= kSimds) {   // one block per SIMD already saturates the four MFMA pipes: no split-K
     int cnt = w < NBLK ? (NBLK - w + NW - 1) / NW : 0;
+    // (blocks divide evenly over the waves: the count does not depend on the wave -- said explicitly, so that with constant
+    //  NBLK / NW the divisions by `nb` below fold away: evaluated with a run-time wave id they were ~100 instructions of
+    //  float-reciprocal division per stage in front of the barrier of the control-network backward)
+    if (NBLK >= NW && NBLK % NW == 0) cnt = NBLK / NW;
     nb = cnt > 4 ? 4 : cnt;
     ok = cnt > 0 && nb != 3;                 // a 3-block group ignores the prefetch
     if (nb < 1) nb = 1;
@@ -221,7 +225,7 @@ __host__ __device__ constexpr WaveWork wave_work_of(const StageDesc& d, int NW, 
   const int NBLK = d.L1.out_pad >> 4, KC1 = d.L1.in_pad >> 4, KC2 = d.L2.in_pad >> 4;
   if (NBLK >= NW || NBLK >= kSimds) {   // one block per SIMD already saturates the four MFMA pipes: no split-K
     x.split = 0; x.blk0 = (unsigned short)w;
-    x.cnt = (unsigned short)(w < NBLK ? (NBLK - w + NW - 1) / NW : 0);
+    x.cnt = (unsigned short)((NBLK >= NW && NBLK % NW == 0) ? NBLK / NW : (w < NBLK ? (NBLK - w + NW - 1) / NW : 0));
     x.active = x.cnt > 0;
     x.kc0a = 0; x.kc1a = (unsigned short)KC1; x.kc0b = 0; x.kc1b = (unsigned short)KC2;
   } else {
