@@ -569,7 +569,7 @@ template <int NW> struct K2Const<NW, void> {
 };
 
 template <int NW, class NET>
-__global__ __launch_bounds__(NW * 64) void unet_bwd_tile_kernel(const TileArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void unet_bwd_tile_kernel(const TileArgs a) {   // (two waves per SIMD is what the LDS admits: no AGPR copies to stay under 128 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool kStatic = !std::is_same<NET, void>::value;
   // constexpr instantiations: the descriptors are constants in the code object (a local copy whose address is handed on
