@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(NW * 64) void mnet_backward_kernel(const MArgs a) {
 // wgrad_body).  Four waves per workgroup, two workgroups per CU (their prologues, combines and barriers interleave); the
 // combine and the masked epilogue are described in the kernel.  Then L1^T as above.
 template <int NW, int NOB>
-__global__ __launch_bounds__(NW * 64) void mnet_backward_wide_kernel(const MArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MArgs a) {   // (two workgroups per CU = two waves per SIMD: the full register budget, no AGPR copies)
   static_assert(NW == 4, "the combine below is written for four waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const MDesc& m = a.m;
