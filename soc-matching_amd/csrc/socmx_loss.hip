@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_mfma2_kernel(const Tar
 // fragments (q, v rows) are shared by the four waves through L1.  Operands of the next 16 batch rows are requested
 // before the current ones are multiplied.
 template <bool NET, int LB>
-__global__ __launch_bounds__(256) void socm_target_bwd_wide_kernel(const TargetBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void socm_target_bwd_wide_kernel(const TargetBwdArgs a) {
   const int d = a.d, K = a.K, B = a.B;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -1314,7 +1314,7 @@ __device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* ld
 }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void mnet_forward_kernel(const MArgs a) {   // (one workgroup per CU measured faster than two at 128 VGPRs: 1.72 vs 1.89 ms)
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mnet_forward_kernel(const MArgs a) {   // (one workgroup per CU measured faster than two at 128 VGPRs: 1.72 vs 1.89 ms)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile = blockIdx.x;
   const MDesc& m = a.m;
