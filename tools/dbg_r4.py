@@ -22,10 +22,8 @@ ts = aux["ts"][: K + 1]
 x0 = torch.randn(B, 10, device="cuda:0")
 noise = torch.randn(K, B, 10, device="cuda:0")
 r = utils.stochastic_trajectories(sde, x0, ts, aux["lmbd"], noise_in=noise, want_nabla_v=True)
-nv = r[8]
-tx = torch.cat([ts[0].expand(B, 1), x0], 1)
-ref = sde.nabla_V.net_forward_torch(tx) if hasattr(sde.nabla_V, "net_forward_torch") else None
-np.savez(sys.argv[2], states=r[0].cpu().numpy(), nabla_v=nv.cpu().numpy())
+nv = r[8]                                   # the network's output on the grid: the first thing to look at when the shapes disagree
+np.savez(sys.argv[2], states=r[0].cpu().numpy(), controls=r[7].cpu().numpy(), lpd=r[4].cpu().numpy(), nabla_v=nv.cpu().numpy())
 np.set_printoptions(linewidth=200, precision=4, suppress=True)
 print(nv[0].cpu().numpy())
 print("saved", sys.argv[2], [tuple(t.shape) for t in r[:3]])
