@@ -231,7 +231,7 @@ def unet_backward_supported(net, n_rows):
     return L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
 
 
-def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None, out=None):
+def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None, out=None, packed_bwd=None):
     """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
     x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
     `net.parameters()` order (views of one flat buffer)."""
@@ -251,10 +251,12 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=No
     #  and all-reduces the whole buffer)
     flat = torch.empty(ng.value, dtype=torch.float32, device=dev) if out is None else out[:ng.value]
     with _lib.on_device(dev):
-        # (`packed`: the forward image of the CURRENT weights when the caller knows it is fresh -- e.g. the one this
-        #  iteration's rollout just used -- instead of re-packing)
+        # (`packed` / `packed_bwd`: the forward / transposed image of the CURRENT weights when the caller knows they are
+        #  fresh -- the one this iteration's rollout just used, the one packed beside it on the second stream -- instead of
+        #  re-packing in front of the backward)
         _lib.check(L.socmx_unet_backward_f32(_lib.ptr(packed if packed is not None else net.packed()),
-                                             _lib.ptr(net.packed_bwd()), d, _lib.i3(net.hdims),
+                                             _lib.ptr(packed_bwd if packed_bwd is not None else net.packed_bwd()), d,
+                                             _lib.i3(net.hdims),
                                              _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N, _lib.ptr(gout),
                                              _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
                    "socmx_unet_backward_f32")

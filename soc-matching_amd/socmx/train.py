@@ -392,9 +392,13 @@ class Trainer:
         # d = 64 rollout took 13.0 instead of 7.3 ms behind the deferred contraction backward)
         (states, noises, stop, frac, lpd, lps, ltw, controls, nabla_v) = R.stochastic_trajectories(
             sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0)
+        packed_bwd = None
         if side is not None:
             with torch.cuda.stream(side):
                 side.wait_event(fork)
+                # (the transposed weight image the control-network backward reads: packed here, beside the rollout, instead of
+                #  in front of the backward on the critical path -- the weights do not change in between)
+                packed_bwd = sde.nabla_V.packed_bwd()
                 net, dnet = m_branch()
         if side is not None:
             main.wait_stream(side)
@@ -422,7 +426,7 @@ class Trainer:
         vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
                                                (G * gout).reshape(Kp * B, d), return_flat=True,
                                                packed=sde.nabla_V._packed,     # (the image this iteration's rollout packed)
-                                               out=main_flat)
+                                               out=main_flat, packed_bwd=packed_bwd)
         vparams = list(sde.nabla_V.parameters())
         nsd = None
         if want_l2:
