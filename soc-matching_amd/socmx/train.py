@@ -376,6 +376,10 @@ class Trainer:
                 self._m_update(t_vec, s_vec)
             net, dnet, _ = nets.pair_net_forward(d, M.hdims, mparams, t_vec, s_vec, packed=D["packed"],
                                                  out=(D["net"], D["dnet"]))
+            # two scalars the main stream needs only behind the rollout: gamma (final once the deferred update above ran) and
+            # 1 / running normaliser = d loss / d objective (main.py:313-320) -- formed here, off the critical path
+            D["gam"].copy_(sde.gamma.detach().reshape(1))
+            torch.reciprocal(D["norm1"], out=D["gout"])
             return net, dnet
 
         main = torch.cuda.current_stream(dev)
@@ -407,11 +411,9 @@ class Trainer:
         weight, stats = L.weights_and_stats(lpd, lps, ltw)
         w_mean, w_std = L.mean_std_from_stats(stats)
         ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls, out=D)
-        gam = D["gam"]
-        gam.copy_(sde.gamma.detach().reshape(1))
+        gam = D["gam"]                                                     # (filled in m_branch)
         obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B_global), G=D["G"])
-        gout = D["gout"]
-        torch.reciprocal(D["norm1"], out=gout)                            # d loss / d objective  (main.py:313-320)
+        gout = D["gout"]                                                   # d loss / d objective, from m_branch
         # (the contraction BACKWARD -- gradients of the pair-grid network and gamma only -- is deferred: _m_update)
         from . import _lib
         Lh, f = _lib.lib(), _lib.ptr
