@@ -109,6 +109,7 @@ struct PrepArgs {
   const float *ts, *states, *noises, *controls, *frac;
   float *v, *q, *gT;      // (K,B,d), (K,B,d), (B,d)      batch-major  (backward kernel)
   float *vT, *qT, *gTT;   // (K,d,B), (K,d,B), (d,B)      batch-fastest copies, optional (NULL = not written)
+  int n_tiled_blocks;     // socm_prep_tiled_kernel: workgroups with row tiles (the ones behind them take the terminal rows)
 };
 
 // one thread per (j, m); j == K handles the terminal row (nabla_g)
@@ -177,8 +178,14 @@ __global__ __launch_bounds__(256) void socm_prep_kernel(const PrepArgs a) {
 // conflicts); thread = (row, quarter of the output columns), so sigma^-T / A / P are wave-uniform scalar loads.
 // Outputs go back through LDS and leave as one coalesced run.  (The per-thread form above walks d*d strided
 // global reads per row: 27 ms at d = 64, K = 400, B = 512.)
+__device__ __forceinline__ void socm_prep_terminal_rows(const PrepArgs& a, int m);
 __global__ __launch_bounds__(256) void socm_prep_tiled_kernel(const PrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // (the workgroups behind the row tiles form the terminal rows' nabla_g: one launch less on the iteration's critical path)
+  if ((int)blockIdx.x >= a.n_tiled_blocks) {
+    socm_prep_terminal_rows(a, ((int)blockIdx.x - a.n_tiled_blocks) * 256 + (int)threadIdx.x);
+    return;
+  }
   const int d = a.d, B = a.B, K = a.K, S = d + 1;
   float* E = lds;             // noise tile, later the q tile
   float* U = E + 64 * S;      // control tile
@@ -244,8 +251,7 @@ __global__ __launch_bounds__(256) void socm_prep_tiled_kernel(const PrepArgs a) 
 }
 
 // terminal rows only (j == K): gT = nabla_g(X_K); thread per batch row
-__global__ __launch_bounds__(256) void socm_prep_terminal_kernel(const PrepArgs a) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void socm_prep_terminal_rows(const PrepArgs& a, int m) {
   const int d = a.d, B = a.B, K = a.K;
   if (m >= B) return;
   const float* x = a.states + ((size_t)K * B + m) * d;
@@ -262,6 +268,9 @@ __global__ __launch_bounds__(256) void socm_prep_terminal_kernel(const PrepArgs 
     a.gT[(size_t)m * d + l] = g;
     if (a.gTT) a.gTT[(size_t)l * B + m] = g;
   }
+}
+__global__ __launch_bounds__(256) void socm_prep_terminal_kernel(const PrepArgs a) {
+  socm_prep_terminal_rows(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---- target + residual (forward) --------------------------------------------------------------------
@@ -2116,6 +2125,7 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
     default: return SOCMX_E_KIND;
   }
   PrepArgs a;
+  a.n_tiled_blocks = 0;
   a.kind = pb->kind; a.d = pb->d; a.K = K; a.B = B; a.sqrt_lmbd = sqrtf(lmbd);
   a.sit = pb->sigma_inv_t; a.A = pb->A; a.P = pb->P; a.Q = pb->Q; a.omega = pb->omega; a.kappa = pb->kappa;
   a.nu = pb->nu;
@@ -2131,9 +2141,8 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
   if (pb->d <= 128 && tile_lds <= 160 * 1024) {
     if (const int err = ensure_max_lds(socm_prep_tiled_kernel)) return err;
     const int64_t rows = (int64_t)K * B;
-    if (const int err = launch(socm_prep_tiled_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), tile_lds, stream, a))
-      return err;
-    return launch(socm_prep_terminal_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
+    a.n_tiled_blocks = (int)((rows + 63) / 64);
+    return launch(socm_prep_tiled_kernel, dim3((unsigned)(a.n_tiled_blocks + (B + 255) / 256)), dim3(256), tile_lds, stream, a);
   }
   const int64_t n = (int64_t)(K + 1) * B;
   return launch(socm_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
