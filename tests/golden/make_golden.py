@@ -308,6 +308,20 @@ FIXTURES = [
     # the other fixtures: with T = 1 the six-step double well diverges to NaN in the reference itself).
     ("cfg5_ou_linear_d64_B256_K3", "OU_linear", 64, 3, 256, DEFAULT, 2.0, 0, dict(with_pairs=False, T=0.15)),
     ("cfg4_double_well_d10_B512_K6", "double_well", 10, 6, 512, DEFAULT, 6.0, 0, dict(with_pairs=False, T=0.06)),
+    # FULL-SIZE PINS (round 4).  (1) The headline config at its own size -- README.md:51 / BASELINE configs[2]: double_well
+    # d = 10, K = 200, B = 128, default widths (the reference holds ~10.6 GB of (Kp,Kp,B,d,d) intermediates and needs a few
+    # minutes on one thread): the 32-workgroup launch bench.py times faces the reference itself.
+    ("cfg3_full_double_well_d10_K200_B128", "double_well", 10, 200, 128, DEFAULT, 6.0, 0, dict(with_pairs=False)),
+    # (2) README.md:60's molecular_dynamics run as written: d = 1, K = 150, B = 64, default control-network widths,
+    # arch.hdims_M=[64,64], gamma = 2 (gamma2 = gamma3 = 1: MolecularDynamics does not forward them, method.py:29-30),
+    # use_stopping_time=True -- the constexpr STOPPING rollout instantiations and stopping_target_kernel<1> at K = 150.
+    ("md_default_d1_K150_B64_stopping", "molecular_dynamics", 1, 150, 64,
+     dict(hdims=[256, 128, 64], hdims_M=[64, 64]), 2.0, 0, dict(use_stopping_time=True)),
+    # (3) the other eight losses at the DEFAULT widths and K = 200 (SOCM_adjoint's costate recursion over 200 steps, the
+    # HIP rollout -> socmx_baselines kernels -> constexpr control-network backward): same seed and draws as
+    # cfg3_double_well_d10_K200 (only the alg.* outputs are kept next to the inputs)
+    ("cfg3_algs_double_well_d10_K200", "double_well", 10, 200, 8, DEFAULT, 6.0, 0,
+     dict(with_pairs=False, with_loss=False, with_algs=True)),
 ]
 
 

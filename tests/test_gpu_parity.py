@@ -347,7 +347,10 @@ def test_contraction_kernels_multi_block_shapes(d, K, B):
 @pytest.mark.parametrize("name", LOSS + ["cfg1_ou_quadratic_easy_d2_K50", "cfg3_double_well_d10_K200",
                                          "cfg5_ou_linear_d64_K20", "ouq20_ou_quadratic_easy_d20_K12",
                                          # B >= 256 at d = 64 / B >= 512 at d = 10: the kernels the BASELINE batch sizes select
-                                         "cfg5_ou_linear_d64_B256_K3", "cfg4_double_well_d10_B512_K6"])
+                                         "cfg5_ou_linear_d64_B256_K3", "cfg4_double_well_d10_B512_K6",
+                                         # the headline config at its own size (README.md:51: K = 200, B = 128 -- the launch
+                                         # bench.py times), generated by the reference itself
+                                         "cfg3_full_double_well_d10_K200_B128"])
 def test_full_socm_loss_on_gpu_vs_golden(name):
     from SOC_matching.method import SOC_Solver
     sde, aux = build_sde(name, DEV)
@@ -575,7 +578,10 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["tiny_molecular_dynamics_d1_stopping", "tiny_molecular_dynamics_d2_stopping",
-                                  "tiny_molecular_dynamics_d5_stopping", "tiny_molecular_dynamics_d10_stopping"])
+                                  "tiny_molecular_dynamics_d5_stopping", "tiny_molecular_dynamics_d10_stopping",
+                                  # README.md:60 as written: default widths -> the constexpr STOPPING rollout kernels,
+                                  # stopping_target_kernel<1> at K = 150, B = 64
+                                  "md_default_d1_K150_B64_stopping"])
 def test_stopping_time_socm_loss_on_gpu_vs_golden(name, fused):
     """a7': SOCM with per-sample pair matrices (TwoBoundarySigmoidMLP, models.py:278-393).  fused = the device path: both
     network evaluations + s-tangents from the pair-grid-network kernel (n_in = 3), the gates, their s-derivatives and their
@@ -1008,7 +1014,10 @@ OTHER_ALGS = ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-
               "rel_entropy")
 
 
-@pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10"])
+@pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10",
+                                  # default widths, K = 200: HIP rollout (static kernels) -> socmx_baselines kernels -> static
+                                  # control-network backward; SOCM_adjoint's costate recursion over 200 steps
+                                  "cfg3_algs_double_well_d10_K200"])
 @pytest.mark.parametrize("alg", OTHER_ALGS)
 def test_other_losses_on_gpu_match_reference(name, alg, monkeypatch):
     """Row f4 on the GPU: the reference's eight other losses on the HIP rollout's buffers (rel_entropy differentiates

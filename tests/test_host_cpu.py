@@ -148,7 +148,9 @@ OTHER_ALGS = ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-
               "rel_entropy")
 
 
-@pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10"])
+@pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10",
+                                  # default widths, K = 200 (SOCM_adjoint's costate recursion over 200 steps)
+                                  "cfg3_algs_double_well_d10_K200"])
 @pytest.mark.parametrize("alg", OTHER_ALGS)
 def test_other_losses_match_reference(name, alg):
     """Row f4: the reference's eight other losses, objective and nabla_V gradients, same injected noise."""

@@ -93,9 +93,11 @@ def test_socm_loss_default_arch(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_molecular_dynamics_d1_stopping", "tiny_molecular_dynamics_d2_stopping",
-                                  "tiny_molecular_dynamics_d5_stopping", "tiny_molecular_dynamics_d10_stopping"])
+                                  "tiny_molecular_dynamics_d5_stopping", "tiny_molecular_dynamics_d10_stopping",
+                                  # README.md:60 as written (default widths, hdims_M=[64,64], K = 150, B = 64)
+                                  "md_default_d1_K150_B64_stopping"])
 def test_socm_loss_stopping_time(name):
-    torch.set_num_threads(4 if "d5" in name else 1)
+    torch.set_num_threads(4 if ("d5" in name or "md_default" in name) else 1)
     pb, vp, mp, gamma, aux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"), requires_grad=True)
     z = aux["z"]
     obj, wm, ws = O.socm_loss_stopping(pb, vp, mp, gamma, aux["gamma2"], aux["gamma3"], aux["x0"], aux["ts"],
