@@ -18,28 +18,9 @@
 #include "socmx_unet.h"
 #include "socmx_launch.h"
 #include "socmx_philox.h"
+#include "socmx_rollout_common.h"
 
 namespace socmx {
-
-struct RolloutArgs {
-  UnetDesc u;
-  TileLayout t;
-  UnetProgram prog;
-  int kind, d, B, K;
-  float lmbd;
-  uint64_t seed, offset;
-  const uint64_t* key_dev;   // device {seed, offset} (socmx_rollout_ex_f32: a replayed hipGraph draws fresh noise) or NULL
-  int64_t row0;
-  const float* packed;
-  const float *sigma, *A, *P, *Q, *omega, *kappa, *nu;
-  const float *x0, *ts, *noise_in;
-  float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
-  float* nabla_v;      // optional (K+1, B, d): the network output at every grid point incl. the terminal one (method.py:272-278)
-  int sigma_identity;  // problem->flags & SOCMX_SIGMA_IDENTITY
-  int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
-  long long* prof;  // diagnostics only (PROF variant): [blocks][64] accumulated s_memtime cycles per phase
-  int prof_wave;    // which wave's view is recorded (SOCMX_PROF_WAVE, default 0)
-};
 
 // drift b_i(x) -- OU_quadratic.py:51-52, OU_linear.py:43-44, double_well.py:44-48, molecular_dynamics.py:49-53
 __device__ __forceinline__ float drift_i(int kind, int d, int i, const float* x, const float* A_l,
@@ -101,32 +82,6 @@ __device__ __forceinline__ float lds_sel(const float* p, bool c) {
   const float t = *p;
   return c ? t : 0.f;
 }
-
-__host__ __device__ constexpr int socmx_sde_stride(int d) { return ((d + 15) & ~15) + 1; }
-
-// the two halves of philox_normal2, for callers that spread them over two phases of a step
-__device__ __forceinline__ void philox_pair_words(uint64_t seed, uint64_t offset, uint32_t grow, uint32_t step,
-                                                  int block, int h, uint32_t& wa, uint32_t& wb) {
-  uint32_t w[4];
-  philox4x32_10(grow, step, (uint32_t)block, (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-  wa = h ? w[2] : w[0];
-  wb = h ? w[3] : w[1];
-}
-__device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, float& z0, float& z1) {
-  const float ua = ((float)wa + 0.5f) * 2.3283064365386963e-10f;
-  const float ub = ((float)wb + 0.5f) * 2.3283064365386963e-10f;
-  const float r = sqrtf(-2.0f * logf(ua));
-  float sn, cs;
-  sincospif(2.0f * ub, &sn, &cs);
-  z0 = r * cs;
-  z1 = r * sn;
-}
-
-struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
-// (SOCMX_H*P: the reference's default arch.hdims = [256,128,64] unless this is a variant build, see socmx_unet.h)
-typedef StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16> DefaultNet;  // d <= 15
-typedef StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
-typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... and at 16 <= d <= 31 (soc.yaml's default d = 20)
 
 template <int NW, bool STOPPING, bool PROF, class NET, bool FAST>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
@@ -1467,6 +1422,13 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   // (d >= 32 with more than 256 rows -- one GPU's slice of BASELINE configs[4] -- keeps the 16-row tiles: there the loss side of
   //  an iteration fills the chip for longer than the rollout runs beside it, and the 4-row form's 4x CUs at half the MFMA rate
   //  per MAC cost more than its shorter latency gives: slice iteration 21.2 ms with 4-row tiles, 19.9 with 16-row ones)
+  // Training-size batches of the sigma = I, d <= 15 settings at the default widths (BASELINE configs[1], [2]; the README's
+  // molecular_dynamics run): ONE ROW per workgroup, the network as matrix-vector products on the VALU with most of the weight
+  // image resident in registers / LDS (socmx_rollout1.hip) -- B workgroups instead of B / 4.  SOCMX_TILE_ROWS=1 forces it
+  // for any B <= 1024 (tests), =4 / =16 exclude it.
+  if (is_default && fast && !prof && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
+      (B <= 256 || (force_rows == 1 && B <= 1024)))
+    return rollout1_launch(a, stopping, stream);
   const bool small4 = blocks <= 16 || (blocks <= 64 && d <= 31);
   if ((is_default || is_wide32 || is_wide64) && !prof && d <= 64 && force_rows != 16 && (small4 || force_rows == 4)) {
     void (*k4)(const RolloutArgs) = nullptr;

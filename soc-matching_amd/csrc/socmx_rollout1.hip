@@ -1,0 +1,605 @@
+// socmx_rollout1.hip -- the fused Euler-Maruyama rollout with ONE ROW PER WORKGROUP (gfx950): training-size batches.
+//
+// Replaces reference SOC_matching/utils.py:17-128 (stochastic_trajectories), method.py:58-80 (control) and
+// models.py:233-242 (FullyConnectedUNet.forward) for B <= 256 rows, sigma = I, d <= 15 and the default hidden widths -- the
+// shape of BASELINE configs[1] / [2] (B = 128) and of the README's molecular_dynamics run (B = 64).
+//
+// Why one row.  A batch of 128 rows is 8 tiles of 16 rows (8 of 256 CUs busy) or 32 tiles of 4 rows (32 CUs, on an MFMA
+// form that runs at half rate); the K-long chain of network evaluations per tile is the whole run time.  With one row per
+// workgroup 128 CUs work, and a network evaluation is a chain of MATRIX-VECTOR products: every weight is used once per
+// step, no MFMA tile exists.  On the VALU the product is
+//     acc[lane (g, n)] += x[k] * W[16 nb + n][k],   k = 16 kc + 4 g + i
+//   = v_fmac_f32_dpp acc, xv, w  row_newbcast:(4 f + i)          (64 MACs per instruction, the matrix pipe's 4x4x1 rate)
+// with `w` one component of the SAME fragment image the MFMA kernels read (socmx_unet.h: lane (g, n), component i of fragment
+// (nb, kc) holds W[16 nb + n][16 kc + 4 g + i]) and `xv` an activation register whose 16-lane row g holds, at position
+// 4 f + i, x[64 C + 16 f + 4 g + i] (f = kc & 3: four fragments = one 64-wide chunk C share one activation register; DPP
+// row_newbcast:j broadcasts position j of each row to the row's lanes).  The four rows of a wave are four k-groups of the
+// same 16 neurons; their partial sums are added across rows when a layer ends (v_permlane32/16_swap).
+// What bounds the step is then where the 677 KB of weights come FROM, every step: 64 MACs per cycle and CU need 256 B per
+// cycle, which only the register file delivers.  So the image is split three ways per wave (compile-time tables below):
+//   RES  blocks live in VGPRs for the whole launch (a block = 16 registers = one (neuron block, chunk) = 4 KiB per wave),
+//   LDS  blocks are copied to LDS once and read back every step (ds_read_b128, 128 B/clk),
+//   STR  blocks stream from L2 every step through a two-block register ring, requested a ring ahead of their use.
+// Wave 0 also integrates: it owns the network's first layer (all 256 units, 11 inputs), the last layer's final sum and the
+// Euler-Maruyama step, runs no stream (its global stores share the vmcnt counter) and keeps its big stage in LDS instead.
+// tools/ubench/valu_row1.hip measured the pieces (profiles/r4/valu_row1_ubench.txt).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "socmx_rollout_common.h"
+#include "socmx_launch.h"
+
+namespace socmx {
+
+constexpr int kR1Waves = 8;
+constexpr int kR1Blocks = 20;   // main-program blocks per wave and step
+constexpr int kR1PD = 2;        // ring depth (blocks)
+
+// Where block b of a wave's program comes from: 'R' registers, 'L' LDS, 'S' L2 stream.  Class 0 = wave 0, class 1 = waves 1..7.
+//   blocks: 0-3 down_1 (chunks 0..3) | 4 down_2 | 5 up_2, 6-7 res_2 | 8-11 up_1 (U0c0 U1c0 U0c1 U1c1) | 12-19 res_1 (R0c0 R1c0 ...)
+__host__ __device__ constexpr char r1_src(int cls, int dm, int b) {
+  // wave 0 also holds 4 (1 + DMAX) + (1 + DMAX) registers of down_0 / res_0: fewer resident blocks at larger d
+  constexpr char plan0_3[kR1Blocks + 1] = "RRRRRLLLLSLSLSLSLSLS";
+  constexpr char plan0_11[kR1Blocks + 1] = "RRRRSLLSLSLSLSLSLSLS";
+  constexpr char plan0_15[kR1Blocks + 1] = "RRRLSLLSLSLSLSLSLSLS";
+  constexpr char plan1[kR1Blocks + 1] = "RSRLSRSRLRSRRLSRLRSR";
+  return cls == 1 ? plan1[b] : dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
+}
+__host__ __device__ constexpr int r1_count(int cls, int dm, char s, int upto = kR1Blocks) {
+  int n = 0;
+  for (int b = 0; b < upto; ++b) n += r1_src(cls, dm, b) == s;
+  return n;
+}
+// block number of a class's i-th block of source s
+__host__ __device__ constexpr int r1_nth(int cls, int dm, char s, int i) {
+  int n = 0;
+  for (int b = 0; b < kR1Blocks; ++b)
+    if (r1_src(cls, dm, b) == s) {
+      if (n == i) return b;
+      ++n;
+    }
+  return -1;
+}
+__host__ __device__ constexpr int r1_lds_blocks(int dm) { return r1_count(0, dm, 'L') + 7 * r1_count(1, dm, 'L'); }
+
+template <class NET>
+__host__ __device__ constexpr bool r1_supported() {
+  constexpr UnetDesc u = NET::desc();
+  return u.in0p == 16 && u.hp[0] == 256 && u.hp[1] == 128 && u.hp[2] == 64 && u.outp == 16;
+}
+
+// float offset of block b of wave w inside the packed image (fragments (nb, 4C .. 4C+3) of a layer are 4 KiB contiguous)
+template <class NET>
+__device__ __forceinline__ int r1_block_off(int b, int w) {
+  constexpr UnetDesc u = NET::desc();
+  if (b < 4) return u.L[1].w_off + (w * 16 + 4 * b) * 256;                                  // down_1: nb = w, chunk b
+  if (b == 4) return u.L[2].w_off + ((w & 3) * 8 + 4 * (w >> 2)) * 256;                     // down_2: nb = w & 3, chunk w >> 2
+  if (b == 5) return u.L[6].w_off + (w * 4) * 256;                                          // up_2: nb = w
+  if (b < 8) return u.L[5].w_off + (w * 8 + 4 * (b - 6)) * 256;                             // res_2: nb = w, chunk b - 6
+  if (b < 12) return u.L[7].w_off + ((2 * w + ((b - 8) & 1)) * 8 + 4 * ((b - 8) >> 1)) * 256;    // up_1: nb = 2w + r
+  return u.L[4].w_off + ((2 * w + ((b - 12) & 1)) * 16 + 4 * ((b - 12) >> 1)) * 256;         // res_1
+}
+
+// ---- instruction helpers -----------------------------------------------------------------------------------------------
+// 16 fmacs of one block: weight register j <-> broadcast position j; two accumulators alternate (no fmac reads the result
+// of the one before it).  The leading s_nop covers VALU-write -> DPP-read of the activation register (2 wait states).
+#define R1FM(J, A, W) "v_fmac_f32_dpp %" #A ", %2, %" #W " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+// half a block (eight fmacs, positions 8 HI .. 8 HI + 7) into two alternating accumulators
+template <int HI>
+__device__ __forceinline__ void r1_fmac8(float& a0, float& a1, float x, const float* w) {
+  if constexpr (HI == 0) {
+    asm("s_nop 1\n\t" R1FM(0, 0, 3) R1FM(1, 1, 4) R1FM(2, 0, 5) R1FM(3, 1, 6) R1FM(4, 0, 7) R1FM(5, 1, 8) R1FM(6, 0, 9)
+            R1FM(7, 1, 10)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+  } else {
+    asm("s_nop 1\n\t" R1FM(8, 0, 3) R1FM(9, 1, 4) R1FM(10, 0, 5) R1FM(11, 1, 6) R1FM(12, 0, 7) R1FM(13, 1, 8) R1FM(14, 0, 9)
+            R1FM(15, 1, 10)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+  }
+}
+// the same half of TWO blocks that share the activation register (two neuron blocks of one chunk), interleaved: block A's
+// fmacs into aA, block B's into aB -- one accumulator per block, and still no fmac reads the result of the one before it
+template <int HI>
+__device__ __forceinline__ void r1_fmac8x2(float& aA, float& aB, float x, const float* wa, const float* wb) {
+  if constexpr (HI == 0) {
+    asm("s_nop 1\n\t" R1FM(0, 0, 3) R1FM(0, 1, 11) R1FM(1, 0, 4) R1FM(1, 1, 12) R1FM(2, 0, 5) R1FM(2, 1, 13) R1FM(3, 0, 6)
+            R1FM(3, 1, 14) R1FM(4, 0, 7) R1FM(4, 1, 15) R1FM(5, 0, 8) R1FM(5, 1, 16) R1FM(6, 0, 9) R1FM(6, 1, 17) R1FM(7, 0, 10)
+                R1FM(7, 1, 18)
+        : "+v"(aA), "+v"(aB)
+        : "v"(x), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wa[4]), "v"(wa[5]), "v"(wa[6]), "v"(wa[7]), "v"(wb[0]),
+          "v"(wb[1]), "v"(wb[2]), "v"(wb[3]), "v"(wb[4]), "v"(wb[5]), "v"(wb[6]), "v"(wb[7]));
+  } else {
+    asm("s_nop 1\n\t" R1FM(8, 0, 3) R1FM(8, 1, 11) R1FM(9, 0, 4) R1FM(9, 1, 12) R1FM(10, 0, 5) R1FM(10, 1, 13) R1FM(11, 0, 6)
+            R1FM(11, 1, 14) R1FM(12, 0, 7) R1FM(12, 1, 15) R1FM(13, 0, 8) R1FM(13, 1, 16) R1FM(14, 0, 9) R1FM(14, 1, 17)
+                R1FM(15, 0, 10) R1FM(15, 1, 18)
+        : "+v"(aA), "+v"(aB)
+        : "v"(x), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wa[4]), "v"(wa[5]), "v"(wa[6]), "v"(wa[7]), "v"(wb[0]),
+          "v"(wb[1]), "v"(wb[2]), "v"(wb[3]), "v"(wb[4]), "v"(wb[5]), "v"(wb[6]), "v"(wb[7]));
+  }
+}
+// acc += x[position J of the lane's row] * w
+template <int J>
+__device__ __forceinline__ void r1_fmac_bc(float& acc, float x, float w) {
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
+}
+
+// sum over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48): every lane ends with the total
+__device__ __forceinline__ float r1_rows_sum(float v) {
+  float t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %1\n\t"
+      "v_add_f32 %0, %0, %1"
+      : "+v"(v), "=&v"(t));
+  return v;
+}
+// lo = the lower half's values in both halves, hi = the upper half's
+__device__ __forceinline__ void r1_halves(float v, float& lo, float& hi) {
+  float a = v, b;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1"
+      : "+v"(a), "=&v"(b));
+  lo = a;
+  hi = b;
+}
+// rows 2, 3 <- the row rotated by eight positions; rows 0, 1 unchanged
+__device__ __forceinline__ float r1_ror8_upper(float v) {
+  float r = v;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xc bank_mask:0xf" : "+v"(r) : "v"(v));
+  return r;
+}
+
+// One streamed fragment as a raw buffer load: descriptor of the packed image (four SGPRs, once per wave) + the lane's 32-bit
+// byte offset + the block's byte offset in an SGPR + the fragment as an immediate -- no 64-bit VGPR address per request.
+// Compiler-visible loads on purpose: with asm requests and written-out vmcnt the compiler does not know that a register
+// is still in flight, and a copy it inserts where a live range is split (the loop's exit into the terminal evaluation)
+// reads the register before the data arrives -- seen as a non-deterministic nabla_V(T, X_K).  Its own wait counts are exact
+// in this straight-line ring (vmcnt(6) / vmcnt(4) in front of a block's two halves).
+typedef int r1_i32x4 __attribute__((ext_vector_type(4)));
+template <int IMM>
+__device__ __forceinline__ f32x4 r1_gload(__amdgpu_buffer_rsrc_t img, uint32_t lane_off, int block_bytes) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, (int)lane_off + IMM, block_bytes, 0));
+}
+
+// the activation layout: lane (g, p) of an activation register of chunk C holds element 64 C + r1_perm(lane); an involution
+__device__ __forceinline__ int r1_perm(int x) { return 16 * ((x >> 2) & 3) + 4 * (x >> 4) + (x & 3); }
+
+// LDS map (floats)
+struct R1Lds {
+  static constexpr int r1 = 0;        // (64 lanes, 4 chunks)  down_0's output, lane-ordered: one ds_read_b128 per lane
+  static constexpr int r2 = 256;      // (64, 2)   down_1's output
+  static constexpr int o2 = 384;      // (64, 2)   stage 3's output
+  static constexpr int p2 = 512;      // (8, 16)   down_2's split-K partials (wave w: neuron block w & 3, chunk w >> 2)
+  static constexpr int p5 = 640;      // (16, 8)   up_0's per-wave partial sums, neuron-major
+  static constexpr int nz = 768;      // (2, 16)   the row's noise of steps k, k + 1
+  static constexpr int wz = 800;      // (2, 8, 2) Philox words of steps k + 1, k + 2
+  static constexpr int amat = 832;    // (16, 16)  A, P of the OU settings (wave 0's drift / running cost)
+  static constexpr int pmat = 1088;
+  static constexpr int bias = 1344;   // the nine layers' padded biases (image order)
+  static constexpr int weights = 1344 + 1248;   // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
+};
+static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(11) * 1024) * 4 <= 160 * 1024 &&
+              (R1Lds::weights + r1_lds_blocks(15) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit");
+
+// ---- one wave of the workgroup --------------------------------------------------------------------------------------------
+// DMAX: the state dimensions this instantiation takes (d <= DMAX): wave 0 holds 1 + DMAX input columns of down_0 / res_0
+template <int CLS, bool STOPPING, class NET, int DMAX>
+__device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const int wave, const int lane) {
+  constexpr UnetDesc u = NET::desc();
+  constexpr int NRES = r1_count(CLS, DMAX, 'R'), NLDS = r1_count(CLS, DMAX, 'L'), NSTR = r1_count(CLS, DMAX, 'S');
+  const float* __restrict__ Wp = a.packed;
+  const int d = a.d, B = a.B, K = a.K, kind = a.kind;
+  const int grow = blockIdx.x;
+  const int g = lane >> 4, n = lane & 15;
+  const uint32_t loff = lane * 16;
+  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+
+  // ---- resident weights ----
+  float wres[NRES][16];
+#pragma unroll
+  for (int r = 0; r < NRES; ++r) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(r1_nth(CLS, DMAX, 'R', r), wave)) + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 v = src[c * 64];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wres[r][c * 4 + e] = v[e];
+    }
+  }
+  // up_0's share of this wave: k = 32 w + 16 (g & 1) + 8 (g >> 1) + j  (rows 2, 3 read the rotated copy of the wave's outputs)
+  float w5[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * wave + 16 * (g & 1) + 8 * (g >> 1) + j;
+    w5[j] = Wp[u.L[8].w_off + (((k >> 4) * 64) + ((k & 15) >> 2) * 16 + n) * 4 + (k & 3)];
+  }
+  // biases of the units whose totals land in this lane
+  static_assert(u.bias_floats <= 1248, "bias copy");
+  const float* BL = lds + R1Lds::bias;          // (copied by the kernel's prologue; read where a layer ends)
+  // LDS-resident blocks: copied once, read back with ds_read_b128 at lane * 16 + fragment * 1 KiB
+  constexpr int lds_first = CLS == 0 ? 0 : r1_count(0, DMAX, 'L');
+  static_assert(r1_count(CLS, DMAX, 'S') % kR1PD == 0 && r1_count(CLS, DMAX, 'S') >= kR1PD, "static ring slots across steps");
+  float* LW = lds + R1Lds::weights + (lds_first + (CLS == 0 ? 0 : (wave - 1) * NLDS)) * 1024;
+#pragma unroll
+  for (int r = 0; r < NLDS; ++r) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(r1_nth(CLS, DMAX, 'L', r), wave)) + lane;
+    f32x4* dst = reinterpret_cast<f32x4*>(LW + r * 1024) + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c * 64] = src[c * 64];
+  }
+  const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, u.total_floats * 4, 0x00020000);
+  // the stream ring: the first kR1PD stream blocks are requested here, every consumed block requests the block kR1PD later
+  f32x4 ring[kR1PD][4];
+  if constexpr (NSTR > 0) {
+#pragma unroll
+    for (int s = 0; s < kR1PD; ++s) {
+      const int p = r1_block_off<NET>(r1_nth(CLS, DMAX, 'S', s), wave) * 4;
+      ring[s][0] = r1_gload<0>(img, loff, p);
+      ring[s][1] = r1_gload<1024>(img, loff, p);
+      ring[s][2] = r1_gload<2048>(img, loff, p);
+      ring[s][3] = r1_gload<3072>(img, loff, p);
+    }
+  }
+
+  // half h of block b into w[8]; `after` = the block is consumed (stream blocks request their successor then)
+  auto fetch = [&](auto bc, auto hc, float (&w)[8]) {
+    constexpr int b = decltype(bc)::value, h = decltype(hc)::value;
+    constexpr char src = r1_src(CLS, DMAX, b);
+    if constexpr (src == 'R') {
+      constexpr int r = r1_count(CLS, DMAX, 'R', b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = wres[r][8 * h + e];
+    } else if constexpr (src == 'L') {
+      constexpr int r = r1_count(CLS, DMAX, 'L', b);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 v = *(reinterpret_cast<const f32x4*>(LW + r * 1024) + (2 * h + c) * 64 + lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[c * 4 + e] = v[e];
+      }
+    } else {
+      constexpr int s = r1_count(CLS, DMAX, 'S', b) % kR1PD;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[c * 4 + e] = ring[s][2 * h + c][e];
+    }
+  };
+  auto refill = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    if constexpr (r1_src(CLS, DMAX, b) == 'S') {
+      constexpr int i = r1_count(CLS, DMAX, 'S', b), s = i % kR1PD;
+      const int p = r1_block_off<NET>(r1_nth(CLS, DMAX, 'S', (i + kR1PD) % NSTR), wave) * 4;   // (wraps into the next step)
+      ring[s][0] = r1_gload<0>(img, loff, p);
+      ring[s][1] = r1_gload<1024>(img, loff, p);
+      ring[s][2] = r1_gload<2048>(img, loff, p);
+      ring[s][3] = r1_gload<3072>(img, loff, p);
+    }
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  // one block: a0 / a1 (alternating) += x . W_b
+  auto blk = [&](auto bc, float& a0, float& a1, float x) {
+    float w[8];
+    fetch(bc, H0{}, w);
+    r1_fmac8<0>(a0, a1, x, w);
+    fetch(bc, H1{}, w);
+    r1_fmac8<1>(a0, a1, x, w);
+    refill(bc);
+  };
+  // two blocks of one chunk: aA += x . W_bA, aB += x . W_bB
+  auto blk2 = [&](auto ba, auto bb, float& aA, float& aB, float x) {
+    float wa[8], wb[8];
+    fetch(ba, H0{}, wa);
+    fetch(bb, H0{}, wb);
+    r1_fmac8x2<0>(aA, aB, x, wa, wb);
+    fetch(ba, H1{}, wa);
+    fetch(bb, H1{}, wb);
+    r1_fmac8x2<1>(aA, aB, x, wa, wb);
+    refill(ba);
+    refill(bb);
+  };
+#define R1B(b) std::integral_constant<int, b>{}
+
+  // ---- wave 0's own state: the row (every 16-lane row of the wave runs the same arithmetic: component i = lane & 15) ----
+  const int i = n, ic = min(i, d - 1);
+  const bool lane_ok = i < d;
+  const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
+  const bool is_quad = kind == SOCMX_OU_QUADRATIC;
+  const bool traj = a.states != nullptr;
+  const bool store = CLS == 0 && lane < 16 && lane_ok && traj;
+  const bool store0 = CLS == 0 && lane == 0 && traj;
+  const size_t rowoff = (size_t)grow * d + i;
+  float x = 0.f, kap = 0.f, stop = 1.f, lpd = 0.f, lps = 0.f, res0 = 0.f;
+  float w0[4][DMAX + 1], b0[4], w3[DMAX + 1], b8 = 0.f, b3 = 0.f;   // down_0 (units 64 m + lane), res_0 (unit n): wave 0 only
+  float* A_l = lds + R1Lds::amat;                         // OU: A, P with row stride 16 (d <= 15)
+  float* P_l = lds + R1Lds::pmat;
+  if constexpr (CLS == 0) {
+    x = lane_ok ? a.x0[(size_t)grow * d + i] : 0.f;
+    kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int unit = 64 * m + lane;
+#pragma unroll
+      for (int kk = 0; kk <= DMAX; ++kk)
+        w0[m][kk] = Wp[u.L[0].w_off + (((unit >> 4) * 64) + (kk >> 2) * 16 + (unit & 15)) * 4 + (kk & 3)];
+      b0[m] = Wp[u.L[0].b_off + unit];
+    }
+#pragma unroll
+    for (int kk = 0; kk <= DMAX; ++kk) w3[kk] = Wp[u.L[3].w_off + ((kk >> 2) * 16 + n) * 4 + (kk & 3)];
+    b8 = Wp[u.L[8].b_off + n];
+    b3 = Wp[u.L[3].b_off + n];
+    for (int e = lane; e < d * d; e += 64) {
+      const int r = e / d, c = e - r * d;
+      if (is_ou) A_l[r * 16 + c] = a.A[e];
+      if (is_quad) P_l[r * 16 + c] = a.P[e];
+    }
+    if (store) a.states[rowoff] = x;
+    if (store0) a.stop_ind[grow] = 1.f;
+  }
+  // y[unit] = relu(down_0 [t, x] + b) for the 256 units, lane-ordered into LDS (wave 0); res_0 [t, x] + b for the step's end
+  auto first_layer = [&](float t) {
+    float acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = b0[m] + t * w0[m][0];
+    res0 = b3 + t * w3[0];
+#define R1IN(J)                                             \
+  if constexpr (J < DMAX) if (J < d) {                      \
+    r1_fmac_bc<J>(acc[0], x, w0[0][J + 1]);                 \
+    r1_fmac_bc<J>(acc[1], x, w0[1][J + 1]);                 \
+    r1_fmac_bc<J>(acc[2], x, w0[2][J + 1]);                 \
+    r1_fmac_bc<J>(acc[3], x, w0[3][J + 1]);                 \
+    r1_fmac_bc<J>(res0, x, w3[J + 1]);                      \
+  }
+    R1IN(0) R1IN(1) R1IN(2) R1IN(3) R1IN(4) R1IN(5) R1IN(6) R1IN(7) R1IN(8) R1IN(9) R1IN(10) R1IN(11) R1IN(12) R1IN(13) R1IN(14)
+#undef R1IN
+    f32x4 y;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) y[m] = relu_keep_nan(acc[m]);
+    *reinterpret_cast<f32x4*>(lds + R1Lds::r1 + r1_perm(lane) * 4) = y;
+  };
+
+  // ---- noise one step ahead: wave 1 the Philox words of step k + 2, wave 2 Box-Muller on the words of step k + 1 ----
+  float* NZ = lds + R1Lds::nz;
+  uint32_t* WZ = reinterpret_cast<uint32_t*>(lds + R1Lds::wz);
+  const bool w_words = CLS == 1 && wave == 1 && lane < 8 && !a.noise_in, w_draws = CLS == 1 && wave == 2 && lane < 8;
+  auto words = [&](int k) {
+    if (!w_words || k >= K) return;
+    uint32_t wa, wb;
+    philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + grow), (uint32_t)k, lane >> 1, lane & 1, wa, wb);
+    WZ[((k & 1) * 8 + lane) * 2] = wa;
+    WZ[((k & 1) * 8 + lane) * 2 + 1] = wb;
+  };
+  auto draws = [&](int k) {
+    if (!w_draws || k >= K) return;
+    float z0 = 0.f, z1 = 0.f;
+    const int c0 = 2 * lane;
+    if (a.noise_in) {
+      const float* src = a.noise_in + ((size_t)k * B + grow) * d;
+      if (c0 < d) z0 = src[c0];
+      if (c0 + 1 < d) z1 = src[c0 + 1];
+    } else {
+      box_muller_pair(WZ[((k & 1) * 8 + lane) * 2], WZ[((k & 1) * 8 + lane) * 2 + 1], z0, z1);
+    }
+    NZ[(k & 1) * 16 + c0] = c0 < d ? z0 : 0.f;
+    NZ[(k & 1) * 16 + c0 + 1] = c0 + 1 < d ? z1 : 0.f;
+  };
+
+  // ---- stages 1..5 of the network on the row; leaves up_0's per-wave partial sums in LDS (p5) ----
+  auto network = [&]() {
+    // stage 1: r2 = relu(down_1 r1 + b)            wave w: units 16 w .. 16 w + 15
+    const f32x4 xr1 = *reinterpret_cast<const f32x4*>(lds + R1Lds::r1 + lane * 4);
+    float s0 = 0.f, s1 = 0.f;
+    blk(R1B(0), s0, s1, xr1[0]);
+    blk(R1B(1), s0, s1, xr1[1]);
+    blk(R1B(2), s0, s1, xr1[2]);
+    blk(R1B(3), s0, s1, xr1[3]);
+    {
+      const float y = relu_keep_nan(r1_rows_sum(s0 + s1) + BL[u.L[1].b_lds + 16 * wave + n]);
+      if (lane < 16) lds[R1Lds::r2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
+    }
+    __syncthreads();
+    // stage 2: down_2's partial sums                 wave w: units 16 (w & 3) .., inputs 64 (w >> 2) .. + 63
+    const float2 xr2 = *reinterpret_cast<const float2*>(lds + R1Lds::r2 + lane * 2);
+    s0 = 0.f; s1 = 0.f;
+    blk(R1B(4), s0, s1, (wave >> 2) ? xr2.y : xr2.x);
+    {
+      const float y = r1_rows_sum(s0 + s1);
+      if (lane < 16) lds[R1Lds::p2 + wave * 16 + n] = y;
+    }
+    __syncthreads();
+    // stage 3: o2 = relu(up_2 r3 + b) + res_2 r2 + b   wave w: units 16 w ..
+    const int pk = r1_perm(lane);
+    const float xr3 = relu_keep_nan(lds[R1Lds::p2 + pk] + lds[R1Lds::p2 + 64 + pk] + BL[u.L[2].b_lds + pk]);
+    float u0 = 0.f, u1 = 0.f, q0 = 0.f, q1 = 0.f;
+    blk(R1B(5), u0, u1, xr3);
+    blk(R1B(6), q0, q1, xr2.x);
+    blk(R1B(7), q0, q1, xr2.y);
+    {
+      const float t = kg_reduce(f32x4{u0 + u1, q0 + q1, 0.f, 0.f});     // rows 0: up_2's totals, rows 2: res_2's
+      float up, rs;
+      r1_halves(t, up, rs);
+      const float y = relu_keep_nan(up + BL[u.L[6].b_lds + 16 * wave + n]) + (rs + BL[u.L[5].b_lds + 16 * wave + n]);
+      if (lane < 16) lds[R1Lds::o2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
+    }
+    __syncthreads();
+    // stage 4: o1 = relu(up_1 o2 + b) + res_1 r1 + b   wave w: units 32 w .. 32 w + 31 (two neuron blocks)
+    const float2 xo2 = *reinterpret_cast<const float2*>(lds + R1Lds::o2 + lane * 2);
+    // (the two accumulators of a block are the two neuron blocks' here: eight live accumulators did not fit beside the
+    //  resident weights, and consecutive fmacs still never depend on each other -- blocks of the same chunk run as a pair)
+    float ua = 0.f, ub = 0.f, ra = 0.f, rb = 0.f;
+    blk2(R1B(8), R1B(9), ua, ub, xo2.x);
+    blk2(R1B(10), R1B(11), ua, ub, xo2.y);
+    blk2(R1B(12), R1B(13), ra, rb, xr1[0]);
+    blk2(R1B(14), R1B(15), ra, rb, xr1[1]);
+    blk2(R1B(16), R1B(17), ra, rb, xr1[2]);
+    blk2(R1B(18), R1B(19), ra, rb, xr1[3]);
+    float o1;
+    {
+      // rows 0: up_1 block 2w, 1: up_1 block 2w + 1, 2: res_1 block 2w, 3: res_1 block 2w + 1
+      const float t = kg_reduce(f32x4{ua, ra, ub, rb});
+      float up, rs;
+      r1_halves(t, up, rs);
+      o1 = relu_keep_nan(up + BL[u.L[7].b_lds + 32 * wave + 16 * (g & 1) + n]) + (rs + BL[u.L[4].b_lds + 32 * wave + 16 * (g & 1) + n]);          // lane (g, n): unit 32 w + 16 (g & 1) + n, both halves alike
+    }
+    // stage 5, this wave's share: up_0 over the wave's own 32 outputs (no barrier in between)
+    {
+      const float x5 = r1_ror8_upper(o1);
+      float p0 = 0.f, p1 = 0.f;
+      r1_fmac8<0>(p0, p1, x5, w5);
+      const float y = r1_rows_sum(p0 + p1);
+      if (lane < 16) lds[R1Lds::p5 + n * 8 + wave] = y;
+    }
+    __syncthreads();
+  };
+  // nabla_V[i] in every row of wave 0 (the other waves: not used)
+  auto network_output = [&]() -> float {
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8);
+    const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8 + 4);
+    const float s = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]));
+    return relu_keep_nan(s + b8) + res0;
+  };
+
+  // ---- prologue ----
+  words(0);
+  if constexpr (CLS == 0) first_layer(a.ts[0]);
+  __syncthreads();
+  draws(0);
+  words(1);
+  __syncthreads();
+  float t_cur = a.ts[0], t_nxt = a.ts[1];
+  for (int k = 0; k < K; ++k) {
+    const float t0 = t_cur, t1 = t_nxt;
+    t_cur = t_nxt;
+    t_nxt = a.ts[min(k + 2, K)];
+    const float dt = t1 - t0;                 // utils.py:38
+    const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
+    const float dt_over_lmbd = dt / a.lmbd, sqrt_dt_over_lmbd = sqrtf(dt_over_lmbd);
+    network();
+    if constexpr (CLS == 0) {
+      const float gv = network_output();
+      if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
+      const float uc = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
+      const float eps = NZ[(k & 1) * 16 + i];                            // drawn during the previous step
+      float bi;
+      if (is_ou) {                                                      // b = A x
+        bi = 0.f;
+        for (int j = 0; j < d; ++j) bi += A_l[ic * 16 + j] * __shfl(x, j, 16);
+        if (!lane_ok) bi = 0.f;
+      } else {
+        bi = -2.f * kap * (x * x - 1.f) * 2.f * x;                      // double_well.py:44-48
+      }
+      const float upd = (bi + uc) * dt + sq_ldt * eps;                  // utils.py:45-47
+      const float xn = x + stop * upd;                                  // utils.py:48
+      float xe = xn, step = dt, stop_new = 1.f;
+      if (STOPPING) {                                                   // utils.py:42-44, 49-75; Phi = -x_0
+        const float phi_b = -__shfl(x, 0, 16), phi_a = -__shfl(xn, 0, 16);
+        const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
+        const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
+        const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
+        xe = js * (x + fr * stop * upd) + (1.f - js) * xn;
+        step = js * (fr * fr) * dt + ns * dt;                           // step_fraction squared (utils.py:70-72)
+        stop_new = (-__shfl(xe, 0, 16) > 0.f) ? 1.f : 0.f;
+      }
+      float f = 0.f;                                                    // f at the NEW state, OLD time (utils.py:92-96)
+      if (is_quad) {
+        float px = 0.f;
+        for (int j = 0; j < d; ++j) px += P_l[ic * 16 + j] * __shfl(xe, j, 16);
+        f = row16_sum(lane_ok ? xe * px : 0.f);
+      } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
+        f = 1.f;
+      }
+      const float uu = row16_sum(uc * uc), ue = row16_sum(uc * eps);
+      const float sol = STOPPING ? step / a.lmbd : dt_over_lmbd;
+      const float ssol = STOPPING ? sqrtf(sol) : sqrt_dt_over_lmbd;
+      lpd = lpd + sol * (-f - 0.5f * uu);
+      lps = lps + ssol * (-ue);
+      if (store) {
+        a.controls[(size_t)k * B * d + rowoff] = uc;
+        a.noises[(size_t)k * B * d + rowoff] = eps;
+        a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
+      }
+      if (store0) {
+        a.frac[(size_t)k * B + grow] = step;
+        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? stop_new : 1.f;
+      }
+      x = lane_ok ? xe : 0.f;
+      if (STOPPING) stop = stop_new;
+      first_layer(t1);                                                  // the next evaluation's first layer: [t_{k+1}, x_{k+1}]
+    } else {
+      words(k + 2);
+      draws(k + 1);
+    }
+    __syncthreads();
+  }
+  if (a.nabla_v) {                        // nabla_V(T, X_K): r1 already holds down_0 [t_K, x_K]
+    network();
+    if constexpr (CLS == 0) {
+      const float gv = network_output();
+      if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
+    }
+  }
+  if constexpr (CLS == 0) {                                             // terminal cost (utils.py:101)
+    float gval = 0.f;
+    if (kind == SOCMX_OU_QUADRATIC) {
+      float qx = 0.f;
+      for (int j = 0; j < d; ++j) qx += a.Q[ic * d + j] * __shfl(x, j, 16);
+      gval = row16_sum(lane_ok ? x * qx : 0.f);
+    } else if (kind == SOCMX_OU_LINEAR) {
+      gval = row16_sum(lane_ok ? a.omega[ic] * x : 0.f);
+    } else if (kind == SOCMX_DOUBLE_WELL) {
+      const float q = x * x - 1.f;
+      gval = row16_sum(lane_ok ? a.nu[ic] * (q * q) : 0.f);
+    }
+    if (lane == 0) {
+      a.lpd[grow] = lpd;
+      a.lps[grow] = lps;
+      a.ltw[grow] = -gval / a.lmbd;
+    }
+  }
+#undef R1B
+}
+
+template <bool STOPPING, class NET, int DMAX>
+__global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < R1Lds::bias; e += kR1Waves * 64) lds[e] = 0.f;
+  unet_load_biases_at(a.packed, NET::desc(), lds + R1Lds::bias, tid, kR1Waves * 64);
+  __syncthreads();
+  if (wave == 0) r1_wave<0, STOPPING, NET, DMAX>(a, lds, 0, lane);
+  else r1_wave<1, STOPPING, NET, DMAX>(a, lds, wave, lane);
+}
+
+bool rollout1_available() { return r1_supported<DefaultNet>(); }
+
+int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream) {
+  if constexpr (r1_supported<DefaultNet>()) {
+    void (*k)(const RolloutArgs);
+    if (a.d <= 3) k = stopping ? rollout1_kernel<true, DefaultNet, 3> : rollout1_kernel<false, DefaultNet, 3>;
+    else if (a.d <= 11) k = stopping ? rollout1_kernel<true, DefaultNet, 11> : rollout1_kernel<false, DefaultNet, 11>;
+    else k = stopping ? rollout1_kernel<true, DefaultNet, 15> : rollout1_kernel<false, DefaultNet, 15>;
+    if (const int err = ensure_max_lds(k)) return err;
+    // (the CU's whole LDS: one workgroup per CU, nobody else's workgroups beside this latency-bound chain)
+    return launch(k, dim3((unsigned)a.B), dim3(kR1Waves * 64), (size_t)kLdsBytesPerCU, stream, a);
+  } else {
+    return SOCMX_E_DIM;
+  }
+}
+
+}  // namespace socmx

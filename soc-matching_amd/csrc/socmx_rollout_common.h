@@ -1,0 +1,66 @@
+// socmx_rollout_common.h -- what the rollout translation units share: the kernel argument block, the Philox pair helpers and
+// the constexpr network instantiations (socmx_rollout.hip: 16-row and 4-row tiles; socmx_rollout1.hip: one row per workgroup).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/socmx.h"
+#include "socmx_unet.h"
+#include "socmx_philox.h"
+
+namespace socmx {
+
+struct RolloutArgs {
+  UnetDesc u;
+  TileLayout t;
+  UnetProgram prog;
+  int kind, d, B, K;
+  float lmbd;
+  uint64_t seed, offset;
+  const uint64_t* key_dev;   // device {seed, offset} (socmx_rollout_ex_f32: a replayed hipGraph draws fresh noise) or NULL
+  int64_t row0;
+  const float* packed;
+  const float *sigma, *A, *P, *Q, *omega, *kappa, *nu;
+  const float *x0, *ts, *noise_in;
+  float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
+  float* nabla_v;      // optional (K+1, B, d): the network output at every grid point incl. the terminal one (method.py:272-278)
+  int sigma_identity;  // problem->flags & SOCMX_SIGMA_IDENTITY
+  int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
+  long long* prof;  // diagnostics only (PROF variant): [blocks][64] accumulated s_memtime cycles per phase
+  int prof_wave;    // which wave's view is recorded (SOCMX_PROF_WAVE, default 0)
+};
+
+__host__ __device__ constexpr int socmx_sde_stride(int d) { return ((d + 15) & ~15) + 1; }
+
+
+// the two halves of philox_normal2, for callers that spread them over two phases of a step
+__device__ __forceinline__ void philox_pair_words(uint64_t seed, uint64_t offset, uint32_t grow, uint32_t step,
+                                                  int block, int h, uint32_t& wa, uint32_t& wb) {
+  uint32_t w[4];
+  philox4x32_10(grow, step, (uint32_t)block, (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  wa = h ? w[2] : w[0];
+  wb = h ? w[3] : w[1];
+}
+__device__ __forceinline__ void box_muller_pair(uint32_t wa, uint32_t wb, float& z0, float& z1) {
+  const float ua = ((float)wa + 0.5f) * 2.3283064365386963e-10f;
+  const float ub = ((float)wb + 0.5f) * 2.3283064365386963e-10f;
+  const float r = sqrtf(-2.0f * logf(ua));
+  float sn, cs;
+  sincospif(2.0f * ub, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
+struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from the kernel arguments (any architecture)
+// (SOCMX_H*P: the reference's default arch.hdims = [256,128,64] unless this is a variant build, see socmx_unet.h)
+typedef StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16> DefaultNet;  // d <= 15
+typedef StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
+typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... and at 16 <= d <= 31 (soc.yaml's default d = 20)
+
+
+// socmx_rollout1.hip: the one-row kernel (B <= 256, sigma = I, d <= 15, default widths); returns false when this build has no
+// such kernel for the architecture (variant libraries)
+bool rollout1_available();
+int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream);
+
+}  // namespace socmx

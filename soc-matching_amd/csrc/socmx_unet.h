@@ -284,6 +284,14 @@ __device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, c
     for (int e = tid; e < u.L[l].out_pad; e += nthr) lds[t.bias + u.L[l].b_lds + e] = Wp[u.L[l].b_off + e];
 }
 
+// the same copy to an explicit LDS address (bias of layer l at dst + u.L[l].b_lds)
+__device__ __forceinline__ void unet_load_biases_at(const float* __restrict__ Wp, const UnetDesc& u, float* dst, int tid,
+                                                    int nthr) {
+#pragma unroll
+  for (int l = 0; l < 9; ++l)
+    for (int e = tid; e < u.L[l].out_pad; e += nthr) dst[u.L[l].b_lds + e] = Wp[u.L[l].b_off + e];
+}
+
 // R4: the 4-row tile.  The SAME weight fragment feeds v_mfma_f32_4x4x1_16b_f32: its 16 blocks are lane quads, block
 // (l >> 2) = (k-group kg = l >> 4, neuron group ng = (l >> 2) & 3); lane l's A value is W[16 nb + (l & 15)][16 kc + 4 kg + i]
 // as before, its B value x[row l & 3][16 kc + 4 kg + i], and D = neurons 4 ng .. 4 ng + 3 of row (l & 3), summed over
