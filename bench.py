@@ -14,8 +14,9 @@ One JSON line on rank 0:
                    producing the reference's 8-tuple, SURVEY 8(d) metric 1), inputs resident in HBM
   socm_iters_per_sec  secondary metric: 1/time_per_iteration of a full SOCM iteration (rollout + loss
                    + backward + ONE flat gradient all-reduce + Adam), timed like main.py:280,351-352
-  roofline         dominant kernel = socmx rollout_kernel; algorithmic flops (and bytes) per launch
-                   over its HIP-event duration, against the fp32 MFMA peak (157.3 TF) / HBM (8 TB/s)
+  roofline         dominant kernel = socmx rollout1_kernel (one row per workgroup, csrc/socmx_rollout1.hip); algorithmic
+                   flops (and bytes) per launch over its HIP-event duration, against the fp32 peak (157.3 TF: MFMA = packed
+                   vector) / HBM (8 TB/s)
   cpu_baseline     the oracle's eager rollout (oracle/socm_oracle.py, "port") timed on this host
 """
 import argparse
@@ -35,12 +36,15 @@ import torch.distributed as dist
 SETTING, D, NUM_STEPS, BATCH_PER_GPU, GAMMA = "double_well", 10, 200, 128, 6.0
 HDIMS, HDIMS_M = [256, 128, 64], [128, 128]
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
-ROLLOUT_KERNEL_TAG = "rollout4_kernel"   # the headline workload (d = 10, B = 128) runs the 4-row small-batch kernel
+ROLLOUT_KERNEL_TAG = "rollout1_kernel"   # the headline workload (d = 10, B = 128) runs the one-row kernel
 
 
 def rollout_workgroups(d, B):
-    """Workgroups of one rollout launch (csrc/socmx_rollout.hip, rollout_launch): 4-row tiles for at most 64 tiles of 16 rows
+    """Workgroups of one rollout launch (csrc/socmx_rollout.hip, rollout_launch) at the default widths: one row per workgroup
+    for B <= 256 at d <= 15 (the bench's settings with d <= 15 have sigma = I), 4-row tiles for at most 64 tiles of 16 rows
     (16 at d >= 32), else 16-row tiles."""
+    if d <= 15 and B <= 256:
+        return B
     t16 = (B + 15) // 16
     return (B + 3) // 4 if (d <= 64 and (t16 <= 16 or (t16 <= 64 and d <= 31))) else t16
 PEAK_HBM_GBPS = 8000.0
@@ -427,12 +431,14 @@ def main():
             "socm_iters_timed": it_steps, "socm_last_loss": last_loss, "socm_iteration_mode": it_mode,
             "socm_ms_per_iter_eager": 1e3 * it_elapsed_eager / it_steps,
             "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps,
-            "roofline": {"bound": "mfma", "kernel": "socmx::rollout4_kernel<8,false,StaticNet<16,256,128,64,16>>",
+            "roofline": {"bound": "mfma", "kernel": "socmx::rollout1_kernel<0,StaticNet<16,256,128,64,16>,11>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "B=128 is 32 tiles of 4 rows (the small-batch kernel, v_mfma_f32_4x4x1_16b_f32 at half the "
-                                 "16x16x4 rate per MAC): 32 of 256 CUs work, frac <= 32/256/2 = 0.0625 by construction; "
-                                 "see roofline_full_chip for the 16-row kernel with 4096 workgroups",
+                         "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU, v_fmac_f32_dpp: 64 "
+                                 "MACs per instruction at ~5 cycles per SIMD, a quarter of the packed-fp32 / MFMA rate the peak "
+                                 "is quoted at): 128 of 256 CUs work, frac <= 128/256/4 = 0.125 by construction; "
+                                 "peak = 157.3 TF is the fp32 MFMA = packed-vector figure; see roofline_full_chip for the "
+                                 "16-row MFMA kernel with 4096 workgroups",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": byts,
                          "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 131 /* 0.1.3 + the 4-row small-batch rollout kernels and the balanced weight-gradient schedule (same entry points) */
+#define SOCMX_VERSION 140 /* 0.1.4: + the one-row rollout kernel for training-size batches (socmx_rollout1.hip; same entry points) */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */

@@ -1243,8 +1243,8 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
 #define SOCMX_STR2(x) #x
 #define SOCMX_STR(x) SOCMX_STR2(x)
   static const char msg[] =
-      "socmx 0.1.3; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
-      "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches); "
+      "socmx 0.1.4; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
+      "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches; one row per workgroup on v_fmac_f32_dpp for B <= 256, sigma = I, d <= 15); "
       "Philox4x32-10 noise; static_hdims=" SOCMX_STR(SOCMX_H0P) "," SOCMX_STR(SOCMX_H1P) "," SOCMX_STR(SOCMX_H2P) "; "
       "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target";
   const int need = (int)sizeof(msg);
@@ -1426,7 +1426,12 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   // molecular_dynamics run): ONE ROW per workgroup, the network as matrix-vector products on the VALU with most of the weight
   // image resident in registers / LDS (socmx_rollout1.hip) -- B workgroups instead of B / 4.  SOCMX_TILE_ROWS=1 forces it
   // for any B <= 1024 (tests), =4 / =16 exclude it.
-  if (is_default && fast && !prof && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
+#ifdef SOCMX_R1_PROF
+  const bool r1_prof_ok = true;     // (developer build: socmx_rollout_phase_cycles_f32 reaches the one-row kernel's marks)
+#else
+  const bool r1_prof_ok = !prof;
+#endif
+  if (is_default && fast && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
       (B <= 256 || (force_rows == 1 && B <= 1024)))
     return rollout1_launch(a, stopping, stream);
   const bool small4 = blocks <= 16 || (blocks <= 64 && d <= 31);

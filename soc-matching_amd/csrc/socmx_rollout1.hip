@@ -39,13 +39,17 @@ constexpr int kR1Blocks = 20;   // main-program blocks per wave and step
 constexpr int kR1PD = 2;        // ring depth (blocks)
 
 // Where block b of a wave's program comes from: 'R' registers, 'L' LDS, 'S' L2 stream.  Class 0 = wave 0, class 1 = waves 1..7.
-//   blocks: 0-3 down_1 (chunks 0..3) | 4 down_2 | 5 up_2, 6-7 res_2 | 8-11 up_1 (U0c0 U1c0 U0c1 U1c1) | 12-19 res_1 (R0c0 R1c0 ...)
+//   blocks in the order a wave consumes them: 0-3 down_1 (chunks 0..3) | 4 down_2 | 5-6 res_2, 7 up_2 | 8-15 res_1 (R0c0 R1c0 R0c1 ...),
+//   16-19 up_1 (U0c0 U1c0 U0c1 U1c1) -- in a two-GEMM stage the skip GEMM runs first: its input is in registers since an earlier
+//   stage, so its fmacs cover the LDS round trip of the stage's other input
 __host__ __device__ constexpr char r1_src(int cls, int dm, int b) {
   // wave 0 also holds 4 (1 + DMAX) + (1 + DMAX) registers of down_0 / res_0: fewer resident blocks at larger d
-  constexpr char plan0_3[kR1Blocks + 1] = "RRRRRLLLLSLSLSLSLSLS";
-  constexpr char plan0_11[kR1Blocks + 1] = "RRRRSLLSLSLSLSLSLSLS";
-  constexpr char plan0_15[kR1Blocks + 1] = "RRRLSLLSLSLSLSLSLSLS";
-  constexpr char plan1[kR1Blocks + 1] = "RSRLSRSRLRSRRLSRLRSR";
+  constexpr char plan0_3[kR1Blocks + 1] = "RSRLSLSLLSLSLSLSLRLS";
+  constexpr char plan0_11[kR1Blocks + 1] = "RSRSSLSLLSLRLSLSLRLS";
+  constexpr char plan0_15[kR1Blocks + 1] = "RSSSSLSLLSLSLSLSLRLS";
+  // (stream blocks spread over the step's TIME, two blocks of lead each: S1 ~1.1k cycles, S2 ~0.5k, S3 ~0.9k, S4 ~2.6k, then wave
+  //  0's serial section ~1.2k with no consumption)
+  constexpr char plan1[kR1Blocks + 1] = "RRSLRSRLRSLRSRRSLRSR";
   return cls == 1 ? plan1[b] : dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
 }
 __host__ __device__ constexpr int r1_count(int cls, int dm, char s, int upto = kR1Blocks) {
@@ -77,10 +81,10 @@ __device__ __forceinline__ int r1_block_off(int b, int w) {
   constexpr UnetDesc u = NET::desc();
   if (b < 4) return u.L[1].w_off + (w * 16 + 4 * b) * 256;                                  // down_1: nb = w, chunk b
   if (b == 4) return u.L[2].w_off + ((w & 3) * 8 + 4 * (w >> 2)) * 256;                     // down_2: nb = w & 3, chunk w >> 2
-  if (b == 5) return u.L[6].w_off + (w * 4) * 256;                                          // up_2: nb = w
-  if (b < 8) return u.L[5].w_off + (w * 8 + 4 * (b - 6)) * 256;                             // res_2: nb = w, chunk b - 6
-  if (b < 12) return u.L[7].w_off + ((2 * w + ((b - 8) & 1)) * 8 + 4 * ((b - 8) >> 1)) * 256;    // up_1: nb = 2w + r
-  return u.L[4].w_off + ((2 * w + ((b - 12) & 1)) * 16 + 4 * ((b - 12) >> 1)) * 256;         // res_1
+  if (b < 7) return u.L[5].w_off + (w * 8 + 4 * (b - 5)) * 256;                             // res_2: nb = w, chunk b - 5
+  if (b == 7) return u.L[6].w_off + (w * 4) * 256;                                          // up_2: nb = w
+  if (b < 16) return u.L[4].w_off + ((2 * w + ((b - 8) & 1)) * 16 + 4 * ((b - 8) >> 1)) * 256;   // res_1: nb = 2w + r
+  return u.L[7].w_off + ((2 * w + ((b - 16) & 1)) * 8 + 4 * ((b - 16) >> 1)) * 256;         // up_1
 }
 
 // ---- instruction helpers -----------------------------------------------------------------------------------------------
@@ -128,6 +132,39 @@ __device__ __forceinline__ void r1_fmac_bc(float& acc, float x, float w) {
   asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(J));
 }
 
+// down_0 / res_0 on the state: a += sum_J x_J w[J] for J < DMAX, x_J broadcast from position J of the lane's row.  Columns past d
+// are zero in the image and positions past d are zero in the state register: no run-time bound.
+template <int DMAX>
+__device__ __forceinline__ void r1_state_pair(float& aA, float& aB, float x, const float* wa, const float* wb) {
+  if constexpr (DMAX == 3) {
+    asm("s_nop 1\n\t" R1FM(0, 0, 3) R1FM(0, 1, 6) R1FM(1, 0, 4) R1FM(1, 1, 7) R1FM(2, 0, 5) R1FM(2, 1, 8)
+        : "+v"(aA), "+v"(aB)
+        : "v"(x), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wb[0]), "v"(wb[1]), "v"(wb[2]));
+  } else {
+    static_assert(DMAX == 11, "pairs: 2 DMAX + 3 asm operands");
+    asm("s_nop 1\n\t" R1FM(0, 0, 3) R1FM(0, 1, 14) R1FM(1, 0, 4) R1FM(1, 1, 15) R1FM(2, 0, 5) R1FM(2, 1, 16) R1FM(3, 0, 6) R1FM(3, 1, 17) R1FM(4, 0, 7) R1FM(4, 1, 18) R1FM(5, 0, 8) R1FM(5, 1, 19) R1FM(6, 0, 9) R1FM(6, 1, 20) R1FM(7, 0, 10) R1FM(7, 1, 21) R1FM(8, 0, 11) R1FM(8, 1, 22) R1FM(9, 0, 12) R1FM(9, 1, 23) R1FM(10, 0, 13) R1FM(10, 1, 24)
+        : "+v"(aA), "+v"(aB)
+        : "v"(x), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wa[4]), "v"(wa[5]), "v"(wa[6]), "v"(wa[7]), "v"(wa[8]), "v"(wa[9]), "v"(wa[10]), "v"(wb[0]), "v"(wb[1]), "v"(wb[2]), "v"(wb[3]), "v"(wb[4]), "v"(wb[5]), "v"(wb[6]), "v"(wb[7]), "v"(wb[8]), "v"(wb[9]), "v"(wb[10]));
+  }
+}
+// one unit, two alternating accumulators
+template <int DMAX>
+__device__ __forceinline__ void r1_state_one(float& a0, float& a1, float x, const float* w) {
+  if constexpr (DMAX == 3) {
+    asm("s_nop 1\n\t" R1FM(0, 0, 3) R1FM(1, 1, 4) R1FM(2, 0, 5)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]));
+  } else if constexpr (DMAX == 11) {
+    asm("s_nop 1\n\t" R1FM(0, 0, 3) R1FM(1, 1, 4) R1FM(2, 0, 5) R1FM(3, 1, 6) R1FM(4, 0, 7) R1FM(5, 1, 8) R1FM(6, 0, 9) R1FM(7, 1, 10) R1FM(8, 0, 11) R1FM(9, 1, 12) R1FM(10, 0, 13)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]));
+  } else {
+    asm("s_nop 1\n\t" R1FM(0, 0, 3) R1FM(1, 1, 4) R1FM(2, 0, 5) R1FM(3, 1, 6) R1FM(4, 0, 7) R1FM(5, 1, 8) R1FM(6, 0, 9) R1FM(7, 1, 10) R1FM(8, 0, 11) R1FM(9, 1, 12) R1FM(10, 0, 13) R1FM(11, 1, 14) R1FM(12, 0, 15) R1FM(13, 1, 16) R1FM(14, 0, 17)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]));
+  }
+}
+
 // sum over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48): every lane ends with the total
 __device__ __forceinline__ float r1_rows_sum(float v) {
   float t;
@@ -143,6 +180,20 @@ __device__ __forceinline__ float r1_rows_sum(float v) {
       "v_add_f32 %0, %0, %1"
       : "+v"(v), "=&v"(t));
   return v;
+}
+// kg_reduce (socmx_unet.h) for VALU-produced accumulators: no MFMA wait states in front
+__device__ __forceinline__ float r1_reduce4(float a, float b, float c, float d) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_permlane32_swap_b32 %2, %3\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_add_f32 %2, %2, %3\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %2\n\t"
+      "v_add_f32 %0, %0, %2"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  return a;
 }
 // lo = the lower half's values in both halves, hi = the upper half's
 __device__ __forceinline__ void r1_halves(float v, float& lo, float& hi) {
@@ -172,7 +223,8 @@ __device__ __forceinline__ float r1_ror8_upper(float v) {
 typedef int r1_i32x4 __attribute__((ext_vector_type(4)));
 template <int IMM>
 __device__ __forceinline__ f32x4 r1_gload(__amdgpu_buffer_rsrc_t img, uint32_t lane_off, int block_bytes) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, (int)lane_off + IMM, block_bytes, 0));
+  // (the fragment's 1 KiB rides in the scalar offset: added to the lane offset it became four loop-invariant VGPRs)
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, (int)lane_off, block_bytes + IMM, 0));
 }
 
 // the activation layout: lane (g, p) of an activation register of chunk C holds element 64 C + r1_perm(lane); an involution
@@ -189,15 +241,30 @@ struct R1Lds {
   static constexpr int wz = 800;      // (2, 8, 2) Philox words of steps k + 1, k + 2
   static constexpr int amat = 832;    // (16, 16)  A, P of the OU settings (wave 0's drift / running cost)
   static constexpr int pmat = 1088;
+  static constexpr int sc = 1336;     // (2, 4) per-step scalars of steps k, k + 1 (dt, sqrt(lambda dt), dt / lambda, its root): the unused tail of pmat
   static constexpr int bias = 1344;   // the nine layers' padded biases (image order)
   static constexpr int weights = 1344 + 1248;   // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
 };
 static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(11) * 1024) * 4 <= 160 * 1024 &&
               (R1Lds::weights + r1_lds_blocks(15) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit");
 
+// Developer instrumentation (-DSOCMX_R1_PROF): per-wave s_memtime deltas between the marks of a step, summed over the launch,
+// written by workgroup 0 to a.prof[wave * 16 + slot] (socmx_rollout_phase_cycles_f32; tools/r1_phases.py).
+#ifdef SOCMX_R1_PROF
+#define R1_TICK(slot)                                \
+  {                                                  \
+    const long long now_ = __builtin_readcyclecounter(); \
+    prof_acc[slot] += now_ - prof_last;              \
+    prof_last = now_;                                \
+  }
+#else
+#define R1_TICK(slot)
+#endif
+
 // ---- one wave of the workgroup --------------------------------------------------------------------------------------------
 // DMAX: the state dimensions this instantiation takes (d <= DMAX): wave 0 holds 1 + DMAX input columns of down_0 / res_0
-template <int CLS, bool STOPPING, class NET, int DMAX>
+// MODE: 0 elementwise drift (double_well), 1 the same with a stopping time (molecular_dynamics), 2 OU drift (A x; x'Px for OU_quadratic)
+template <int CLS, int MODE, class NET, int DMAX>
 __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const int wave, const int lane) {
   constexpr UnetDesc u = NET::desc();
   constexpr int NRES = r1_count(CLS, DMAX, 'R'), NLDS = r1_count(CLS, DMAX, 'L'), NSTR = r1_count(CLS, DMAX, 'S');
@@ -208,6 +275,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   const uint32_t loff = lane * 16;
   const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
 
+#ifdef SOCMX_R1_PROF
+  long long prof_acc[16] = {0}, prof_last = 0;
+#endif
   // ---- resident weights ----
   float wres[NRES][16];
 #pragma unroll
@@ -255,7 +325,25 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     }
   }
 
-  // half h of block b into w[8]; `after` = the block is consumed (stream blocks request their successor then)
+  // The first half of an LDS block is read one unit AHEAD of its fmacs (lq: eight landing registers; pre(b) sits in front
+  // of the fmacs of the unit before b), the second half in front of the first half's fmacs.
+  float lq[8];
+  auto pre = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    if constexpr (b < kR1Blocks) {
+      if constexpr (r1_src(CLS, DMAX, b) == 'L') {
+        constexpr int r = r1_count(CLS, DMAX, 'L', b);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const f32x4 v = *(reinterpret_cast<const f32x4*>(LW + r * 1024) + c * 64 + lane);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lq[c * 4 + e] = v[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // half h of block b into w[8]
   auto fetch = [&](auto bc, auto hc, float (&w)[8]) {
     constexpr int b = decltype(bc)::value, h = decltype(hc)::value;
     constexpr char src = r1_src(CLS, DMAX, b);
@@ -264,12 +352,17 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #pragma unroll
       for (int e = 0; e < 8; ++e) w[e] = wres[r][8 * h + e];
     } else if constexpr (src == 'L') {
-      constexpr int r = r1_count(CLS, DMAX, 'L', b);
+      if constexpr (h == 0) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const f32x4 v = *(reinterpret_cast<const f32x4*>(LW + r * 1024) + (2 * h + c) * 64 + lane);
+        for (int e = 0; e < 8; ++e) w[e] = lq[e];
+      } else {
+        constexpr int r = r1_count(CLS, DMAX, 'L', b);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[c * 4 + e] = v[e];
+        for (int c = 0; c < 2; ++c) {
+          const f32x4 v = *(reinterpret_cast<const f32x4*>(LW + r * 1024) + (2 + c) * 64 + lane);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[c * 4 + e] = v[e];
+        }
       }
     } else {
       constexpr int s = r1_count(CLS, DMAX, 'S', b) % kR1PD;
@@ -292,38 +385,44 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   };
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
-  // one block: a0 / a1 (alternating) += x . W_b
-  auto blk = [&](auto bc, float& a0, float& a1, float x) {
-    float w[8];
-    fetch(bc, H0{}, w);
-    r1_fmac8<0>(a0, a1, x, w);
-    fetch(bc, H1{}, w);
-    r1_fmac8<1>(a0, a1, x, w);
+  // one block: a0 / a1 (alternating) += x . W_b; `nx` = the block whose LDS reads are issued in front of this one's fmacs
+  auto blk = [&](auto bc, auto nx, float& a0, float& a1, float x) {
+    float w0h[8], w1h[8];
+    fetch(bc, H0{}, w0h);
+    fetch(bc, H1{}, w1h);
+    pre(nx);
+    r1_fmac8<0>(a0, a1, x, w0h);
+    r1_fmac8<1>(a0, a1, x, w1h);
     refill(bc);
   };
-  // two blocks of one chunk: aA += x . W_bA, aB += x . W_bB
-  auto blk2 = [&](auto ba, auto bb, float& aA, float& aB, float x) {
-    float wa[8], wb[8];
-    fetch(ba, H0{}, wa);
-    fetch(bb, H0{}, wb);
-    r1_fmac8x2<0>(aA, aB, x, wa, wb);
-    fetch(ba, H1{}, wa);
-    fetch(bb, H1{}, wb);
-    r1_fmac8x2<1>(aA, aB, x, wa, wb);
+  // two blocks of one chunk: aA += x . W_bA, aB += x . W_bB (at most one of them an LDS block); nx as above
+  auto blk2 = [&](auto ba, auto bb, auto nx, float& aA, float& aB, float x) {
+    static_assert(!(r1_src(CLS, DMAX, decltype(ba)::value) == 'L' && r1_src(CLS, DMAX, decltype(bb)::value) == 'L'), "one landing buffer");
+    float wa0[8], wb0[8], wa1[8], wb1[8];
+    fetch(ba, H0{}, wa0);
+    fetch(bb, H0{}, wb0);
+    fetch(ba, H1{}, wa1);
+    fetch(bb, H1{}, wb1);
+    pre(nx);
+    r1_fmac8x2<0>(aA, aB, x, wa0, wb0);
+    r1_fmac8x2<1>(aA, aB, x, wa1, wb1);
     refill(ba);
     refill(bb);
   };
+  static_assert(r1_src(CLS, DMAX, 0) != 'L', "a step's first block has nobody in front of it to issue its LDS reads");
 #define R1B(b) std::integral_constant<int, b>{}
 
   // ---- wave 0's own state: the row (every 16-lane row of the wave runs the same arithmetic: component i = lane & 15) ----
   const int i = n, ic = min(i, d - 1);
   const bool lane_ok = i < d;
-  const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
+  constexpr bool STOPPING = MODE == 1, is_ou = MODE == 2;
   const bool is_quad = kind == SOCMX_OU_QUADRATIC;
   const bool traj = a.states != nullptr;
   const bool store = CLS == 0 && lane < 16 && lane_ok && traj;
   const bool store0 = CLS == 0 && lane == 0 && traj;
-  const size_t rowoff = (size_t)grow * d + i;
+  const uint32_t rowoff = (uint32_t)(grow * d + i);     // (32-bit lane offset against wave-uniform step bases: SGPR-base stores)
+  const size_t step_floats = (size_t)B * d;
+  size_t kbd = 0, kb = 0;                                // k * B * d, k * B
   float x = 0.f, kap = 0.f, stop = 1.f, lpd = 0.f, lps = 0.f, res0 = 0.f;
   float w0[4][DMAX + 1], b0[4], w3[DMAX + 1], b8 = 0.f, b3 = 0.f;   // down_0 (units 64 m + lane), res_0 (unit n): wave 0 only
   float* A_l = lds + R1Lds::amat;                         // OU: A, P with row stride 16 (d <= 15)
@@ -353,20 +452,22 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   }
   // y[unit] = relu(down_0 [t, x] + b) for the 256 units, lane-ordered into LDS (wave 0); res_0 [t, x] + b for the step's end
   auto first_layer = [&](float t) {
-    float acc[4];
+    float acc[4], r0 = b3 + t * w3[0], r1v = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = b0[m] + t * w0[m][0];
-    res0 = b3 + t * w3[0];
-#define R1IN(J)                                             \
-  if constexpr (J < DMAX) if (J < d) {                      \
-    r1_fmac_bc<J>(acc[0], x, w0[0][J + 1]);                 \
-    r1_fmac_bc<J>(acc[1], x, w0[1][J + 1]);                 \
-    r1_fmac_bc<J>(acc[2], x, w0[2][J + 1]);                 \
-    r1_fmac_bc<J>(acc[3], x, w0[3][J + 1]);                 \
-    r1_fmac_bc<J>(res0, x, w3[J + 1]);                      \
-  }
-    R1IN(0) R1IN(1) R1IN(2) R1IN(3) R1IN(4) R1IN(5) R1IN(6) R1IN(7) R1IN(8) R1IN(9) R1IN(10) R1IN(11) R1IN(12) R1IN(13) R1IN(14)
-#undef R1IN
+    if constexpr (DMAX <= 11) {
+      r1_state_pair<DMAX>(acc[0], acc[1], x, &w0[0][1], &w0[1][1]);
+      r1_state_pair<DMAX>(acc[2], acc[3], x, &w0[2][1], &w0[3][1]);
+    } else {
+      float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+      r1_state_one<DMAX>(acc[0], e0, x, &w0[0][1]);
+      r1_state_one<DMAX>(acc[1], e1, x, &w0[1][1]);
+      r1_state_one<DMAX>(acc[2], e2, x, &w0[2][1]);
+      r1_state_one<DMAX>(acc[3], e3, x, &w0[3][1]);
+      acc[0] += e0; acc[1] += e1; acc[2] += e2; acc[3] += e3;
+    }
+    r1_state_one<DMAX>(r0, r1v, x, &w3[1]);
+    res0 = r0 + r1v;
     f32x4 y;
 #pragma unroll
     for (int m = 0; m < 4; ++m) y[m] = relu_keep_nan(acc[m]);
@@ -400,61 +501,77 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   };
 
   // ---- stages 1..5 of the network on the row; leaves up_0's per-wave partial sums in LDS (p5) ----
+  // the LDS block among blocks [first, first + count), kR1Blocks if none: what the unit in front of them prefetches
+#define R1NX(first, count)                                                                                         \
+  std::integral_constant<int, (r1_src(CLS, DMAX, first) == 'L'                         ? (first)                     \
+                               : ((count) > 1 && r1_src(CLS, DMAX, (first) + 1) == 'L') ? (first) + 1                 \
+                                                                                        : kR1Blocks)>{}
   auto network = [&]() {
     // stage 1: r2 = relu(down_1 r1 + b)            wave w: units 16 w .. 16 w + 15
     const f32x4 xr1 = *reinterpret_cast<const f32x4*>(lds + R1Lds::r1 + lane * 4);
+    const float bias1 = BL[u.L[1].b_lds + 16 * wave + n];
     float s0 = 0.f, s1 = 0.f;
-    blk(R1B(0), s0, s1, xr1[0]);
-    blk(R1B(1), s0, s1, xr1[1]);
-    blk(R1B(2), s0, s1, xr1[2]);
-    blk(R1B(3), s0, s1, xr1[3]);
+    blk(R1B(0), R1NX(1, 1), s0, s1, xr1[0]);
+    blk(R1B(1), R1NX(2, 1), s0, s1, xr1[1]);
+    blk(R1B(2), R1NX(3, 1), s0, s1, xr1[2]);
+    blk(R1B(3), R1NX(4, 1), s0, s1, xr1[3]);
     {
-      const float y = relu_keep_nan(r1_rows_sum(s0 + s1) + BL[u.L[1].b_lds + 16 * wave + n]);
+      const float y = relu_keep_nan(r1_rows_sum(s0 + s1) + bias1);
       if (lane < 16) lds[R1Lds::r2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
     }
+    R1_TICK(1)
     __syncthreads();
+    R1_TICK(2)
     // stage 2: down_2's partial sums                 wave w: units 16 (w & 3) .., inputs 64 (w >> 2) .. + 63
     const float2 xr2 = *reinterpret_cast<const float2*>(lds + R1Lds::r2 + lane * 2);
     s0 = 0.f; s1 = 0.f;
-    blk(R1B(4), s0, s1, (wave >> 2) ? xr2.y : xr2.x);
+    blk(R1B(4), R1NX(5, 1), s0, s1, (wave >> 2) ? xr2.y : xr2.x);
     {
       const float y = r1_rows_sum(s0 + s1);
       if (lane < 16) lds[R1Lds::p2 + wave * 16 + n] = y;
     }
+    R1_TICK(3)
     __syncthreads();
-    // stage 3: o2 = relu(up_2 r3 + b) + res_2 r2 + b   wave w: units 16 w ..
+    R1_TICK(4)
+    // stage 3: o2 = relu(up_2 r3 + b) + res_2 r2 + b   wave w: units 16 w ..   (res_2 first: r2 is in registers)
     const int pk = r1_perm(lane);
-    const float xr3 = relu_keep_nan(lds[R1Lds::p2 + pk] + lds[R1Lds::p2 + 64 + pk] + BL[u.L[2].b_lds + pk]);
+    const float p2a = lds[R1Lds::p2 + pk], p2b = lds[R1Lds::p2 + 64 + pk], bias2 = BL[u.L[2].b_lds + pk];
+    const float bu3 = BL[u.L[6].b_lds + 16 * wave + n], br3 = BL[u.L[5].b_lds + 16 * wave + n];
     float u0 = 0.f, u1 = 0.f, q0 = 0.f, q1 = 0.f;
-    blk(R1B(5), u0, u1, xr3);
-    blk(R1B(6), q0, q1, xr2.x);
-    blk(R1B(7), q0, q1, xr2.y);
+    blk(R1B(5), R1NX(6, 1), q0, q1, xr2.x);
+    blk(R1B(6), R1NX(7, 1), q0, q1, xr2.y);
+    const float xr3 = relu_keep_nan((p2a + p2b) + bias2);
+    blk(R1B(7), R1NX(8, 2), u0, u1, xr3);
     {
-      const float t = kg_reduce(f32x4{u0 + u1, q0 + q1, 0.f, 0.f});     // rows 0: up_2's totals, rows 2: res_2's
+      const float t = r1_reduce4(u0 + u1, q0 + q1, 0.f, 0.f);     // rows 0: up_2's totals, rows 2: res_2's
       float up, rs;
       r1_halves(t, up, rs);
-      const float y = relu_keep_nan(up + BL[u.L[6].b_lds + 16 * wave + n]) + (rs + BL[u.L[5].b_lds + 16 * wave + n]);
+      const float y = relu_keep_nan(up + bu3) + (rs + br3);
       if (lane < 16) lds[R1Lds::o2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
     }
+    R1_TICK(5)
     __syncthreads();
-    // stage 4: o1 = relu(up_1 o2 + b) + res_1 r1 + b   wave w: units 32 w .. 32 w + 31 (two neuron blocks)
+    R1_TICK(6)
+    // stage 4: o1 = relu(up_1 o2 + b) + res_1 r1 + b   wave w: units 32 w .. 32 w + 31 (two neuron blocks; res_1 first)
     const float2 xo2 = *reinterpret_cast<const float2*>(lds + R1Lds::o2 + lane * 2);
-    // (the two accumulators of a block are the two neuron blocks' here: eight live accumulators did not fit beside the
+    const float bu4 = BL[u.L[7].b_lds + 32 * wave + 16 * (g & 1) + n], br4 = BL[u.L[4].b_lds + 32 * wave + 16 * (g & 1) + n];
+    // (the two accumulators of a block pair are the two neuron blocks': eight live accumulators did not fit beside the
     //  resident weights, and consecutive fmacs still never depend on each other -- blocks of the same chunk run as a pair)
     float ua = 0.f, ub = 0.f, ra = 0.f, rb = 0.f;
-    blk2(R1B(8), R1B(9), ua, ub, xo2.x);
-    blk2(R1B(10), R1B(11), ua, ub, xo2.y);
-    blk2(R1B(12), R1B(13), ra, rb, xr1[0]);
-    blk2(R1B(14), R1B(15), ra, rb, xr1[1]);
-    blk2(R1B(16), R1B(17), ra, rb, xr1[2]);
-    blk2(R1B(18), R1B(19), ra, rb, xr1[3]);
+    blk2(R1B(8), R1B(9), R1NX(10, 2), ra, rb, xr1[0]);
+    blk2(R1B(10), R1B(11), R1NX(12, 2), ra, rb, xr1[1]);
+    blk2(R1B(12), R1B(13), R1NX(14, 2), ra, rb, xr1[2]);
+    blk2(R1B(14), R1B(15), R1NX(16, 2), ra, rb, xr1[3]);
+    blk2(R1B(16), R1B(17), R1NX(18, 2), ua, ub, xo2.x);
+    blk2(R1B(18), R1B(19), std::integral_constant<int, kR1Blocks>{}, ua, ub, xo2.y);
     float o1;
     {
       // rows 0: up_1 block 2w, 1: up_1 block 2w + 1, 2: res_1 block 2w, 3: res_1 block 2w + 1
-      const float t = kg_reduce(f32x4{ua, ra, ub, rb});
+      const float t = r1_reduce4(ua, ra, ub, rb);
       float up, rs;
       r1_halves(t, up, rs);
-      o1 = relu_keep_nan(up + BL[u.L[7].b_lds + 32 * wave + 16 * (g & 1) + n]) + (rs + BL[u.L[4].b_lds + 32 * wave + 16 * (g & 1) + n]);          // lane (g, n): unit 32 w + 16 (g & 1) + n, both halves alike
+      R1_TICK(7)
+      o1 = relu_keep_nan(up + bu4) + (rs + br4);          // lane (g, n): unit 32 w + 16 (g & 1) + n, both halves alike
     }
     // stage 5, this wave's share: up_0 over the wave's own 32 outputs (no barrier in between)
     {
@@ -464,7 +581,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       const float y = r1_rows_sum(p0 + p1);
       if (lane < 16) lds[R1Lds::p5 + n * 8 + wave] = y;
     }
+    R1_TICK(8)
     __syncthreads();
+    R1_TICK(9)
   };
   // nabla_V[i] in every row of wave 0 (the other waves: not used)
   auto network_output = [&]() -> float {
@@ -474,25 +593,37 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     return relu_keep_nan(s + b8) + res0;
   };
 
+  // The step's scalars -- dt (utils.py:38), sqrt(lambda dt) (utils.py:47), dt / lambda and its root -- are an IEEE division and
+  // two square roots, ~40 dependent instructions: wave 3 (idle while wave 0 integrates) forms those of step k + 1 during
+  // step k and leaves them in LDS; on wave 0 they would sit on the step's serial chain or in front of its first stage.
+  float* SC = lds + R1Lds::sc;
+  auto step_scalars = [&](int k) {
+    if (CLS == 1 && wave == 3 && lane == 0 && k < K) {
+      const float dt = a.ts[k + 1] - a.ts[k];
+      const float dol = dt / a.lmbd;
+      *reinterpret_cast<f32x4*>(SC + (k & 1) * 4) = f32x4{dt, sqrtf(a.lmbd * dt), dol, sqrtf(dol)};
+    }
+  };
   // ---- prologue ----
   words(0);
   if constexpr (CLS == 0) first_layer(a.ts[0]);
   __syncthreads();
   draws(0);
   words(1);
+  step_scalars(0);
   __syncthreads();
-  float t_cur = a.ts[0], t_nxt = a.ts[1];
   for (int k = 0; k < K; ++k) {
-    const float t0 = t_cur, t1 = t_nxt;
-    t_cur = t_nxt;
-    t_nxt = a.ts[min(k + 2, K)];
-    const float dt = t1 - t0;                 // utils.py:38
-    const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
-    const float dt_over_lmbd = dt / a.lmbd, sqrt_dt_over_lmbd = sqrtf(dt_over_lmbd);
+#ifdef SOCMX_R1_PROF
+    if (k == 0) prof_last = __builtin_readcyclecounter();
+#endif
+    const float t1 = a.ts[k + 1];             // (a scalar load: requested here, long before wave 0 needs it)
     network();
     if constexpr (CLS == 0) {
+      const f32x4 scal = *reinterpret_cast<const f32x4*>(SC + (k & 1) * 4);
+      const float dt = scal[0], sq_ldt = scal[1], dt_over_lmbd = scal[2], sqrt_dt_over_lmbd = scal[3];
       const float gv = network_output();
-      if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
+      R1_TICK(12)
+      if (store && a.nabla_v) (a.nabla_v + kbd)[rowoff] = gv;
       const float uc = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
       const float eps = NZ[(k & 1) * 16 + i];                            // drawn during the previous step
       float bi;
@@ -529,23 +660,33 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       lpd = lpd + sol * (-f - 0.5f * uu);
       lps = lps + ssol * (-ue);
       if (store) {
-        a.controls[(size_t)k * B * d + rowoff] = uc;
-        a.noises[(size_t)k * B * d + rowoff] = eps;
-        a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
+        (a.controls + kbd)[rowoff] = uc;
+        (a.noises + kbd)[rowoff] = eps;
+        (a.states + kbd + step_floats)[rowoff] = xe;
       }
+      kbd += step_floats;
       if (store0) {
-        a.frac[(size_t)k * B + grow] = step;
-        a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? stop_new : 1.f;
+        (a.frac + kb)[grow] = step;
+        (a.stop_ind + kb + B)[grow] = STOPPING ? stop_new : 1.f;
       }
+      kb += B;
       x = lane_ok ? xe : 0.f;
       if (STOPPING) stop = stop_new;
+      R1_TICK(13)
       first_layer(t1);                                                  // the next evaluation's first layer: [t_{k+1}, x_{k+1}]
     } else {
       words(k + 2);
       draws(k + 1);
+      step_scalars(k + 1);
     }
+    R1_TICK(10)
     __syncthreads();
+    R1_TICK(11)
   }
+#ifdef SOCMX_R1_PROF
+  if (a.prof && blockIdx.x == 0 && lane == 0)
+    for (int sl = 0; sl < 16; ++sl) a.prof[wave * 16 + sl] = prof_acc[sl];
+#endif
   if (a.nabla_v) {                        // nabla_V(T, X_K): r1 already holds down_0 [t_K, x_K]
     network();
     if constexpr (CLS == 0) {
@@ -574,7 +715,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #undef R1B
 }
 
-template <bool STOPPING, class NET, int DMAX>
+template <int MODE, class NET, int DMAX>
 __global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -582,8 +723,8 @@ __global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutAr
   for (int e = tid; e < R1Lds::bias; e += kR1Waves * 64) lds[e] = 0.f;
   unet_load_biases_at(a.packed, NET::desc(), lds + R1Lds::bias, tid, kR1Waves * 64);
   __syncthreads();
-  if (wave == 0) r1_wave<0, STOPPING, NET, DMAX>(a, lds, 0, lane);
-  else r1_wave<1, STOPPING, NET, DMAX>(a, lds, wave, lane);
+  if (wave == 0) r1_wave<0, MODE, NET, DMAX>(a, lds, 0, lane);
+  else r1_wave<1, MODE, NET, DMAX>(a, lds, wave, lane);
 }
 
 bool rollout1_available() { return r1_supported<DefaultNet>(); }
@@ -591,9 +732,12 @@ bool rollout1_available() { return r1_supported<DefaultNet>(); }
 int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream) {
   if constexpr (r1_supported<DefaultNet>()) {
     void (*k)(const RolloutArgs);
-    if (a.d <= 3) k = stopping ? rollout1_kernel<true, DefaultNet, 3> : rollout1_kernel<false, DefaultNet, 3>;
-    else if (a.d <= 11) k = stopping ? rollout1_kernel<true, DefaultNet, 11> : rollout1_kernel<false, DefaultNet, 11>;
-    else k = stopping ? rollout1_kernel<true, DefaultNet, 15> : rollout1_kernel<false, DefaultNet, 15>;
+    const bool ou = a.kind == SOCMX_OU_QUADRATIC || a.kind == SOCMX_OU_LINEAR;
+#define R1PICK(DM) (stopping ? rollout1_kernel<1, DefaultNet, DM> : ou ? rollout1_kernel<2, DefaultNet, DM> : rollout1_kernel<0, DefaultNet, DM>)
+    if (a.d <= 3) k = R1PICK(3);
+    else if (a.d <= 11) k = R1PICK(11);
+    else k = R1PICK(15);
+#undef R1PICK
     if (const int err = ensure_max_lds(k)) return err;
     // (the CU's whole LDS: one workgroup per CU, nobody else's workgroups beside this latency-bound chain)
     return launch(k, dim3((unsigned)a.B), dim3(kR1Waves * 64), (size_t)kLdsBytesPerCU, stream, a);

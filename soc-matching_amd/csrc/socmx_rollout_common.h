@@ -60,7 +60,9 @@ typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... a
 
 // socmx_rollout1.hip: the one-row kernel (B <= 256, sigma = I, d <= 15, default widths); returns false when this build has no
 // such kernel for the architecture (variant libraries)
-bool rollout1_available();
-int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream);
+// (hidden: libsocmx.so is loaded RTLD_GLOBAL and an architecture-variant library beside it -- with default visibility the
+//  variant's calls bound to the DEFAULT library's definitions, i.e. to kernels compiled for other widths)
+__attribute__((visibility("hidden"))) bool rollout1_available();
+__attribute__((visibility("hidden"))) int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream);
 
 }  // namespace socmx

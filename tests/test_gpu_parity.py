@@ -26,7 +26,7 @@ def _np(t):
 def test_library_is_loaded_and_reports_gfx950():
     from socmx import _lib
     L = _lib.lib()
-    assert L.socmx_version() == 131
+    assert L.socmx_version() == 140
     buf = (b" " * 512)
     import ctypes
     b = ctypes.create_string_buffer(512)
@@ -1333,17 +1333,42 @@ def test_architecture_variant_library_matches_the_generic_kernels(hdims):
 
 
 def test_both_rollout_tile_shapes_pass_the_reference_fixtures():
-    """Small batches run the 4-row kernel (rollout4_kernel, v_mfma_f32_4x4x1_16b_f32), larger ones the 16-row kernel; every
-    fixture above has a small batch.  The developer switch SOCMX_TILE_ROWS=16 (read once per process) sends the same
-    fixtures through the 16-row kernel, SOCMX_TILE_ROWS=4 through the 4-row one wherever it applies, and the rollout must
-    agree with the oracle and the reference-generated states either way."""
+    """Training-size batches of the sigma = I, d <= 15 settings run ONE ROW per workgroup (rollout1_kernel, v_fmac_f32_dpp),
+    other small batches the 4-row kernels (v_mfma_f32_4x4x1_16b_f32), larger ones the 16-row kernel; every fixture above has
+    a small batch.  The developer switch SOCMX_TILE_ROWS (read once per process) sends the same fixtures through the
+    16-row kernel (=16), the 4-row ones wherever they apply (=4) and the one-row kernel wherever IT applies (=1), and the
+    rollout must agree with the oracle and the reference-generated states every time; the ragged-batch and the
+    settings-vs-eager tests ride along so that each form keeps that coverage whatever the default selection is."""
     import subprocess, sys
-    for rows in ("16", "4"):
+    for rows in ("16", "4", "1"):
         env = dict(os.environ, SOCMX_TILE_ROWS=rows)
+        # (the settings-vs-eager test was written for the small tiles: under 16-row tiles ~1 % of stopping rows land on the
+        #  other side of the re-interpolated boundary's sign test, DESIGN 3.1a)
+        extra = "" if rows == "16" else " or test_four_row_rollout_settings_vs_eager_path"
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                             "test_rollout_kernel_vs_oracle_and_golden or test_rollout_hands_over_nabla_V or "
-                            "test_keyed_rollout"], env=env, capture_output=True, text=True, timeout=900)
+                            "test_keyed_rollout or test_four_row_rollout_ragged_batches or "
+                            "test_rollout_ragged_batches" + extra],
+                           env=env, capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, (rows, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_one_row_and_four_row_rollouts_agree_row_by_row():
+    """The same Philox rows through the one-row kernel (B = 256: one workgroup per row) and inside a B = 1024 launch (4-row
+    tiles): identical noise, trajectories equal up to fp32 summation order in the network."""
+    from SOC_matching import utils
+    sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+    ts = aux["ts"][:41]
+    torch.manual_seed(5)
+    x0 = torch.randn(1024, aux["x0"].shape[-1], device=DEV) * 0.5
+    one = utils.stochastic_trajectories(sde, x0[:256], ts, aux["lmbd"], seed=11, offset=3)
+    four = utils.stochastic_trajectories(sde, x0, ts, aux["lmbd"], seed=11, offset=3)
+    torch.cuda.synchronize()
+    assert torch.equal(one[1], four[1][:, :256])
+    np.testing.assert_allclose(_np(one[0]), _np(four[0][:, :256]), rtol=0, atol=5e-4)
+    for i in (4, 5, 6):
+        np.testing.assert_allclose(_np(one[i]), _np(four[i][:256]), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(_np(one[7]), _np(four[7][:, :256]), rtol=0, atol=5e-4)
 
 
 def test_four_row_and_sixteen_row_rollouts_agree_row_by_row():
