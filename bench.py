@@ -206,6 +206,25 @@ def cpu_baseline(budget_s=12.0):
     return best
 
 
+def launch_command(args, port, environ=None):
+    """(argv, env) of the launcher child: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` + every flag of this invocation that the ranks must
+    see (tests/test_entry.py checks the forwarding)."""
+    n = args.gpus
+    env = dict(os.environ if environ is None else environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
+           str(args.warmup)]
+    for flag in ("no_cpu_baseline", "no_burst", "no_secondary", "no_dist_graph", "defer_graph"):
+        if getattr(args, flag):
+            cmd.append("--" + flag.replace("_", "-"))
+    if args.force_dist or args.spawn:
+        cmd.append("--force-dist")
+    return cmd, env
+
+
 def launch_ranks(args):
     """One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` as a
     CHILD process (never an exec: this process may not replace itself once anything has initialised the GPU, and the
@@ -219,21 +238,11 @@ def launch_ranks(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
-           str(args.warmup)]
-    for flag in ("no_cpu_baseline", "no_burst", "no_secondary", "no_dist_graph", "defer_graph"):
-        if getattr(args, flag):
-            cmd.append("--" + flag.replace("_", "-"))
-    if args.force_dist or args.spawn:
-        cmd.append("--force-dist")
+    cmd, env = launch_command(args, port)
     return subprocess.run(cmd, env=env).returncode
 
 
-def main():
+def make_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -250,11 +259,16 @@ def main():
                     "replayed with its RCCL all-reduces captured inside).  They run LAST, after every eager number is in the "
                     "line, under a watchdog that prints the line and exits if they do not finish -- this builder could "
                     "validate the capture at world size 1 only")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = make_parser().parse_args()
 
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         # `python bench.py --gpus N` without a launcher: start N fresh ranks under torch.distributed.run and relay rank 0's
-        # JSON line.  This parent has not touched the GPU (device_count() does not initialise it) and never does.
+        # JSON line.  This parent never runs a kernel; the ranks are fresh child processes whatever device_count() did here
+        # (on ROCm it may call hipGetDeviceCount).
         sys.exit(launch_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -285,6 +299,20 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+
+    # who is here: world size as the process group sees it and every rank's device (index + PCI bus id / uuid), gathered over
+    # the group -- the line of an N-GPU run shows N distinct GPUs
+    rccl_ranks, rank_devices = 1, None
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": device.index,
+          "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "name": props.name}
+    if use_dist:
+        rccl_ranks = dist.get_world_size()
+        gathered = [None] * rccl_ranks
+        dist.all_gather_object(gathered, me)
+        rank_devices = gathered
+    else:
+        rank_devices = [me]
 
     from socmx import _lib, rollout, dist as sdist
     from socmx.train import Trainer, make_optimizer
@@ -424,6 +452,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+            "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in rank_devices}),
             "config": {"workload": "double_well d=10 num_steps=200 batch=128/GPU SOCM (BASELINE configs[2]; "
                                    "global batch 128*N)", "step": "one stochastic_trajectories call (full 8-tuple)",
                        "parallelism": f"dp{world} (batch-sharded, no data-path collective in the rollout)"},
@@ -467,7 +497,9 @@ def main():
             if line is not None:
                 line["dist_graph"] = "hipGraph legs did not finish within 300 s: eager numbers reported"
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            # rank 0 delivered the line (exit 0 so that the launcher relays it as a result); every other rank reports the
+            # hang as a failure -- a wedged capture must not look like a clean run
+            os._exit(0 if rank == 0 else 3)
 
         timer = threading.Timer(300.0, bail)
         timer.daemon = True

@@ -49,7 +49,11 @@ __host__ __device__ constexpr char r1_src(int cls, int dm, int b) {
   constexpr char plan0_15[kR1Blocks + 1] = "RSSSSLSLLSLSLSLSLRLS";
   // (stream blocks spread over the step's TIME, two blocks of lead each: S1 ~1.1k cycles, S2 ~0.5k, S3 ~0.9k, S4 ~2.6k, then wave
   //  0's serial section ~1.2k with no consumption)
+#ifdef SOCMX_R1_PLAN1
+  constexpr char plan1[kR1Blocks + 1] = SOCMX_R1_PLAN1;     // (developer sweeps: tools/r1_plans.sh)
+#else
   constexpr char plan1[kR1Blocks + 1] = "RRSLRSRLRSLRSRRSLRSR";
+#endif
   return cls == 1 ? plan1[b] : dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
 }
 __host__ __device__ constexpr int r1_count(int cls, int dm, char s, int upto = kR1Blocks) {

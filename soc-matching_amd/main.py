@@ -7,8 +7,8 @@
 
 Uses Hydra (`@hydra.main(config_path="configs", config_name="soc")`) when it is installed, otherwise
 the same `configs/soc.yaml` through PyYAML with Hydra-style `a.b=value` overrides.  Differences from the
-reference: no warm start, no `multiagent_8`, no Hydra multirun (`-m` with a comma list: run the
-algorithms one by one); the NVML print at iteration 0 is replaced by a ROCm-safe memory report; with
+reference: no warm start, no `multiagent_8`; without Hydra a multirun (`-m` with comma lists, the README's
+command lines) runs its jobs one after the other; the NVML print at iteration 0 is replaced by a ROCm-safe memory report; with
 WORLD_SIZE > 1 the global batch is sharded across ranks (socmx.dist) and only rank 0 prints and saves.
 """
 import os
@@ -42,16 +42,21 @@ def run(cfg):
         import torch.distributed as dist
         from socmx.dist import Shard
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if cfg.method.use_gpu else "gloo")
+        if not dist.is_initialized():             # (a multirun's second job finds the group of the first)
+            dist.init_process_group("nccl" if cfg.method.use_gpu else "gloo")
         shard = Shard()
     if cfg.method.use_gpu and bool((cfg.get("backend", {}) or {}).get("specialize_arch", True)):
         # arch.hdims other than [256,128,64]: build (once, rank 0) / load the kernel variant with these widths as constants
         from socmx import _lib as _socmx_lib
         _socmx_lib.set_specialize(True)
         if world > 1:
-            if rank == 0:
+            # one build per NODE (local rank 0; the others wait, then only load).  A failed build warns and falls back to
+            # the descriptor-driven kernels inside variant(): no rank raises, so nobody is left waiting at the barrier
+            if local_rank == 0:
                 _socmx_lib.variant(list(cfg.arch.hdims))
             dist.barrier()
+            if local_rank != 0:
+                _socmx_lib.variant(list(cfg.arch.hdims), build=False)
     log = print if rank == 0 else (lambda *a, **k: None)
     log(cfg)
     torch.manual_seed(cfg.method.seed)          # every rank builds the same problem and the same initial weights
@@ -89,7 +94,7 @@ def run(cfg):
     trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm,
                       gemm_select=bool(backend.get("gemm_select", True)),
                       tune_new_shapes=bool(backend.get("tune_new_shapes", False)),
-                      hip_graph=bool(backend.get("hip_graph", False)))
+                      hip_graph=bool(backend.get("hip_graph", True)), log=log)
 
     solver.algorithm = algorithm
     info = solver.training_info = {k: [] for k in (
@@ -146,19 +151,40 @@ def run(cfg):
                 save_results(solver, folder_name, get_file_name(folder_name, num_iterations=itr + 1))
                 save_results(solver, folder_name, get_file_name(folder_name, num_iterations=itr + 1, last=True))
                 solver.shard = keep
+    # (the reference prints seconds with three decimals, main.py:421: a millisecond iteration reads "0.001s/it"; one more line
+    #  with the resolution this backend needs -- steady-state iterations only: no checkpoint bursts, no eager warm-up / capture)
+    steady = [t for i, t in enumerate(info["time_per_iteration"])
+              if i >= min(10, n_it // 2) and not (i == 0 or i % every == every - 1 or i == n_it - 1)]
+    if steady:
+        steady.sort()
+        log(f"time_per_iteration: median {1e3 * steady[len(steady) // 2]:.3f} ms over {len(steady)} steady-state iterations "
+            f"({'hipGraph replay' if trainer.hip_graph else 'eager two-stream'} iteration)")
     return solver
 
 
-def _main_fallback():
-    from socmx.config import load_config
-    overrides = [a for a in sys.argv[1:] if "=" in a]
-    cfg = load_config(overrides)
-    out_dir = os.path.join("outputs", "runs")
-    os.makedirs(out_dir, exist_ok=True)
-    os.chdir(out_dir)                            # hydra.job.chdir: True, run dir ./outputs/runs (soc.yaml:45-49)
-    with open("cmd.sh", "w") as f:               # main.py:60-63
-        f.write("#!/bin/bash\n\n" + " \\\n".join([f"python {sys.argv[0]}"] + ["\t" + x for x in sys.argv[1:]]) + "\n")
-    return run(cfg)
+def _main_fallback(argv=None):
+    """No Hydra in this image: the same configs/soc.yaml through PyYAML with Hydra-style overrides.  `-m` / `--multirun` with
+    comma lists runs the combinations ONE AFTER THE OTHER in ./outputs/multiruns/<job number> (soc.yaml's hydra.sweep.dir /
+    subdir; the reference fans them out through the submitit launcher), so the README's command lines work verbatim."""
+    from socmx.config import expand_multirun, load_config
+    argv = sys.argv[1:] if argv is None else argv
+    jobs, multirun = expand_multirun(argv)
+    root = os.getcwd()
+    solver = None
+    for num, overrides in enumerate(jobs):
+        cfg = load_config(overrides)
+        out_dir = os.path.join(root, "outputs", "multiruns", str(num)) if multirun else os.path.join(root, "outputs", "runs")
+        os.makedirs(out_dir, exist_ok=True)
+        os.chdir(out_dir)                        # hydra.job.chdir: True (soc.yaml:45-52)
+        if multirun:
+            print(f"[multirun] job {num} of {len(jobs)}: {' '.join(overrides)}", flush=True)
+        with open("cmd.sh", "w") as f:           # main.py:60-63
+            f.write("#!/bin/bash\n\n" + " \\\n".join([f"python {sys.argv[0]}"] + ["\t" + x for x in overrides]) + "\n")
+        try:
+            solver = run(cfg)
+        finally:
+            os.chdir(root)
+    return solver
 
 
 if __name__ == "__main__":

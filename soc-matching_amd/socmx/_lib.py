@@ -180,11 +180,13 @@ def variant_path(hdims):
 
 
 def build_variant(hdims, quiet=False):
-    """`make -C csrc VARIANT=h0_h1_h2` (hipcc; cross-compiles without a GPU).  Returns the library path."""
+    """`make -C csrc VARIANT=h0_h1_h2` (hipcc; cross-compiles without a GPU; a no-op when the library is up to date; the
+    Makefile links to a temporary name and renames it into place, so a concurrent reader never maps a half-written file).
+    Returns the library path."""
     import subprocess
     hp = tuple(_pad16(h) for h in hdims)
     csrc = os.path.join(os.path.dirname(_HERE), "csrc")
-    if not quiet:
+    if not quiet and not os.path.exists(variant_path(hdims)):
         print(f"socmx: compiling kernels specialised for arch.hdims -> {list(hp)} (one-time, a few minutes) ...", flush=True)
     res = subprocess.run(["make", "-C", csrc, "-j8", "VARIANT=%d_%d_%d" % hp], capture_output=True, text=True)
     if res.returncode != 0:
@@ -192,34 +194,68 @@ def build_variant(hdims, quiet=False):
     return variant_path(hdims)
 
 
-def variant(hdims):
+class _VariantLock:
+    """Inter-process lock (flock on `<library>.lock`) around build + load of one variant: the jobs of a sweep, or the ranks
+    of a node, that start together with the same non-default arch.hdims build it once and load it complete.  Where the
+    package directory is read-only the lock is skipped (nothing can be built there either)."""
+
+    def __init__(self, path):
+        self.path, self.fd = path + ".lock", None
+
+    def __enter__(self):
+        try:
+            import fcntl
+            self.fd = os.open(self.path, os.O_CREAT | os.O_RDWR, 0o644)
+            fcntl.flock(self.fd, fcntl.LOCK_EX)
+        except OSError:
+            if self.fd is not None:
+                os.close(self.fd)
+            self.fd = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.fd is not None:
+            import fcntl
+            fcntl.flock(self.fd, fcntl.LOCK_UN)
+            os.close(self.fd)
+
+
+def variant(hdims, build=None):
     """The library whose constexpr kernels match `hdims` (padded to multiples of 16): the default library for the default
-    architecture, an existing variant library, a freshly built one when `specialize_enabled()`, else the default library
-    (whose descriptor-driven kernels take any architecture)."""
+    architecture, an existing variant library, a freshly built one when `specialize_enabled()` (or `build=True`), else the
+    default library (whose descriptor-driven kernels take any architecture).  With building enabled `make` always runs -- a
+    no-op when the library is newer than its sources, a rebuild after a source edit.  A build that fails (no hipcc, a
+    read-only package directory) is reported once and the default library serves the architecture: slower, never wrong."""
     hp = tuple(_pad16(h) for h in hdims)
     if hp == DEFAULT_HDIMS:
         return lib()
     if hp in _variants:
         return _variants[hp]
     path = variant_path(hdims)
-    if not os.path.exists(path) and specialize_enabled():
-        build_variant(hdims)
-    if os.path.exists(path):
-        base = lib()                                      # (also makes torch's HIP runtime the one in this process)
-        handle = C.CDLL(path, mode=C.RTLD_LOCAL)
-        for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(handle, name)
-            fn.restype = res
-            fn.argtypes = args
-        if handle.socmx_version() != base.socmx_version():
-            raise SocmxError(f"{path} is a stale build (version {handle.socmx_version()} != {base.socmx_version()}): "
-                             "delete it or rebuild with make VARIANT=...")
-        buf = C.create_string_buffer(512)
-        handle.socmx_capabilities(buf, 512)
-        assert ("static_hdims=%d,%d,%d" % hp).encode() in buf.value, buf.value
-        _variants[hp] = handle
-    else:
-        _variants[hp] = lib()
+    base = lib()                                          # (also makes torch's HIP runtime the one in this process)
+    with _VariantLock(path):
+        if specialize_enabled() if build is None else build:
+            try:
+                build_variant(hdims)
+            except (SocmxError, OSError) as e:
+                import warnings
+                warnings.warn(f"socmx: could not build the kernel variant for arch.hdims {list(hp)} ({str(e)[-300:]}); "
+                              + ("using the library already there" if os.path.exists(path) else
+                                 "the descriptor-driven kernels of libsocmx.so serve this architecture (~1.6x slower per step)"))
+        handle = None
+        if os.path.exists(path):
+            handle = C.CDLL(path, mode=C.RTLD_LOCAL)
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+            if handle.socmx_version() != base.socmx_version():
+                raise SocmxError(f"{path} is a stale build (version {handle.socmx_version()} != {base.socmx_version()}): "
+                                 "delete it or rebuild with make VARIANT=...")
+            buf = C.create_string_buffer(512)
+            handle.socmx_capabilities(buf, 512)
+            assert ("static_hdims=%d,%d,%d" % hp).encode() in buf.value, buf.value
+    _variants[hp] = handle if handle is not None else base
     return _variants[hp]
 
 

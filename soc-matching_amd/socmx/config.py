@@ -59,6 +59,54 @@ def apply_overrides(cfg, overrides):
     return cfg
 
 
+def split_sweep(value):
+    """Hydra's comma-separated sweep syntax: `a,b,c` -> ['a', 'b', 'c'], commas inside brackets / quotes kept
+    (`arch.hdims_M=[64,64]` is ONE value)."""
+    out, depth, quote, cur = [], 0, None, []
+    for ch in value:
+        if quote:
+            cur.append(ch)
+            if ch == quote:
+                quote = None
+        elif ch in "'\"":
+            quote = ch
+            cur.append(ch)
+        elif ch in "[({":
+            depth += 1
+            cur.append(ch)
+        elif ch in "])}":
+            depth -= 1
+            cur.append(ch)
+        elif ch == "," and depth == 0:
+            out.append("".join(cur))
+            cur = []
+        else:
+            cur.append(ch)
+    out.append("".join(cur))
+    return out
+
+
+def expand_multirun(argv):
+    """The reference's README command lines (README.md:15-60) are Hydra MULTIRUNS: `method.algorithm='SOCM','SOCM_const_M',... -m`.
+    Returns (list of override lists, multirun flag): the cartesian product of the comma lists, in Hydra's job order (the
+    LAST swept key varies fastest), one job per combination.  A comma list without -m / --multirun is the error it is
+    under Hydra."""
+    import itertools
+    multirun = any(a in ("-m", "--multirun") for a in argv)
+    overrides = [a for a in argv if "=" in a and not a.startswith("-")]
+    keys, choices = [], []
+    for item in overrides:
+        key, val = item.split("=", 1)
+        keys.append(key)
+        choices.append(split_sweep(val))
+    swept = [k for k, c in zip(keys, choices) if len(c) > 1]
+    if swept and not multirun:
+        raise ValueError(f"override(s) {swept} hold a comma-separated list: add -m / --multirun to sweep them "
+                         "(one run per value, as Hydra does), or quote the value")
+    jobs = [[f"{k}={v}" for k, v in zip(keys, combo)] for combo in itertools.product(*choices)]
+    return jobs, multirun
+
+
 def load_config(overrides=(), path=DEFAULT_YAML):
     with open(path) as f:
         raw = yaml.safe_load(f)

@@ -46,7 +46,7 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
                  ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=False, overlap_M_backward=True,
-                 grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2, fused_adam=True):
+                 grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2, fused_adam=True, log=None):
         self.solver, self.optimizer = solver, optimizer
         self.batch_size = batch_size
         self.normalization_const = normalization_const
@@ -67,7 +67,12 @@ class Trainer:
         # hipGraph mode (SOCM with or without stopping times; sharded runs: plain SOCM on the hand-written kernels, with the
         # RCCL all-reduces captured inside the graph): the whole iteration -- rollout, loss, backward, collectives, Adam, EMA
         # normaliser, gradient telemetry -- is captured once and replayed; see _graph_step
+        self._log = log if log is not None else (lambda *a, **k: None)
         self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda)
+        if hip_graph and not self.hip_graph:
+            # (never silent: `backend.hip_graph` is on by default, so a run that cannot use it says why)
+            why = f"algorithm {algorithm!r} has no captured body (SOCM does)" if algorithm != "SOCM" else "the solver is not on a GPU"
+            self._log(f"backend.hip_graph: running the eager two-stream iteration instead -- {why}")
         self.graph_warmup = int(graph_warmup)
         self.fused_adam = bool(fused_adam)    # hipGraph body: control-network Adam + telemetry as one launch (socmx_adam_step_f32)
         self._graphs = {}
@@ -606,8 +611,11 @@ class Trainer:
                 #  captures -- under the default "global" error mode that invalidates the capture now and then; the
                 #  collectives themselves are enqueued by this thread)
                 mode = "thread_local" if solver.shard is not None else "global"
-                with torch.cuda.graph(g, capture_error_mode=mode):
-                    static_vals = body()
+                try:
+                    with torch.cuda.graph(g, capture_error_mode=mode):
+                        static_vals = body()
+                except Exception as e:                       # noqa: BLE001 -- whatever the capture choked on, training goes on
+                    return self._capture_failed(e, loss_kwargs)
                 self._graphs[key] = entry = (g, static_vals)
                 g.replay()                                   # capture does not execute: this replay IS the iteration
                 vals = static_vals.clone()
@@ -629,6 +637,25 @@ class Trainer:
         if self.grad_telemetry:
             info.update(grad_norm_sqd=vals[3], EMA_grad_norm_sqd=vals[4], sqd_norm_EMA_grad=vals[5])
         return info
+
+    def _capture_failed(self, err, loss_kwargs):
+        """A body that cannot be captured (an operation that synchronises, a library call without capture support on this
+        stack, ...) must not end a training run that `backend.hip_graph: True` started by default: say so once, drop graph
+        mode for the rest of the run and take this iteration -- nothing of it has executed -- on the eager path, from the
+        device-side state the warm-up iterations left (normaliser, telemetry EMAs, outstanding pair-grid-network update)."""
+        import warnings
+        msg = f"backend.hip_graph: capture failed ({type(err).__name__}: {err}); the run continues on the eager two-stream iteration"
+        warnings.warn(msg)
+        self._log(msg)
+        torch.cuda.synchronize(self.solver.x0.device)
+        self._flush_M()
+        self._sync_from_device_state()
+        if self._dev is not None and self.itr > 0:
+            self._ema_grad = [g.clone() for g in self._dev["ema_grad"]]
+            self._ema_grad_norm_sqd = self._dev["ema_gn"].clone()
+        self.hip_graph = False
+        self._graphs.clear()
+        return self._eager_step(**loss_kwargs)
 
     def _graph_eligible(self, loss_kwargs):
         # (sharded: only the autograd-free body carries its collectives inside the graph; anything else runs eagerly)

@@ -74,3 +74,41 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libsocmx.so"))
     with pytest.raises(_lib.SocmxError):
         _lib.lib()
+
+
+def test_variant_library_falls_back_when_it_cannot_be_built(monkeypatch):
+    """A host without hipcc / make (or a read-only package directory) must not turn `backend.specialize_arch: True` into a
+    crash, or into ranks waiting for each other: the build failure is reported and the default library's descriptor-driven
+    kernels serve the architecture."""
+    from socmx import _lib
+
+    def broken(hdims, quiet=False):
+        raise _lib.SocmxError("building the architecture variant failed: make: hipcc: No such file or directory")
+
+    monkeypatch.setattr(_lib, "build_variant", broken)
+    monkeypatch.setattr(_lib, "_variants", {})
+    hd = [96, 48, 24]
+    assert not os.path.exists(_lib.variant_path(hd))
+    with pytest.warns(UserWarning, match="could not build the kernel variant"):
+        got = _lib.variant(hd, build=True)
+    assert got is _lib.lib()
+    assert _lib.variant(hd) is _lib.lib()                 # cached: no second attempt, no second warning
+
+
+def test_variant_library_loads_in_concurrent_processes():
+    """Several processes asking for the same prebuilt variant at once (the jobs of a sweep, the ranks of a node) serialise on
+    the lock file and each loads the complete library."""
+    import subprocess
+    import sys
+    from socmx import _lib
+    path = _lib.variant_path([128, 64, 32])
+    if not os.path.exists(path):
+        pytest.skip("libsocmx_128_64_32.so not built")
+    code = ("import sys; sys.path.insert(0, %r); from socmx import _lib; h = _lib.variant([128, 64, 32], build=False); "
+            "assert h is not _lib.lib() and h.socmx_version() == _lib.lib().socmx_version(); print('ok')"
+            % os.path.join(ROOT, "soc-matching_amd"))
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(4)]
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0 and "ok" in out, err[-1500:]

@@ -128,24 +128,27 @@ def _train_worker(rank, world, port, name, ret):
     state = {("V." + k): v.detach().numpy().copy() for k, v in sde.nabla_V.state_dict().items()}
     state.update({("M." + k): v.detach().numpy().copy() for k, v in sde.M.state_dict().items()})
     state["gamma"] = sde.gamma.detach().numpy().copy()
-    ret[rank] = dict(rec=rec, state=state, collectives=dict(counts), iters=n_it)
+    ret[rank] = dict(rec=rec, state=state, collectives=dict(counts), iters=n_it, rows=(Bl, row0))
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name", ["train_ou_quadratic_easy_d2", "train_double_well_d10"])
-def test_sharded_trainer_steps_equal_the_reference_training_run(name):
-    """world_size 2 (gloo): `Trainer.step` with a batch shard -- loss, backward, ONE flat all-reduce (gradients + loss value +
-    shifted weight sums), Adam with the reference's groups, EMA normaliser -- reproduces the reference's own training run on
-    the same noise, both ranks end with identical parameters, and exactly one collective is issued per iteration."""
-    world = 2
+def test_sharded_trainer_steps_equal_the_reference_training_run(name, world):
+    """world_size 2 and 3 (gloo): `Trainer.step` with a batch shard -- loss, backward, ONE flat all-reduce (gradients + loss
+    value + shifted weight sums), Adam with the reference's groups, EMA normaliser -- reproduces the reference's own training
+    run on the same noise, all ranks end with identical parameters, and exactly one collective is issued per iteration.
+    The fixtures' batch is 16 rows: three ranks hold 6 / 5 / 5 of them (a split that does not divide)."""
     port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_train_worker, args=(world, port, name, ret), nprocs=world, join=True)
         ret = {k: v for k, v in ret.items()}
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
-    r0, r1 = ret[0], ret[1]
+    r0, r1 = ret[0], ret[world - 1]
+    assert sorted(ret) == list(range(world))
     assert r0["collectives"] == {"all_reduce": r0["iters"], "all_gather": 0}, r0["collectives"]
+    assert [ret[r]["rows"] for r in range(world)] == ([(8, 0), (8, 8)] if world == 2 else [(6, 0), (5, 6), (5, 11)])
     np.testing.assert_allclose(r0["rec"]["loss"], z["train_loss"], rtol=2e-4)
     np.testing.assert_allclose(r0["rec"]["weight_mean"], z["train_weight_mean"], rtol=2e-4)
     np.testing.assert_allclose(r0["rec"]["norm"], z["train_norm_const"], rtol=2e-4)

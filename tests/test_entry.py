@@ -104,6 +104,99 @@ def test_main_runs_a_tiny_training_on_cpu(tmp_path):
     assert folders[0].name.startswith("SOCM_double_well_1.0_1.0_40_False_0_8_")
 
 
+def test_split_sweep_and_multirun_expansion():
+    """Hydra's sweep syntax as the README uses it (README.md:15-60): comma lists outside brackets, -m required."""
+    from socmx.config import expand_multirun, split_sweep
+    assert split_sweep("SOCM,SOCM_const_M,log-variance") == ["SOCM", "SOCM_const_M", "log-variance"]
+    assert split_sweep("[64,64]") == ["[64,64]"] and split_sweep("'a,b',c") == ["'a,b'", "c"]
+    jobs, multi = expand_multirun(["method.algorithm=SOCM,rel_entropy", "arch.hdims_M=[64,64]", "method.seed=0,1", "-m"])
+    assert multi and len(jobs) == 4
+    assert jobs[0] == ["method.algorithm=SOCM", "arch.hdims_M=[64,64]", "method.seed=0"]
+    assert jobs[1] == ["method.algorithm=SOCM", "arch.hdims_M=[64,64]", "method.seed=1"]          # the last swept key varies fastest
+    assert jobs[3] == ["method.algorithm=rel_entropy", "arch.hdims_M=[64,64]", "method.seed=1"]
+    with pytest.raises(ValueError, match="multirun"):
+        expand_multirun(["method.algorithm=SOCM,rel_entropy"])
+    jobs, multi = expand_multirun(["method.d=3"])
+    assert not multi and jobs == [["method.d=3"]]
+
+
+def test_readme_style_multirun_command_line_runs_every_algorithm(tmp_path):
+    """`python main.py method.algorithm='SOCM','log-variance' ... -m` (the form of every README command, README.md:15-60):
+    without Hydra the jobs run one after the other in outputs/multiruns/<n>, each with the reference's checkpoint files."""
+    cmd = [sys.executable, os.path.join(ROOT, "soc-matching_amd", "main.py"), "method.algorithm=SOCM,log-variance",
+           "method.lmbd=1.0", "method.setting=OU_quadratic_easy", "method.gamma=2.0", "method.scaling_factor_M=0.1",
+           "optim.M_lr=1e-3", "optim.batch_size=8", "method.num_iterations=3", "method.use_gpu=False", "method.device=cpu",
+           "method.d=2", "method.num_steps=10", "arch.hdims=[16,8,8]", "arch.hdims_M=[8,8]", "method.n_samples_control=32",
+           "+method.n_batches_normalization=2", "method.compute_control_objective_every=2", "-m"]
+    res = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "[multirun] job 0 of 2: method.algorithm=SOCM" in res.stdout
+    assert "[multirun] job 1 of 2: method.algorithm=log-variance" in res.stdout
+    for num, alg in ((0, "SOCM"), (1, "log-variance")):
+        job = tmp_path / "outputs" / "multiruns" / str(num)
+        folders = [p for p in job.iterdir() if p.is_dir()]
+        assert len(folders) == 1 and folders[0].name.startswith(alg + "_OU_quadratic_easy_"), [f.name for f in folders]
+        assert (folders[0] / "last.pkl").exists() and (job / "cmd.sh").exists()
+    # on a CPU run the default backend.hip_graph = True falls back to the eager iteration, and says so
+    assert "backend.hip_graph: running the eager" in res.stdout
+
+
+def test_last_pkl_holds_every_series_the_plotting_code_reads(tmp_path):
+    """f3: the checkpoint is what the reference's plots.py consumes (plots.py:39-49, 118, 147, 177): unpickle `last.pkl`,
+    take `training_info`, and torch.stack every series it reads."""
+    import pickle
+    cmd = [sys.executable, os.path.join(ROOT, "soc-matching_amd", "main.py"), "method.setting=OU_quadratic_easy", "method.d=2",
+           "method.num_steps=10", "method.num_iterations=5", "method.use_gpu=False", "method.device=cpu", "arch.hdims=[16,8,8]",
+           "arch.hdims_M=[8,8]", "method.n_samples_control=32", "+method.n_batches_normalization=2", "optim.batch_size=8",
+           "method.gamma=2.0", "method.compute_control_objective_every=2"]
+    res = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    folders = [p for p in (tmp_path / "outputs" / "runs").iterdir() if p.is_dir()]
+    sys.path.insert(0, os.path.join(ROOT, "soc-matching_amd"))
+    with open(folders[0] / "last.pkl", "rb") as f:
+        solver = pickle.load(f)
+    info = solver.training_info
+    n_it = 5
+    for key in ("time_per_iteration", "EMA_time_per_iteration"):
+        assert len(info[key]) == n_it and all(float(v) > 0 for v in info[key])
+    for key in ("loss", "EMA_loss", "norm_sqd_diff", "EMA_norm_sqd_diff", "weight_mean", "EMA_weight_mean", "weight_std",
+                "EMA_weight_std", "grad_norm_sqd", "EMA_grad_norm_sqd", "sqd_norm_EMA_grad"):
+        series = torch.stack([torch.as_tensor(v).reshape(()) for v in info[key]])
+        assert series.shape == (n_it,) and torch.isfinite(series).all(), key
+    itr = info["control_objective_itr"]
+    assert itr == [1, 2, 4, 5]                                    # iteration 0, every 2nd, the last one
+    for key in ("control_objective_mean", "control_objective_std_err"):
+        series = torch.stack([torch.as_tensor(v).reshape(()) for v in info[key]])
+        assert series.shape == (len(itr),) and torch.isfinite(series).all(), key
+    assert len(info["trajectories"]) == len(itr) and info["cfg"].method.setting == "OU_quadratic_easy"
+    assert solver.num_iterations == n_it and solver.algorithm == "SOCM"
+
+
+def test_bench_launcher_command_line_and_flag_forwarding():
+    """`python bench.py --gpus N` starts its ranks itself: the child command is the contract's launcher line
+    (torch.distributed.run, one node, N processes, 127.0.0.1 rendezvous) and carries every flag the ranks must see."""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.make_parser().parse_args(["--gpus", "8", "--steps", "7", "--warmup", "3", "--no-burst", "--no-dist-graph"])
+    cmd, env = bench.launch_command(args, 12345, environ={"PATH": os.environ.get("PATH", "")})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    tail = cmd[script + 1:]
+    assert tail[:6] == ["--gpus", "8", "--steps", "7", "--warmup", "3"]
+    assert "--no-burst" in tail and "--no-dist-graph" in tail
+    assert "--no-cpu-baseline" not in tail and "--no-secondary" not in tail and "--force-dist" not in tail
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and int(env["OMP_NUM_THREADS"]) >= 1
+    # --spawn (the launcher path on one GPU) makes the child take the sharded code path
+    args = bench.make_parser().parse_args(["--gpus", "1", "--spawn", "--defer-graph"])
+    cmd, _ = bench.launch_command(args, 1, environ={})
+    assert "--force-dist" in cmd and "--defer-graph" in cmd and "--nproc-per-node=1" in cmd
+    # the ranks themselves parse what the launcher hands them
+    child = bench.make_parser().parse_args(cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:])
+    assert child.gpus == 1 and child.force_dist and child.defer_graph
+
+
 def test_double_well_pde_ground_truth_matches_reference():
     """f2: vectorised 1-D PDE solve + table lookup against the reference's double-loop solver (coarse grid)."""
     from socmx import ground_truth as G

@@ -672,6 +672,27 @@ def test_main_trains_on_the_gpu(tmp_path, overrides):
     assert len(folders) == 1 and (folders[0] / "last.pkl").exists()
 
 
+def test_readme_double_well_command_line_prints_the_fast_iteration(tmp_path):
+    """The reference README's double_well line (README.md:51) as written -- multirun syntax included, the algorithm list cut
+    to SOCM and the iteration count to 80 -- through main.py with the shipped defaults (backend.hip_graph: True): the user
+    sees the replayed iteration, not the eager one.  Bound: 1.85 ms per iteration (round 3: 1.76 ms replayed, 2.1 eager;
+    with the one-row rollout kernel ~1.1 ms)."""
+    import re, subprocess, sys
+    cmd = [sys.executable, os.path.join(os.path.dirname(GOLDEN), "..", "soc-matching_amd", "main.py"),
+           "method.algorithm=SOCM", "method.lmbd=1.0", "method.gamma=6.0", "method.setting=double_well", "method.d=10",
+           "method.num_steps=200", "method.delta_t_optimal=0.001", "method.delta_x_optimal=0.001",
+           "method.n_samples_control=65536", "method.scaling_factor_M=0.1", "optim.M_lr=1e-3", "optim.batch_size=128",
+           "method.num_iterations=80", "method.seed=0", "-m"]
+    res = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "[multirun] job 0 of 1" in res.stdout and "nan" not in res.stdout.lower()
+    m = re.search(r"time_per_iteration: median ([0-9.]+) ms over (\d+) steady-state iterations \(hipGraph replay", res.stdout)
+    assert m, res.stdout[-2000:]
+    assert float(m.group(1)) <= 1.85 and int(m.group(2)) >= 30, m.group(0)
+    assert re.search(r"^70 - 0\.00[0-2]s/it", res.stdout, re.M), res.stdout[-1500:]      # the reference's own line format
+    assert (tmp_path / "outputs" / "multiruns" / "0").is_dir()
+
+
 def test_the_integration_stub_in_the_docs_runs(monkeypatch):
     """the ctypes stub a reference maintainer would paste is executed verbatim (struct layouts,
     argument order) and must reproduce this package's own rollout for the same Philox key."""
