@@ -27,6 +27,8 @@ import torch
 
 from . import _lib
 
+import weakref
+_TIDX_CHECKED = weakref.WeakKeyDictionary()   # ground-truth control -> (time grid, version, K, table rows) already range-checked
 _philox_calls = 0  # advances the Philox offset so successive rollouts draw fresh noise
 
 
@@ -125,13 +127,17 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
         tidx = tidx.to(device=dev, dtype=torch.int32).contiguous()
         # the kernel indexes the table with tidx unchecked; an index past the table raises in the reference's lookup
         # (models.py:15-23, 72-75, 98-150) -- checked once per (control, time grid), not per rollout
-        seen = (tc.data_ptr(), K, int(table.shape[0]))
-        if getattr(sde.u, "_tidx_checked", None) != seen:
+        # (keyed on the CALLER's time-grid tensor -- the object, held weakly, and its version counter -- not on the fp32 /
+        #  contiguous / on-device copy made above, which is a new allocation on every call whenever the caller's grid is not
+        #  already in that form: the check's host synchronisation then recurred per rollout, and an address reused by
+        #  another grid of the same length skipped it)
+        seen = _TIDX_CHECKED.get(sde.u)         # (a module-level weak table: the control object stays picklable)
+        if not (seen is not None and seen[0]() is t and seen[1:] == (t._version, K, int(table.shape[0]))):
             lo, hi = int(tidx.min()), int(tidx.max())
             if lo < 0 or hi >= table.shape[0]:
                 raise IndexError(f"ground-truth control: time index range [{lo}, {hi}] outside the table of "
                                  f"{table.shape[0]} rows")
-            sde.u._tidx_checked = seen
+            _TIDX_CHECKED[sde.u] = (weakref.ref(t), t._version, K, int(table.shape[0]))
         ctrl = _lib.Control(kind=ckind, n_t=int(table.shape[0]), n_x=int(n_x), table=_lib.ptr(table),
                             tidx=tidx.data_ptr(), xb=float(xb), delta_x=float(dx))
         if seed is None:

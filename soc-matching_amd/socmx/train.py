@@ -564,6 +564,33 @@ class Trainer:
                 if st and torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
                     st["step"] = st["step"].to(dev)
 
+    def _optimizer_signature(self):
+        """Everything a captured iteration has baked in from the optimiser, fused table or not: the data pointers of every
+        parameter and of its Adam state, and each group's hyper-parameters (torch's capturable Adam freezes lr / betas / eps
+        into the captured kernels' arguments)."""
+        st = self.optimizer.state
+        sig = []
+        for g in self.optimizer.param_groups:
+            lr = g.get("lr")
+            sig.append((float(lr) if not torch.is_tensor(lr) else ("t", lr.data_ptr()), tuple(g.get("betas", ())),
+                        float(g.get("eps", 0.0)), float(g.get("weight_decay", 0.0)),
+                        tuple((p.data_ptr(),) + tuple(v.data_ptr() for v in st.get(p, {}).values() if torch.is_tensor(v))
+                              for p in g["params"])))
+        return tuple(sig)
+
+    def _drop_stale_graphs(self):
+        """`optimizer.load_state_dict` (resume), an lr change or a re-allocated state tensor after a capture: the captured
+        graphs would keep stepping the old tensors with the old hyper-parameters -- drop them (the next iterations warm up
+        and capture again).  Checked for every captured body, with or without the fused Adam table."""
+        if not any(not (isinstance(k, tuple) and k and k[0] == "warm") for k in self._graphs):
+            return
+        if getattr(self, "_graphs_sig", None) != self._optimizer_signature():
+            self._graphs = {}
+            if self._dev is not None:
+                for k in ("adam_table", "adam_sig", "adam_scratch"):
+                    self._dev.pop(k, None)
+            self._make_capturable()
+
     def _drop_stale_adam_state(self):
         D = self._dev
         if D is None or "adam_table" not in D:
@@ -579,6 +606,7 @@ class Trainer:
         solver = self.solver
         dev = solver.x0.device
         manual = self._manual_ok(loss_kwargs)
+        self._drop_stale_graphs()
         if not manual:
             self._flush_M()
         else:
@@ -617,6 +645,7 @@ class Trainer:
                 except Exception as e:                       # noqa: BLE001 -- whatever the capture choked on, training goes on
                     return self._capture_failed(e, loss_kwargs)
                 self._graphs[key] = entry = (g, static_vals)
+                self._graphs_sig = self._optimizer_signature()
                 g.replay()                                   # capture does not execute: this replay IS the iteration
                 vals = static_vals.clone()
         elif manual and not self._m_pending:

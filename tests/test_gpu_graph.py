@@ -174,10 +174,13 @@ def test_fused_adam_step_matches_torch_adam():
     assert float(scratch[0]) == 0.0              # the ticket is re-armed; the rest holds per-workgroup partial sums
 
 
-def test_graph_mode_survives_an_optimizer_reload_and_an_lr_change():
-    """the captured iteration bakes in the Adam state's data pointers and the groups' hyper-parameters.  A resume
-    (`optimizer.load_state_dict`: new state tensors) or an lr change must drop the device table and the captured graphs --
-    the run must continue exactly like an eager Trainer that went through the same reload."""
+@pytest.mark.parametrize("fused_adam", [True, False])
+def test_graph_mode_survives_an_optimizer_reload_and_an_lr_change(fused_adam):
+    """the captured iteration bakes in the Adam state's data pointers and the groups' hyper-parameters.  A
+    resume (`optimizer.load_state_dict`: new state tensors) or an lr change must drop the device table and the captured
+    graphs -- the run must continue exactly like an eager Trainer that went through the same reload -- with the fused Adam
+    table (socmx_adam_step_f32) and without it (torch's capturable Adam inside the graph: the signature of the optimiser
+    state is checked for every captured body)."""
     import copy
     out = {}
     for graph in (False, True):
@@ -188,7 +191,8 @@ def test_graph_mode_survives_an_optimizer_reload_and_an_lr_change():
         solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
         solver.philox_key = PhiloxKey(torch.device(DEV), seed=3, offset=0)
         opt = make_optimizer(solver, M_lr=1e-3)
-        tr = Trainer(solver, opt, 32, normalization_const=0.9, sync_timing=False, hip_graph=graph, overlap_M_backward=False)
+        tr = Trainer(solver, opt, 32, normalization_const=0.9, sync_timing=False, hip_graph=graph, overlap_M_backward=False,
+                     fused_adam=fused_adam)
         rec = []
         for it in range(12):
             if it == 5:
