@@ -1246,7 +1246,13 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
       "socmx 0.1.4; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
       "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches; one row per workgroup on v_fmac_f32_dpp for B <= 256, sigma = I, d <= 15); "
       "Philox4x32-10 noise; static_hdims=" SOCMX_STR(SOCMX_H0P) "," SOCMX_STR(SOCMX_H1P) "," SOCMX_STR(SOCMX_H2P) "; "
-      "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target";
+      "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target; "
+      // what the hand-written kernels take (outside these ranges the entry points return SOCMX_E_LDS / SOCMX_E_DIM and the
+      // Python layer routes to torch autograd + library GEMMs on the GPU, with a warning -- never to the CPU)
+      "ranges: rollout any arch.hdims, d <= 64 (OU_quadratic) .. 96 (double_well) at the default widths; "
+      "control-network backward: architectures whose 16-row tiles fit 160 KiB of LDS (h0 <= 256 at the default depth); "
+      "pair-grid network: d*d <= 26*26 with hdims_M <= [128,128], or d % 4 == 0 with d <= 64 and hdims_M[1] <= 128 (wide form); "
+      "stopping-time SOCM kernels: d <= 16; costate (SOCM_adjoint) kernel: d <= 64";
   const int need = (int)sizeof(msg);
   if (buf && cap > 0) {
     const int n = need < cap ? need : cap;

@@ -92,7 +92,7 @@ def run(cfg):
     optimizer.zero_grad()
     backend = cfg.get("backend", {}) or {}
     trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm,
-                      gemm_select=bool(backend.get("gemm_select", True)),
+                      gemm_select=bool(backend.get("gemm_select", False)),
                       tune_new_shapes=bool(backend.get("tune_new_shapes", False)),
                       hip_graph=bool(backend.get("hip_graph", True)), log=log)
 

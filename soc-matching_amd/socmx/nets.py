@@ -224,11 +224,27 @@ class FullyConnectedUNet(nn.Module):
         return st
 
 
+_warned = set()
+
+
+def warn_library_fallback(what, why):
+    """Once per process and per kind: a run on the GPU that leaves the hand-written kernels for torch autograd + library GEMMs
+    (still on the GPU, same results, slower) says so -- `socmx_capabilities` lists the ranges the kernels take."""
+    if what not in _warned:
+        _warned.add(what)
+        import warnings
+        warnings.warn(f"socmx: {what} runs on torch autograd + library GEMMs for this configuration ({why}); "
+                      "see socmx_capabilities() for the ranges the HIP kernels take")
+
+
 def unet_backward_supported(net, n_rows):
     """True when socmx_unet_backward_f32 takes this architecture (its 16-row tiles must fit 160 KiB of LDS)."""
     L = net.hip_lib()
     ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
-    return L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
+    ok = L.socmx_unet_backward_sizes(net.dim, _lib.i3(net.hdims), int(n_rows), _lib.C.byref(ws), _lib.C.byref(ng)) == 0
+    if not ok:
+        warn_library_fallback("the control-network backward", f"arch.hdims={list(net.hdims)}, d={net.dim}: tiles beyond 160 KiB of LDS")
+    return ok
 
 
 def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None, out=None, packed_bwd=None):
@@ -386,8 +402,11 @@ def pair_net_supported(mlp, n_pairs):
     L = _lib.lib()
     ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
     n_in = int(mlp.sigmoid_layers[0].weight.shape[1])
-    return L.socmx_mnet_backward_sizes(mlp.dim, _lib.i2(mlp.hdims), n_in, int(n_pairs), _lib.C.byref(ws),
-                                       _lib.C.byref(ng)) == 0
+    ok = L.socmx_mnet_backward_sizes(mlp.dim, _lib.i2(mlp.hdims), n_in, int(n_pairs), _lib.C.byref(ws),
+                                     _lib.C.byref(ng)) == 0
+    if not ok:
+        warn_library_fallback("the pair-grid network (M)", f"d={mlp.dim}, arch.hdims_M={list(mlp.hdims)}")
+    return ok
 
 
 class SigmoidMLP(nn.Module):
@@ -512,8 +531,12 @@ class TwoBoundarySigmoidMLP(nn.Module):
         l0, l2 = self.sigmoid_layers[0], self.sigmoid_layers[2]
         L = _lib.lib()
         ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
-        return L.socmx_mnet_backward_sizes(self.dim, _lib.i2((l0.weight.shape[0], l2.weight.shape[0])), 3, 2 * int(n_pairs),
-                                           _lib.C.byref(ws), _lib.C.byref(ng)) == 0
+        ok = L.socmx_mnet_backward_sizes(self.dim, _lib.i2((l0.weight.shape[0], l2.weight.shape[0])), 3, 2 * int(n_pairs),
+                                         _lib.C.byref(ws), _lib.C.byref(ng)) == 0
+        if not ok:
+            warn_library_fallback("the stopping-time pair-grid network", f"d={self.dim}, arch.hdims_M="
+                                  f"{[l0.weight.shape[0], l2.weight.shape[0]]}")
+        return ok
 
     def forward(self, t, s, stopping_timestep_values):
         tau = stopping_timestep_values                       # (N, B)

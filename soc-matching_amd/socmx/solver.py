@@ -131,6 +131,10 @@ class SOC_Solver(nn.Module):
         Kp, B, d = states.shape
         tau = ((sde.Phi(states) > 0).to(torch.int).sum(dim=0) - 1) / (Kp - 1)            # method.py:525-530
         tau_vec = tau.unsqueeze(0).expand(t_vec.shape[0], B)
+        if states.is_cuda and d > 16 and getattr(self, "fused_stopping", True):
+            from .nets import warn_library_fallback
+            warn_library_fallback("the stopping-time SOCM target", f"d={d} > 16: the (Np, B, d, d) pair matrices are "
+                                  "materialised by torch")
         if states.is_cuda and d <= 16 and getattr(self, "fused_stopping", True):
             # HIP path: the two network evaluations and their s-tangents from one launch of the pair-grid-network kernel
             # (n_in = 3), the gates (models.py:341-392), their s-derivatives and the (Np,B,d,d) matrices formed per

@@ -76,6 +76,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.lib()
 
 
+def test_capabilities_list_the_supported_ranges():
+    from socmx import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(2048)
+    need = L.socmx_capabilities(buf, 2048)
+    text = buf.value.decode()
+    assert need <= 2048 and "gfx950" in text and "static_hdims=256,128,64" in text
+    for piece in ("ranges:", "stopping-time SOCM kernels: d <= 16", "pair-grid network:", "control-network backward:",
+                  "one row per workgroup"):
+        assert piece in text, piece
+
+
 def test_variant_library_falls_back_when_it_cannot_be_built(monkeypatch):
     """A host without hipcc / make (or a read-only package directory) must not turn `backend.specialize_arch: True` into a
     crash, or into ranks waiting for each other: the build failure is reported and the default library's descriptor-driven

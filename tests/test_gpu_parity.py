@@ -693,6 +693,34 @@ def test_readme_double_well_command_line_prints_the_fast_iteration(tmp_path):
     assert (tmp_path / "outputs" / "multiruns" / "0").is_dir()
 
 
+def test_configurations_outside_the_kernels_ranges_warn_once_and_stay_on_the_gpu():
+    """arch.hdims_M / d combinations the pair-grid-network kernels do not take (d = 30: neither d*d <= 26*26 nor d % 4 == 0)
+    run torch autograd + library GEMMs ON THE GPU and say so once per process; objective and gradients are finite and the
+    run continues (the routing is explicit, never a CPU or oracle path)."""
+    import contextlib, io, warnings
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from socmx import nets
+    from SOC_matching.method import SOC_Solver
+    cfg = load_config(["method.setting=OU_linear", "method.d=30", "method.num_steps=6", "method.gamma=2.0",
+                       "method.scaling_factor_M=0.1", "arch.hdims_M=[32,32]"])
+    cfg.method.device = DEV
+    torch.manual_seed(0)
+    ts = torch.linspace(0, 1.0, 7).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, _, sde, _ = define_variables(cfg, ts)
+    solver = SOC_Solver(sde, x0, None, T=1.0, num_steps=6, lmbd=1.0, d=30, sigma=sigma)
+    nets._warned.discard("the pair-grid network (M)")
+    with pytest.warns(UserWarning, match="pair-grid network"):
+        out = solver.loss(16, algorithm="SOCM", use_warm_start=False, use_stopping_time=False)
+    out[0].backward()
+    assert out[0].is_cuda and torch.isfinite(out[0])
+    assert all(torch.isfinite(p.grad).all() for p in sde.M.sigmoid_layers.parameters())
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # second call: no second warning
+        solver.loss(16, algorithm="SOCM", use_warm_start=False, use_stopping_time=False)
+
+
 def test_the_integration_stub_in_the_docs_runs(monkeypatch):
     """the ctypes stub a reference maintainer would paste is executed verbatim (struct layouts,
     argument order) and must reproduce this package's own rollout for the same Philox key."""
