@@ -245,7 +245,7 @@ struct R1Lds {
   static constexpr int wz = 800;      // (2, 8, 2) Philox words of steps k + 1, k + 2
   static constexpr int amat = 832;    // (16, 16)  A, P of the OU settings (wave 0's drift / running cost)
   static constexpr int pmat = 1088;
-  static constexpr int sc = 1336;     // (2, 4) per-step scalars of steps k, k + 1 (dt, sqrt(lambda dt), dt / lambda, its root): the unused tail of pmat
+  static constexpr int sc = 1332;     // (3, 4) per-step scalars of steps k - 1, k, k + 1 (dt, sqrt(lambda dt), dt / lambda, its root): the unused tail of pmat
   static constexpr int bias = 1344;   // the nine layers' padded biases (image order)
   static constexpr int weights = 1344 + 1248;   // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
 };
@@ -420,7 +420,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   const int i = n, ic = min(i, d - 1);
   const bool lane_ok = i < d;
   constexpr bool STOPPING = MODE == 1, is_ou = MODE == 2;
-  const bool is_quad = kind == SOCMX_OU_QUADRATIC;
+  const bool is_quad = is_ou && kind == SOCMX_OU_QUADRATIC;
   const bool traj = a.states != nullptr;
   const bool store = CLS == 0 && lane < 16 && lane_ok && traj;
   const bool store0 = CLS == 0 && lane == 0 && traj;
@@ -504,6 +504,59 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     NZ[(k & 1) * 16 + c0 + 1] = c0 + 1 < d ? z1 : 0.f;
   };
 
+  // The step's scalars -- dt (utils.py:38), sqrt(lambda dt) (utils.py:47), dt / lambda and its root -- are an IEEE division and
+  // two square roots, ~40 dependent instructions: wave 3 (idle while wave 0 integrates) forms those of step k + 1 during
+  // step k and leaves them in LDS; on wave 0 they would sit on the step's serial chain or in front of its first stage.
+  float* SC = lds + R1Lds::sc;
+  auto step_scalars = [&](int k) {
+    if (CLS == 1 && wave == 3 && lane == 0 && k < K) {
+      const float dt = a.ts[k + 1] - a.ts[k];
+      const float dol = dt / a.lmbd;
+      *reinterpret_cast<f32x4*>(SC + (k % 3) * 4) = f32x4{dt, sqrtf(a.lmbd * dt), dol, sqrtf(dol)};
+    }
+  };
+  // ---- what a step leaves behind for later (wave 0): only x_{k+1} -> down_0 -> r1 is on the path to the next evaluation;
+  // the running costs (two row sums), the trajectory stores and nabla_V's hand-over are issued at the end of the NEXT
+  // evaluation's stage 4, where wave 0 waits for the others anyway, from a few registers (the step's scalars sit in a
+  // three-deep LDS ring: wave 3 writes those of step k + 2 in the same slack)
+  int cur_k = 0;                       // the step network() runs for (the noise waves prepare steps cur_k + 1, cur_k + 2 inside)
+  int bk_k = -1;                       // the step whose bookkeeping is outstanding
+  float bk_gv = 0.f, bk_step = 0.f, bk_eps = 0.f;
+  auto bookkeeping = [&]() {
+    if (bk_k < 0) return;
+    const int k = bk_k;
+    bk_k = -1;
+    const f32x4 scal = *reinterpret_cast<const f32x4*>(lds + R1Lds::sc + (k % 3) * 4);
+    const float eps = bk_eps;
+    const float uc = lane_ok ? -bk_gv : 0.f;
+    const float xe = x;                                                 // x_{k+1}
+    float f = 0.f;                                                      // f at the NEW state, OLD time (utils.py:92-96)
+    if (is_quad) {
+      float px = 0.f;
+      for (int j = 0; j < d; ++j) px += P_l[ic * 16 + j] * __shfl(xe, j, 16);
+      f = row16_sum(lane_ok ? xe * px : 0.f);
+    } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
+      f = 1.f;
+    }
+    const float uu = row16_sum(uc * uc), ue = row16_sum(uc * eps);
+    const float sol = STOPPING ? bk_step / a.lmbd : scal[2];
+    const float ssol = STOPPING ? sqrtf(sol) : scal[3];
+    lpd = lpd + sol * (-f - 0.5f * uu);
+    lps = lps + ssol * (-ue);
+    if (store) {
+      if (a.nabla_v) (a.nabla_v + kbd)[rowoff] = bk_gv;
+      (a.controls + kbd)[rowoff] = uc;
+      (a.noises + kbd)[rowoff] = eps;
+      (a.states + kbd + step_floats)[rowoff] = xe;
+    }
+    kbd += step_floats;
+    if (store0) {
+      (a.frac + kb)[grow] = STOPPING ? bk_step : scal[0];
+      (a.stop_ind + kb + B)[grow] = STOPPING ? stop : 1.f;
+    }
+    kb += B;
+  };
+
   // ---- stages 1..5 of the network on the row; leaves up_0's per-wave partial sums in LDS (p5) ----
   // the LDS block among blocks [first, first + count), kR1Blocks if none: what the unit in front of them prefetches
 #define R1NX(first, count)                                                                                         \
@@ -585,6 +638,19 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       const float y = r1_rows_sum(p0 + p1);
       if (lane < 16) lds[R1Lds::p5 + n * 8 + wave] = y;
     }
+    // The first wave of every SIMD reaches this barrier ~900 cycles before the second one (the older wave has issue
+    // priority through the long stage 4): wave 0 closes the previous step's books in that slack, waves 1 .. 3 prepare the
+    // next steps' noise and scalars -- none of it is left for the serial section behind the barrier.
+    // (at the lowest issue priority: the SIMD's other wave is still inside stage 4 and everybody waits for IT)
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (CLS == 0) {
+      bookkeeping();
+    } else {
+      words(cur_k + 2);
+      draws(cur_k + 1);
+      step_scalars(cur_k + 1);
+    }
+    __builtin_amdgcn_s_setprio(2);
     R1_TICK(8)
     __syncthreads();
     R1_TICK(9)
@@ -597,18 +663,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     return relu_keep_nan(s + b8) + res0;
   };
 
-  // The step's scalars -- dt (utils.py:38), sqrt(lambda dt) (utils.py:47), dt / lambda and its root -- are an IEEE division and
-  // two square roots, ~40 dependent instructions: wave 3 (idle while wave 0 integrates) forms those of step k + 1 during
-  // step k and leaves them in LDS; on wave 0 they would sit on the step's serial chain or in front of its first stage.
-  float* SC = lds + R1Lds::sc;
-  auto step_scalars = [&](int k) {
-    if (CLS == 1 && wave == 3 && lane == 0 && k < K) {
-      const float dt = a.ts[k + 1] - a.ts[k];
-      const float dol = dt / a.lmbd;
-      *reinterpret_cast<f32x4*>(SC + (k & 1) * 4) = f32x4{dt, sqrtf(a.lmbd * dt), dol, sqrtf(dol)};
-    }
-  };
   // ---- prologue ----
+  __builtin_amdgcn_s_setprio(2);
   words(0);
   if constexpr (CLS == 0) first_layer(a.ts[0]);
   __syncthreads();
@@ -621,15 +677,19 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     if (k == 0) prof_last = __builtin_readcyclecounter();
 #endif
     const float t1 = a.ts[k + 1];             // (a scalar load: requested here, long before wave 0 needs it)
+    cur_k = k;
     network();
     if constexpr (CLS == 0) {
-      const f32x4 scal = *reinterpret_cast<const f32x4*>(SC + (k & 1) * 4);
-      const float dt = scal[0], sq_ldt = scal[1], dt_over_lmbd = scal[2], sqrt_dt_over_lmbd = scal[3];
-      const float gv = network_output();
-      R1_TICK(12)
-      if (store && a.nabla_v) (a.nabla_v + kbd)[rowoff] = gv;
-      const float uc = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
+      // every LDS operand of the chain is requested at once (left to the scheduler the three round trips ran one after the other)
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8);
+      const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8 + 4);
+      const f32x4 scal = *reinterpret_cast<const f32x4*>(SC + (k % 3) * 4);
       const float eps = NZ[(k & 1) * 16 + i];                            // drawn during the previous step
+      __builtin_amdgcn_sched_barrier(0);
+      const float dt = scal[0], sq_ldt = scal[1];
+      const float gv = relu_keep_nan((((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + b8) + res0;
+      R1_TICK(12)
+      const float uc = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
       float bi;
       if (is_ou) {                                                      // b = A x
         bi = 0.f;
@@ -650,38 +710,11 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
         step = js * (fr * fr) * dt + ns * dt;                           // step_fraction squared (utils.py:70-72)
         stop_new = (-__shfl(xe, 0, 16) > 0.f) ? 1.f : 0.f;
       }
-      float f = 0.f;                                                    // f at the NEW state, OLD time (utils.py:92-96)
-      if (is_quad) {
-        float px = 0.f;
-        for (int j = 0; j < d; ++j) px += P_l[ic * 16 + j] * __shfl(xe, j, 16);
-        f = row16_sum(lane_ok ? xe * px : 0.f);
-      } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
-        f = 1.f;
-      }
-      const float uu = row16_sum(uc * uc), ue = row16_sum(uc * eps);
-      const float sol = STOPPING ? step / a.lmbd : dt_over_lmbd;
-      const float ssol = STOPPING ? sqrtf(sol) : sqrt_dt_over_lmbd;
-      lpd = lpd + sol * (-f - 0.5f * uu);
-      lps = lps + ssol * (-ue);
-      if (store) {
-        (a.controls + kbd)[rowoff] = uc;
-        (a.noises + kbd)[rowoff] = eps;
-        (a.states + kbd + step_floats)[rowoff] = xe;
-      }
-      kbd += step_floats;
-      if (store0) {
-        (a.frac + kb)[grow] = step;
-        (a.stop_ind + kb + B)[grow] = STOPPING ? stop_new : 1.f;
-      }
-      kb += B;
       x = lane_ok ? xe : 0.f;
       if (STOPPING) stop = stop_new;
+      bk_k = k; bk_gv = gv; bk_step = step; bk_eps = eps;               // costs + stores: see bookkeeping()
       R1_TICK(13)
       first_layer(t1);                                                  // the next evaluation's first layer: [t_{k+1}, x_{k+1}]
-    } else {
-      words(k + 2);
-      draws(k + 1);
-      step_scalars(k + 1);
     }
     R1_TICK(10)
     __syncthreads();
@@ -691,13 +724,15 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   if (a.prof && blockIdx.x == 0 && lane == 0)
     for (int sl = 0; sl < 16; ++sl) a.prof[wave * 16 + sl] = prof_acc[sl];
 #endif
+  cur_k = K;                              // (nothing left to prepare)
   if (a.nabla_v) {                        // nabla_V(T, X_K): r1 already holds down_0 [t_K, x_K]
-    network();
+    network();                            // (wave 0 closes the last step's books inside)
     if constexpr (CLS == 0) {
       const float gv = network_output();
       if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
     }
   }
+  if constexpr (CLS == 0) bookkeeping();  // (no terminal evaluation: the last step's costs and stores)
   if constexpr (CLS == 0) {                                             // terminal cost (utils.py:101)
     float gval = 0.f;
     if (kind == SOCMX_OU_QUADRATIC) {

@@ -703,7 +703,7 @@ def test_configurations_outside_the_kernels_ranges_warn_once_and_stay_on_the_gpu
     from socmx import nets
     from SOC_matching.method import SOC_Solver
     cfg = load_config(["method.setting=OU_linear", "method.d=30", "method.num_steps=6", "method.gamma=2.0",
-                       "method.scaling_factor_M=0.1", "arch.hdims_M=[32,32]"])
+                       "method.scaling_factor_M=0.1"])          # default arch.hdims_M = [128,128]
     cfg.method.device = DEV
     torch.manual_seed(0)
     ts = torch.linspace(0, 1.0, 7).to(DEV)
