@@ -616,11 +616,17 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     //  resident weights, and consecutive fmacs still never depend on each other -- blocks of the same chunk run as a pair)
     float ua = 0.f, ub = 0.f, ra = 0.f, rb = 0.f;
     blk2(R1B(8), R1B(9), R1NX(10, 2), ra, rb, xr1[0]);
+    R1_TICK(14)
     blk2(R1B(10), R1B(11), R1NX(12, 2), ra, rb, xr1[1]);
+    R1_TICK(15)
     blk2(R1B(12), R1B(13), R1NX(14, 2), ra, rb, xr1[2]);
+    R1_TICK(14)
     blk2(R1B(14), R1B(15), R1NX(16, 2), ra, rb, xr1[3]);
+    R1_TICK(15)
     blk2(R1B(16), R1B(17), R1NX(18, 2), ua, ub, xo2.x);
+    R1_TICK(14)
     blk2(R1B(18), R1B(19), std::integral_constant<int, kR1Blocks>{}, ua, ub, xo2.y);
+    R1_TICK(15)
     float o1;
     {
       // rows 0: up_1 block 2w, 1: up_1 block 2w + 1, 2: res_1 block 2w, 3: res_1 block 2w + 1
