@@ -438,7 +438,13 @@ def main():
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
             try:
                 pm = json.load(open(path))
+                # (a summary taken on another library version, or without the kernel this run launches, is refused: the
+                #  traffic of a kernel that no longer exists must not ride along silently)
+                if (pm.get("_meta") or {}).get("socmx_version") != _lib.lib().socmx_version():
+                    continue
                 for kname, v in pm.items():
+                    if kname == "_meta":
+                        continue
                     if ROLLOUT_KERNEL_TAG in kname and "StaticNet<16" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                         traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
                         traffic_src = (os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "

@@ -1392,7 +1392,7 @@ def test_both_rollout_tile_shapes_pass_the_reference_fixtures():
     for rows in ("16", "4", "1"):
         env = dict(os.environ, SOCMX_TILE_ROWS=rows)
         # (the settings-vs-eager test was written for the small tiles: under 16-row tiles ~1 % of stopping rows land on the
-        #  other side of the re-interpolated boundary's sign test)
+        #  other side of the re-interpolated boundary's sign test, CHANGELOG 3.1a)
         extra = "" if rows == "16" else " or test_four_row_rollout_settings_vs_eager_path"
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                             "test_rollout_kernel_vs_oracle_and_golden or test_rollout_hands_over_nabla_V or "

@@ -13,14 +13,14 @@ CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-burst"
 # the counter passes see the headline configuration only (the secondary configurations launch the same kernel template with
 # other shapes; their dispatches would be averaged into the per-launch traffic that bench.py reads back)
 PMC_CMD="$CMD --no-secondary"
-KERNELS="rollout_kernel|rollout4_kernel|rollout_ctrl|socm_|stopping_|colsum|weights_stats|unet_bwd|unet_wgrad|mnet_"
+KERNELS="rollout_kernel|rollout4_kernel|rollout1_kernel|rollout_ctrl|socm_|stopping_|colsum|weights_stats|unet_bwd|unet_wgrad|mnet_"
 # kernel_stats.csv: the headline configuration alone, so that the rollout kernel's AVERAGE is the number bench.py reports as
 # roofline.kernel_ms; kernel_stats_full.csv: the whole default command (secondary configurations included)
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o $RND -- $PMC_CMD > $OUT/trace_bench.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_full -o $RND -- $CMD > $OUT/trace_full.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KERNELS" -f csv -d $OUT/pmc_fetch -o $RND -- $PMC_CMD > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KERNELS" -f csv -d $OUT/pmc_write -o $RND -- $PMC_CMD > $OUT/pmc_write.log 2>&1
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-include-regex "rollout_kernel|rollout4_kernel|unet_bwd|unet_wgrad_kernel" -f csv -d $OUT/pmc_sq -o $RND -- $PMC_CMD > $OUT/pmc_sq.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-include-regex "rollout_kernel|rollout4_kernel|rollout1_kernel|unet_bwd|unet_wgrad_kernel" -f csv -d $OUT/pmc_sq -o $RND -- $PMC_CMD > $OUT/pmc_sq.log 2>&1
 python3 tools/summarize_profile.py $OUT $R > $R/summarize.log 2>&1
 f=$(find $OUT/trace_full -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/kernel_stats_full.csv
 python3 bench.py > $R/bench.json 2> $R/bench.err
@@ -47,8 +47,10 @@ python3 bench.py --gpus 1 --spawn --defer-graph --steps 20 --warmup 5 --no-cpu-b
 (hipcc -O3 --offload-arch=gfx950 -o /tmp/r4c tools/ubench/r4_check.hip 2>/dev/null && timeout 60 /tmp/r4c) > $R/r4_check.txt 2>&1
 (hipcc -O3 --offload-arch=gfx950 -o /tmp/m44 tools/ubench/mfma4x4.hip 2>/dev/null && timeout 60 /tmp/m44) > $R/mfma4x4.txt 2>&1
 (hipcc -O3 --offload-arch=gfx950 -o /tmp/l2r tools/ubench/l2ring.hip 2>/dev/null && timeout 60 /tmp/l2r) > $R/l2ring.txt 2>&1
-# SQ counters of the 4-row rollout kernel alone
-bash tools/pmc_any.sh "rollout4_kernel" r4 python3 tools/quick_bench.py cfg3 > $R/rollout4_pmc.txt 2>&1
+# SQ counters of the one-row rollout kernel alone (VALU issue, waits, LDS conflicts)
+bash tools/pmc_any.sh "rollout1_kernel" r1 python3 tools/quick_bench.py cfg3 > $R/rollout1_pmc.txt 2>&1
+# the one-row design's building blocks: DPP-broadcast fmac rate, L2 stream / LDS weight reads beside it
+(hipcc -O3 --offload-arch=gfx950 -o /tmp/vr1 tools/ubench/valu_row1.hip 2>/dev/null && timeout 120 /tmp/vr1 2.4) > $R/valu_row1_ubench.txt 2>&1
 python3 tools/iter_bench.py md eager > $R/iter_md.txt 2>&1; python3 tools/iter_bench.py md graph >> $R/iter_md.txt 2>&1
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o stage_chain stage_chain.hip 2>/dev/null && ./stage_chain) > $R/stage_chain.txt 2>&1
 python3 tools/quick_bench.py cfg3 cfg2 ouq20 cfg5r burst 2>&1 | grep -E "parity|rollout|iteration" > $R/quick.txt

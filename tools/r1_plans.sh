@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer sweep of the one-row kernel's class-1 source plans: objects prebuilt under tools/ubench/_bin/plans/ (see DESIGN 3.1b),
+# Developer sweep of the one-row kernel's class-1 source plans: objects prebuilt under tools/ubench/_bin/plans/ (CHANGELOG, round 4 notes),
 # relinked into the library one at a time on the GPU box and timed with tools/quick_bench.py.
 cd $GRAFT_REPO_ROOT/soc-matching_amd/csrc
 for o in ../../tools/ubench/_bin/plans/r1_*.o; do

@@ -59,5 +59,12 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
             for d, v in vals:
                 per[d] += v
             e[c] = dict(mean_per_dispatch=sum(per.values()) / len(per), dispatches=len(per))
+# which library the counters were taken on: bench.py refuses a summary of another version (roofline.traffic stays null)
+try:
+    sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "soc-matching_amd")]
+    from socmx import _lib
+    summary["_meta"] = dict(socmx_version=int(_lib.lib().socmx_version()))
+except Exception as e:  # noqa: BLE001
+    summary["_meta"] = dict(socmx_version=None, error=str(e))
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
