@@ -563,6 +563,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   std::integral_constant<int, (r1_src(CLS, DMAX, first) == 'L'                         ? (first)                     \
                                : ((count) > 1 && r1_src(CLS, DMAX, (first) + 1) == 'L') ? (first) + 1                 \
                                                                                         : kR1Blocks)>{}
+  // (The two waves of a SIMD share its VALU; at equal priority the older one wins most slots, finishes a multi-block stage
+  //  early and leaves the younger one to run the rest alone.  Alternating s_setprio block by block to keep them abreast was
+  //  measured and is slower -- 0.626 ms against 0.559: both waves then stall more often than they gain.)
   auto network = [&]() {
     // stage 1: r2 = relu(down_1 r1 + b)            wave w: units 16 w .. 16 w + 15
     const f32x4 xr1 = *reinterpret_cast<const f32x4*>(lds + R1Lds::r1 + lane * 4);
