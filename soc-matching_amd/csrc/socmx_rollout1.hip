@@ -39,14 +39,14 @@ constexpr int kR1Blocks = 20;   // main-program blocks per wave and step
 constexpr int kR1PD = 2;        // ring depth (blocks)
 
 // Where block b of a wave's program comes from: 'R' registers, 'L' LDS, 'S' L2 stream.  Class 0 = wave 0, class 1 = waves 1..7.
-//   blocks in the order a wave consumes them: 0-3 down_1 (chunks 0..3) | 4 down_2 | 5-6 res_2, 7 up_2 | 8-15 res_1 (R0c0 R1c0 R0c1 ...),
+//   blocks in the order a wave consumes them: 0-3 down_1 (chunks 0..3), 4 down_2 over the wave's own outputs (always resident) | 5-6 res_2, 7 up_2 | 8-15 res_1 (R0c0 R1c0 R0c1 ...),
 //   16-19 up_1 (U0c0 U1c0 U0c1 U1c1) -- in a two-GEMM stage the skip GEMM runs first: its input is in registers since an earlier
 //   stage, so its fmacs cover the LDS round trip of the stage's other input
 __host__ __device__ constexpr char r1_src(int cls, int dm, int b) {
   // wave 0 also holds 4 (1 + DMAX) + (1 + DMAX) registers of down_0 / res_0: fewer resident blocks at larger d
-  constexpr char plan0_3[kR1Blocks + 1] = "RSRLSLSLLSLSLSLSLRLS";
-  constexpr char plan0_11[kR1Blocks + 1] = "RSRSSLSLLSLRLSLSLRLS";
-  constexpr char plan0_15[kR1Blocks + 1] = "RSSSSLSLLSLSLSLSLRLS";
+  constexpr char plan0_3[kR1Blocks + 1] = "RSSLRLSLLSLSLSLSLRLS";
+  constexpr char plan0_11[kR1Blocks + 1] = "RSSSRLSLLSLRLSLSLRLS";
+  constexpr char plan0_15[kR1Blocks + 1] = "RSSSRLSLLSLSLSLSLSLS";
   // (stream blocks spread over the step's TIME, two blocks of lead each: S1 ~1.1k cycles, S2 ~0.5k, S3 ~0.9k, S4 ~2.6k, then wave
   //  0's serial section ~1.2k with no consumption)
 #ifdef SOCMX_R1_PLAN1
@@ -84,12 +84,15 @@ template <class NET>
 __device__ __forceinline__ int r1_block_off(int b, int w) {
   constexpr UnetDesc u = NET::desc();
   if (b < 4) return u.L[1].w_off + (w * 16 + 4 * b) * 256;                                  // down_1: nb = w, chunk b
-  if (b == 4) return u.L[2].w_off + ((w & 3) * 8 + 4 * (w >> 2)) * 256;                     // down_2: nb = w & 3, chunk w >> 2
+  if (b == 4) return u.L[2].w_off + w * 256;      // down_2: unit blocks 0..3, input chunk w (the wave's own stage-1 outputs): r1_frag_stride
   if (b < 7) return u.L[5].w_off + (w * 8 + 4 * (b - 5)) * 256;                             // res_2: nb = w, chunk b - 5
   if (b == 7) return u.L[6].w_off + (w * 4) * 256;                                          // up_2: nb = w
   if (b < 16) return u.L[4].w_off + ((2 * w + ((b - 8) & 1)) * 16 + 4 * ((b - 8) >> 1)) * 256;   // res_1: nb = 2w + r
   return u.L[7].w_off + ((2 * w + ((b - 16) & 1)) * 8 + 4 * ((b - 16) >> 1)) * 256;         // up_1
 }
+
+// floats between the four fragments of block b (4 KiB contiguous, except down_2's: one fragment per unit block, KC = 8 apart)
+__host__ __device__ constexpr int r1_frag_stride(int b) { return b == 4 ? 8 * 256 : 256; }
 
 // ---- instruction helpers -----------------------------------------------------------------------------------------------
 // 16 fmacs of one block: weight register j <-> broadcast position j; two accumulators alternate (no fmac reads the result
@@ -109,6 +112,17 @@ __device__ __forceinline__ void r1_fmac8(float& a0, float& a1, float x, const fl
         : "+v"(a0), "+v"(a1)
         : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
   }
+}
+// sixteen fmacs whose four fragments belong to four different unit blocks: fragment f into accumulator f
+__device__ __forceinline__ void r1_fmac16_4acc(float& a0, float& a1, float& a2, float& a3, float x, const float* w) {
+#define R1FM4(J, A, W) "v_fmac_f32_dpp %" #A ", %4, %" #W " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t" R1FM4(0, 0, 5) R1FM4(4, 1, 9) R1FM4(8, 2, 13) R1FM4(12, 3, 17) R1FM4(1, 0, 6) R1FM4(5, 1, 10) R1FM4(9, 2, 14)
+          R1FM4(13, 3, 18) R1FM4(2, 0, 7) R1FM4(6, 1, 11) R1FM4(10, 2, 15) R1FM4(14, 3, 19) R1FM4(3, 0, 8) R1FM4(7, 1, 12)
+              R1FM4(11, 2, 16) R1FM4(15, 3, 20)
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+      : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),
+        "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+#undef R1FM4
 }
 // the same half of TWO blocks that share the activation register (two neuron blocks of one chunk), interleaved: block A's
 // fmacs into aA, block B's into aB -- one accumulator per block, and still no fmac reads the result of the one before it
@@ -239,15 +253,15 @@ struct R1Lds {
   static constexpr int r1 = 0;        // (64 lanes, 4 chunks)  down_0's output, lane-ordered: one ds_read_b128 per lane
   static constexpr int r2 = 256;      // (64, 2)   down_1's output
   static constexpr int o2 = 384;      // (64, 2)   stage 3's output
-  static constexpr int p2 = 512;      // (8, 16)   down_2's split-K partials (wave w: neuron block w & 3, chunk w >> 2)
-  static constexpr int p5 = 640;      // (16, 8)   up_0's per-wave partial sums, neuron-major
-  static constexpr int nz = 768;      // (2, 16)   the row's noise of steps k, k + 1
-  static constexpr int wz = 800;      // (2, 8, 2) Philox words of steps k + 1, k + 2
-  static constexpr int amat = 832;    // (16, 16)  A, P of the OU settings (wave 0's drift / running cost)
-  static constexpr int pmat = 1088;
-  static constexpr int sc = 1332;     // (3, 4) per-step scalars of steps k - 1, k, k + 1 (dt, sqrt(lambda dt), dt / lambda, its root): the unused tail of pmat
-  static constexpr int bias = 1344;   // the nine layers' padded biases (image order)
-  static constexpr int weights = 1344 + 1248;   // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
+  static constexpr int p5 = 512;      // (16, 8)   up_0's per-wave partial sums, neuron-major
+  static constexpr int nz = 640;      // (2, 16)   the row's noise of steps k, k + 1
+  static constexpr int wz = 672;      // (2, 8, 2) Philox words of steps k + 1, k + 2
+  static constexpr int amat = 704;    // (16, 16)  A, P of the OU settings (wave 0's drift / running cost)
+  static constexpr int pmat = 960;
+  static constexpr int sc = 1204;     // (3, 4) per-step scalars of steps k - 1, k, k + 1 (dt, sqrt(lambda dt), dt / lambda, its root): the unused tail of pmat
+  static constexpr int bias = 1216;   // the nine layers' padded biases (image order)
+  static constexpr int p2 = 1216 + 1248;        // (8, 64)   down_2's per-wave partial sums: wave w's contribution of ITS 16 down_1 outputs to all 64 units
+  static constexpr int weights = p2 + 512;      // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
 };
 static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(11) * 1024) * 4 <= 160 * 1024 &&
               (R1Lds::weights + r1_lds_blocks(15) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit");
@@ -286,14 +300,16 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   float wres[NRES][16];
 #pragma unroll
   for (int r = 0; r < NRES; ++r) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(r1_nth(CLS, DMAX, 'R', r), wave)) + lane;
+    const int rb = r1_nth(CLS, DMAX, 'R', r);            // (a constant once the loop is unrolled)
+    const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(rb, wave)) + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const f32x4 v = src[c * 64];
+      const f32x4 v = src[c * (r1_frag_stride(rb) / 4)];
 #pragma unroll
       for (int e = 0; e < 4; ++e) wres[r][c * 4 + e] = v[e];
     }
   }
+  static_assert(r1_src(CLS, DMAX, 4) == 'R', "down_2's strided fragments are only loaded by the resident path");
   // up_0's share of this wave: k = 32 w + 16 (g & 1) + 8 (g >> 1) + j  (rows 2, 3 read the rotated copy of the wave's outputs)
   float w5[8];
 #pragma unroll
@@ -576,31 +592,38 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     blk(R1B(2), R1NX(3, 1), s0, s1, xr1[2]);
     blk(R1B(3), R1NX(4, 1), s0, s1, xr1[3]);
     {
-      const float y = relu_keep_nan(r1_rows_sum(s0 + s1) + bias1);
+      const float y = relu_keep_nan(r1_rows_sum(s0 + s1) + bias1);         // r2[16 w + n], in every row of the wave
       if (lane < 16) lds[R1Lds::r2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
+      // stage 2 without a barrier of its own: down_2 is linear in r2, so the wave multiplies ITS 16 outputs into all 64
+      // units right away (block 4: unit blocks 0..3 x input chunk w) and stage 3 adds the eight waves' partial sums.
+      // Row g of the operand register holds r2[16 w + 4 g + (p & 3)] at every position p: one cross-lane gather.
+      const float x4 = __shfl(y, (lane & 48) + 4 * g + (lane & 3));
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+      pre(R1NX(5, 1));                          // (stage 3's first block, if it is an LDS block: read behind these fmacs)
+      r1_fmac16_4acc(c0, c1, c2, c3, x4, wres[r1_count(CLS, DMAX, 'R', 4)]);
+      const float tsum = r1_reduce4(c0, c1, c2, c3);                         // lane (g, n): unit 16 {0, 2, 1, 3}[g] + n
+      lds[R1Lds::p2 + wave * 64 + 16 * (((g & 1) << 1) | (g >> 1)) + n] = tsum;
     }
     R1_TICK(1)
     __syncthreads();
     R1_TICK(2)
-    // stage 2: down_2's partial sums                 wave w: units 16 (w & 3) .., inputs 64 (w >> 2) .. + 63
     const float2 xr2 = *reinterpret_cast<const float2*>(lds + R1Lds::r2 + lane * 2);
-    s0 = 0.f; s1 = 0.f;
-    blk(R1B(4), R1NX(5, 1), s0, s1, (wave >> 2) ? xr2.y : xr2.x);
-    {
-      const float y = r1_rows_sum(s0 + s1);
-      if (lane < 16) lds[R1Lds::p2 + wave * 16 + n] = y;
-    }
-    R1_TICK(3)
-    __syncthreads();
-    R1_TICK(4)
     // stage 3: o2 = relu(up_2 r3 + b) + res_2 r2 + b   wave w: units 16 w ..   (res_2 first: r2 is in registers)
     const int pk = r1_perm(lane);
-    const float p2a = lds[R1Lds::p2 + pk], p2b = lds[R1Lds::p2 + 64 + pk], bias2 = BL[u.L[2].b_lds + pk];
+    // (down_2's eight partial sums per unit: four are requested in front of each res_2 block and folded behind it -- all
+    //  eight at once held eight more registers live across both blocks)
+    float p2a[4], p2b[4];
+#pragma unroll
+    for (int w8 = 0; w8 < 4; ++w8) p2a[w8] = lds[R1Lds::p2 + w8 * 64 + pk];
+    const float bias2 = BL[u.L[2].b_lds + pk];
     const float bu3 = BL[u.L[6].b_lds + 16 * wave + n], br3 = BL[u.L[5].b_lds + 16 * wave + n];
     float u0 = 0.f, u1 = 0.f, q0 = 0.f, q1 = 0.f;
     blk(R1B(5), R1NX(6, 1), q0, q1, xr2.x);
+    const float p2lo = (p2a[0] + p2a[1]) + (p2a[2] + p2a[3]);
+#pragma unroll
+    for (int w8 = 0; w8 < 4; ++w8) p2b[w8] = lds[R1Lds::p2 + (4 + w8) * 64 + pk];
     blk(R1B(6), R1NX(7, 1), q0, q1, xr2.y);
-    const float xr3 = relu_keep_nan((p2a + p2b) + bias2);
+    const float xr3 = relu_keep_nan((p2lo + ((p2b[0] + p2b[1]) + (p2b[2] + p2b[3]))) + bias2);
     blk(R1B(7), R1NX(8, 2), u0, u1, xr3);
     {
       const float t = r1_reduce4(u0 + u1, q0 + q1, 0.f, 0.f);     // rows 0: up_2's totals, rows 2: res_2's

@@ -7,7 +7,8 @@ import torch, bench
 from socmx.train import Trainer, make_optimizer
 CFG = {"cfg2": ("OU_quadratic_easy", 2, 50, 2.0, 128), "cfg3": ("double_well", 10, 200, 6.0, 128),
        "cfg5r": ("OU_linear", 64, 400, 2.0, 512), "ouq20": ("OU_quadratic_easy", 20, 50, 2.0, 128),
-       "cfg4r": ("double_well", 10, 200, 6.0, 1024), "md": ("molecular_dynamics", 1, 150, 2.0, 64)}
+       "cfg4r": ("double_well", 10, 200, 6.0, 1024), "md": ("molecular_dynamics", 1, 150, 2.0, 64),
+       "cfg3b256": ("double_well", 10, 200, 6.0, 256), "cfg3b192": ("double_well", 10, 200, 6.0, 192)}
 name, mode = sys.argv[1], sys.argv[2]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda", 0)

@@ -32,7 +32,7 @@ cyc = torch.zeros(8 * 16 + 64 * 64, dtype=torch.int64, device=dev)
 rollout.hip_trajectories(sde, state0, ts, 1.0, seed=0, phase_cycles=cyc)
 torch.cuda.synchronize()
 c = cyc[:128].double().cpu().numpy().reshape(8, 16) / K
-names = ["-", "S1", "bar", "S2", "bar", "S3", "bar", "S4end", "S5p", "bar", "serial/noise", "bar", "out", "sde", "S4pairs135", "S4pairs246"]
+names = ["-", "S1+S2", "bar", "(S2)", "(bar)", "S3", "bar", "S4end", "S5p", "bar", "serial/noise", "bar", "out", "sde", "S4pairs135", "S4pairs246"]
 tot = c.sum(1)
 print(f"rollout {ms:.3f} ms = {ms*1e3/K:.3f} us/step; ticks per step per wave (sum {tot.mean():.1f}) -> one tick = {ms*1e6/K/tot.mean():.2f} ns")
 scale = ms * 1e6 / K / tot.mean() * 2.4   # cycles at 2.4 GHz per tick
