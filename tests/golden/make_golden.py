@@ -322,6 +322,9 @@ FIXTURES = [
     # cfg3_double_well_d10_K200 (only the alg.* outputs are kept next to the inputs)
     ("cfg3_algs_double_well_d10_K200", "double_well", 10, 200, 8, DEFAULT, 6.0, 0,
      dict(with_pairs=False, with_loss=False, with_algs=True)),
+    # (4) BASELINE configs[1] at its own size (README.md:15: OU_quadratic_easy d = 2, K = 50, B = 128): the OU form of the one-row
+    # rollout kernel (A x drift, x'Px running cost) and the whole loss at the batch bench.py's secondary entry times
+    ("cfg1_full_ou_quadratic_easy_d2_K50_B128", "OU_quadratic_easy", 2, 50, 128, DEFAULT, 2.0, 0, dict(with_pairs=False)),
 ]
 
 

@@ -350,7 +350,9 @@ def test_contraction_kernels_multi_block_shapes(d, K, B):
                                          "cfg5_ou_linear_d64_B256_K3", "cfg4_double_well_d10_B512_K6",
                                          # the headline config at its own size (README.md:51: K = 200, B = 128 -- the launch
                                          # bench.py times), generated by the reference itself
-                                         "cfg3_full_double_well_d10_K200_B128"])
+                                         "cfg3_full_double_well_d10_K200_B128",
+                                         # ... and BASELINE configs[1] at ITS size (README.md:15: d = 2, K = 50, B = 128)
+                                         "cfg1_full_ou_quadratic_easy_d2_K50_B128"])
 def test_full_socm_loss_on_gpu_vs_golden(name):
     from SOC_matching.method import SOC_Solver
     sde, aux = build_sde(name, DEV)

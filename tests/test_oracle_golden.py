@@ -76,7 +76,8 @@ def test_socm_loss_and_grads(name, derivative):
     _close(gamma.grad, z["grad_gamma"], rtol=1e-3, atol=1e-5 * max(1.0, np.abs(z["grad_gamma"]).max()))
 
 
-@pytest.mark.parametrize("name", ["cfg1_ou_quadratic_easy_d2_K50", "ouq20_ou_quadratic_easy_d20_K12",
+@pytest.mark.parametrize("name", ["cfg1_ou_quadratic_easy_d2_K50", "cfg1_full_ou_quadratic_easy_d2_K50_B128",
+                                  "ouq20_ou_quadratic_easy_d20_K12",
                                   "cfg5_ou_linear_d64_K20", "cfg5_ou_linear_d64_B256_K3",
                                   "cfg4_double_well_d10_B512_K6"])
 def test_socm_loss_default_arch(name):
