@@ -68,11 +68,18 @@ class Trainer:
         # RCCL all-reduces captured inside the graph): the whole iteration -- rollout, loss, backward, collectives, Adam, EMA
         # normaliser, gradient telemetry -- is captured once and replayed; see _graph_step
         self._log = log if log is not None else (lambda *a, **k: None)
-        self.hip_graph = bool(hip_graph and algorithm == "SOCM" and solver.x0.is_cuda)
+        # (SOCM replays the autograd-free body below; the other eight losses of the README sweeps replay the captured autograd
+        #  body -- HIP rollout, fused loss kernels, control-network backward, Adam, EMA normaliser -- as one graph as well)
+        # Measured at configs[2] (tools/alg_bench.py, ms per iteration eager / replayed): SOCM 1.68 / 0.96, rel_entropy 251 / 120
+        # (it differentiates through ~16k eager rollout launches), log-variance 1.23 / 1.13, moment 1.20 / 1.12, variance
+        # 1.29 / 1.13, cross_entropy 1.09 / 1.08 -- and SOCM_const_M 1.04 / 1.13, SOCM_adjoint 1.09 / 1.18: those (and SOCM_exp,
+        # the same kernels) are GPU-bound already and keep the eager iteration unless asked with hip_graph="force".
+        eager_is_faster = algorithm in ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint") and hip_graph != "force"
+        self.hip_graph = bool(hip_graph and solver.x0.is_cuda and not eager_is_faster)
         if hip_graph and not self.hip_graph:
             # (never silent: `backend.hip_graph` is on by default, so a run that cannot use it says why)
-            why = f"algorithm {algorithm!r} has no captured body (SOCM does)" if algorithm != "SOCM" else "the solver is not on a GPU"
-            self._log(f"backend.hip_graph: running the eager two-stream iteration instead -- {why}")
+            self._log("backend.hip_graph: running the eager two-stream iteration instead -- " +
+                      (f"measured faster for algorithm {algorithm!r}" if solver.x0.is_cuda else "the solver is not on a GPU"))
         self.graph_warmup = int(graph_warmup)
         self.fused_adam = bool(fused_adam)    # hipGraph body: control-network Adam + telemetry as one launch (socmx_adam_step_f32)
         self._graphs = {}
@@ -221,10 +228,15 @@ class Trainer:
         """One iteration expressed on device-resident state only (capturable); returns a (7,) tensor
         [loss, weight_mean, weight_std, grad_norm_sqd, EMA_grad_norm_sqd, sqd_norm_EMA_grad, normaliser before]."""
         solver, D = self.solver, self._graph_state()
-        out = solver.loss(self.batch_size, algorithm="SOCM", use_warm_start=False,
+        out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
                           use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)), **loss_kwargs)
         norm_before = D["norm"].clone()
-        loss = out[0] / D["norm"]                                        # main.py:313-320
+        if self.algorithm in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
+            loss = out[0] / D["norm"]                                    # main.py:313-320
+        elif self.algorithm == "variance":
+            loss = out[0] / D["norm"] ** 2                               # main.py:321-322
+        else:
+            loss = out[0]
         # main.py:323 -- as torch.autograd.grad: `.backward()` routes every parameter's gradient through its AccumulateGrad
         # node, which is pinned to the stream that was current when the node was first created.  If any earlier autograd
         # graph is still alive (an eager iteration's outputs kept by the caller) that is the DEFAULT stream, and the
@@ -274,7 +286,7 @@ class Trainer:
                  if k not in ("compute_L2_error", "optimal_control", "total_n_samples") and v}
         if loss_kwargs.get("compute_L2_error") and loss_kwargs.get("optimal_control") is None:
             return False
-        if extra or getattr(sde, "use_stopping_time", False) or type(sde.M) is not nets.SigmoidMLP:
+        if self.algorithm != "SOCM" or extra or getattr(sde, "use_stopping_time", False) or type(sde.M) is not nets.SigmoidMLP:
             return False
         if not getattr(solver, "fused_nabla_V", True) or not getattr(sde.M, "fused_pair_net", True):
             return False

@@ -63,6 +63,55 @@ def test_graph_replay_equals_the_eager_iteration(name, B):
         assert np.linalg.norm(par_g[k] - par_e[k]) <= 2e-6 * max(np.linalg.norm(par_e[k]), 1e-12) + 1e-9, k
 
 
+@pytest.mark.parametrize("alg", ["SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-variance", "variance",
+                                 "moment", "rel_entropy"])
+def test_graph_replay_of_the_other_losses_equals_the_eager_iteration(alg):
+    """The README sweeps run nine algorithms (README.md:15-60); with `backend.hip_graph: True` as the default every one of
+    them replays its iteration as one captured graph -- the eight other losses the captured AUTOGRAD body (HIP rollout on the
+    device Philox key, fused loss kernels, control-network backward, Adam incl. the y0 / gamma groups, EMA normaliser).
+    Eager Trainer on the same device key = the reference: losses, weight statistics, normaliser, final parameters.
+    rel_entropy differentiates through the eager rollout, whose noise comes from torch's generator (other draws under a
+    capture): there the run must capture, replay and stay finite."""
+    from SOC_matching.method import SOC_Solver
+    from socmx.rollout import PhiloxKey
+    from socmx.train import Trainer, make_optimizer
+    name, B, steps = ("tiny_double_well_d10", 16, 7)
+    out = {}
+    for graph in (False, True):
+        sde, aux = build_sde(name, DEV)
+        solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
+        if alg == "SOCM_exp":
+            solver.gamma = torch.nn.Parameter(torch.tensor([2.0], device=DEV))
+        else:
+            solver.gamma = 2.0
+        with torch.no_grad():
+            solver.y0.fill_(0.37)                 # (method.py:172 draws it: the same start for both runs)
+        solver.philox_key = PhiloxKey(torch.device(DEV), seed=21, offset=3)
+        opt = make_optimizer(solver, M_lr=1e-3, algorithm=alg)
+        logs = []
+        tr = Trainer(solver, opt, B, normalization_const=0.7, algorithm=alg, sync_timing=False,
+                     hip_graph="force" if graph else False, graph_warmup=2, log=logs.append)
+        rec = []
+        for _ in range(steps):
+            info = tr.step()
+            rec.append([float(info["loss"]), float(info["weight_mean"]), float(info["weight_std"]), float(tr.normalization_const)])
+        tr.join()
+        torch.cuda.synchronize()
+        if graph:
+            assert tr.hip_graph and not logs, logs                        # captured, no fall-back
+            assert len([k for k in tr._graphs if not (isinstance(k, tuple) and k and k[0] == "warm")]) == 1
+        out[graph] = (np.array(rec), {k: _np(v) for k, v in sde.state_dict().items()},
+                      float(solver.y0.detach()) if alg == "moment" else None)
+    assert np.isfinite(out[True][0]).all()
+    if alg == "rel_entropy":
+        return
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-5, atol=1e-7)
+    for k in out[False][1]:
+        np.testing.assert_allclose(out[True][1][k], out[False][1][k], rtol=5e-5, atol=1e-6, err_msg=k)
+    if alg == "moment":
+        np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["train_ou_quadratic_easy_d2", "train_double_well_d10"])
 def test_graph_mode_replays_the_reference_training_fixture(name):
     """Reference-generated TRAINING fixture (main.py:280-359 replayed by the reference itself): the noise of iteration n is
