@@ -2194,7 +2194,9 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
 #undef SOCMX_LDS_LAUNCH
     launched = true;
   }
-  const int ct = B > 32 ? 4 : (B > 16 ? 2 : 1);        // 16-column batch tiles per wave
+  // 16-column batch tiles per wave (developer override SOCMX_TARGET_CT, read once)
+  static const int ct_env = [] { const char* e = getenv("SOCMX_TARGET_CT"); return e ? atoi(e) : 0; }();
+  const int ct = (ct_env == 1 || ct_env == 2 || ct_env == 4) ? ct_env : (B > 32 ? 4 : (B > 16 ? 2 : 1));
   dim3 grid((K + 2) / 2, (B + 16 * ct - 1) / (16 * ct), (d + 15) / 16);
   const dim3 blk(64 * kTargetWaves);
 #define SOCMX_TARGET_LAUNCH(NETV, CTV, N1V) \
