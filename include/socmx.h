@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 140 /* 0.1.4: + the one-row rollout kernel for training-size batches (socmx_rollout1.hip; same entry points) */
+#define SOCMX_VERSION 141 /* 0.1.4: + the one-row rollout kernel for training-size batches (socmx_rollout1.hip); socmx_rollout_extra.flags */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -213,9 +213,18 @@ int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, co
  *            one evaluation at (T, X_K).  These are the forward values of method.py:272-278 (nabla_V on all (K+1) B
  *            trajectory rows), so the loss needs no second forward pass; needs the trajectory buffers (not costs-only).
  */
+/*   flags    SOCMX_ROLLOUT_SHARES_CHIP: the caller runs chip-filling kernels beside this launch on another stream (a training
+ *            iteration's loss side: pair-grid network, deferred contraction backward).  Where two tile shapes apply
+ *            (d >= 32, 256 < rows <= 1024: one GPU's slice of BASELINE configs[4]) the launcher then keeps the rollout on few
+ *            CUs (16-row tiles, 7.3 ms at the slice, hidden beside the loss); without the flag -- a stand-alone rollout:
+ *            evaluation, a user calling stochastic_trajectories -- it spreads over 4-row tiles (4.9 ms).
+ */
+#define SOCMX_ROLLOUT_SHARES_CHIP 1u
 typedef struct socmx_rollout_extra {
   const uint64_t* key;
   float* nabla_v;
+  uint32_t flags;
+  uint32_t reserved;
 } socmx_rollout_extra;
 int socmx_rollout_ex_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
                          const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,

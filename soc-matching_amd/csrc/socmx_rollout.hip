@@ -1342,7 +1342,7 @@ static bool r4_pick(bool fast_form, bool stopping, void (**k)(const RolloutArgs)
 
 static int rollout_launch(const socmx_problem* pb, const float* packed_unet, const int32_t hdims[3], const float* x0,
                           const float* ts, int32_t B, int32_t K, float lmbd, uint64_t seed, uint64_t offset,
-                          const uint64_t* key_dev, float* nabla_v, int64_t row0, const float* noise_in, float* states,
+                          const uint64_t* key_dev, float* nabla_v, uint32_t flags, int64_t row0, const float* noise_in, float* states,
                           float* noises, float* controls,
                           float* stop_indicators, float* fractional_timesteps, float* lpd, float* lps, float* ltw,
                           long long* prof, socmx_stream_t stream) {
@@ -1440,7 +1440,9 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   if (is_default && fast && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
       (B <= 256 || (force_rows == 1 && B <= 1024)))
     return rollout1_launch(a, stopping, stream);
-  const bool small4 = blocks <= 16 || (blocks <= 64 && d <= 31);
+  // (... unless the launch is stand-alone -- no SOCMX_ROLLOUT_SHARES_CHIP: nothing beside it to starve -- then the shorter
+  //  latency of the 4-row tiles is simply taken: 7.3 -> 4.9 ms at that slice)
+  const bool small4 = blocks <= 16 || (blocks <= 64 && (d <= 31 || !(flags & SOCMX_ROLLOUT_SHARES_CHIP)));
   if ((is_default || is_wide32 || is_wide64) && !prof && d <= 64 && force_rows != 16 && (small4 || force_rows == 4)) {
     void (*k4)(const RolloutArgs) = nullptr;
     const bool fast4 = is_default && fast;
@@ -1480,7 +1482,7 @@ extern "C" int socmx_rollout_f32(const socmx_problem* pb, const float* packed_un
                                  uint64_t offset, int64_t row0, const float* noise_in, float* states, float* noises,
                                  float* controls, float* stop_indicators, float* fractional_timesteps, float* lpd,
                                  float* lps, float* ltw, socmx_stream_t stream) {
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, nullptr, row0, noise_in, states,
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, nullptr, 0u, row0, noise_in, states,
                         noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
 }
 
@@ -1491,7 +1493,7 @@ extern "C" int socmx_rollout_ex_f32(const socmx_problem* pb, const float* packed
                                     float* lps, float* ltw, const socmx_rollout_extra* extra, socmx_stream_t stream) {
   const uint64_t* key = extra ? extra->key : nullptr;
   float* nabla_v = extra ? extra->nabla_v : nullptr;
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, key, nabla_v, row0, noise_in, states,
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, key, nabla_v, extra ? extra->flags : 0u, row0, noise_in, states,
                         noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
 }
 
@@ -1507,6 +1509,6 @@ extern "C" int socmx_rollout_phase_cycles_f32(const socmx_problem* pb, const flo
                                               float* stop_indicators, float* fractional_timesteps, float* lpd,
                                               float* lps, float* ltw, int64_t* cycles, socmx_stream_t stream) {
   if (!cycles) return SOCMX_E_NULL;
-  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, nullptr, row0, noise_in, states,
-                        noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, (long long*)cycles, stream);
+  return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, nullptr, nullptr, SOCMX_ROLLOUT_SHARES_CHIP, row0,
+                        noise_in, states, noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, (long long*)cycles, stream);
 }

@@ -29,7 +29,10 @@ class Problem(C.Structure):
 
 
 class RolloutExtra(C.Structure):
-    _fields_ = [("key", _fp), ("nabla_v", _fp)]
+    _fields_ = [("key", _fp), ("nabla_v", _fp), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+ROLLOUT_SHARES_CHIP = 1
 
 
 class Control(C.Structure):

@@ -59,11 +59,11 @@ def burst_eligible(sde, x0):
 
 
 def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noise_in=None, seed=None,
-                            offset=None, row0=0, key=None, want_nabla_v=False):
+                            offset=None, row0=0, key=None, want_nabla_v=False, shares_chip=False):
     """`want_nabla_v` (HIP path only; ignored -- no ninth entry -- on the eager path): see hip_trajectories."""
     if _eligible_for_hip(sde, x0, detach):
         return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0, key=key,
-                                want_nabla_v=want_nabla_v)
+                                want_nabla_v=want_nabla_v, shares_chip=shares_chip)
     if _eligible_for_hip_control(sde, x0, detach):
         return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0)
     return eager_trajectories(sde, x0, t, lmbd, detach=detach, verbose=verbose, noise_in=noise_in)
@@ -90,7 +90,7 @@ class PhiloxKey:
 
 
 def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0, phase_cycles=None,
-                     costs_only=False, key=None, want_nabla_v=False):
+                     costs_only=False, key=None, want_nabla_v=False, shares_chip=False):
     """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 64) -> run the instrumented kernel.
     `costs_only`: write lpd / lps / ltw only (the five trajectory entries of the returned tuple are None).
     `key`: a PhiloxKey -- seed/offset are read from device memory and advanced behind the launch.
@@ -174,8 +174,10 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
             assert phase_cycles.dtype == torch.int64 and phase_cycles.is_cuda and phase_cycles.is_contiguous()
             assert not want_nabla_v
             status = L.socmx_rollout_phase_cycles_f32(*head, *mid, *tail, phase_cycles.data_ptr(), _lib.stream_ptr(dev))
-        elif key is not None or want_nabla_v:
-            extra = _lib.RolloutExtra(key=None if key is None else key.key.data_ptr(), nabla_v=_lib.ptr(nabla_v))
+        elif key is not None or want_nabla_v or shares_chip:
+            # (shares_chip: the caller runs chip-filling kernels beside this launch -- SOCMX_ROLLOUT_SHARES_CHIP, include/socmx.h)
+            extra = _lib.RolloutExtra(key=None if key is None else key.key.data_ptr(), nabla_v=_lib.ptr(nabla_v),
+                                      flags=_lib.ROLLOUT_SHARES_CHIP if shares_chip else 0, reserved=0)
             status = L.socmx_rollout_ex_f32(*head, *mid, *tail, extra, _lib.stream_ptr(dev))
         else:
             status = L.socmx_rollout_f32(*head, *mid, *tail, _lib.stream_ptr(dev))

@@ -210,7 +210,8 @@ class SOC_Solver(nn.Module):
         fused_V = (detach and R._eligible_for_hip(sde, state0, detach) and getattr(self, "fused_nabla_V", True)
                    and _nets.unet_backward_supported(sde.nabla_V, Kp * B))
         rolled = R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0,
-                                           key=getattr(self, "philox_key", None), want_nabla_v=fused_V)
+                                           key=getattr(self, "philox_key", None), want_nabla_v=fused_V,
+                                           shares_chip=side is not None)     # (the pair-grid network runs beside it)
         (states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls) = rolled[:8]
         if side is not None:
             with torch.cuda.stream(side):

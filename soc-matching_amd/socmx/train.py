@@ -412,7 +412,8 @@ class Trainer:
         # behind a chip-filling kernel that keeps refilling every CU with small workgroups they wait for CUs to drain (the
         # d = 64 rollout took 13.0 instead of 7.3 ms behind the deferred contraction backward)
         (states, noises, stop, frac, lpd, lps, ltw, controls, nabla_v) = R.stochastic_trajectories(
-            sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0)
+            sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0,
+            shares_chip=True)        # (the second stream's branch -- deferred contraction backward, pair-grid network -- runs beside it)
         packed_bwd = None
         if side is not None:
             with torch.cuda.stream(side):
