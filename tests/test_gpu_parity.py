@@ -1404,6 +1404,33 @@ def test_both_rollout_tile_shapes_pass_the_reference_fixtures():
         assert r.returncode == 0, (rows, r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("K", [1, 2, 3])
+@pytest.mark.parametrize("name", ["cfg3_double_well_d10_K200", "cfg1_ou_quadratic_easy_d2_K50", "md_default_d1_K150_B64_stopping"])
+def test_one_row_rollout_on_the_shortest_grids(name, K):
+    """One, two and three steps (the noise / scalar / bookkeeping pipeline of the one-row kernel runs one to two steps ahead of
+    the integrator: its prologue and its flush are the whole launch here), with and without the terminal nabla_V evaluation,
+    for the three step forms (elementwise drift, OU drift, stopping time) against the oracle."""
+    from socmx import rollout as R
+    sde, aux = build_sde(name, DEV)
+    pb, vp, mp, gamma, oaux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    B, d = 5, aux["d"]
+    ts = aux["ts"][: K + 1].contiguous()
+    g = torch.Generator().manual_seed(K)
+    noise = torch.randn(K, B, d, generator=g)
+    x0 = aux["x0"].cpu().repeat(B, 1) + 0.1 * torch.randn(B, d, generator=g)
+    with torch.no_grad():
+        want = O.stochastic_trajectories(pb, vp, x0, oaux["ts"][: K + 1], aux["lmbd"], noise)
+    for want_v in (False, True):
+        got = R.hip_trajectories(sde, x0.to(DEV), ts, aux["lmbd"], noise_in=noise.to(DEV), want_nabla_v=want_v)
+        for a, b in zip(got[:8], want):
+            np.testing.assert_allclose(_np(a), b.numpy(), rtol=1e-4, atol=1e-4)
+        if want_v:
+            tx = torch.cat([oaux["ts"][: K + 1].reshape(-1, 1, 1).expand(K + 1, B, 1), want[0]], -1).reshape(-1, d + 1)
+            with torch.no_grad():
+                ref = O.unet_forward(vp, tx).reshape(K + 1, B, d).numpy()
+            np.testing.assert_allclose(_np(got[8]), ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
+
+
 def test_one_row_and_four_row_rollouts_agree_row_by_row():
     """The same Philox rows through the one-row kernel (B = 256: one workgroup per row) and inside a B = 1024 launch (4-row
     tiles): identical noise, trajectories equal up to fp32 summation order in the network."""
