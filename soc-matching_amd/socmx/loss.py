@@ -273,6 +273,40 @@ class _StoppingTargetHip(torch.autograd.Function):
                 None)
 
 
+class _ResidualHip(torch.autograd.Function):
+    """objective = inv_norm sum_{i,m} w_m |sigma^T (nabla_V - target)[i,m]|^2 for ANY target (socmx_socm_residual_f32: the
+    SOCM loss's residual kernels behind their own entry point); d obj / d nabla_V = G, d obj / d target = -G."""
+
+    @staticmethod
+    def forward(ctx, target, nabla_V, weight, pb, K, inv_norm):
+        Lh, f = _lib.lib(), _lib.ptr
+        Kp, B, d = nabla_V.shape
+        dev = nabla_V.device
+        c = lambda t: t.detach().to(torch.float32).contiguous()
+        tg, nv, w = c(target), c(nabla_V), c(weight)
+        G = torch.empty_like(nv)
+        obj = torch.zeros(1, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(Lh.socmx_socm_residual_f32(pb.c_struct(), K, B, f(tg), f(nv), f(w), float(inv_norm), f(G), f(obj),
+                                                  _lib.stream_ptr(dev)), "socmx_socm_residual_f32")
+        ctx.save_for_backward(G)
+        return obj[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        (G,) = ctx.saved_tensors
+        g = G * gout
+        return (-g if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+def masked_residual_hip(pb, K, target, nabla_V, weight, stop_indicators):
+    """sum_{i,m} w_m |stop[i,m] sigma^T (nabla_V - target)[i,m]|^2 (method.py:692-712, the numerator of the stopping-time
+    objective): the 0 / 1 mask commutes with sigma^T, so it is applied to both operands and the plain residual kernel does
+    the rest -- instead of a (d, d) library GEMM per direction and ~20 elementwise launches with their autograd."""
+    sm = stop_indicators.unsqueeze(2)
+    return _ResidualHip.apply(sm * target, sm * nabla_V, weight, pb, K, 1.0)
+
+
 def stopping_target_hip(gamma, gamma2, gamma3, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops, K, T_model):
     return _StoppingTargetHip.apply(gamma, gamma2, gamma3, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops, K, T_model)
 

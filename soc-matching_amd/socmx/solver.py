@@ -146,8 +146,7 @@ class SOC_Solver(nn.Module):
                 N0, N1, dN0, dN1 = M.nets_with_ds(t_vec, s_vec)
             ops = L.socm_operands_hip(pb, ts, self.lmbd, states, noises, controls, frac=frac)
             target = L.stopping_target_hip(M.gamma, M.gamma2, M.gamma3, N0, N1, dN0, dN1, t_vec, s_vec, tau, ops, K, M.T)
-            r = stop_indicators.unsqueeze(2) * ((nabla_V - target) @ pb.sigma)
-            return torch.sum(r * r * weight.reshape(1, -1, 1)) / self._stop_normaliser(stop_indicators)
+            return L.masked_residual_hip(pb, K, target, nabla_V, weight, stop_indicators) / self._stop_normaliser(stop_indicators)
         # dM/ds as a forward-mode tangent (the reference: functorch.jacrev over the batch-summed output)
         M_all, dM_all = torch.func.jvp(lambda s_: sde.M(t_vec, s_, tau_vec), (s_vec,), (torch.ones_like(s_vec),))
         dM_all = torch.nan_to_num(dM_all)                                                   # method.py:553-555
