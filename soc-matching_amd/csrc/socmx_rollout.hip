@@ -1437,7 +1437,10 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
 #else
   const bool r1_prof_ok = !prof;
 #endif
-  if (is_default && fast && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
+  // (a dense sigma at d <= 15 -- the README's Linear OU, d = 10 -- takes the same kernel: sigma u = -(sigma sigma^T) nabla_V is the
+  //  one extra product on its serial chain; not with a stopping time, which is built for sigma = I)
+  const bool one_row_form = fast || (!force_slow && !a.sigma_identity && d <= 15 && !stopping);
+  if (is_default && one_row_form && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
       (B <= 256 || (force_rows == 1 && B <= 1024)))
     return rollout1_launch(a, stopping, stream);
   // (... unless the launch is stand-alone -- no SOCMX_ROLLOUT_SHARES_CHIP: nothing beside it to starve -- then the shorter

@@ -42,11 +42,14 @@ constexpr int kR1PD = 2;        // ring depth (blocks)
 //   blocks in the order a wave consumes them: 0-3 down_1 (chunks 0..3), 4 down_2 over the wave's own outputs (always resident) | 5-6 res_2, 7 up_2 | 8-15 res_1 (R0c0 R1c0 R0c1 ...),
 //   16-19 up_1 (U0c0 U1c0 U0c1 U1c1) -- in a two-GEMM stage the skip GEMM runs first: its input is in registers since an earlier
 //   stage, so its fmacs cover the LDS round trip of the stage's other input
-__host__ __device__ constexpr char r1_src(int cls, int dm, int b) {
+__host__ __device__ constexpr char r1_src(int cls, int dmx, int b) {
   // wave 0 also holds 4 (1 + DMAX) + (1 + DMAX) registers of down_0 / res_0: fewer resident blocks at larger d
-  constexpr char plan0_3[kR1Blocks + 1] = "RSSLRLSLLSLSLSLSLRLS";
-  constexpr char plan0_11[kR1Blocks + 1] = "RSSSRLSLLSLRLSLSLRLS";
-  constexpr char plan0_15[kR1Blocks + 1] = "RSSSRLSLLSLSLSLSLSLS";
+  // dmx = DMAX (+ 100 for a dense sigma: sigma and sigma sigma^T take the LDS of two blocks, which wave 0 streams instead)
+  const bool dense = dmx >= 100;
+  const int dm = dmx % 100;
+  constexpr char plan0_3[kR1Blocks + 1] = "RSSLRLSLLSLSLSLSLRLS", plan0_3d[kR1Blocks + 1] = "RSSLRLSLLSLSSSLSSRLS";
+  constexpr char plan0_11[kR1Blocks + 1] = "RSSSRLSLLSLRLSLSLRLS", plan0_11d[kR1Blocks + 1] = "RSSSRLSLLSLRSSLSSRLS";
+  constexpr char plan0_15[kR1Blocks + 1] = "RSSSRLSLLSLSLSLSLSLS", plan0_15d[kR1Blocks + 1] = "RSSSRLSLLSLSSSLSSSLS";
   // (stream blocks spread over the step's TIME, two blocks of lead each: S1 ~1.1k cycles, S2 ~0.5k, S3 ~0.9k, S4 ~2.6k, then wave
   //  0's serial section ~1.2k with no consumption)
 #ifdef SOCMX_R1_PLAN1
@@ -54,7 +57,9 @@ __host__ __device__ constexpr char r1_src(int cls, int dm, int b) {
 #else
   constexpr char plan1[kR1Blocks + 1] = "RRSLRSRLRSLRSRRSLRSR";
 #endif
-  return cls == 1 ? plan1[b] : dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
+  if (cls == 1) return plan1[b];
+  if (dense) return dm <= 3 ? plan0_3d[b] : dm <= 11 ? plan0_11d[b] : plan0_15d[b];
+  return dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
 }
 __host__ __device__ constexpr int r1_count(int cls, int dm, char s, int upto = kR1Blocks) {
   int n = 0;
@@ -265,6 +270,9 @@ struct R1Lds {
 };
 static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(11) * 1024) * 4 <= 160 * 1024 &&
               (R1Lds::weights + r1_lds_blocks(15) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit");
+// dense sigma: sigma and S = sigma sigma^T (16 x 16 each) behind the weight blocks
+static_assert((R1Lds::weights + r1_lds_blocks(103) * 1024 + 512) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(111) * 1024 + 512) * 4 <= 160 * 1024 &&
+              (R1Lds::weights + r1_lds_blocks(115) * 1024 + 512) * 4 <= 160 * 1024, "dense sigma: no room for sigma, sigma sigma^T");
 
 // Developer instrumentation (-DSOCMX_R1_PROF): per-wave s_memtime deltas between the marks of a step, summed over the launch,
 // written by workgroup 0 to a.prof[wave * 16 + slot] (socmx_rollout_phase_cycles_f32; tools/r1_phases.py).
@@ -281,11 +289,15 @@ static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R
 
 // ---- one wave of the workgroup --------------------------------------------------------------------------------------------
 // DMAX: the state dimensions this instantiation takes (d <= DMAX): wave 0 holds 1 + DMAX input columns of down_0 / res_0
-// MODE: 0 elementwise drift (double_well), 1 the same with a stopping time (molecular_dynamics), 2 OU drift (A x; x'Px for OU_quadratic)
-template <int CLS, int MODE, class NET, int DMAX>
+// MODE: 0 elementwise drift (double_well), 1 the same with a stopping time (molecular_dynamics), 2 OU drift (A x; x'Px for
+// OU_quadratic); + 4: a dense sigma (u = -sigma^T nabla_V, sigma u = -(sigma sigma^T) nabla_V, sigma eps) -- MODE 4, 6
+template <int CLS, int MODE, class NET, int DMAX0>
 __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const int wave, const int lane) {
+  constexpr bool DENSE = (MODE & 4) != 0;
+  constexpr int DMAX = DMAX0;                       // state dimensions this instantiation takes
+  constexpr int DMX = DMAX0 + (DENSE ? 100 : 0);    // ... as the key of the source plans
   constexpr UnetDesc u = NET::desc();
-  constexpr int NRES = r1_count(CLS, DMAX, 'R'), NLDS = r1_count(CLS, DMAX, 'L'), NSTR = r1_count(CLS, DMAX, 'S');
+  constexpr int NRES = r1_count(CLS, DMX, 'R'), NLDS = r1_count(CLS, DMX, 'L'), NSTR = r1_count(CLS, DMX, 'S');
   const float* __restrict__ Wp = a.packed;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
   const int grow = blockIdx.x;
@@ -300,7 +312,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   float wres[NRES][16];
 #pragma unroll
   for (int r = 0; r < NRES; ++r) {
-    const int rb = r1_nth(CLS, DMAX, 'R', r);            // (a constant once the loop is unrolled)
+    const int rb = r1_nth(CLS, DMX, 'R', r);            // (a constant once the loop is unrolled)
     const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(rb, wave)) + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -309,7 +321,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       for (int e = 0; e < 4; ++e) wres[r][c * 4 + e] = v[e];
     }
   }
-  static_assert(r1_src(CLS, DMAX, 4) == 'R', "down_2's strided fragments are only loaded by the resident path");
+  static_assert(r1_src(CLS, DMX, 4) == 'R', "down_2's strided fragments are only loaded by the resident path");
   // up_0's share of this wave: k = 32 w + 16 (g & 1) + 8 (g >> 1) + j  (rows 2, 3 read the rotated copy of the wave's outputs)
   float w5[8];
 #pragma unroll
@@ -321,12 +333,12 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   static_assert(u.bias_floats <= 1248, "bias copy");
   const float* BL = lds + R1Lds::bias;          // (copied by the kernel's prologue; read where a layer ends)
   // LDS-resident blocks: copied once, read back with ds_read_b128 at lane * 16 + fragment * 1 KiB
-  constexpr int lds_first = CLS == 0 ? 0 : r1_count(0, DMAX, 'L');
-  static_assert(r1_count(CLS, DMAX, 'S') % kR1PD == 0 && r1_count(CLS, DMAX, 'S') >= kR1PD, "static ring slots across steps");
+  constexpr int lds_first = CLS == 0 ? 0 : r1_count(0, DMX, 'L');
+  static_assert(r1_count(CLS, DMX, 'S') % kR1PD == 0 && r1_count(CLS, DMX, 'S') >= kR1PD, "static ring slots across steps");
   float* LW = lds + R1Lds::weights + (lds_first + (CLS == 0 ? 0 : (wave - 1) * NLDS)) * 1024;
 #pragma unroll
   for (int r = 0; r < NLDS; ++r) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(r1_nth(CLS, DMAX, 'L', r), wave)) + lane;
+    const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(r1_nth(CLS, DMX, 'L', r), wave)) + lane;
     f32x4* dst = reinterpret_cast<f32x4*>(LW + r * 1024) + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c) dst[c * 64] = src[c * 64];
@@ -337,7 +349,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   if constexpr (NSTR > 0) {
 #pragma unroll
     for (int s = 0; s < kR1PD; ++s) {
-      const int p = r1_block_off<NET>(r1_nth(CLS, DMAX, 'S', s), wave) * 4;
+      const int p = r1_block_off<NET>(r1_nth(CLS, DMX, 'S', s), wave) * 4;
       ring[s][0] = r1_gload<0>(img, loff, p);
       ring[s][1] = r1_gload<1024>(img, loff, p);
       ring[s][2] = r1_gload<2048>(img, loff, p);
@@ -351,8 +363,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   auto pre = [&](auto bc) {
     constexpr int b = decltype(bc)::value;
     if constexpr (b < kR1Blocks) {
-      if constexpr (r1_src(CLS, DMAX, b) == 'L') {
-        constexpr int r = r1_count(CLS, DMAX, 'L', b);
+      if constexpr (r1_src(CLS, DMX, b) == 'L') {
+        constexpr int r = r1_count(CLS, DMX, 'L', b);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const f32x4 v = *(reinterpret_cast<const f32x4*>(LW + r * 1024) + c * 64 + lane);
@@ -366,9 +378,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   // half h of block b into w[8]
   auto fetch = [&](auto bc, auto hc, float (&w)[8]) {
     constexpr int b = decltype(bc)::value, h = decltype(hc)::value;
-    constexpr char src = r1_src(CLS, DMAX, b);
+    constexpr char src = r1_src(CLS, DMX, b);
     if constexpr (src == 'R') {
-      constexpr int r = r1_count(CLS, DMAX, 'R', b);
+      constexpr int r = r1_count(CLS, DMX, 'R', b);
 #pragma unroll
       for (int e = 0; e < 8; ++e) w[e] = wres[r][8 * h + e];
     } else if constexpr (src == 'L') {
@@ -376,7 +388,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = lq[e];
       } else {
-        constexpr int r = r1_count(CLS, DMAX, 'L', b);
+        constexpr int r = r1_count(CLS, DMX, 'L', b);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const f32x4 v = *(reinterpret_cast<const f32x4*>(LW + r * 1024) + (2 + c) * 64 + lane);
@@ -385,7 +397,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
         }
       }
     } else {
-      constexpr int s = r1_count(CLS, DMAX, 'S', b) % kR1PD;
+      constexpr int s = r1_count(CLS, DMX, 'S', b) % kR1PD;
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -394,9 +406,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   };
   auto refill = [&](auto bc) {
     constexpr int b = decltype(bc)::value;
-    if constexpr (r1_src(CLS, DMAX, b) == 'S') {
-      constexpr int i = r1_count(CLS, DMAX, 'S', b), s = i % kR1PD;
-      const int p = r1_block_off<NET>(r1_nth(CLS, DMAX, 'S', (i + kR1PD) % NSTR), wave) * 4;   // (wraps into the next step)
+    if constexpr (r1_src(CLS, DMX, b) == 'S') {
+      constexpr int i = r1_count(CLS, DMX, 'S', b), s = i % kR1PD;
+      const int p = r1_block_off<NET>(r1_nth(CLS, DMX, 'S', (i + kR1PD) % NSTR), wave) * 4;   // (wraps into the next step)
       ring[s][0] = r1_gload<0>(img, loff, p);
       ring[s][1] = r1_gload<1024>(img, loff, p);
       ring[s][2] = r1_gload<2048>(img, loff, p);
@@ -417,7 +429,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   };
   // two blocks of one chunk: aA += x . W_bA, aB += x . W_bB (at most one of them an LDS block); nx as above
   auto blk2 = [&](auto ba, auto bb, auto nx, float& aA, float& aB, float x) {
-    static_assert(!(r1_src(CLS, DMAX, decltype(ba)::value) == 'L' && r1_src(CLS, DMAX, decltype(bb)::value) == 'L'), "one landing buffer");
+    static_assert(!(r1_src(CLS, DMX, decltype(ba)::value) == 'L' && r1_src(CLS, DMX, decltype(bb)::value) == 'L'), "one landing buffer");
     float wa0[8], wb0[8], wa1[8], wb1[8];
     fetch(ba, H0{}, wa0);
     fetch(bb, H0{}, wb0);
@@ -429,13 +441,14 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     refill(ba);
     refill(bb);
   };
-  static_assert(r1_src(CLS, DMAX, 0) != 'L', "a step's first block has nobody in front of it to issue its LDS reads");
+  static_assert(r1_src(CLS, DMX, 0) != 'L', "a step's first block has nobody in front of it to issue its LDS reads");
 #define R1B(b) std::integral_constant<int, b>{}
 
   // ---- wave 0's own state: the row (every 16-lane row of the wave runs the same arithmetic: component i = lane & 15) ----
   const int i = n, ic = min(i, d - 1);
   const bool lane_ok = i < d;
-  constexpr bool STOPPING = MODE == 1, is_ou = MODE == 2;
+  constexpr bool STOPPING = MODE == 1, is_ou = (MODE & 2) != 0;
+  static_assert(!(STOPPING && DENSE), "the stopping-time step is built for sigma = I");
   const bool is_quad = is_ou && kind == SOCMX_OU_QUADRATIC;
   const bool traj = a.states != nullptr;
   const bool store = CLS == 0 && lane < 16 && lane_ok && traj;
@@ -447,6 +460,10 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   float w0[4][DMAX + 1], b0[4], w3[DMAX + 1], b8 = 0.f, b3 = 0.f;   // down_0 (units 64 m + lane), res_0 (unit n): wave 0 only
   float* A_l = lds + R1Lds::amat;                         // OU: A, P with row stride 16 (d <= 15)
   float* P_l = lds + R1Lds::pmat;
+  float* S_l = lds + R1Lds::weights + r1_lds_blocks(DMX) * 1024;   // dense sigma: sigma, then S = sigma sigma^T (stride 16)
+  float* SS_l = S_l + 256;
+  float srow[DENSE ? DMAX : 1];                           // row i of S: sigma u = -S nabla_V is on the step's serial chain
+  float pre_b = 0.f, pre_se = 0.f;                        // drift b(x_k) and (sigma eps_k)_i of the coming step, formed in the slack
   if constexpr (CLS == 0) {
     x = lane_ok ? a.x0[(size_t)grow * d + i] : 0.f;
     kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
@@ -467,9 +484,40 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       if (is_ou) A_l[r * 16 + c] = a.A[e];
       if (is_quad) P_l[r * 16 + c] = a.P[e];
     }
+    if constexpr (DENSE) {
+      for (int e = lane; e < 256; e += 64) S_l[e] = ((e >> 4) < d && (e & 15) < d) ? a.sigma[(e >> 4) * d + (e & 15)] : 0.f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-private LDS traffic: no barrier needed)
+      for (int e = lane; e < 256; e += 64) {
+        float acc = 0.f;
+        for (int c = 0; c < 16; ++c) acc += S_l[(e >> 4) * 16 + c] * S_l[(e & 15) * 16 + c];
+        SS_l[e] = acc;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < DMAX; ++j) srow[j] = SS_l[n * 16 + j];
+    }
     if (store) a.states[rowoff] = x;
     if (store0) a.stop_ind[grow] = 1.f;
   }
+  // what the coming step's chain needs besides nabla_V, from values known a stage earlier: b(x_k) and sigma eps_k
+  auto prepare_step = [&](int k) {
+    if (k >= K) return;
+    const float eps = lds[R1Lds::nz + (k & 1) * 16 + i];
+    if (is_ou) {                                                        // b = A x   (OU_quadratic.py:51-52, OU_linear.py:43-44)
+      float bi = 0.f;
+      for (int j = 0; j < d; ++j) bi += A_l[ic * 16 + j] * __shfl(x, j, 16);
+      pre_b = lane_ok ? bi : 0.f;
+    } else {
+      pre_b = -2.f * kap * (x * x - 1.f) * 2.f * x;                     // double_well.py:44-48
+    }
+    if constexpr (DENSE) {
+      float se = 0.f;
+      for (int j = 0; j < d; ++j) se += S_l[ic * 16 + j] * __shfl(eps, j, 16);
+      pre_se = lane_ok ? se : 0.f;
+    } else {
+      pre_se = eps;
+    }
+  };
   // y[unit] = relu(down_0 [t, x] + b) for the 256 units, lane-ordered into LDS (wave 0); res_0 [t, x] + b for the step's end
   auto first_layer = [&](float t) {
     float acc[4], r0 = b3 + t * w3[0], r1v = 0.f;
@@ -544,7 +592,12 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     bk_k = -1;
     const f32x4 scal = *reinterpret_cast<const f32x4*>(lds + R1Lds::sc + (k % 3) * 4);
     const float eps = bk_eps;
-    const float uc = lane_ok ? -bk_gv : 0.f;
+    float uc = lane_ok ? -bk_gv : 0.f;                                  // u = -sigma^T nabla_V (method.py:58-80)
+    if constexpr (DENSE) {
+      float t = 0.f;
+      for (int j = 0; j < d; ++j) t += S_l[j * 16 + ic] * __shfl(bk_gv, j, 16);
+      uc = lane_ok ? -t : 0.f;
+    }
     const float xe = x;                                                 // x_{k+1}
     float f = 0.f;                                                      // f at the NEW state, OLD time (utils.py:92-96)
     if (is_quad) {
@@ -576,8 +629,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   // ---- stages 1..5 of the network on the row; leaves up_0's per-wave partial sums in LDS (p5) ----
   // the LDS block among blocks [first, first + count), kR1Blocks if none: what the unit in front of them prefetches
 #define R1NX(first, count)                                                                                         \
-  std::integral_constant<int, (r1_src(CLS, DMAX, first) == 'L'                         ? (first)                     \
-                               : ((count) > 1 && r1_src(CLS, DMAX, (first) + 1) == 'L') ? (first) + 1                 \
+  std::integral_constant<int, (r1_src(CLS, DMX, first) == 'L'                         ? (first)                     \
+                               : ((count) > 1 && r1_src(CLS, DMX, (first) + 1) == 'L') ? (first) + 1                 \
                                                                                         : kR1Blocks)>{}
   // (The two waves of a SIMD share its VALU; at equal priority the older one wins most slots, finishes a multi-block stage
   //  early and leaves the younger one to run the rest alone.  Alternating s_setprio block by block to keep them abreast was
@@ -600,7 +653,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       const float x4 = __shfl(y, (lane & 48) + 4 * g + (lane & 3));
       float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
       pre(R1NX(5, 1));                          // (stage 3's first block, if it is an LDS block: read behind these fmacs)
-      r1_fmac16_4acc(c0, c1, c2, c3, x4, wres[r1_count(CLS, DMAX, 'R', 4)]);
+      r1_fmac16_4acc(c0, c1, c2, c3, x4, wres[r1_count(CLS, DMX, 'R', 4)]);
       const float tsum = r1_reduce4(c0, c1, c2, c3);                         // lane (g, n): unit 16 {0, 2, 1, 3}[g] + n
       lds[R1Lds::p2 + wave * 64 + 16 * (((g & 1) << 1) | (g >> 1)) + n] = tsum;
     }
@@ -677,6 +730,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     __builtin_amdgcn_s_setprio(0);
     if constexpr (CLS == 0) {
       bookkeeping();
+      prepare_step(cur_k);
     } else {
       words(cur_k + 2);
       draws(cur_k + 1);
@@ -704,6 +758,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   words(1);
   step_scalars(0);
   __syncthreads();
+  if constexpr (CLS == 0) prepare_step(0);
   for (int k = 0; k < K; ++k) {
 #ifdef SOCMX_R1_PROF
     if (k == 0) prof_last = __builtin_readcyclecounter();
@@ -721,16 +776,17 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       const float dt = scal[0], sq_ldt = scal[1];
       const float gv = relu_keep_nan((((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + b8) + res0;
       R1_TICK(12)
-      const float uc = lane_ok ? -gv : 0.f;                             // u = -sigma^T nabla_V, sigma = I
-      float bi;
-      if (is_ou) {                                                      // b = A x
-        bi = 0.f;
-        for (int j = 0; j < d; ++j) bi += A_l[ic * 16 + j] * __shfl(x, j, 16);
-        if (!lane_ok) bi = 0.f;
+      // sigma u = -sigma sigma^T nabla_V: the one product that waits for the network (sigma = I: u = -nabla_V itself); the drift
+      // and sigma eps were formed a stage ago (prepare_step)
+      float su;
+      if constexpr (DENSE) {
+        float s0 = 0.f, s1 = 0.f;
+        r1_state_one<DMAX>(s0, s1, gv, srow);
+        su = lane_ok ? -(s0 + s1) : 0.f;
       } else {
-        bi = -2.f * kap * (x * x - 1.f) * 2.f * x;                      // double_well.py:44-48
+        su = lane_ok ? -gv : 0.f;
       }
-      const float upd = (bi + uc) * dt + sq_ldt * eps;                  // utils.py:45-47
+      const float upd = (pre_b + su) * dt + sq_ldt * pre_se;            // utils.py:45-47
       const float xn = x + stop * upd;                                  // utils.py:48
       float xe = xn, step = dt, stop_new = 1.f;
       if (STOPPING) {                                                   // utils.py:42-44, 49-75; Phi = -x_0
@@ -787,7 +843,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 }
 
 template <int MODE, class NET, int DMAX>
-__global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutArgs a) {
+__global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutArgs a) {  // MODE: see r1_wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -804,7 +860,12 @@ int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream) {
   if constexpr (r1_supported<DefaultNet>()) {
     void (*k)(const RolloutArgs);
     const bool ou = a.kind == SOCMX_OU_QUADRATIC || a.kind == SOCMX_OU_LINEAR;
-#define R1PICK(DM) (stopping ? rollout1_kernel<1, DefaultNet, DM> : ou ? rollout1_kernel<2, DefaultNet, DM> : rollout1_kernel<0, DefaultNet, DM>)
+    const bool dense = !a.sigma_identity;
+    if (dense && stopping) return SOCMX_E_DIM;          // (the launcher does not send this combination here)
+#define R1PICK(DM)                                                                                       \
+  (stopping ? rollout1_kernel<1, DefaultNet, DM>                                                         \
+            : dense ? (ou ? rollout1_kernel<6, DefaultNet, DM> : rollout1_kernel<4, DefaultNet, DM>)     \
+                    : (ou ? rollout1_kernel<2, DefaultNet, DM> : rollout1_kernel<0, DefaultNet, DM>))
     if (a.d <= 3) k = R1PICK(3);
     else if (a.d <= 11) k = R1PICK(11);
     else k = R1PICK(15);

@@ -1492,6 +1492,8 @@ def test_four_row_rollout_ragged_batches(B):
     ("molecular_dynamics", 6, ["method.use_stopping_time=True", "method.T=2.0", "method.lmbd=2.0"]),
     ("molecular_dynamics", 20, ["method.use_stopping_time=True", "method.T=2.0", "method.lmbd=2.0"]),
     ("double_well", 24, []), ("OU_linear", 16, []), ("OU_linear", 64, []), ("OU_quadratic_hard", 31, []),
+    # dense sigma at d <= 15 (the README's Linear OU is d = 10): the one-row kernel's sigma sigma^T form / the 4-row general step
+    ("OU_linear", 10, []), ("OU_linear", 3, []), ("OU_linear", 15, []),
 ])
 def test_four_row_rollout_settings_vs_eager_path(setting, d, extra):
     """The 4-row kernels at the DEFAULT widths for the settings / sizes no reference fixture covers in that form -- stopping

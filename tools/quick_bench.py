@@ -19,6 +19,9 @@ CONFIGS = {
     "ouq20": ("OU_quadratic_easy", 20, 50, 128, 2.0),            # soc.yaml defaults (d = 20)
     "ouq20b": ("OU_quadratic_hard", 20, 50, 2048, 2.0),
     "burst": ("double_well", 10, 200, 65536, 6.0),
+    "oul10": ("OU_linear", 10, 100, 64, 2.0),                    # README "Linear OU": dense sigma, d = 10
+    "ouh20": ("OU_quadratic_hard", 20, 50, 128, 2.0),            # README "Quadratic OU hard" (method.d from soc.yaml: 20)
+    "md": ("molecular_dynamics", 1, 150, 64, 2.0),
 }
 which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg3"]
 
