@@ -391,8 +391,8 @@ def main():
 
     # (after the iteration leg: its 2 GB of buffers and the empty_cache() would otherwise cost the next leg its warm
     #  allocator state)
-    # ---- the same kernel with the chip full: one evaluation-burst launch (65,536 rows = 4,096 workgroups,
-    #      what control_objective / normalization_constant issue, utils.py:131-231) --------------------------
+    # ---- the MFMA form of the rollout with the chip full: one evaluation-burst launch (65,536 rows = 2,048 workgroups of two
+    #      16-row tiles, csrc/socmx_rollout32.hip; what control_objective / normalization_constant issue, utils.py:131-231) ----
     burst = None
     if rank == 0 and not args.no_burst:
         Bb = 65536
@@ -408,6 +408,7 @@ def main():
         bms = e0.elapsed_time(e1) / 3
         bfl = flops_per_traj_step(d, HDIMS) * Bb * K
         burst = {"workload": "double_well d=10 num_steps=200, 65536 rows in one launch (evaluation burst)",
+                 "kernel": "socmx::rollout32_kernel<false,StaticNet<16,256,128,64,16>,false> (2,048 workgroups of 32 rows)",
                  "kernel_ms": bms, "trajectory_steps_per_s": Bb * K / (bms * 1e-3),
                  "bound": "mfma", "achieved": bfl / (bms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                  "frac": bfl / (bms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
@@ -474,7 +475,7 @@ def main():
                                  "MACs per instruction at ~5 cycles per SIMD, a quarter of the packed-fp32 / MFMA rate the peak "
                                  "is quoted at): 128 of 256 CUs work, frac <= 128/256/4 = 0.125 by construction; "
                                  "peak = 157.3 TF is the fp32 MFMA = packed-vector figure; see roofline_full_chip for the "
-                                 "16-row MFMA kernel with 4096 workgroups",
+                                 "MFMA kernel with the chip full (2,048 workgroups of two 16-row tiles)",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": byts,
                          "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,

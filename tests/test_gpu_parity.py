@@ -513,6 +513,62 @@ def test_eval_burst_single_launch_matches_looped_statistics():
     assert abs(nc.item() - w.mean().item()) < 4 * (nc_err.item() + (w.std() / np.sqrt(w.numel() - 1)).item())
 
 
+@pytest.mark.parametrize("name,K", [("cfg3_double_well_d10_K200", 5), ("cfg1_ou_quadratic_easy_d2_K50", 4),
+                                    ("md_default_d1_K150_B64_stopping", 12)])
+def test_two_tile_burst_rollout_vs_oracle(name, K):
+    """More 16-row tiles than CUs (B > 4096) at the default widths, sigma = I, d <= 15: csrc/socmx_rollout32.hip, two tiles per
+    workgroup -- against the ORACLE on injected noise with distinct initial rows, a ragged last tile (4,107 = 128 x 32 + 11
+    rows), with and without the stopping time, and again as a costs-only launch."""
+    from SOC_matching import utils
+    from socmx import rollout as R
+    sde, aux = build_sde(name, DEV)
+    pb, vp, mp, gamma, oaux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    B, d = 4107, aux["d"]
+    g = torch.Generator().manual_seed(7)
+    noise = torch.randn(K, B, d, generator=g)
+    x0 = oaux["x0"].reshape(1, -1) + 0.3 * torch.randn(B, d, generator=g)
+    ts = oaux["ts"][:K + 1].clone()
+    with torch.no_grad():
+        want = O.stochastic_trajectories(pb, vp, x0, ts, aux["lmbd"], noise)
+    got = utils.stochastic_trajectories(sde, x0.to(DEV), ts.to(DEV), aux["lmbd"], noise_in=noise.to(DEV))
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(_np(a), b.numpy(), rtol=1e-4, atol=1e-4)
+    if "stopping" in name:
+        assert 0.0 < float(got[2][-1].mean()) < 1.0, "want both stopped and running rows"
+    cost = R.hip_trajectories(sde, x0.to(DEV), ts.to(DEV), aux["lmbd"], noise_in=noise.to(DEV), costs_only=True)
+    for i in (4, 5, 6):
+        assert torch.equal(cost[i], got[i])
+
+
+def test_two_tile_burst_rollout_equals_the_16_row_kernel():
+    """Per tile the two-tile workgroups issue the same MFMAs in the same order, the same split-K combine, the same SDE-step
+    arithmetic and Philox counters as the one-tile kernel: the 8-tuples are equal bit for bit (SOCMX_BURST_ROWS is read once
+    per process, hence subprocesses)."""
+    import subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, os, numpy as np, torch\n"
+        f"sys.path[:0] = [{root!r}, os.path.join({root!r}, 'soc-matching_amd'), os.path.join({root!r}, 'tests')]\n"
+        "from test_host_cpu import build_sde\n"
+        "from SOC_matching import utils\n"
+        "out = {}\n"
+        "for name, K in (('cfg3_double_well_d10_K200', 9), ('cfg1_ou_quadratic_easy_d2_K50', 6), ('md_default_d1_K150_B64_stopping', 40)):\n"
+        "    sde, aux = build_sde(name, 'cuda:0')\n"
+        "    r = utils.stochastic_trajectories(sde, aux['x0'].repeat(4107, 1), aux['ts'][:K + 1], aux['lmbd'], seed=3, offset=1)\n"
+        "    for i, t in enumerate(r): out[f'{name}_{i}'] = t.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for rows in ("16", "32"):
+            path = os.path.join(tmp, f"rows{rows}.npz")
+            env = dict(os.environ, SOCMX_BURST_ROWS=rows)
+            subprocess.run([sys.executable, "-c", script, path], check=True, env=env)
+            res[rows] = dict(np.load(path))
+    assert res["16"].keys() == res["32"].keys()
+    for k in res["16"]:
+        assert np.array_equal(res["16"][k], res["32"][k]), k
+
+
 def test_specialised_and_generic_kernels_agree(tmp_path):
     """The constexpr-specialised + fused-SDE instantiation (default arch, sigma = I) against the table-driven
     generic one (SOCMX_GENERIC / SOCMX_NOFAST are read once per process, hence subprocesses)."""

@@ -88,7 +88,7 @@ int main() {
   hipMalloc(&buf, (size_t)n_frag * 1024); hipMemset(buf, 0, (size_t)n_frag * 1024);
   hipMalloc(&out, 1 << 22); hipMalloc(&cyc, 4096 * 8);
   hipFuncSetAttribute((const void*)lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  for (int blocks : {1, 32}) {
+  for (int blocks : {1, 32, 256}) {
     run<4, false>(buf, n_frag, blocks, 8, out, cyc);
     run<8, false>(buf, n_frag, blocks, 8, out, cyc);
     run<12, false>(buf, n_frag, blocks, 8, out, cyc);
