@@ -324,6 +324,15 @@ __device__ __forceinline__ const void* scalar_ptr(const void* p) {     // a wave
   return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
 }
 
+// four consecutive floats at ubase[float_off ..] with ubase WAVE-UNIFORM: a buffer load -- the base in a scalar resource, one 32-bit
+// offset register per lane -- instead of a global load with a 64-bit address per lane (whose address arithmetic and issue are
+// time the SIMD's matrix pipe does not get back, see csrc/socmx_rollout32.hip).  Alignment as load4<true>: 4 bytes.
+__device__ __forceinline__ f32x4 uload4(const float* ubase, int float_off) {
+  const __amdgpu_buffer_rsrc_t r =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(reinterpret_cast<const float*>(scalar_ptr(ubase))), 0, 0x7FFFFFFF, 0x00020000);
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, 0));
+}
+
 constexpr int kTargetWaves = 8;  // waves per workgroup: the (pair, l-block) iterations of a row are dealt round-robin
 
 // CT = 16-column batch tiles per wave: the A fragments (and, for NET, the blend that forms them) are built once
@@ -379,12 +388,12 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       // a 16-byte read can cross the end of a buffer only in the last pair matrix / the last operand rows:
       // those iterations (j + 1 >= K: the row's last two pairs) take clamped scalar reads -- in a loop of their own (below)
       if (FAST) {
-        sl.nt = load4<true>(Ap, aoff, 0);
-        sl.dn = load4<true>(Dp, aoff, 0);
+        sl.nt = uload4(Ap, aoff);
+        sl.dn = uload4(Dp, aoff);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          sl.q[c] = load4<true>(qs, boff0[c] + l0, 0);
-          sl.v[c] = load4<true>(vs, boff0[c] + l0, 0);
+          sl.q[c] = uload4(qs, boff0[c] + l0);
+          sl.v[c] = uload4(vs, boff0[c] + l0);
         }
       } else {
         sl.nt = load4<false>(Ap, aoff, dd);
@@ -535,8 +544,8 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       const float* Dp = a.dM_all + prow_dd + (int64_t)jr * dd;
       const int aoff = min(ak, d - 1) * d + l0;
       if (j + 1 < K) {
-        p.nt = load4<true>(Ap, aoff, 0);
-        p.dn = load4<true>(Dp, aoff, 0);
+        p.nt = uload4(Ap, aoff);
+        p.dn = uload4(Dp, aoff);
       } else {
         p.nt = load4<false>(Ap, aoff, dd);
         p.dn = load4<false>(Dp, aoff, dd);
@@ -580,8 +589,8 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_lds_kernel(cons
       if (j + 1 < K) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          b.q[c] = load4<true>(qs, boff0[c] + l0, 0);
-          b.v[c] = load4<true>(vs, boff0[c] + l0, 0);
+          b.q[c] = uload4(qs, boff0[c] + l0);
+          b.v[c] = uload4(vs, boff0[c] + l0);
         }
       } else {
 #pragma unroll
@@ -1733,7 +1742,7 @@ __global__ __launch_bounds__(256, 2) void socm_target_bwd_lds2_kernel(const Targ
   auto gload = [&](int m0, int sl) {
     if (piece_on && !tensor_zero) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) pr[sl][s] = load4<true>(src, min(m0 + 4 * rg + s, B - 1) * d + 4 * pc, 0);
+      for (int s = 0; s < 4; ++s) pr[sl][s] = uload4(src, min(m0 + 4 * rg + s, B - 1) * d + 4 * pc);
     }
   };
   auto stage = [&](int m0, int st, int sl) {   // rows past the batch, columns past d and absent tensors are zeroed here

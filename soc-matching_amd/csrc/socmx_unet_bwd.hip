@@ -259,11 +259,25 @@ __device__ __forceinline__ void export4(float* slab, int r, int n0, const f32x4 
 }
 // the same from the direct stages, where the tile's slab and the 16-unit block are wave-uniform: scalar base + ONE lane
 // offset, the four units as immediates (no per-store 64-bit address arithmetic: 3 vector instructions per store before)
+// (buffer stores: the block's base in a scalar resource, the lane offset in one 32-bit register -- a global store carries a
+//  64-bit address per lane, and issuing those is time the SIMD's matrix pipe does not get back, see socmx_rollout32.hip)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* ubase) {       // ubase: wave-uniform
+  const uint64_t u = reinterpret_cast<uint64_t>(ubase);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFFF, 0x00020000);
+}
 __device__ __forceinline__ void export4_block(float* slab_block, uint32_t lane_off, const f32x4 v) {
   if (!slab_block) return;
-  char* base = reinterpret_cast<char*>(slab_block);
+  const __amdgpu_buffer_rsrc_t r = uniform_rsrc(slab_block);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<float*>(base + (size_t)lane_off + 64 * i) = v[i];
+  for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), r, (int)lane_off, 64 * i, 0);
+}
+// export4 with a wave-uniform slab (the pair network's tiles: one per workgroup)
+__device__ __forceinline__ void export4_u(float* slab, int r, int n0, const f32x4 v) {
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(slab);
+  const int off = (n0 * 16 + (r & 15)) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), rs, off, 64 * i, 0);
 }
 
 struct EpiCtx {
@@ -1066,10 +1080,12 @@ struct MEpi {
   __device__ __forceinline__ void fin(f32x4 vq, f32x4 tq, int r, int n0) const {
     if (kind == ME_OUT) {
       if (p0 + r < Np) {
-        if ((d2 & 3) == 0) {           // rows are whole 16-byte pieces: one store per quad
+        if ((d2 & 3) == 0) {           // rows are whole 16-byte pieces: one (buffer) store per quad
           if (n0 < d2) {
-            *reinterpret_cast<f32x4*>(net + (size_t)(p0 + r) * d2 + n0) = vq;
-            *reinterpret_cast<f32x4*>(dnet + (size_t)(p0 + r) * d2 + n0) = tq;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const int off = (r * d2 + n0) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vq), uniform_rsrc(net + (size_t)p0 * d2), off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tq), uniform_rsrc(dnet + (size_t)p0 * d2), off, 0, 0);
           }
         } else {
 #pragma unroll
@@ -1098,8 +1114,8 @@ struct MEpi {
       *reinterpret_cast<f32x4*>(lds + y + (16 + r) * sy + n0) = tq;
     }
     if (slab) {
-      export4(slab, r, n0, vq);                         // value tile
-      export4(slab + (size_t)sw * 16, r, n0, tq);       // the tangent tile follows it
+      export4_u(slab, r, n0, vq);                       // value tile
+      export4_u(slab + (size_t)sw * 16, r, n0, tq);     // the tangent tile follows it
     }
   }
 };

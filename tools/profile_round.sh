@@ -53,6 +53,13 @@ bash tools/pmc_any.sh "rollout1_kernel" r1 python3 tools/quick_bench.py cfg3 > $
 (hipcc -O3 --offload-arch=gfx950 -o /tmp/vr1 tools/ubench/valu_row1.hip 2>/dev/null && timeout 120 /tmp/vr1 2.4) > $R/valu_row1_ubench.txt 2>&1
 python3 tools/iter_bench.py md eager > $R/iter_md.txt 2>&1; python3 tools/iter_bench.py md graph >> $R/iter_md.txt 2>&1
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o stage_chain stage_chain.hip 2>/dev/null && ./stage_chain) > $R/stage_chain.txt 2>&1
-python3 tools/quick_bench.py cfg3 cfg2 ouq20 cfg5r burst 2>&1 | grep -E "parity|rollout|iteration" > $R/quick.txt
+python3 tools/quick_bench.py cfg3 cfg2 ouq20 ouh20 oul10 cfg5r cfg4r burst 2>&1 | grep -E "parity|rollout|iteration" > $R/quick.txt
+# the two-tile burst kernel (csrc/socmx_rollout32.hip): rocprof average and SQ counters of 65,536-row launches, its phase table, the
+# A/B against the 16-row form (bit-identity included) and the issue micro-benchmark its design rests on
+bash tools/prof_any.sh burst32 tools/quick_bench.py burst --phases > $R/burst32.txt 2>&1
+bash tools/pmc_any.sh "rollout32_kernel" b32 python3 tools/quick_bench.py burst > $R/burst32_pmc.txt 2>&1
+python3 tools/burst_ab.py 2>&1 | grep -v amdgpu.ids > $R/burst_ab.txt
+(hipcc -O3 --offload-arch=gfx950 -o /tmp/mvm tools/ubench/mfma_valu_mix.hip 2>/dev/null && timeout 120 /tmp/mvm) > $R/mfma_valu_mix.txt 2>&1
+rm -rf gpurun_out/pmc_b32
 rm -rf $OUT gpurun_out/k2prof gpurun_out/iterprof gpurun_out/prof gpurun_out/pmc_k3
 ls -la $R
