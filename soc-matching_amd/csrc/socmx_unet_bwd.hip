@@ -1526,7 +1526,6 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
   const int ncol = colok ? n0 + 4 * pc : 0;
   // B operand: H2 slab, value tile 2t (with g_net), tangent tile 2t + 1 (with g_dnet)
   const int cb0 = wave * NCB;
-  const float* hb = a.h2slab + (size_t)c16 * 16 + 4 * g4;
   f32x4 acc[4][NCB];
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1542,13 +1541,23 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
     f32x4 bq[3][2][NCB];             // [slot][value | tangent][c-block]
     // (slots are plain ints, constant at every call site: after inlining each switch leaves one asm statement with a fixed
     //  register -- a generic lambda may not name captured variables in asm operands)
-#define SOCMX_GLD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+// (scalar base + 32-bit lane offset: a 64-bit address per lane is issue time the matrix pipe does not get back; the s_nop
+    //  covers the five wait states a VALU-written SGPR -- v_readfirstlane -- needs before a VMEM instruction reads it)
+#define SOCMX_GLD(dst, voff, sbase) \
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+    auto spin = [](const float* q) -> const float* {             // a wave-uniform pointer, pinned to scalar registers
+      const uint64_t uq = reinterpret_cast<uint64_t>(q);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)uq), hi = __builtin_amdgcn_readfirstlane((uint32_t)(uq >> 32));
+      return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+    };
     auto tile_load = [&](int t, int sl) {
-      const int64_t p0 = (int64_t)min(t, t1 - 1) * 16 + 4 * rg + 2 * lh;
+      const int tc = min(t, t1 - 1);
+      const float* base = spin(src + (size_t)tc * 16 * a.d2);
+      const int64_t p0 = (int64_t)tc * 16 + 4 * rg + 2 * lh;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float* ptr = src + (size_t)min(p0 + i, a.Np - 1) * a.d2 + ncol;
-        if (sl == 0) SOCMX_GLD(tl[0][i], ptr); else SOCMX_GLD(tl[1][i], ptr);
+        const uint32_t voff = (uint32_t)((int)(min(p0 + i, a.Np - 1) - (int64_t)tc * 16) * a.d2 + ncol) * 4u;
+        if (sl == 0) SOCMX_GLD(tl[0][i], voff, base); else SOCMX_GLD(tl[1][i], voff, base);
       }
     };
     auto tile_park = [&](int t, int sl, int st) {
@@ -1562,6 +1571,7 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
         *reinterpret_cast<float2*>(&T[st][lx][4 * pc + e][4 * rg + 2 * lh]) = col;
       }
     };
+    const uint32_t hoff = (uint32_t)(c16 * 16 + 4 * g4) * 4u;
     auto bload = [&](int t, int sl) {
       const int tc = min(t, t1 - 1);
 #pragma unroll
@@ -1569,8 +1579,8 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
 #pragma unroll
         for (int k = 0; k < NCB; ++k) {
           const int cb = min(cb0 + k, a.IB - 1);
-          const float* ptr = hb + ((size_t)(2 * tc + x) * a.h1p + cb * 16) * 16;
-          if (sl == 0) SOCMX_GLD(bq[0][x][k], ptr); else if (sl == 1) SOCMX_GLD(bq[1][x][k], ptr); else SOCMX_GLD(bq[2][x][k], ptr);
+          const float* base = spin(a.h2slab + ((size_t)(2 * tc + x) * a.h1p + cb * 16) * 16);
+          if (sl == 0) SOCMX_GLD(bq[0][x][k], hoff, base); else if (sl == 1) SOCMX_GLD(bq[1][x][k], hoff, base); else SOCMX_GLD(bq[2][x][k], hoff, base);
         }
     };
 #undef SOCMX_GLD
