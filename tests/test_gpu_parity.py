@@ -556,6 +556,11 @@ def test_two_tile_burst_rollout_equals_the_16_row_kernel():
         "    sde, aux = build_sde(name, 'cuda:0')\n"
         "    r = utils.stochastic_trajectories(sde, aux['x0'].repeat(4107, 1), aux['ts'][:K + 1], aux['lmbd'], seed=3, offset=1)\n"
         "    for i, t in enumerate(r): out[f'{name}_{i}'] = t.cpu().numpy()\n"
+        "    # ... with nabla_V handed over on every grid point (what the SOCM loss asks for) and the Philox key on the device\n"
+        "    from socmx import rollout as R\n"
+        "    key = R.PhiloxKey(torch.device('cuda:0'), seed=11, offset=5)\n"
+        "    r = R.hip_trajectories(sde, aux['x0'].repeat(4100, 1), aux['ts'][:K + 1], aux['lmbd'], key=key, want_nabla_v=True)\n"
+        "    for i, t in enumerate(r): out[f'{name}_nv_{i}'] = t.cpu().numpy()\n"
         "np.savez(sys.argv[1], **out)\n")
     with tempfile.TemporaryDirectory() as tmp:
         res = {}
