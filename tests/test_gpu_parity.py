@@ -574,6 +574,39 @@ def test_two_tile_burst_rollout_equals_the_16_row_kernel():
         assert np.array_equal(res["16"][k], res["32"][k]), k
 
 
+@pytest.mark.parametrize("setting,d,K", [("double_well", 15, 4), ("double_well", 1, 3), ("OU_quadratic_easy", 7, 5),
+                                         ("OU_quadratic_hard", 15, 3), ("molecular_dynamics", 2, 30), ("molecular_dynamics", 9, 6)])
+def test_two_tile_burst_rows_equal_a_16_row_launch_of_the_same_rows(setting, d, K):
+    """Rows are keyed by their global index: the first 4,096 rows of a 4,203-row launch (two-tile kernel, ragged last
+    workgroup with ONE live tile) against a 4,096-row launch (256 tiles: the 16-row kernel) -- every d-dependent path of the SDE
+    step (OU drift and x'Px at the largest d, the stopping time), bit for bit, in one process."""
+    import contextlib, io
+    from socmx import rollout as R
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    over = [f"method.setting={setting}", f"method.d={d}", f"method.num_steps={K}"]
+    if setting == "molecular_dynamics":
+        over += ["method.use_stopping_time=True", "method.T=2.0", "method.lmbd=2.0"]
+    cfg = load_config(over)
+    cfg.method.device = DEV
+    torch.manual_seed(1)
+    ts = torch.linspace(0, float(cfg.method.T), K + 1).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)
+    g = torch.Generator().manual_seed(d)
+    x0s = (x0.reshape(1, -1).cpu() + 0.4 * torch.randn(4203, d, generator=g)).to(DEV)
+    big = R.hip_trajectories(sde, x0s, ts, float(cfg.method.lmbd), seed=21, offset=3, want_nabla_v=True)
+    ref = R.hip_trajectories(sde, x0s[:4096].contiguous(), ts, float(cfg.method.lmbd), seed=21, offset=3, want_nabla_v=True)
+    # (the molecular_dynamics rows started 0.4 sigma off the well diverge within a few steps at d = 9: their NaNs must sit at
+    #  the same places in both launches -- the integer-max ReLU of the two-tile kernel keeps NaNs as the 16-row kernel's does)
+    for a, b in zip(big, ref):
+        a = (a[:4096] if a.dim() == 1 else a[:, :4096]).contiguous()
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), (setting, d)
+        assert torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0)), (setting, d)
+    if setting == "molecular_dynamics":
+        assert 0.0 < float(big[2][-1].mean()) < 1.0
+
+
 def test_specialised_and_generic_kernels_agree(tmp_path):
     """The constexpr-specialised + fused-SDE instantiation (default arch, sigma = I) against the table-driven
     generic one (SOCMX_GENERIC / SOCMX_NOFAST are read once per process, hence subprocesses)."""
