@@ -2,7 +2,8 @@
 //
 // Replaces the same reference code as socmx_rollout.hip (SOC_matching/utils.py:17-128 with the per-step control evaluation,
 // method.py:58-80, models.py:233-242) for the launches utils.py:131-231 issue (control_objective / normalization_constant:
-// 65,536 rows and more per call): sigma = I, d <= 15, the constexpr-specialised default widths, more 16-row tiles than CUs.
+// 65,536 rows and more per call): d <= 15 (sigma = I, or dense without a stopping time), the constexpr-specialised default
+// widths, more 16-row tiles than CUs.
 //
 // Why.  On this chip an fp32 MFMA does not overlap with anything else the SIMD issues: VALU instructions between the MFMAs
 // of a wave cost their full time (tools/ubench/mfma_valu_mix.hip: two v_fma_f32 per v_mfma_f32_16x16x4_f32 turn 32 cycles
@@ -349,7 +350,8 @@ struct Burst32Lds {                       // float offsets behind the two tiles
   static constexpr int A = 0;             // (d, 17) OU drift
   static constexpr int P = 256;           // (d, 17) OU_quadratic running cost
   static constexpr int nz = 512;          // (32 rows, 16): the noise of the step under way
-  static constexpr int floats = 1024;
+  static constexpr int sig = 1024;        // (d, 17) a dense sigma (OU_linear)
+  static constexpr int floats = 1280;
 };
 
 // Can the two-tile stages run this architecture?  The shapes the reference's default widths give: down_0 one chunk and two
@@ -403,12 +405,15 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
   float* A_l = SD + Burst32Lds::A;
   float* P_l = SD + Burst32Lds::P;
   float* NZ = SD + Burst32Lds::nz;
+  float* SIG = SD + Burst32Lds::sig;
+  const bool dense = !a.sigma_identity;         // u = -sigma^T nabla_V, sigma u, sigma eps: three d x d products per row
   const int tile = tid >> 8, r = (tid >> 4) & 15, i = tid & 15;
   float* X0 = lds + tile * TS + tl.x0;
   for (int e = tid; e < d * d; e += NW * 64) {
     const int rr = e / d, cc = e - rr * d;
     if (is_ou) A_l[rr * ds + cc] = a.A[e];
     if (is_quad) P_l[rr * ds + cc] = a.P[e];
+    if (dense) SIG[rr * ds + cc] = a.sigma[e];
   }
   unet_load_biases(a.packed, ud, tl, lds, tid, NW * 64);
   const B32Img img = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, ud.total_floats * 4, 0x00020000), (tid & 63) * 16};
@@ -462,8 +467,20 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
     unet_forward2<NET, TS>(img, lds, carry, &gv, hook, [&]() { produce(k); });
     if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
     {
-      const float u = lane_ok ? -gv : 0.f;                              // u = -sigma^T nabla_V, sigma = I
       const float eps = injected ? eps_in : (lane_ok ? NZ[(tile * 16 + r) * 16 + i] : 0.f);
+      float u = lane_ok ? -gv : 0.f;                                    // u = -sigma^T nabla_V (method.py:68-72)
+      float su = u, se = eps;                                           // sigma u, sigma eps (utils.py:45-47)
+      if (dense) {                                                      // (sums in the order of the 16-row kernel: j ascending)
+        float s_ = 0.f;
+        for (int j = 0; j < d; ++j) s_ += SIG[j * ds + ic] * __shfl(gv, j, 16);
+        u = lane_ok ? -s_ : 0.f;
+        su = 0.f; se = 0.f;
+        for (int j = 0; j < d; ++j) {
+          su += SIG[ic * ds + j] * __shfl(u, j, 16);
+          se += SIG[ic * ds + j] * __shfl(eps, j, 16);
+        }
+        if (!lane_ok) { su = 0.f; se = 0.f; }
+      }
       float bi;
       if (is_ou) {                                                      // b = A x
         bi = 0.f;
@@ -472,7 +489,7 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
       } else {
         bi = -2.f * kap * (x * x - 1.f) * 2.f * x;                      // double_well.py:44-48
       }
-      const float upd = (bi + u) * dt + sq_ldt * eps;                   // utils.py:45-47
+      const float upd = (bi + su) * dt + sq_ldt * se;                   // utils.py:45-47
       const float xn = x + stop * upd;                                  // utils.py:48
       float xe = xn, step = dt, stop_new = 1.f;
       if (STOPPING) {                                                   // utils.py:42-44, 49-75; Phi = -x_0

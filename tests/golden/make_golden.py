@@ -325,6 +325,10 @@ FIXTURES = [
     # (4) BASELINE configs[1] at its own size (README.md:15: OU_quadratic_easy d = 2, K = 50, B = 128): the OU form of the one-row
     # rollout kernel (A x drift, x'Px running cost) and the whole loss at the batch bench.py's secondary entry times
     ("cfg1_full_ou_quadratic_easy_d2_K50_B128", "OU_quadratic_easy", 2, 50, 128, DEFAULT, 2.0, 0, dict(with_pairs=False)),
+    # (5) the README's Linear OU run at its own size (OU_linear d = 10, K = 100, B = 64, default widths): a DENSE sigma at
+    # d <= 15 -- the dense forms of the one-row rollout kernel (u = -sigma^T nabla_V, sigma u, sigma eps on the serial chain) and,
+    # through the tests that re-launch its rows in larger batches, of the 4-row / 16-row / two-tile kernels
+    ("oul10_ou_linear_d10_K100_B64", "OU_linear", 10, 100, 64, DEFAULT, 2.0, 0, dict(with_pairs=False)),
 ]
 
 

@@ -40,6 +40,7 @@ def _run(name, graph, steps, B, seed=77):
 @pytest.mark.parametrize("name,B", [("cfg1_ou_quadratic_easy_d2_K50", 128), ("cfg3_double_well_d10_K200", 64),
                                     ("cfg3_full_double_well_d10_K200_B128", 128),
                                     ("cfg1_full_ou_quadratic_easy_d2_K50_B128", 128),
+                                    ("oul10_ou_linear_d10_K100_B64", 64),      # dense sigma: the one-row kernel's dense form
                                     ("ouq20_ou_quadratic_easy_d20_K12", 40), ("tiny_molecular_dynamics_d2_stopping", 48)])
 def test_graph_replay_equals_the_eager_iteration(name, B):
     """7 iterations = 2 eager warm-up + the captured one + 4 replays, fresh Philox noise in every one; the eager Trainer on
