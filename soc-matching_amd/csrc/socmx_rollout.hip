@@ -1477,7 +1477,8 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   // operand latency, prefetch hand-over) are paid once per 32 rows.  Bit-identical results; SOCMX_BURST_ROWS=16 keeps the
   // one-tile form (developer A/B switch, tests).
   static const int burst_rows = [] { const char* e = getenv("SOCMX_BURST_ROWS"); return e ? atoi(e) : 32; }();
-  if (is_default && one_row_form && !force_slow && !(prof && stopping) && blocks > 256 && burst_rows == 32 && force_rows == 0 && rollout32_available())
+  const bool burst32 = (is_default && one_row_form) || (is_wide32 && a.sigma_identity && d >= 16 && d <= 31);
+  if (burst32 && !force_slow && !(prof && stopping) && blocks > 256 && burst_rows == 32 && force_rows == 0 && rollout32_available(a.u.in0p))
     return rollout32_launch(a, stopping, stream);
   if (const int err = ensure_max_lds(kern)) return err;
   // Few row tiles (a training batch: B / 16 workgroups on a 256-CU chip): claim the CU's whole LDS, so that no workgroup

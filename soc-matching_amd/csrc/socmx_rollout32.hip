@@ -52,8 +52,19 @@ constexpr bool kB32Roll = B32_ROLL != 0;   // request the next stage's ring slot
 //   first  down_0's two fragments (blocks wave, wave + 8), requested while the previous step's last stage multiplies
 struct Frags2 {
   f32x4 ring[8];
-  f32x4 first[2];
+  f32x4 first[4];       // (down_0: two blocks per wave x one or two 16-input chunks)
 };
+
+// The tile layout of socmx_unet.h with the split-K scratch cut to what the last stage writes here (eight waves' partial tiles of
+// up_0 + up to four of res_0): two tiles of the 16 <= d <= 31 network would not fit 160 KiB with the full-size scratch.
+constexpr int kB32ScratchFloats = 12 * 256;
+template <class NET>
+__host__ __device__ constexpr TileLayout b32_layout() {
+  TileLayout t = NET::layout(kB32Waves);
+  t.bias = t.scratch + kB32ScratchFloats;
+  t.floats = t.bias + NET::desc().bias_floats;
+  return t;
+}
 
 // The packed weight image as a buffer resource: a fragment load is buffer_load_dwordx4 with the lane's 16-byte slot in ONE
 // offset VGPR (the same for every load) and the fragment's position in the scalar offset -- no 64-bit per-lane addresses.
@@ -85,7 +96,7 @@ template <class NET, int SI>
 struct B32Stage {
   static constexpr int NW = kB32Waves;
   static constexpr UnetDesc u = NET::desc();
-  static constexpr TileLayout t = NET::layout(NW);
+  static constexpr TileLayout t = b32_layout<NET>();
   static constexpr StageDesc sd = unet_stage_desc(u, t, SI);
   static constexpr int NBLK = sd.L1.out_pad >> 4, KC1 = sd.L1.in_pad >> 4, KC2 = sd.L2.in_pad >> 4;
   static constexpr int NB = NBLK >= NW ? NBLK / NW : 1;      // blocks per active wave
@@ -103,16 +114,19 @@ __device__ __forceinline__ void request_fragment(const B32Img& Wp, int wave, int
 }
 
 // request number f of what stage SI starts from: its first GEMM-1 ring (stages 1..4), down_0's two fragments (stage 0, into
-// `first`), or the split stage's share -- chunks 2 wave, 2 wave + 1 of up_0 and chunk `wave` of res_0 (stage 5, ring[0..2])
+// `first`), or the split stage's share of up_0 and res_0 (stage 5, ring[0 .. CPW])
 template <class NET, int SI>
 __device__ __forceinline__ void b32_request(const B32Img& Wp, int wave, int lane, Frags2& fr, int f) {
   typedef B32Stage<NET, SI> S;
   if constexpr (SI == 0) {
-    if (f < 2) request_fragment<NET, 0>(Wp, wave, lane, fr.first[f], f);
+    if (f < S::NB * S::KC1) request_fragment<NET, 0>(Wp, wave, lane, fr.first[f], f);
   } else if constexpr (SI == 5) {
-    constexpr int CPW = S::KC1 / S::NW;
-    if (f < CPW) fr.ring[f] = b32_frag(Wp, S::sd.L1.w_off + (wave * CPW + f) * 256);
-    else if (f == CPW && wave < S::KC2) fr.ring[f] = b32_frag(Wp, S::sd.L2.w_off + wave * 256);
+    // wave -> (block wave % NBLK, part wave / NBLK) of up_0: chunks part CPW .. + CPW - 1; unit `wave` of res_0 = (block
+    // wave % NBLK, chunk wave / NBLK) while there are units
+    constexpr int PARTS = S::NW / S::NBLK, CPW = S::KC1 / PARTS;
+    const int blk = wave % S::NBLK, part = wave / S::NBLK;
+    if (f < CPW) fr.ring[f] = b32_frag(Wp, S::sd.L1.w_off + (blk * S::KC1 + part * CPW + f) * 256);
+    else if (f == CPW && wave < S::NBLK * S::KC2) fr.ring[f] = b32_frag(Wp, S::sd.L2.w_off + (blk * S::KC2 + part) * 256);
   } else {
     request_fragment<NET, SI>(Wp, wave, lane, fr.ring[f], f);
   }
@@ -183,14 +197,14 @@ __device__ __forceinline__ void gemm2_run(const B32Img& im, f32x4 (&acc)[2][NB],
     asm volatile("" : "+v"((fr).ring[4]), "+v"((fr).ring[5]), "+v"((fr).ring[6]), "+v"((fr).ring[7]));       \
   } while (0)
 
-// stage 0: r1 = relu(down_0 [t, x]) -- one chunk, two blocks per wave, from the `first` fragments (the ring already holds
-// stage 1's)
+// stage 0: r1 = relu(down_0 [t, x]) -- one or two chunks, two blocks per wave, from the `first` fragments (chunk kc, block j at
+// first[kc * 2 + j]; the ring already holds stage 1's)
 template <class NET, int TS>
 __device__ __forceinline__ void b32_stage0(float* lds, Frags2& fr, int wave) {
   typedef B32Stage<NET, 0> S;
-  static_assert(S::NB == 2 && S::KC1 == 1 && !S::HAS2, "down_0: one chunk, two blocks per wave");
+  static_assert(S::NB == 2 && S::KC1 <= 2 && !S::HAS2, "down_0: at most two chunks, two blocks per wave");
   const int lane = threadIdx.x & 63, row = lane & 15, g = lane >> 4;
-  asm volatile("" : "+v"(fr.first[0]), "+v"(fr.first[1]));
+  asm volatile("" : "+v"(fr.first[0]), "+v"(fr.first[1]), "+v"(fr.first[2]), "+v"(fr.first[3]));
   const float* bias_lds = lds + S::t.bias;
   f32x4 acc[2][2];
 #pragma unroll
@@ -199,7 +213,9 @@ __device__ __forceinline__ void b32_stage0(float* lds, Frags2& fr, int wave) {
     acc[1][j] = acc[0][j];
   }
   const float* xrow = lds + S::sd.x1 + row * S::sd.s1 + 4 * g;
-  mfma_chunk2<2>(acc, fr.first, *reinterpret_cast<const f32x4*>(xrow), *reinterpret_cast<const f32x4*>(xrow + TS));
+#pragma unroll
+  for (int kc = 0; kc < S::KC1; ++kc)
+    mfma_chunk2<2>(acc, &fr.first[kc * 2], *reinterpret_cast<const f32x4*>(xrow + kc * 16), *reinterpret_cast<const f32x4*>(xrow + TS + kc * 16));
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
@@ -271,37 +287,40 @@ __device__ __forceinline__ void b32_stage(const B32Img& Wp, float* lds, Frags2& 
   __syncthreads();
 }
 
-// stage 5: nabla_V = relu(up_0 o1) + res_0 [t, x], one 16-wide block: wave p multiplies chunks 2p, 2p + 1 of up_0 (wave p < KC2:
-// chunk p of res_0 as well) from the fragments in ring[0..2], partial sums through the tile's scratch, and after the barrier
-// thread (tile, e) adds up element e of its tile -- the 16-row kernel's split and order of summation (unet_stage_static).
+// stage 5: nabla_V = relu(up_0 o1) + res_0 [t, x], one or two 16-wide blocks: wave w multiplies part w / NBLK of block w % NBLK of
+// up_0 (CPW consecutive chunks; with one block: chunks 2w, 2w + 1 -- the 16-row kernel's split) and, while there are units, chunk
+// w / NBLK of block w % NBLK of res_0, from the fragments in ring[0 .. CPW]; partial sums through the tile's scratch, and after
+// the barrier thread (tile, e) adds up element e of each block of its tile in the order of unet_stage_static.
 // Requests down_0's fragments and stage 1's whole first ring for the step that follows: the ring is idle until then.
 template <class NET, int TS>
 __device__ __forceinline__ void b32_stage5(const B32Img& Wp, float* lds, Frags2& fr, int wave, float* to_reg) {
   typedef B32Stage<NET, 5> S;
-  constexpr int NW = kB32Waves, CPW = S::KC1 / NW;
-  static_assert(S::NBLK == 1 && S::KC1 % NW == 0 && CPW + 1 <= 8 && S::HAS2 && S::KC2 <= NW, "one block split over the waves");
+  constexpr int NW = kB32Waves, NBLK = S::NBLK, PARTS = NW / NBLK, CPW = S::KC1 / PARTS, UNITS2 = NBLK * S::KC2;
+  static_assert(NBLK <= 2 && S::KC1 % PARTS == 0 && CPW + 1 <= 8 && S::HAS2 && UNITS2 <= NW &&
+                (NW + UNITS2) * 256 <= kB32ScratchFloats, "one or two blocks split over the waves");
   const int lane = threadIdx.x & 63, row = lane & 15, g = lane >> 4;
+  const int blk = wave % NBLK, part = wave / NBLK;
   B32_SETTLE(fr);
   {
-    const float* xrow = lds + S::sd.x1 + row * S::sd.s1 + 4 * g + wave * (CPW * 16);
+    const float* xrow = lds + S::sd.x1 + row * S::sd.s1 + 4 * g + part * (CPW * 16);
     f32x4 acc[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
 #pragma unroll
     for (int f = 0; f < CPW; ++f)
       mfma_chunk2<1>(acc, &fr.ring[f], *reinterpret_cast<const f32x4*>(xrow + f * 16), *reinterpret_cast<const f32x4*>(xrow + TS + f * 16));
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
-      *reinterpret_cast<f32x4*>(lds + tl * TS + S::t.scratch + (wave * 16 + row) * 16 + 4 * g) = acc[tl][0];
+      *reinterpret_cast<f32x4*>(lds + tl * TS + S::t.scratch + ((blk * PARTS + part) * 16 + row) * 16 + 4 * g) = acc[tl][0];
   }
-  if (wave < S::KC2) {
-    const float* xrow = lds + S::sd.x2 + row * S::sd.s2 + 4 * g + wave * 16;
+  if (wave < UNITS2) {                                 // (unit = (block blk, chunk part) of res_0)
+    const float* xrow = lds + S::sd.x2 + row * S::sd.s2 + 4 * g + part * 16;
     f32x4 acc[2][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}}};
     mfma_chunk2<1>(acc, &fr.ring[CPW], *reinterpret_cast<const f32x4*>(xrow), *reinterpret_cast<const f32x4*>(xrow + TS));
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
-      *reinterpret_cast<f32x4*>(lds + tl * TS + S::t.scratch + NW * 256 + (wave * 16 + row) * 16 + 4 * g) = acc[tl][0];
+      *reinterpret_cast<f32x4*>(lds + tl * TS + S::t.scratch + NW * 256 + ((blk * S::KC2 + part) * 16 + row) * 16 + 4 * g) = acc[tl][0];
   }
-  b32_request<NET, 0>(Wp, wave, lane, fr, 0);
-  b32_request<NET, 0>(Wp, wave, lane, fr, 1);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) b32_request<NET, 0>(Wp, wave, lane, fr, f);
 #pragma unroll
   for (int f = 0; f < 8; ++f) b32_request<NET, 1>(Wp, wave, lane, fr, f);
   __syncthreads();
@@ -310,14 +329,17 @@ __device__ __forceinline__ void b32_stage5(const B32Img& Wp, float* lds, Frags2&
   const float* P1 = lds + tile * TS + S::t.scratch;
   const float* P2 = P1 + NW * 256;
   const int n = e & 15;
-  float v = bias_lds[S::sd.L1.b_lds + n];
 #pragma unroll
-  for (int p = 0; p < NW; ++p) v += P1[p * 256 + e];
-  v = relu_keep_nan(v);
-  float v2 = bias_lds[S::sd.L2.b_lds + n];
+  for (int b = 0; b < NBLK; ++b) {
+    float v = bias_lds[S::sd.L1.b_lds + b * 16 + n];
 #pragma unroll
-  for (int p = 0; p < S::KC2; ++p) v2 += P2[p * 256 + e];
-  *to_reg = v + v2;
+    for (int p = 0; p < PARTS; ++p) v += P1[(b * PARTS + p) * 256 + e];
+    v = relu_keep_nan(v);
+    float v2 = bias_lds[S::sd.L2.b_lds + b * 16 + n];
+#pragma unroll
+    for (int p = 0; p < S::KC2; ++p) v2 += P2[(b * S::KC2 + p) * 256 + e];
+    to_reg[b] = v + v2;
+  }
 }
 
 // the fragments the first stages of the first step start from
@@ -326,8 +348,10 @@ __device__ __forceinline__ void b32_frags_init(const B32Img& Wp, Frags2& fr, int
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int f = 0; f < 8; ++f) fr.ring[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-  request_fragment<NET, 0>(Wp, wave, lane, fr.first[0], 0);
-  request_fragment<NET, 0>(Wp, wave, lane, fr.first[1], 1);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) fr.first[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) b32_request<NET, 0>(Wp, wave, lane, fr, f);
 #pragma unroll
   for (int f = 0; f < 8; ++f) request_fragment<NET, 1>(Wp, wave, lane, fr.ring[f], f);
 }
@@ -346,12 +370,14 @@ __device__ __forceinline__ void unet_forward2(const B32Img& Wp, float* lds, Frag
   b32_stage5<NET, TS>(Wp, lds, fr, wave, gv_reg); hook(6);
 }
 
+template <int H>                          // H = 16-component halves of a row: 1 (d <= 15) or 2 (16 <= d <= 31)
 struct Burst32Lds {                       // float offsets behind the two tiles
-  static constexpr int A = 0;             // (d, 17) OU drift
-  static constexpr int P = 256;           // (d, 17) OU_quadratic running cost
-  static constexpr int nz = 512;          // (32 rows, 16): the noise of the step under way
-  static constexpr int sig = 1024;        // (d, 17) a dense sigma (OU_linear)
-  static constexpr int floats = 1280;
+  static constexpr int mat = H == 1 ? 256 : 1024;   // a (d, stride) matrix: stride 17 / 33 (socmx_sde_stride)
+  static constexpr int A = 0;             // OU drift
+  static constexpr int P = mat;           // OU_quadratic running cost
+  static constexpr int nz = 2 * mat;      // (32 rows, 16 H): the noise of the step under way
+  static constexpr int sig = nz + 512 * H;          // a dense sigma (OU_linear; d <= 15 only)
+  static constexpr int floats = sig + (H == 1 ? 256 : 0);
 };
 
 // Can the two-tile stages run this architecture?  The shapes the reference's default widths give: down_0 one chunk and two
@@ -364,16 +390,18 @@ __host__ __device__ constexpr bool b32_supported() {
   typedef B32Stage<NET, 0> S0; typedef B32Stage<NET, 1> S1; typedef B32Stage<NET, 2> S2; typedef B32Stage<NET, 3> S3;
   typedef B32Stage<NET, 4> S4; typedef B32Stage<NET, 5> S5;
   constexpr UnetDesc u = NET::desc();
-  constexpr TileLayout t = NET::layout(NW);
+  constexpr TileLayout t = b32_layout<NET>();
   auto ring_ok = [](int kc, int nb) { return kc < 8 / nb || kc % (8 / nb) == 0; };
-  if (u.in0p != 16 || u.outp != 16) return false;
-  if (!(S0::NBLK == 2 * NW && S0::KC1 == 1 && !S0::HAS2)) return false;
+  if (!((u.in0p == 16 && u.outp == 16) || (u.in0p == 32 && u.outp == 32))) return false;
+  if (!(S0::NBLK == 2 * NW && S0::KC1 <= 2 && !S0::HAS2)) return false;
   if (!(S1::NBLK == NW && !S1::HAS2 && ring_ok(S1::KC1, 1))) return false;
   if (!(S2::NBLK * 2 == NW && !S2::HAS2 && ring_ok(S2::KC1, 1))) return false;
   if (!(S3::NBLK == NW && S3::HAS2 && ring_ok(S3::KC1, 1) && ring_ok(S3::KC2, 1))) return false;
   if (!(S4::NBLK == 2 * NW && S4::HAS2 && ring_ok(S4::KC1, 2) && ring_ok(S4::KC2, 2))) return false;
-  if (!(S5::NBLK == 1 && S5::HAS2 && S5::KC1 % NW == 0 && S5::KC1 / NW + 1 <= 8 && S5::KC2 <= NW)) return false;
-  return ((((t.floats + 3) & ~3) + t.bias + Burst32Lds::floats) * 4 <= 160 * 1024);
+  if (!(S5::NBLK <= 2 && S5::HAS2 && S5::KC1 % (NW / S5::NBLK) == 0 && S5::KC1 / (NW / S5::NBLK) + 1 <= 8 &&
+        S5::NBLK * S5::KC2 <= NW && (NW + S5::NBLK * S5::KC2) * 256 <= kB32ScratchFloats))
+    return false;
+  return ((((t.floats + 3) & ~3) + t.bias + Burst32Lds<(NET::outp >> 4)>::floats) * 4 <= 160 * 1024);
 }
 
 // thread (tile = tid >> 8, r = (tid >> 4) & 15, i = tid & 15): component i of row r of that tile -- the whole SDE step of a
@@ -390,11 +418,15 @@ template <bool STOPPING, class NET, bool PROF>
 __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NW = kB32Waves;
-  constexpr TileLayout tl = NET::layout(NW);
+  constexpr TileLayout tl = b32_layout<NET>();
   constexpr UnetDesc ud = NET::desc();
   constexpr int TS = (tl.floats + 3) & ~3;
-  static_assert(NET::outp == 16 && NET::in0p == 16, "d <= 15");
-  static_assert((TS + tl.bias + Burst32Lds::floats) * 4 <= 160 * 1024, "two tiles in one CU's LDS");
+  // H: 16-component halves of a row.  16 <= d <= 31 (the 32-wide network input / output): thread (row, i) carries components i
+  // and 16 + i, so that a row is still one 16-lane group (row sums by DPP) -- every per-component statement below loops over h.
+  constexpr int H = NET::outp >> 4, CW = 16 * H;
+  typedef Burst32Lds<H> LM;
+  static_assert((NET::outp == 16 && NET::in0p == 16) || (NET::outp == 32 && NET::in0p == 32), "d <= 15 or 16 <= d <= 31");
+  static_assert((TS + tl.bias + LM::floats) * 4 <= 160 * 1024, "two tiles in one CU's LDS");
   const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
   const int tid = threadIdx.x;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
@@ -402,11 +434,11 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
   const bool is_ou = (kind == SOCMX_OU_QUADRATIC || kind == SOCMX_OU_LINEAR);
   const bool is_quad = kind == SOCMX_OU_QUADRATIC;
   float* SD = lds + TS + tl.bias;
-  float* A_l = SD + Burst32Lds::A;
-  float* P_l = SD + Burst32Lds::P;
-  float* NZ = SD + Burst32Lds::nz;
-  float* SIG = SD + Burst32Lds::sig;
-  const bool dense = !a.sigma_identity;         // u = -sigma^T nabla_V, sigma u, sigma eps: three d x d products per row
+  float* A_l = SD + LM::A;
+  float* P_l = SD + LM::P;
+  float* NZ = SD + LM::nz;
+  float* SIG = SD + LM::sig;
+  const bool dense = H == 1 && !a.sigma_identity;   // u = -sigma^T nabla_V, sigma u, sigma eps: three d x d products per row
   const int tile = tid >> 8, r = (tid >> 4) & 15, i = tid & 15;
   float* X0 = lds + tile * TS + tl.x0;
   for (int e = tid; e < d * d; e += NW * 64) {
@@ -420,30 +452,52 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
   Frags2 carry;
   b32_frags_init<NET>(img, carry, __builtin_amdgcn_readfirstlane(tid >> 6));
 
-  const int ic = min(i, d - 1);
-  const bool lane_ok = i < d;
   const int grow = blockIdx.x * 32 + tile * 16 + r;
   const bool traj = a.states != nullptr;        // costs-only launches (evaluation bursts) pass no trajectory buffers
-  const bool store = lane_ok && grow < B && traj;
-  const bool store0 = i == 0 && grow < B && traj;
-  const size_t rowoff = (size_t)grow * d + i;
+  const bool row_live = grow < B;
+  const bool store0 = i == 0 && row_live && traj;
+  const size_t rowbase = (size_t)grow * d;
   auto gsum = [](float v) { return row16_sum(v); };
-  float x = lane_ok ? a.x0[(size_t)min(grow, B - 1) * d + i] : 0.f;
-  const float kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
+  int comp[H], ic[H];
+  bool lane_ok[H], store[H];
+  float x[H], kap[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    comp[h] = i + 16 * h;
+    ic[h] = min(comp[h], d - 1);
+    lane_ok[h] = comp[h] < d;
+    store[h] = lane_ok[h] && row_live && traj;
+    x[h] = lane_ok[h] ? a.x0[(size_t)min(grow, B - 1) * d + comp[h]] : 0.f;
+    kap[h] = (lane_ok[h] && !is_ou) ? a.kappa[comp[h]] : 0.f;
+    if (store[h]) a.states[rowbase + comp[h]] = x[h];
+  }
+  // component j of this row's vector v (any j < d): the 16-lane group's lane j & 15, half j >> 4
+  auto comp_of = [&](const float (&v)[H], int j) -> float {
+    float t = __shfl(v[0], j & 15, 16);
+    if constexpr (H == 2) { const float t1 = __shfl(v[1], j & 15, 16); t = (j & 16) ? t1 : t; }
+    return t;
+  };
   float stop = 1.f, lpd = 0.f, lps = 0.f;
-  if (store) a.states[rowoff] = x;
   if (store0) a.stop_ind[grow] = 1.f;
-  if (i < 15) X0[r * tl.s0 + 1 + i] = x;        // columns 1..15; lanes i >= d hold x = 0
-  if (i == 0) X0[r * tl.s0] = a.ts[0];
+  auto put_input = [&](float t) {                // the network input [t, x, 0..]: column 1 + component (lanes past d hold x = 0)
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (1 + comp[h] < NET::in0p) X0[r * tl.s0 + 1 + comp[h]] = x[h];
+    if (i == 0) X0[r * tl.s0] = t;
+  };
+  put_input(a.ts[0]);
   const bool injected = a.noise_in != nullptr;
-  auto produce = [&](int k) {                   // waves 4..7 (pairs past d are never read)
-    const int p = tid - 256, prow = p >> 3, q = p & 7;
-    if (!injected && 2 * q < d) {
-      uint32_t wa, wb;
-      philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + blockIdx.x * 32 + prow), (uint32_t)k, q >> 1, q & 1, wa, wb);
-      float z0, z1;
-      box_muller_pair(wa, wb, z0, z1);
-      *reinterpret_cast<float2*>(NZ + prow * 16 + 2 * q) = make_float2(z0, z1);
+  auto produce = [&](int k) {                   // waves 4..7: thread p draws pairs p, p + 256 (H = 2) of the 32 x 8 H (pairs past d are never read)
+#pragma unroll
+    for (int rep = 0; rep < H; ++rep) {
+      const int unit = tid - 256 + 256 * rep, prow = unit / (8 * H), q = unit % (8 * H);
+      if (!injected && 2 * q < d) {
+        uint32_t wa, wb;
+        philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + blockIdx.x * 32 + prow), (uint32_t)k, q >> 1, q & 1, wa, wb);
+        float z0, z1;
+        box_muller_pair(wa, wb, z0, z1);
+        *reinterpret_cast<float2*>(NZ + prow * CW + 2 * q) = make_float2(z0, z1);
+      }
     }
   };
   long long acc_prof[16];
@@ -462,69 +516,109 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
     const float sq_ldt = sqrtf(a.lmbd * dt);  // utils.py:47
     __syncthreads();
     hook(0);
-    const float eps_in = (injected && lane_ok) ? a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + i] : 0.f;
-    float gv = 0.f;                           // nabla_V[r][i] of this thread's tile
-    unet_forward2<NET, TS>(img, lds, carry, &gv, hook, [&]() { produce(k); });
-    if (store && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowoff] = gv;
+    float eps[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      eps[h] = (injected && lane_ok[h]) ? a.noise_in[((size_t)k * B + min(grow, B - 1)) * d + comp[h]] : 0.f;
+    float gv[H];                              // nabla_V[r][comp] of this thread's tile
+#pragma unroll
+    for (int h = 0; h < H; ++h) gv[h] = 0.f;
+    unet_forward2<NET, TS>(img, lds, carry, gv, hook, [&]() { produce(k); });
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (store[h] && a.nabla_v) a.nabla_v[(size_t)k * B * d + rowbase + comp[h]] = gv[h];
     {
-      const float eps = injected ? eps_in : (lane_ok ? NZ[(tile * 16 + r) * 16 + i] : 0.f);
-      float u = lane_ok ? -gv : 0.f;                                    // u = -sigma^T nabla_V (method.py:68-72)
-      float su = u, se = eps;                                           // sigma u, sigma eps (utils.py:45-47)
-      if (dense) {                                                      // (sums in the order of the 16-row kernel: j ascending)
-        float s_ = 0.f;
-        for (int j = 0; j < d; ++j) s_ += SIG[j * ds + ic] * __shfl(gv, j, 16);
-        u = lane_ok ? -s_ : 0.f;
-        su = 0.f; se = 0.f;
-        for (int j = 0; j < d; ++j) {
-          su += SIG[ic * ds + j] * __shfl(u, j, 16);
-          se += SIG[ic * ds + j] * __shfl(eps, j, 16);
+      float u[H], su[H], se[H], bi[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        if (!injected) eps[h] = lane_ok[h] ? NZ[(tile * 16 + r) * CW + comp[h]] : 0.f;
+        u[h] = lane_ok[h] ? -gv[h] : 0.f;                               // u = -sigma^T nabla_V (method.py:68-72)
+        su[h] = u[h]; se[h] = eps[h];                                   // sigma u, sigma eps (utils.py:45-47)
+      }
+      if constexpr (H == 1) {
+        if (dense) {                                                    // (sums in the order of the 16-row kernel: j ascending)
+          float s_ = 0.f;
+          for (int j = 0; j < d; ++j) s_ += SIG[j * ds + ic[0]] * __shfl(gv[0], j, 16);
+          u[0] = lane_ok[0] ? -s_ : 0.f;
+          float a_ = 0.f, b_ = 0.f;
+          for (int j = 0; j < d; ++j) {
+            a_ += SIG[ic[0] * ds + j] * __shfl(u[0], j, 16);
+            b_ += SIG[ic[0] * ds + j] * __shfl(eps[0], j, 16);
+          }
+          su[0] = lane_ok[0] ? a_ : 0.f;
+          se[0] = lane_ok[0] ? b_ : 0.f;
         }
-        if (!lane_ok) { su = 0.f; se = 0.f; }
       }
-      float bi;
       if (is_ou) {                                                      // b = A x
-        bi = 0.f;
-        for (int j = 0; j < d; ++j) bi += A_l[ic * ds + j] * __shfl(x, j, 16);
-        if (!lane_ok) bi = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) bi[h] = 0.f;
+        for (int j = 0; j < d; ++j) {
+          const float xj = comp_of(x, j);
+#pragma unroll
+          for (int h = 0; h < H; ++h) bi[h] += A_l[ic[h] * ds + j] * xj;
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) bi[h] = lane_ok[h] ? bi[h] : 0.f;
       } else {
-        bi = -2.f * kap * (x * x - 1.f) * 2.f * x;                      // double_well.py:44-48
+#pragma unroll
+        for (int h = 0; h < H; ++h) bi[h] = -2.f * kap[h] * (x[h] * x[h] - 1.f) * 2.f * x[h];      // double_well.py:44-48
       }
-      const float upd = (bi + su) * dt + sq_ldt * se;                   // utils.py:45-47
-      const float xn = x + stop * upd;                                  // utils.py:48
-      float xe = xn, step = dt, stop_new = 1.f;
+      float upd[H], xn[H], xe[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        upd[h] = (bi[h] + su[h]) * dt + sq_ldt * se[h];                 // utils.py:45-47
+        xn[h] = x[h] + stop * upd[h];                                   // utils.py:48
+        xe[h] = xn[h];
+      }
+      float step = dt, stop_new = 1.f;
       if (STOPPING) {                                                   // utils.py:42-44, 49-75; Phi = -x_0
-        const float phi_b = -__shfl(x, 0, 16), phi_a = -__shfl(xn, 0, 16);
+        const float phi_b = -__shfl(x[0], 0, 16), phi_a = -__shfl(xn[0], 0, 16);
         const float ns = (phi_b > 0.f && phi_a > 0.f) ? 1.f : 0.f;
         const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
         const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
-        xe = js * (x + fr * stop * upd) + (1.f - js) * xn;
+#pragma unroll
+        for (int h = 0; h < H; ++h) xe[h] = js * (x[h] + fr * stop * upd[h]) + (1.f - js) * xn[h];
         step = js * (fr * fr) * dt + ns * dt;                           // step_fraction squared (utils.py:70-72)
-        stop_new = (-__shfl(xe, 0, 16) > 0.f) ? 1.f : 0.f;
+        stop_new = (-__shfl(xe[0], 0, 16) > 0.f) ? 1.f : 0.f;
       }
       float f = 0.f;                                                    // f at the NEW state, OLD time (utils.py:92-96)
       if (kind == SOCMX_OU_QUADRATIC) {
-        float px = 0.f;
-        for (int j = 0; j < d; ++j) px += P_l[ic * ds + j] * __shfl(xe, j, 16);
-        f = gsum(lane_ok ? xe * px : 0.f);
+        float px[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) px[h] = 0.f;
+        for (int j = 0; j < d; ++j) {
+          const float xj = comp_of(xe, j);
+#pragma unroll
+          for (int h = 0; h < H; ++h) px[h] += P_l[ic[h] * ds + j] * xj;
+        }
+        // (H = 1: the very expressions of the 16-row kernel -- the compiler's multiply-add contraction follows the shape of the
+        //  source, and the two kernels are compared bit for bit)
+        float part = lane_ok[0] ? xe[0] * px[0] : 0.f;
+        if constexpr (H == 2) part += lane_ok[1] ? xe[1] * px[1] : 0.f;
+        f = gsum(part);
       } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
         f = 1.f;
       }
-      const float uu = gsum(u * u), ue = gsum(u * eps);
+      float puu = u[0] * u[0], pue = u[0] * eps[0];
+      if constexpr (H == 2) { puu += u[1] * u[1]; pue += u[1] * eps[1]; }
+      const float uu = gsum(puu), ue = gsum(pue);
       lpd = lpd + step / a.lmbd * (-f - 0.5f * uu);
       lps = lps + sqrtf(step / a.lmbd) * (-ue);
-      if (store) {
-        a.controls[(size_t)k * B * d + rowoff] = u;
-        a.noises[(size_t)k * B * d + rowoff] = eps;
-        a.states[(size_t)(k + 1) * B * d + rowoff] = xe;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        if (store[h]) {
+          a.controls[(size_t)k * B * d + rowbase + comp[h]] = u[h];
+          a.noises[(size_t)k * B * d + rowbase + comp[h]] = eps[h];
+          a.states[(size_t)(k + 1) * B * d + rowbase + comp[h]] = xe[h];
+        }
+        x[h] = lane_ok[h] ? xe[h] : 0.f;
       }
       if (store0) {
         a.frac[(size_t)k * B + grow] = step;
         a.stop_ind[(size_t)(k + 1) * B + grow] = STOPPING ? stop_new : 1.f;
       }
-      x = lane_ok ? xe : 0.f;
       if (STOPPING) stop = stop_new;
-      if (i < 15) X0[r * tl.s0 + 1 + i] = x;                            // next step's network input [t, x, 0..]
-      if (i == 0) X0[r * tl.s0] = t1;
+      put_input(t1);                                                    // next step's network input [t, x, 0..]
     }
     hook(7);
   }
@@ -532,20 +626,39 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
     for (int sl = 0; sl < 16; ++sl) a.prof[(size_t)blockIdx.x * 64 + sl] = acc_prof[sl];
   if (a.nabla_v) {                        // nabla_V(T, X_K): X0 already holds [t_K, x_K]
     __syncthreads();
-    float gv = 0.f;
-    unet_forward2<NET, TS>(img, lds, carry, &gv, [](int) {}, []() {});
-    if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
+    float gv[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) gv[h] = 0.f;
+    unet_forward2<NET, TS>(img, lds, carry, gv, [](int) {}, []() {});
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      if (store[h]) a.nabla_v[(size_t)K * B * d + rowbase + comp[h]] = gv[h];
   }
   float gval = 0.f;                       // terminal cost (utils.py:101)
   if (kind == SOCMX_OU_QUADRATIC) {
-    float qx = 0.f;
-    for (int j = 0; j < d; ++j) qx += a.Q[ic * d + j] * __shfl(x, j, 16);
-    gval = gsum(lane_ok ? x * qx : 0.f);
+    float qx[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) qx[h] = 0.f;
+    for (int j = 0; j < d; ++j) {
+      const float xj = comp_of(x, j);
+#pragma unroll
+      for (int h = 0; h < H; ++h) qx[h] += a.Q[ic[h] * d + j] * xj;
+    }
+    float part = lane_ok[0] ? x[0] * qx[0] : 0.f;
+    if constexpr (H == 2) part += lane_ok[1] ? x[1] * qx[1] : 0.f;
+    gval = gsum(part);
   } else if (kind == SOCMX_OU_LINEAR) {
-    gval = gsum(lane_ok ? a.omega[ic] * x : 0.f);
+    float part = lane_ok[0] ? a.omega[ic[0]] * x[0] : 0.f;
+    if constexpr (H == 2) part += lane_ok[1] ? a.omega[ic[1]] * x[1] : 0.f;
+    gval = gsum(part);
   } else if (kind == SOCMX_DOUBLE_WELL) {
-    const float q = x * x - 1.f;
-    gval = gsum(lane_ok ? a.nu[ic] * (q * q) : 0.f);
+    const float q0 = x[0] * x[0] - 1.f;
+    float part = lane_ok[0] ? a.nu[ic[0]] * (q0 * q0) : 0.f;
+    if constexpr (H == 2) {
+      const float q1 = x[1] * x[1] - 1.f;
+      part += lane_ok[1] ? a.nu[ic[1]] * (q1 * q1) : 0.f;
+    }
+    gval = gsum(part);
   }
   if (i == 0 && grow < B) {
     a.lpd[grow] = lpd;
@@ -558,9 +671,9 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
 template <class NET>
 static int rollout32_launch_t(const RolloutArgs& a, bool stopping, void* stream) {
   if constexpr (b32_supported<NET>()) {
-    constexpr TileLayout tl = NET::layout(kB32Waves);
+    constexpr TileLayout tl = b32_layout<NET>();
     constexpr int TS = (tl.floats + 3) & ~3;
-    const size_t lds_bytes = (size_t)(TS + tl.bias + Burst32Lds::floats) * sizeof(float);
+    const size_t lds_bytes = (size_t)(TS + tl.bias + Burst32Lds<(NET::outp >> 4)>::floats) * sizeof(float);
     void (*k)(const RolloutArgs) = a.prof ? rollout32_kernel<false, NET, true>
                                  : stopping ? rollout32_kernel<true, NET, false> : rollout32_kernel<false, NET, false>;
     if (a.prof && stopping) return SOCMX_E_DIM;       // (the phase table is taken on the settings without a stopping time)
@@ -571,7 +684,10 @@ static int rollout32_launch_t(const RolloutArgs& a, bool stopping, void* stream)
   }
 }
 
-bool rollout32_available() { return b32_supported<DefaultNet>(); }
-int rollout32_launch(const RolloutArgs& a, bool stopping, void* stream) { return rollout32_launch_t<DefaultNet>(a, stopping, stream); }
+// in0p = 16: d <= 15 (sigma = I or dense); in0p = 32: 16 <= d <= 31 with sigma = I
+bool rollout32_available(int in0p) { return in0p == 16 ? b32_supported<DefaultNet>() : in0p == 32 ? b32_supported<Wide32Net>() : false; }
+int rollout32_launch(const RolloutArgs& a, bool stopping, void* stream) {
+  return a.u.in0p == 16 ? rollout32_launch_t<DefaultNet>(a, stopping, stream) : rollout32_launch_t<Wide32Net>(a, stopping, stream);
+}
 
 }  // namespace socmx
