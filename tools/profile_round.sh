@@ -59,6 +59,7 @@ python3 tools/quick_bench.py cfg3 cfg2 ouq20 ouh20 oul10 cfg5r cfg4r burst 2>&1 
 bash tools/prof_any.sh burst32 tools/quick_bench.py burst --phases > $R/burst32.txt 2>&1
 bash tools/pmc_any.sh "rollout32_kernel" b32 python3 tools/quick_bench.py burst > $R/burst32_pmc.txt 2>&1
 python3 tools/burst_ab.py 2>&1 | grep -v amdgpu.ids > $R/burst_ab.txt
+python3 tools/burst_settings.py 2>&1 | grep -v amdgpu.ids > $R/burst_settings.txt
 (hipcc -O3 --offload-arch=gfx950 -o /tmp/mvm tools/ubench/mfma_valu_mix.hip 2>/dev/null && timeout 120 /tmp/mvm) > $R/mfma_valu_mix.txt 2>&1
 rm -rf gpurun_out/pmc_b32
 rm -rf $OUT gpurun_out/k2prof gpurun_out/iterprof gpurun_out/prof gpurun_out/pmc_k3
