@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void socm_prep_kernel(const PrepArgs a) {
 // conflicts); thread = (row, quarter of the output columns), so sigma^-T / A / P are wave-uniform scalar loads.
 // Outputs go back through LDS and leave as one coalesced run.  (The per-thread form above walks d*d strided
 // global reads per row: 27 ms at d = 64, K = 400, B = 512.)
-__device__ __forceinline__ void socm_prep_terminal_rows(const PrepArgs& a, int m);
+__device__ __forceinline__ void socm_prep_terminal_rows(const PrepArgs& a, int e);
 __global__ __launch_bounds__(256) void socm_prep_tiled_kernel(const PrepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // (the workgroups behind the row tiles form the terminal rows' nabla_g: one launch less on the iteration's critical path)
@@ -251,23 +251,24 @@ __global__ __launch_bounds__(256) void socm_prep_tiled_kernel(const PrepArgs a) 
 }
 
 // terminal rows only (j == K): gT = nabla_g(X_K); thread per batch row
-__device__ __forceinline__ void socm_prep_terminal_rows(const PrepArgs& a, int m) {
+// nabla_g of the terminal rows: thread e = (row m, component l) -- one thread per ROW walked d * d strided reads in a chain
+// (33 us at d = 20, B = 128 on the critical path of every iteration; 128 threads busy)
+__device__ __forceinline__ void socm_prep_terminal_rows(const PrepArgs& a, int e) {
   const int d = a.d, B = a.B, K = a.K;
+  const int m = e / d, l = e - m * d;
   if (m >= B) return;
   const float* x = a.states + ((size_t)K * B + m) * d;
-  for (int l = 0; l < d; ++l) {
-    float g = 0.f;
-    if (a.kind == SOCMX_OU_QUADRATIC) {
-      for (int c = 0; c < d; ++c) g += a.Q[l * d + c] * x[c];
-      g *= 2.f;
-    } else if (a.kind == SOCMX_OU_LINEAR) {
-      g = a.omega[l];
-    } else if (a.kind == SOCMX_DOUBLE_WELL) {
-      g = 2.f * a.nu[l] * (x[l] * x[l] - 1.f) * 2.f * x[l];
-    }
-    a.gT[(size_t)m * d + l] = g;
-    if (a.gTT) a.gTT[(size_t)l * B + m] = g;
+  float g = 0.f;
+  if (a.kind == SOCMX_OU_QUADRATIC) {
+    for (int c = 0; c < d; ++c) g += a.Q[l * d + c] * x[c];
+    g *= 2.f;
+  } else if (a.kind == SOCMX_OU_LINEAR) {
+    g = a.omega[l];
+  } else if (a.kind == SOCMX_DOUBLE_WELL) {
+    g = 2.f * a.nu[l] * (x[l] * x[l] - 1.f) * 2.f * x[l];
   }
+  a.gT[(size_t)m * d + l] = g;
+  if (a.gTT) a.gTT[(size_t)l * B + m] = g;
 }
 __global__ __launch_bounds__(256) void socm_prep_terminal_kernel(const PrepArgs a) {
   socm_prep_terminal_rows(a, blockIdx.x * blockDim.x + threadIdx.x);
@@ -2145,13 +2146,13 @@ extern "C" int socmx_socm_prep_f32(const socmx_problem* pb, const float* ts, int
     const int64_t tiles = ((int64_t)K * B + 15) / 16;
     const unsigned blocks = (unsigned)std::min<int64_t>((tiles + 3) / 4, 1024);
     if (const int err = launch(socm_prep_mfma_kernel, dim3(blocks), dim3(256), 0, stream, a)) return err;
-    return launch(socm_prep_terminal_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
+    return launch(socm_prep_terminal_kernel, dim3((B * pb->d + 255) / 256), dim3(256), 0, stream, a);
   }
   if (pb->d <= 128 && tile_lds <= 160 * 1024) {
     if (const int err = ensure_max_lds(socm_prep_tiled_kernel)) return err;
     const int64_t rows = (int64_t)K * B;
     a.n_tiled_blocks = (int)((rows + 63) / 64);
-    return launch(socm_prep_tiled_kernel, dim3((unsigned)(a.n_tiled_blocks + (B + 255) / 256)), dim3(256), tile_lds, stream, a);
+    return launch(socm_prep_tiled_kernel, dim3((unsigned)(a.n_tiled_blocks + (B * pb->d + 255) / 256)), dim3(256), tile_lds, stream, a);
   }
   const int64_t n = (int64_t)(K + 1) * B;
   return launch(socm_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);

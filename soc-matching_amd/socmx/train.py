@@ -8,6 +8,7 @@ the reference: wall clock from before `.loss()` to after `optimizer.step(); zero
 import time
 
 import numpy as np
+import os
 import torch
 
 
@@ -400,7 +401,10 @@ class Trainer:
             return net, dnet
 
         main = torch.cuda.current_stream(dev)
-        side = solver._side_stream(dev) if Np >= 4096 else None
+        # (inside a captured graph a second stream costs nothing on the host: the pair-grid network's branch runs beside the rollout at
+        #  every grid size -- the eager iteration keeps its 4,096-pair threshold, solver.py.  configs[1]: 0.40 -> 0.33 ms, soc.yaml's
+        #  default d = 20: 0.73 -> 0.62 ms)
+        side = solver._side_stream(dev)
         state0 = solver.x0.repeat(B, 1)
         noise_in, solver.noise_in = solver.noise_in, None
         if side is not None:
