@@ -231,7 +231,6 @@ class Trainer:
         solver, D = self.solver, self._graph_state()
         out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
                           use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)), **loss_kwargs)
-        norm_before = D["norm"].clone()
         if self.algorithm in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
             loss = out[0] / D["norm"]                                    # main.py:313-320
         elif self.algorithm == "variance":
@@ -245,29 +244,41 @@ class Trainer:
         params = [p for g in self.optimizer.param_groups for p in g["params"]]
         for p, g in zip(params, torch.autograd.grad(loss, params, allow_unused=True)):
             p.grad = g
-        zero = torch.zeros((), device=D["norm"].device)
-        gn = ema_gn = gne = zero
+        # Scalar bookkeeping on the device by socmx_iteration_scalars_f32 (two one-thread launches) instead of ~25 elementwise
+        # torch launches per iteration (the (A, B) coefficients, two compute_EMA evaluations with torch.where, the counter, the
+        # stack of the outputs): the README's molecular_dynamics iteration is launch-bound -- 119 launches, 1.21 ms.
+        from . import _lib
+        Lh, f = _lib.lib(), _lib.ptr
+        dev = D["norm"].device
+        gn = gne = None
         if self.grad_telemetry:                                          # main.py:325-345
             with torch.no_grad():
                 grads = [p.grad for p in solver.neural_sde.nabla_V.parameters()]
-                sq = lambda ts: torch.stack(torch._foreach_norm(ts)).square().sum()
+                sq = lambda ts: torch.stack(torch._foreach_norm(ts)).square().sum().reshape(1)
                 gn = sq(grads)
-                itr, c = D["itr"], 0.01
-                warm = float(int(np.floor(1 / c)))
-                a = torch.where(itr == 0, zero, torch.where(itr <= warm, itr / (itr + 1), zero + (1 - c)))
-                b = torch.where(itr == 0, zero + 1, torch.where(itr <= warm, 1 / (itr + 1), zero + c))
-                torch._foreach_mul_(D["ema_grad"], a)
-                torch._foreach_add_(D["ema_grad"], torch._foreach_mul(grads, b))
-                D["ema_gn"].copy_(self._ema_dev(gn, D["ema_gn"], c, itr))
-                ema_gn, gne = D["ema_gn"], sq(D["ema_grad"])
+                with _lib.on_device(dev):
+                    _lib.check(Lh.socmx_iteration_scalars_f32(0, f(D["itr1"]), None, None, None, None, None, None, None,
+                                                              self.coeff, 0.01, f(D["ab"]), None, _lib.stream_ptr(dev)),
+                               "socmx_iteration_scalars_f32")
+                torch._foreach_mul_(D["ema_grad"], D["ab"][0])
+                torch._foreach_add_(D["ema_grad"], torch._foreach_mul(grads, D["ab"][1]))
+                gne = sq(D["ema_grad"])
         with torch.no_grad():
             self.optimizer.step()                                        # main.py:347-349
             self.optimizer.zero_grad(set_to_none=True)
-            D["norm"].copy_(self._ema_dev(out[5].detach(), D["norm"], self.coeff, D["itr"]))     # main.py:354-359
-            D["itr"] += 1
-            extra = [out[1].detach().reshape(())] if out[1] is not None else []
-            return torch.stack([loss.detach().reshape(()), out[5].detach().reshape(()), out[6].detach().reshape(()),
-                                gn.reshape(()), ema_gn.reshape(()), gne.reshape(()), norm_before] + extra)
+            f32 = lambda t: t.detach().to(torch.float32).reshape(1).contiguous()
+            w_mean, w_std, obj = f32(out[5]), f32(out[6]), f32(out[0])
+            vals = torch.empty(7, dtype=torch.float32, device=dev)
+            with _lib.on_device(dev):                                    # main.py:313-320, 354-359: loss / normaliser, EMAs, counter
+                _lib.check(Lh.socmx_iteration_scalars_f32(
+                    1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(w_mean), f(w_std), f(obj),
+                    f(gn) if gn is not None else None, f(gne) if gne is not None else None, self.coeff, 0.01, None, f(vals),
+                    _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
+            if self.algorithm not in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
+                vals[0:1].copy_(loss.detach().reshape(1))                # (another scaling of the objective: main.py:321-322)
+            if out[1] is not None:
+                vals = torch.cat([vals, out[1].detach().reshape(1).to(torch.float32)])
+            return vals
 
     # ---- the iteration without autograd (plain SOCM, every network on the hand-written kernels) -----------------------
     # main stream: rollout (+ nabla_V values) -> weights -> operands -> contraction forward (objective, G) -> control-network
