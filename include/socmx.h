@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 141 /* 0.1.4: + the one-row rollout kernel for training-size batches (socmx_rollout1.hip); socmx_rollout_extra.flags */
+#define SOCMX_VERSION 142 /* 0.1.4: + the one-row rollout kernel for training-size batches (socmx_rollout1.hip); socmx_rollout_extra.flags */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -220,6 +220,13 @@ int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, co
  *            evaluation, a user calling stochastic_trajectories -- it spreads over 4-row tiles (4.9 ms).
  */
 #define SOCMX_ROLLOUT_SHARES_CHIP 1u
+/*            SOCMX_ROLLOUT_ADVANCES_KEY: `key` is device uint64[3] = {seed, offset, ticket} and the LAUNCH ITSELF performs
+ *            key[1] += 1 -- every workgroup takes a ticket once it has read (seed, offset), and the one that draws the last ticket
+ *            stores offset + 1 and clears the ticket -- instead of a socmx_philox_advance node behind it (one launch and its
+ *            dependency gap less on a captured iteration's critical path).  ticket must be 0 before the first such launch; the
+ *            launch leaves it 0.  Not to be combined with another launch reading the same key concurrently.
+ */
+#define SOCMX_ROLLOUT_ADVANCES_KEY 2u
 typedef struct socmx_rollout_extra {
   const uint64_t* key;
   float* nabla_v;

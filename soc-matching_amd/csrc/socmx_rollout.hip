@@ -87,7 +87,8 @@ template <int NW, bool STOPPING, bool PROF, class NET, bool FAST>
 __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // Philox key: by value, or read from device memory (uniform scalar loads, once per workgroup)
-  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+  uint64_t key_seed, key_offset;
+  rollout_key(a, key_seed, key_offset);
   constexpr bool kStatic = !std::is_same<NET, DynamicNet>::value;
   TileLayout tl;
   UnetDesc ud;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
 
   for (float* z = sig + tid; z < NZ + 512; z += nthr) *z = 0.f;   // (the padding columns stay zero for good)
   __syncthreads();
+  rollout_key_advance(a, key_offset);
   for (int e = tid; e < d * d; e += nthr) {
     const int r = e / d, c = e - r * d;
     sig[r * ds + c] = a.sigma[e];
@@ -752,7 +754,8 @@ template <int NW, bool STOPPING, class NET>
 __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(NET::outp == 16 && NW >= 3, "4-row tile: d <= 15, at least three waves");
-  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+  uint64_t key_seed, key_offset;
+  rollout_key(a, key_seed, key_offset);
   constexpr TileLayout tl = NET::layout4(NW);
   constexpr UnetDesc ud = NET::desc();
   const int tid = threadIdx.x;
@@ -779,6 +782,7 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
     for (int e = tid; e < res_floats / 4; e += nthr) dst[e] = src[e];
   }
   __syncthreads();
+  rollout_key_advance(a, key_offset);
   for (int e = tid; e < d * d; e += nthr) {
     const int r = e / d, c = e - r * d;
     if (is_ou) A_l[r * ds + c] = a.A[e];
@@ -982,7 +986,8 @@ template <int NW, bool STOPPING, class NET>
 __global__ __launch_bounds__(NW * 64) void rollout4g_kernel(const RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(NW == 8, "four integrating waves, four noise waves");
-  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+  uint64_t key_seed, key_offset;
+  rollout_key(a, key_seed, key_offset);
   constexpr TileLayout tl = NET::layout4(NW);
   constexpr UnetDesc ud = NET::desc();
   constexpr int RS = kRow4Stride;
@@ -1007,6 +1012,7 @@ __global__ __launch_bounds__(NW * 64) void rollout4g_kernel(const RolloutArgs a)
   float* E1 = E0 + 4 * RS;                              // ... and of the odd ones (drawn one step ahead)
   for (float* z = lds + tid; z < E1 + 4 * RS; z += nthr) *z = 0.f;
   __syncthreads();
+  rollout_key_advance(a, key_offset);
   for (int e = tid; e < d * d; e += nthr) {
     const int r = e / d, c = e - r * d;
     if (!sid) sig[r * ds + c] = a.sigma[e];
@@ -1243,7 +1249,7 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
 #define SOCMX_STR2(x) #x
 #define SOCMX_STR(x) SOCMX_STR2(x)
   static const char msg[] =
-      "socmx 0.1.4; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
+      "socmx 0.1.5; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
       "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches; one row per workgroup on v_fmac_f32_dpp for B <= 256, sigma = I, d <= 15); "
       "Philox4x32-10 noise; static_hdims=" SOCMX_STR(SOCMX_H0P) "," SOCMX_STR(SOCMX_H1P) "," SOCMX_STR(SOCMX_H2P) "; "
       "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target; "
@@ -1370,6 +1376,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   fill_wave_work(a.prog, nw);
   a.kind = pb->kind; a.d = d; a.B = B; a.K = K; a.lmbd = lmbd;
   a.seed = seed; a.offset = offset; a.key_dev = key_dev; a.row0 = row0;
+  a.advance_key = (key_dev && (flags & SOCMX_ROLLOUT_ADVANCES_KEY)) ? 1 : 0;
   a.sigma_identity = (pb->flags & SOCMX_SIGMA_IDENTITY) ? 1 : 0;
   a.packed = packed_unet;
   a.sigma = pb->sigma; a.A = pb->A; a.P = pb->P; a.Q = pb->Q; a.omega = pb->omega; a.kappa = pb->kappa; a.nu = pb->nu;

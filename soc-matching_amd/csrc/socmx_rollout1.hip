@@ -303,7 +303,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   const int grow = blockIdx.x;
   const int g = lane >> 4, n = lane & 15;
   const uint32_t loff = lane * 16;
-  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+  uint64_t key_seed, key_offset;
+  rollout_key(a, key_seed, key_offset);
 
 #ifdef SOCMX_R1_PROF
   long long prof_acc[16] = {0}, prof_last = 0;
@@ -754,6 +755,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   words(0);
   if constexpr (CLS == 0) first_layer(a.ts[0]);
   __syncthreads();
+  if constexpr (CLS == 0) rollout_key_advance(a, key_offset);     // (every wave read the key in front of this barrier)
   draws(0);
   words(1);
   step_scalars(0);

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
   typedef Burst32Lds<H> LM;
   static_assert((NET::outp == 16 && NET::in0p == 16) || (NET::outp == 32 && NET::in0p == 32), "d <= 15 or 16 <= d <= 31");
   static_assert((TS + tl.bias + LM::floats) * 4 <= 160 * 1024, "two tiles in one CU's LDS");
-  const uint64_t key_seed = a.key_dev ? a.key_dev[0] : a.seed, key_offset = a.key_dev ? a.key_dev[1] : a.offset;
+  uint64_t key_seed, key_offset;
+  rollout_key(a, key_seed, key_offset);
   const int tid = threadIdx.x;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
   const int ds = socmx_sde_stride(d);
@@ -486,6 +487,8 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
     if (i == 0) X0[r * tl.s0] = t;
   };
   put_input(a.ts[0]);
+  __syncthreads();
+  rollout_key_advance(a, key_offset);           // (every thread read the key above)
   const bool injected = a.noise_in != nullptr;
   auto produce = [&](int k) {                   // waves 4..7: thread p draws pairs p, p + 256 (H = 2) of the 32 x 8 H (pairs past d are never read)
 #pragma unroll

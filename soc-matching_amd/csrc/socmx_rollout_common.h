@@ -18,6 +18,7 @@ struct RolloutArgs {
   float lmbd;
   uint64_t seed, offset;
   const uint64_t* key_dev;   // device {seed, offset} (socmx_rollout_ex_f32: a replayed hipGraph draws fresh noise) or NULL
+  int advance_key;           // SOCMX_ROLLOUT_ADVANCES_KEY: key_dev has a third word (ticket) and the launch adds 1 to the offset
   int64_t row0;
   const float* packed;
   const float *sigma, *A, *P, *Q, *omega, *kappa, *nu;
@@ -31,6 +32,29 @@ struct RolloutArgs {
 };
 
 __host__ __device__ constexpr int socmx_sde_stride(int d) { return ((d + 15) & ~15) + 1; }
+
+#if defined(__HIPCC__)
+// The Philox key of a launch: by value, or read from device memory.  With SOCMX_ROLLOUT_ADVANCES_KEY the launch advances the key
+// itself: rollout_key() makes sure the values have ARRIVED in this thread's registers (a barrier alone does not wait for loads in
+// flight), and rollout_key_advance() -- called by all threads BEHIND a workgroup barrier that follows every thread's
+// rollout_key() -- lets thread 0 take the workgroup's ticket; the workgroup that draws the last one stores offset + 1: every
+// workgroup of the launch has read the old value by then.
+__device__ __forceinline__ void rollout_key(const RolloutArgs& a, uint64_t& seed, uint64_t& offset) {
+  seed = a.key_dev ? a.key_dev[0] : a.seed;
+  offset = a.key_dev ? a.key_dev[1] : a.offset;
+  if (a.key_dev && a.advance_key) asm volatile("" : : "v"((uint32_t)offset), "v"((uint32_t)(offset >> 32)), "v"((uint32_t)seed) : "memory");
+}
+__device__ __forceinline__ void rollout_key_advance(const RolloutArgs& a, uint64_t offset) {
+  if (a.key_dev && a.advance_key && threadIdx.x == 0) {
+    unsigned long long* k = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(a.key_dev));
+    const unsigned long long t = atomicAdd(k + 2, 1ull);
+    if (t == (unsigned long long)gridDim.x * gridDim.y * gridDim.z - 1ull) {
+      k[1] = offset + 1ull;
+      k[2] = 0ull;
+    }
+  }
+}
+#endif
 
 
 // the two halves of philox_normal2, for callers that spread them over two phases of a step

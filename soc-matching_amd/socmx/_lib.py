@@ -33,6 +33,7 @@ class RolloutExtra(C.Structure):
 
 
 ROLLOUT_SHARES_CHIP = 1
+ROLLOUT_ADVANCES_KEY = 2      # include/socmx.h: the launch itself performs key[1] += 1 (key = {seed, offset, ticket})
 
 
 class Control(C.Structure):

@@ -74,14 +74,15 @@ def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noi
 # --------------------------------------------------------------------------------------
 
 class PhiloxKey:
-    """Philox (seed, offset) held in DEVICE memory (2 x int64): the keyed rollout reads it when the kernel starts and
-    `advance()` enqueues key[1] += 1 behind it, so a hipGraph that captured both draws fresh noise on every replay.
-    Eager use is equivalent to passing `seed`, `offset = 0, 1, 2, ...` by value."""
+    """Philox (seed, offset) held in DEVICE memory (3 x int64: seed, offset, ticket): the keyed rollout reads it when the kernel
+    starts and ADVANCES it itself (key[1] += 1 by the last workgroup to have read it: SOCMX_ROLLOUT_ADVANCES_KEY), so a hipGraph
+    that captured the launch draws fresh noise on every replay.  Eager use is equivalent to passing `seed`,
+    `offset = 0, 1, 2, ...` by value.  `advance()` is the separate one-thread launch (socmx_philox_advance)."""
 
     def __init__(self, device, seed=None, offset=0):
         seed = torch.initial_seed() if seed is None else int(seed)
         to_i64 = lambda v: ((int(v) & (2**64 - 1)) ^ (1 << 63)) - (1 << 63)      # same 64 bits, as a signed value
-        self.key = torch.tensor([to_i64(seed), to_i64(offset)], dtype=torch.int64, device=device)
+        self.key = torch.tensor([to_i64(seed), to_i64(offset), 0], dtype=torch.int64, device=device)
 
     def advance(self, inc=1):
         with _lib.on_device(self.key.device):
@@ -177,13 +178,12 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
         elif key is not None or want_nabla_v or shares_chip:
             # (shares_chip: the caller runs chip-filling kernels beside this launch -- SOCMX_ROLLOUT_SHARES_CHIP, include/socmx.h)
             extra = _lib.RolloutExtra(key=None if key is None else key.key.data_ptr(), nabla_v=_lib.ptr(nabla_v),
-                                      flags=_lib.ROLLOUT_SHARES_CHIP if shares_chip else 0, reserved=0)
+                                      flags=(_lib.ROLLOUT_SHARES_CHIP if shares_chip else 0) |
+                                            (_lib.ROLLOUT_ADVANCES_KEY if key is not None else 0), reserved=0)
             status = L.socmx_rollout_ex_f32(*head, *mid, *tail, extra, _lib.stream_ptr(dev))
         else:
             status = L.socmx_rollout_f32(*head, *mid, *tail, _lib.stream_ptr(dev))
     _lib.check(status, "socmx_rollout_f32")
-    if key is not None:
-        key.advance()
     out = (states, noises, stop, frac, lpd, lps, ltw, controls)
     return out + (nabla_v,) if want_nabla_v else out
 
