@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 142 /* 0.1.4: + the one-row rollout kernel for training-size batches (socmx_rollout1.hip); socmx_rollout_extra.flags */
+#define SOCMX_VERSION 142 /* 0.1.5: + the two-tile burst kernel (socmx_rollout32.hip); SOCMX_ROLLOUT_ADVANCES_KEY */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
