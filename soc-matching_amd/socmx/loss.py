@@ -163,16 +163,17 @@ class _TargetResidualHip(torch.autograd.Function):
         return gM, gdM, gV, None, None, None, None, None, None
 
 
-def target_fwd_net(pb, K, net, dnet, delta, gam, ops, nablaV, w, inv_norm, G=None):
+def target_fwd_net(pb, K, net, dnet, delta, gam, ops, nablaV, w, inv_norm, G=None, obj=None):
     """socmx_socm_target_fwd_net_f32 on plain tensors: (objective (1,), G = d obj / d nablaV, target); `G` may be a
-    caller-owned buffer."""
+    caller-owned buffer, `obj` a caller-owned (1,) accumulator the caller has ZEROED (the kernels add into it)."""
     L = _lib.lib()
     dev = net.device
     B, d = ops["gT"].shape
     if G is None:
         G = torch.empty_like(nablaV)
     target = torch.empty_like(nablaV)
-    obj = torch.zeros(1, dtype=torch.float32, device=dev)
+    if obj is None:
+        obj = torch.zeros(1, dtype=torch.float32, device=dev)
     with _lib.on_device(dev):
         _lib.check(L.socmx_socm_target_fwd_net_f32(
             pb.c_struct(), K, B, _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(ops["q"]),

@@ -388,6 +388,7 @@ class Trainer:
             D["gT"] = torch.empty(B, d, **f32)
             D["G"] = torch.empty(Kp, B, d, **f32)
             D["gout"], D["gam"] = torch.ones(1, **f32), torch.ones(1, **f32)
+            D["obj"] = torch.zeros(1, **f32)
             D["delta"] = delta
             # the telemetry EMA of the control-network gradient as one flat buffer, in parameters() order (= the order of
             # socmx_unet_backward_f32's output); D["ema_grad"] (shared with the autograd body / the eager mirrors) = its views
@@ -409,6 +410,7 @@ class Trainer:
             # 1 / running normaliser = d loss / d objective (main.py:313-320) -- formed here, off the critical path
             D["gam"].copy_(sde.gamma.detach().reshape(1))
             torch.reciprocal(D["norm1"], out=D["gout"])
+            D["obj"].zero_()           # (the objective's accumulator: cleared here instead of in front of the contraction)
             return net, dnet
 
         main = torch.cuda.current_stream(dev)
@@ -450,7 +452,8 @@ class Trainer:
         w_mean, w_std = L.mean_std_from_stats(stats)
         ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls, out=D)
         gam = D["gam"]                                                     # (filled in m_branch)
-        obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B_global), G=D["G"])
+        obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B_global), G=D["G"],
+                                     obj=D["obj"])
         gout = D["gout"]                                                   # d loss / d objective, from m_branch
         # (the contraction BACKWARD -- gradients of the pair-grid network and gamma only -- is deferred: _m_update)
         from . import _lib
