@@ -50,6 +50,10 @@ __host__ __device__ constexpr char r1_src(int cls, int dmx, int b) {
   constexpr char plan0_3[kR1Blocks + 1] = "RSSLRLSLLSLSLSLSLRLS", plan0_3d[kR1Blocks + 1] = "RSSLRLSLLSLSSSLSSRLS";
   constexpr char plan0_11[kR1Blocks + 1] = "RSSSRLSLLSLRLSLSLRLS", plan0_11d[kR1Blocks + 1] = "RSSSRLSLLSLRSSLSSRLS";
   constexpr char plan0_15[kR1Blocks + 1] = "RSSSRLSLLSLSLSLSLSLS", plan0_15d[kR1Blocks + 1] = "RSSSRLSLLSLSSSLSSSLS";
+  // 16 <= d <= 31 (dm = 31; the 32-wide input / output network): down_0 runs on all eight waves (two resident fragments pairs per
+  // wave) instead of from wave 0's registers -- wave 0 keeps five blocks resident; the others two fewer than at d <= 15 (the
+  // down_0 fragments and the second up_0 block take their registers); A, P (32 x 32) take the LDS of two blocks
+  constexpr char plan0_31[kR1Blocks + 1] = "RSSLRLSRLSRSLSLSLRLS", plan1_31[kR1Blocks + 1] = "RRSLRSRLRSLRSRSSLRSS";
   // (stream blocks spread over the step's TIME, two blocks of lead each: S1 ~1.1k cycles, S2 ~0.5k, S3 ~0.9k, S4 ~2.6k, then wave
   //  0's serial section ~1.2k with no consumption)
 #ifdef SOCMX_R1_PLAN1
@@ -57,6 +61,7 @@ __host__ __device__ constexpr char r1_src(int cls, int dmx, int b) {
 #else
   constexpr char plan1[kR1Blocks + 1] = "RRSLRSRLRSLRSRRSLRSR";
 #endif
+  if (dm > 15) return cls == 1 ? plan1_31[b] : plan0_31[b];
   if (cls == 1) return plan1[b];
   if (dense) return dm <= 3 ? plan0_3d[b] : dm <= 11 ? plan0_11d[b] : plan0_15d[b];
   return dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
@@ -81,7 +86,7 @@ __host__ __device__ constexpr int r1_lds_blocks(int dm) { return r1_count(0, dm,
 template <class NET>
 __host__ __device__ constexpr bool r1_supported() {
   constexpr UnetDesc u = NET::desc();
-  return u.in0p == 16 && u.hp[0] == 256 && u.hp[1] == 128 && u.hp[2] == 64 && u.outp == 16;
+  return ((u.in0p == 16 && u.outp == 16) || (u.in0p == 32 && u.outp == 32)) && u.hp[0] == 256 && u.hp[1] == 128 && u.hp[2] == 64;
 }
 
 // float offset of block b of wave w inside the packed image (fragments (nb, 4C .. 4C+3) of a layer are 4 KiB contiguous)
@@ -267,7 +272,30 @@ struct R1Lds {
   static constexpr int bias = 1216;   // the nine layers' padded biases (image order)
   static constexpr int p2 = 1216 + 1248;        // (8, 64)   down_2's per-wave partial sums: wave w's contribution of ITS 16 down_1 outputs to all 64 units
   static constexpr int weights = p2 + 512;      // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
+  static constexpr int xin = 0, res0 = 0, pb = 0, fq = 0;   // (16 <= d <= 31 only: R1LdsW; named here so that the shared code compiles)
 };
+// 16 <= d <= 31: 32-wide vectors, 32 x 32 matrices, the network input and res_0's output through LDS
+struct R1LdsW {
+  static constexpr int r1 = 0;
+  static constexpr int r2 = 256;
+  static constexpr int o2 = 384;
+  static constexpr int p5 = 512;      // (32, 8)
+  static constexpr int nz = 768;      // (2, 32)
+  static constexpr int wz = 832;      // (2, 16, 2)
+  static constexpr int xin = 896;     // (32)   the network input [t, x, 0..] of the coming evaluation (wave 0 writes it)
+  static constexpr int res0 = 928;    // (32)   res_0 [t, x] + b of the evaluation under way
+  static constexpr int sc = 960;      // (3, 4)
+  static constexpr int pb = 976;      // (32)   b = A x of the evaluation's state (OU settings: formed by wave 2 in the slack)
+  static constexpr int fq = 1008;     // (1)    x' P x of the same state (OU_quadratic: wave 3)
+  static constexpr int amat = 1024;   // (32, 32), TRANSPOSED: amat[j * 32 + i] = A[i][j] (lanes along i: conflict-free)
+  static constexpr int pmat = 2048;
+  static constexpr int bias = 3072;
+  static constexpr int p2 = 3072 + 1344;
+  static constexpr int weights = p2 + 512;
+};
+static_assert((R1LdsW::weights + r1_lds_blocks(31) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit (16 <= d <= 31)");
+template <int H> struct R1LdsOf { typedef R1Lds type; };
+template <> struct R1LdsOf<2> { typedef R1LdsW type; };
 static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(11) * 1024) * 4 <= 160 * 1024 &&
               (R1Lds::weights + r1_lds_blocks(15) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit");
 // dense sigma: sigma and S = sigma sigma^T (16 x 16 each) behind the weight blocks
@@ -297,6 +325,12 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   constexpr int DMAX = DMAX0;                       // state dimensions this instantiation takes
   constexpr int DMX = DMAX0 + (DENSE ? 100 : 0);    // ... as the key of the source plans
   constexpr UnetDesc u = NET::desc();
+  // H: 16-component halves of the row's vectors.  H = 2 (16 <= d <= 31, the 32-wide network input / output): lane n of a row
+  // carries components n and 16 + n; down_0 and res_0 run as a stage of their own on all waves (network(): stage 0)
+  constexpr int H = NET::outp >> 4;
+  static_assert(H == 1 || (H == 2 && DMAX0 == 31 && !DENSE), "16 <= d <= 31: sigma = I, one instantiation");
+  typedef typename R1LdsOf<H>::type LM;
+  constexpr int MS = 16 * H;                        // row stride of A, P in LDS
   constexpr int NRES = r1_count(CLS, DMX, 'R'), NLDS = r1_count(CLS, DMX, 'L'), NSTR = r1_count(CLS, DMX, 'S');
   const float* __restrict__ Wp = a.packed;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
@@ -324,19 +358,35 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   }
   static_assert(r1_src(CLS, DMX, 4) == 'R', "down_2's strided fragments are only loaded by the resident path");
   // up_0's share of this wave: k = 32 w + 16 (g & 1) + 8 (g >> 1) + j  (rows 2, 3 read the rotated copy of the wave's outputs)
-  float w5[8];
+  float w5[H][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = 32 * wave + 16 * (g & 1) + 8 * (g >> 1) + j;
-    w5[j] = Wp[u.L[8].w_off + (((k >> 4) * 64) + ((k & 15) >> 2) * 16 + n) * 4 + (k & 3)];
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * wave + 16 * (g & 1) + 8 * (g >> 1) + j;           // (output block h: KC = 16 fragments further on)
+      w5[h][j] = Wp[u.L[8].w_off + (((h * 16 + (k >> 4)) * 64) + ((k & 15) >> 2) * 16 + n) * 4 + (k & 3)];
+    }
+  // H = 2: this wave's two unit blocks of down_0 (blocks 2 w, 2 w + 1; two 16-input fragments each: register 4 kc + i <->
+  // broadcast position 4 kc + i of the input register) and, on wave 0, res_0's two blocks
+  float wd0[H == 2 ? 2 : 1][8], w3f[H == 2 ? 2 : 1][8];
+  if constexpr (H == 2) {
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const f32x4 v = *(reinterpret_cast<const f32x4*>(Wp + u.L[0].w_off) + ((2 * wave + bb) * 2 + kc) * 64 + lane);
+        const f32x4 v3 = *(reinterpret_cast<const f32x4*>(Wp + u.L[3].w_off) + (bb * 2 + kc) * 64 + lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wd0[bb][kc * 4 + e] = v[e]; w3f[bb][kc * 4 + e] = v3[e]; }
+      }
   }
   // biases of the units whose totals land in this lane
-  static_assert(u.bias_floats <= 1248, "bias copy");
-  const float* BL = lds + R1Lds::bias;          // (copied by the kernel's prologue; read where a layer ends)
+  static_assert(u.bias_floats <= LM::p2 - LM::bias, "bias copy");
+  const float* BL = lds + LM::bias;          // (copied by the kernel's prologue; read where a layer ends)
   // LDS-resident blocks: copied once, read back with ds_read_b128 at lane * 16 + fragment * 1 KiB
   constexpr int lds_first = CLS == 0 ? 0 : r1_count(0, DMX, 'L');
   static_assert(r1_count(CLS, DMX, 'S') % kR1PD == 0 && r1_count(CLS, DMX, 'S') >= kR1PD, "static ring slots across steps");
-  float* LW = lds + R1Lds::weights + (lds_first + (CLS == 0 ? 0 : (wave - 1) * NLDS)) * 1024;
+  float* LW = lds + LM::weights + (lds_first + (CLS == 0 ? 0 : (wave - 1) * NLDS)) * 1024;
 #pragma unroll
   for (int r = 0; r < NLDS; ++r) {
     const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(r1_nth(CLS, DMX, 'L', r), wave)) + lane;
@@ -446,44 +496,57 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #define R1B(b) std::integral_constant<int, b>{}
 
   // ---- wave 0's own state: the row (every 16-lane row of the wave runs the same arithmetic: component i = lane & 15) ----
-  const int i = n, ic = min(i, d - 1);
-  const bool lane_ok = i < d;
+  const int i = n;
+  int icv[H];
+  bool okv[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) { icv[h] = min(i + 16 * h, d - 1); okv[h] = i + 16 * h < d; }
+  const int ic = icv[0];
+  const bool lane_ok = okv[0];
   constexpr bool STOPPING = MODE == 1, is_ou = (MODE & 2) != 0;
   static_assert(!(STOPPING && DENSE), "the stopping-time step is built for sigma = I");
   const bool is_quad = is_ou && kind == SOCMX_OU_QUADRATIC;
   const bool traj = a.states != nullptr;
   const bool store = CLS == 0 && lane < 16 && lane_ok && traj;
+  const bool store_h = H == 2 && CLS == 0 && lane < 16 && okv[H - 1] && traj;
   const bool store0 = CLS == 0 && lane == 0 && traj;
   const uint32_t rowoff = (uint32_t)(grow * d + i);     // (32-bit lane offset against wave-uniform step bases: SGPR-base stores)
   const size_t step_floats = (size_t)B * d;
   size_t kbd = 0, kb = 0;                                // k * B * d, k * B
   float x = 0.f, kap = 0.f, stop = 1.f, lpd = 0.f, lps = 0.f, res0 = 0.f;
-  float w0[4][DMAX + 1], b0[4], w3[DMAX + 1], b8 = 0.f, b3 = 0.f;   // down_0 (units 64 m + lane), res_0 (unit n): wave 0 only
-  float* A_l = lds + R1Lds::amat;                         // OU: A, P with row stride 16 (d <= 15)
-  float* P_l = lds + R1Lds::pmat;
-  float* S_l = lds + R1Lds::weights + r1_lds_blocks(DMX) * 1024;   // dense sigma: sigma, then S = sigma sigma^T (stride 16)
+  float xh = 0.f, kaph = 0.f, pre_bh = 0.f, pre_seh = 0.f, b8h = 0.f;   // H = 2: the upper halves (components 16 + n)
+  float w0[4][H == 1 ? DMAX + 1 : 1], b0[4], w3[H == 1 ? DMAX + 1 : 1], b8 = 0.f, b3 = 0.f;   // H = 1: down_0 (units 64 m + lane), res_0 (unit n): wave 0 only
+  float* A_l = lds + LM::amat;                         // OU: A, P with row stride 16 (d <= 15)
+  float* P_l = lds + LM::pmat;
+  float* S_l = lds + LM::weights + r1_lds_blocks(DMX) * 1024;   // dense sigma: sigma, then S = sigma sigma^T (stride 16)
   float* SS_l = S_l + 256;
   float srow[DENSE ? DMAX : 1];                           // row i of S: sigma u = -S nabla_V is on the step's serial chain
   float pre_b = 0.f, pre_se = 0.f;                        // drift b(x_k) and (sigma eps_k)_i of the coming step, formed in the slack
   if constexpr (CLS == 0) {
     x = lane_ok ? a.x0[(size_t)grow * d + i] : 0.f;
     kap = (lane_ok && !is_ou) ? a.kappa[i] : 0.f;
+    if constexpr (H == 2) {
+      xh = okv[1] ? a.x0[(size_t)grow * d + 16 + i] : 0.f;
+      kaph = (okv[1] && !is_ou) ? a.kappa[16 + i] : 0.f;
+      b8h = Wp[u.L[8].b_off + 16 + n];
+    } else {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int unit = 64 * m + lane;
+      for (int m = 0; m < 4; ++m) {
+        const int unit = 64 * m + lane;
 #pragma unroll
-      for (int kk = 0; kk <= DMAX; ++kk)
-        w0[m][kk] = Wp[u.L[0].w_off + (((unit >> 4) * 64) + (kk >> 2) * 16 + (unit & 15)) * 4 + (kk & 3)];
-      b0[m] = Wp[u.L[0].b_off + unit];
+        for (int kk = 0; kk <= DMAX; ++kk)
+          w0[m][kk] = Wp[u.L[0].w_off + (((unit >> 4) * 64) + (kk >> 2) * 16 + (unit & 15)) * 4 + (kk & 3)];
+        b0[m] = Wp[u.L[0].b_off + unit];
+      }
+#pragma unroll
+      for (int kk = 0; kk <= DMAX; ++kk) w3[kk] = Wp[u.L[3].w_off + ((kk >> 2) * 16 + n) * 4 + (kk & 3)];
     }
-#pragma unroll
-    for (int kk = 0; kk <= DMAX; ++kk) w3[kk] = Wp[u.L[3].w_off + ((kk >> 2) * 16 + n) * 4 + (kk & 3)];
     b8 = Wp[u.L[8].b_off + n];
     b3 = Wp[u.L[3].b_off + n];
     for (int e = lane; e < d * d; e += 64) {
       const int r = e / d, c = e - r * d;
-      if (is_ou) A_l[r * 16 + c] = a.A[e];
-      if (is_quad) P_l[r * 16 + c] = a.P[e];
+      if (is_ou) A_l[H == 2 ? c * MS + r : r * MS + c] = a.A[e];
+      if (is_quad) P_l[H == 2 ? c * MS + r : r * MS + c] = a.P[e];
     }
     if constexpr (DENSE) {
       for (int e = lane; e < 256; e += 64) S_l[e] = ((e >> 4) < d && (e & 15) < d) ? a.sigma[(e >> 4) * d + (e & 15)] : 0.f;
@@ -498,18 +561,29 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       for (int j = 0; j < DMAX; ++j) srow[j] = SS_l[n * 16 + j];
     }
     if (store) a.states[rowoff] = x;
+    if (H == 2 && store_h) a.states[rowoff + 16] = xh;
     if (store0) a.stop_ind[grow] = 1.f;
   }
+  // component j (any j < d) of a vector held as (lo, hi) halves in the 16-lane rows
+  auto comp = [&](float lo, float hi, int j) -> float {
+    const float t0 = __shfl(lo, j & 15, 16);
+    if constexpr (H == 2) { const float t1 = __shfl(hi, j & 15, 16); return (j & 16) ? t1 : t0; }
+    return t0;
+  };
   // what the coming step's chain needs besides nabla_V, from values known a stage earlier: b(x_k) and sigma eps_k
   auto prepare_step = [&](int k) {
     if (k >= K) return;
-    const float eps = lds[R1Lds::nz + (k & 1) * 16 + i];
+    const float eps = lds[LM::nz + (k & 1) * MS + i];
+    if constexpr (H == 2) pre_seh = lds[LM::nz + (k & 1) * MS + 16 + i];
     if (is_ou) {                                                        // b = A x   (OU_quadratic.py:51-52, OU_linear.py:43-44)
-      float bi = 0.f;
-      for (int j = 0; j < d; ++j) bi += A_l[ic * 16 + j] * __shfl(x, j, 16);
-      pre_b = lane_ok ? bi : 0.f;
+      if constexpr (H == 1) {
+        float bi = 0.f;
+        for (int j = 0; j < d; ++j) bi += A_l[ic * MS + j] * comp(x, xh, j);
+        pre_b = lane_ok ? bi : 0.f;
+      }                                                                 // (H = 2: wave 2 forms it, ou_products(); read behind the barrier)
     } else {
       pre_b = -2.f * kap * (x * x - 1.f) * 2.f * x;                     // double_well.py:44-48
+      if constexpr (H == 2) pre_bh = -2.f * kaph * (xh * xh - 1.f) * 2.f * xh;
     }
     if constexpr (DENSE) {
       float se = 0.f;
@@ -521,6 +595,15 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   };
   // y[unit] = relu(down_0 [t, x] + b) for the 256 units, lane-ordered into LDS (wave 0); res_0 [t, x] + b for the step's end
   auto first_layer = [&](float t) {
+    if constexpr (H == 2) {
+      // the network input [t, x_0 .. x_30, 0]: stage 0 of the evaluation that follows reads it (all waves, behind the barrier)
+      if (lane < 16) {
+        lds[LM::xin + 1 + i] = x;
+        if (i < 15) lds[LM::xin + 17 + i] = xh;
+        if (i == 0) lds[LM::xin] = t;
+      }
+      return;
+    }
     float acc[4], r0 = b3 + t * w3[0], r1v = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = b0[m] + t * w0[m][0];
@@ -540,19 +623,19 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     f32x4 y;
 #pragma unroll
     for (int m = 0; m < 4; ++m) y[m] = relu_keep_nan(acc[m]);
-    *reinterpret_cast<f32x4*>(lds + R1Lds::r1 + r1_perm(lane) * 4) = y;
+    *reinterpret_cast<f32x4*>(lds + LM::r1 + r1_perm(lane) * 4) = y;
   };
 
   // ---- noise one step ahead: wave 1 the Philox words of step k + 2, wave 2 Box-Muller on the words of step k + 1 ----
-  float* NZ = lds + R1Lds::nz;
-  uint32_t* WZ = reinterpret_cast<uint32_t*>(lds + R1Lds::wz);
-  const bool w_words = CLS == 1 && wave == 1 && lane < 8 && !a.noise_in, w_draws = CLS == 1 && wave == 2 && lane < 8;
+  float* NZ = lds + LM::nz;
+  uint32_t* WZ = reinterpret_cast<uint32_t*>(lds + LM::wz);
+  const bool w_words = CLS == 1 && wave == 1 && lane < 8 * H && !a.noise_in, w_draws = CLS == 1 && wave == 2 && lane < 8 * H;
   auto words = [&](int k) {
     if (!w_words || k >= K) return;
     uint32_t wa, wb;
     philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + grow), (uint32_t)k, lane >> 1, lane & 1, wa, wb);
-    WZ[((k & 1) * 8 + lane) * 2] = wa;
-    WZ[((k & 1) * 8 + lane) * 2 + 1] = wb;
+    WZ[((k & 1) * 8 * H + lane) * 2] = wa;
+    WZ[((k & 1) * 8 * H + lane) * 2 + 1] = wb;
   };
   auto draws = [&](int k) {
     if (!w_draws || k >= K) return;
@@ -563,16 +646,16 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       if (c0 < d) z0 = src[c0];
       if (c0 + 1 < d) z1 = src[c0 + 1];
     } else {
-      box_muller_pair(WZ[((k & 1) * 8 + lane) * 2], WZ[((k & 1) * 8 + lane) * 2 + 1], z0, z1);
+      box_muller_pair(WZ[((k & 1) * 8 * H + lane) * 2], WZ[((k & 1) * 8 * H + lane) * 2 + 1], z0, z1);
     }
-    NZ[(k & 1) * 16 + c0] = c0 < d ? z0 : 0.f;
-    NZ[(k & 1) * 16 + c0 + 1] = c0 + 1 < d ? z1 : 0.f;
+    NZ[(k & 1) * MS + c0] = c0 < d ? z0 : 0.f;
+    NZ[(k & 1) * MS + c0 + 1] = c0 + 1 < d ? z1 : 0.f;
   };
 
   // The step's scalars -- dt (utils.py:38), sqrt(lambda dt) (utils.py:47), dt / lambda and its root -- are an IEEE division and
   // two square roots, ~40 dependent instructions: wave 3 (idle while wave 0 integrates) forms those of step k + 1 during
   // step k and leaves them in LDS; on wave 0 they would sit on the step's serial chain or in front of its first stage.
-  float* SC = lds + R1Lds::sc;
+  float* SC = lds + LM::sc;
   auto step_scalars = [&](int k) {
     if (CLS == 1 && wave == 3 && lane == 0 && k < K) {
       const float dt = a.ts[k + 1] - a.ts[k];
@@ -586,12 +669,45 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   // three-deep LDS ring: wave 3 writes those of step k + 2 in the same slack)
   int cur_k = 0;                       // the step network() runs for (the noise waves prepare steps cur_k + 1, cur_k + 2 inside)
   int bk_k = -1;                       // the step whose bookkeeping is outstanding
-  float bk_gv = 0.f, bk_step = 0.f, bk_eps = 0.f;
+  float bk_gv = 0.f, bk_step = 0.f, bk_eps = 0.f, bk_gvh = 0.f, bk_epsh = 0.f;
+  float bk_sol = 0.f;                  // H = 2, OU_quadratic: step / lambda of the step whose -f x'Px term is outstanding
+  // H = 2, OU settings: the d x d products of the state leave wave 0.  Waves 2 and 3 read the evaluation's input vector from LDS
+  // (xin = [t_k, x_k]) in the slack behind stage 4 -- lane (i = lane & 31, half = lane >> 5) adds the terms j = half, half + 2, ..
+  // of row i from the TRANSPOSED matrix (lanes along i: one LDS pass per term, x_j a broadcast) -- and leave b = A x_k (wave 2) and
+  // x_k' P x_k (wave 3) in LDS; wave 0 picks them up behind the barrier.  (On wave 0 they were forty ds_bpermute + eighty
+  // multiply-adds per step at d = 20: 6.5 us per step against 3.7 for the elementwise drift.)
+  auto ou_products = [&]() {
+    if constexpr (H == 2 && is_ou && CLS == 1) {
+      if (wave == 2 || (wave == 3 && is_quad)) {
+        const float* Mt = wave == 2 ? A_l : P_l;
+        const int ii = lane & 31, hf = lane >> 5;
+        // (a rolled loop on purpose: all sixteen terms unrolled -- thirty-two LDS reads in flight beside the other waves' weight
+        //  blocks -- measured slower, 4.96 against 4.49 us per step at d = 20)
+        float acc = 0.f;
+        for (int j = hf; j < d; j += 2) acc = fmaf(Mt[j * MS + ii], lds[LM::xin + 1 + j], acc);
+        acc = __fadd_rn(acc, __shfl_xor(acc, 32));
+        if (wave == 2) {
+          if (lane < 32) lds[LM::pb + lane] = ii < d ? acc : 0.f;
+        } else {
+          float t = (lane < 32 && ii < d) ? __fmul_rn(lds[LM::xin + 1 + ii], acc) : 0.f;
+          t = row16_sum(t);
+          t = __fadd_rn(t, __shfl_xor(t, 16));
+          if (lane == 0) lds[LM::fq] = t;
+        }
+      }
+    }
+  };
+  auto apply_quad_cost = [&]() {       // wave 0, behind the barrier that follows ou_products()
+    if constexpr (H == 2 && CLS == 0) {
+      if (is_quad) lpd = fmaf(-bk_sol, lds[LM::fq], lpd);
+      bk_sol = 0.f;
+    }
+  };
   auto bookkeeping = [&]() {
     if (bk_k < 0) return;
     const int k = bk_k;
     bk_k = -1;
-    const f32x4 scal = *reinterpret_cast<const f32x4*>(lds + R1Lds::sc + (k % 3) * 4);
+    const f32x4 scal = *reinterpret_cast<const f32x4*>(lds + LM::sc + (k % 3) * 4);
     const float eps = bk_eps;
     float uc = lane_ok ? -bk_gv : 0.f;                                  // u = -sigma^T nabla_V (method.py:58-80)
     if constexpr (DENSE) {
@@ -600,24 +716,41 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       uc = lane_ok ? -t : 0.f;
     }
     const float xe = x;                                                 // x_{k+1}
+    const float uch = (H == 2 && okv[H - 1]) ? -bk_gvh : 0.f;
     float f = 0.f;                                                      // f at the NEW state, OLD time (utils.py:92-96)
     if (is_quad) {
-      float px = 0.f;
-      for (int j = 0; j < d; ++j) px += P_l[ic * 16 + j] * __shfl(xe, j, 16);
-      f = row16_sum(lane_ok ? xe * px : 0.f);
+      if constexpr (H == 1) {
+        float px = 0.f;
+        for (int j = 0; j < d; ++j) px += P_l[ic * MS + j] * comp(xe, xh, j);
+        f = row16_sum(lane_ok ? xe * px : 0.f);
+      }                                       // (H = 2: x'Px comes from wave 3 behind the barrier -- apply_quad_cost())
     } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
       f = 1.f;
     }
-    const float uu = row16_sum(uc * uc), ue = row16_sum(uc * eps);
+    float puu = uc * uc, pue = uc * eps;
+    if constexpr (H == 2) { puu = fmaf(uch, uch, __fmul_rn(uc, uc)); pue = fmaf(uch, bk_epsh, __fmul_rn(uc, eps)); }
+    const float uu = row16_sum(puu), ue = row16_sum(pue);
     const float sol = STOPPING ? bk_step / a.lmbd : scal[2];
     const float ssol = STOPPING ? sqrtf(sol) : scal[3];
-    lpd = lpd + sol * (-f - 0.5f * uu);
-    lps = lps + ssol * (-ue);
+    if constexpr (H == 2) {
+      lpd = fmaf(sol, fmaf(-0.5f, uu, -f), lpd);
+      lps = fmaf(ssol, -ue, lps);
+      bk_sol = sol;
+    } else {
+      lpd = lpd + sol * (-f - 0.5f * uu);
+      lps = lps + ssol * (-ue);
+    }
     if (store) {
       if (a.nabla_v) (a.nabla_v + kbd)[rowoff] = bk_gv;
       (a.controls + kbd)[rowoff] = uc;
       (a.noises + kbd)[rowoff] = eps;
       (a.states + kbd + step_floats)[rowoff] = xe;
+    }
+    if (H == 2 && store_h) {
+      if (a.nabla_v) (a.nabla_v + kbd)[rowoff + 16] = bk_gvh;
+      (a.controls + kbd)[rowoff + 16] = uch;
+      (a.noises + kbd)[rowoff + 16] = bk_epsh;
+      (a.states + kbd + step_floats)[rowoff + 16] = xh;
     }
     kbd += step_floats;
     if (store0) {
@@ -637,8 +770,27 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   //  early and leaves the younger one to run the rest alone.  Alternating s_setprio block by block to keep them abreast was
   //  measured and is slower -- 0.626 ms against 0.559: both waves then stall more often than they gain.)
   auto network = [&]() {
+    if constexpr (H == 2) {
+      // stage 0 (16 <= d <= 31): r1 = relu(down_0 [t, x] + b), wave w: units 32 w .. 32 w + 31 from its sixteen resident
+      // registers; wave 0 also res_0 [t, x] + b.  The input register: row g holds input 16 f + 4 g + i at position 4 f + i.
+      const float xin = (lane & 15) < 8 ? lds[LM::xin + 16 * ((lane & 15) >> 2) + 4 * g + (lane & 3)] : 0.f;
+      float aA = 0.f, aB = 0.f;
+      r1_fmac8x2<0>(aA, aB, xin, wd0[0], wd0[1]);
+      const float t = r1_reduce4(aA, 0.f, aB, 0.f);                       // rows 0: block 2 w's totals, 1: block 2 w + 1's
+      if (lane < 32) {
+        const int unit = 32 * wave + lane;
+        lds[LM::r1 + r1_perm(unit & 63) * 4 + (unit >> 6)] = relu_keep_nan(t + BL[u.L[0].b_lds + unit]);
+      }
+      if constexpr (CLS == 0) {
+        float rA = 0.f, rB = 0.f;
+        r1_fmac8x2<0>(rA, rB, xin, w3f[0], w3f[1]);
+        const float tr = r1_reduce4(rA, 0.f, rB, 0.f);
+        if (lane < 32) lds[LM::res0 + lane] = tr + BL[u.L[3].b_lds + lane];
+      }
+      __syncthreads();
+    }
     // stage 1: r2 = relu(down_1 r1 + b)            wave w: units 16 w .. 16 w + 15
-    const f32x4 xr1 = *reinterpret_cast<const f32x4*>(lds + R1Lds::r1 + lane * 4);
+    const f32x4 xr1 = *reinterpret_cast<const f32x4*>(lds + LM::r1 + lane * 4);
     const float bias1 = BL[u.L[1].b_lds + 16 * wave + n];
     float s0 = 0.f, s1 = 0.f;
     blk(R1B(0), R1NX(1, 1), s0, s1, xr1[0]);
@@ -647,7 +799,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     blk(R1B(3), R1NX(4, 1), s0, s1, xr1[3]);
     {
       const float y = relu_keep_nan(r1_rows_sum(s0 + s1) + bias1);         // r2[16 w + n], in every row of the wave
-      if (lane < 16) lds[R1Lds::r2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
+      if (lane < 16) lds[LM::r2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
       // stage 2 without a barrier of its own: down_2 is linear in r2, so the wave multiplies ITS 16 outputs into all 64
       // units right away (block 4: unit blocks 0..3 x input chunk w) and stage 3 adds the eight waves' partial sums.
       // Row g of the operand register holds r2[16 w + 4 g + (p & 3)] at every position p: one cross-lane gather.
@@ -656,26 +808,26 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       pre(R1NX(5, 1));                          // (stage 3's first block, if it is an LDS block: read behind these fmacs)
       r1_fmac16_4acc(c0, c1, c2, c3, x4, wres[r1_count(CLS, DMX, 'R', 4)]);
       const float tsum = r1_reduce4(c0, c1, c2, c3);                         // lane (g, n): unit 16 {0, 2, 1, 3}[g] + n
-      lds[R1Lds::p2 + wave * 64 + 16 * (((g & 1) << 1) | (g >> 1)) + n] = tsum;
+      lds[LM::p2 + wave * 64 + 16 * (((g & 1) << 1) | (g >> 1)) + n] = tsum;
     }
     R1_TICK(1)
     __syncthreads();
     R1_TICK(2)
-    const float2 xr2 = *reinterpret_cast<const float2*>(lds + R1Lds::r2 + lane * 2);
+    const float2 xr2 = *reinterpret_cast<const float2*>(lds + LM::r2 + lane * 2);
     // stage 3: o2 = relu(up_2 r3 + b) + res_2 r2 + b   wave w: units 16 w ..   (res_2 first: r2 is in registers)
     const int pk = r1_perm(lane);
     // (down_2's eight partial sums per unit: four are requested in front of each res_2 block and folded behind it -- all
     //  eight at once held eight more registers live across both blocks)
     float p2a[4], p2b[4];
 #pragma unroll
-    for (int w8 = 0; w8 < 4; ++w8) p2a[w8] = lds[R1Lds::p2 + w8 * 64 + pk];
+    for (int w8 = 0; w8 < 4; ++w8) p2a[w8] = lds[LM::p2 + w8 * 64 + pk];
     const float bias2 = BL[u.L[2].b_lds + pk];
     const float bu3 = BL[u.L[6].b_lds + 16 * wave + n], br3 = BL[u.L[5].b_lds + 16 * wave + n];
     float u0 = 0.f, u1 = 0.f, q0 = 0.f, q1 = 0.f;
     blk(R1B(5), R1NX(6, 1), q0, q1, xr2.x);
     const float p2lo = (p2a[0] + p2a[1]) + (p2a[2] + p2a[3]);
 #pragma unroll
-    for (int w8 = 0; w8 < 4; ++w8) p2b[w8] = lds[R1Lds::p2 + (4 + w8) * 64 + pk];
+    for (int w8 = 0; w8 < 4; ++w8) p2b[w8] = lds[LM::p2 + (4 + w8) * 64 + pk];
     blk(R1B(6), R1NX(7, 1), q0, q1, xr2.y);
     const float xr3 = relu_keep_nan((p2lo + ((p2b[0] + p2b[1]) + (p2b[2] + p2b[3]))) + bias2);
     blk(R1B(7), R1NX(8, 2), u0, u1, xr3);
@@ -684,13 +836,13 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       float up, rs;
       r1_halves(t, up, rs);
       const float y = relu_keep_nan(up + bu3) + (rs + br3);
-      if (lane < 16) lds[R1Lds::o2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
+      if (lane < 16) lds[LM::o2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
     }
     R1_TICK(5)
     __syncthreads();
     R1_TICK(6)
     // stage 4: o1 = relu(up_1 o2 + b) + res_1 r1 + b   wave w: units 32 w .. 32 w + 31 (two neuron blocks; res_1 first)
-    const float2 xo2 = *reinterpret_cast<const float2*>(lds + R1Lds::o2 + lane * 2);
+    const float2 xo2 = *reinterpret_cast<const float2*>(lds + LM::o2 + lane * 2);
     const float bu4 = BL[u.L[7].b_lds + 32 * wave + 16 * (g & 1) + n], br4 = BL[u.L[4].b_lds + 32 * wave + 16 * (g & 1) + n];
     // (the two accumulators of a block pair are the two neuron blocks': eight live accumulators did not fit beside the
     //  resident weights, and consecutive fmacs still never depend on each other -- blocks of the same chunk run as a pair)
@@ -720,9 +872,15 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     {
       const float x5 = r1_ror8_upper(o1);
       float p0 = 0.f, p1 = 0.f;
-      r1_fmac8<0>(p0, p1, x5, w5);
+      r1_fmac8<0>(p0, p1, x5, w5[0]);
       const float y = r1_rows_sum(p0 + p1);
-      if (lane < 16) lds[R1Lds::p5 + n * 8 + wave] = y;
+      if (lane < 16) lds[LM::p5 + n * 8 + wave] = y;
+      if constexpr (H == 2) {                                              // the second 16-unit block of up_0's outputs
+        float q0_ = 0.f, q1_ = 0.f;
+        r1_fmac8<0>(q0_, q1_, x5, w5[1]);
+        const float yh = r1_rows_sum(q0_ + q1_);
+        if (lane < 16) lds[LM::p5 + (16 + n) * 8 + wave] = yh;
+      }
     }
     // The first wave of every SIMD reaches this barrier ~900 cycles before the second one (the older wave has issue
     // priority through the long stage 4): wave 0 closes the previous step's books in that slack, waves 1 .. 3 prepare the
@@ -736,6 +894,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       words(cur_k + 2);
       draws(cur_k + 1);
       step_scalars(cur_k + 1);
+      ou_products();
     }
     __builtin_amdgcn_s_setprio(2);
     R1_TICK(8)
@@ -744,10 +903,17 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   };
   // nabla_V[i] in every row of wave 0 (the other waves: not used)
   auto network_output = [&]() -> float {
-    const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8);
-    const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8 + 4);
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8);
+    const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8 + 4);
     const float s = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]));
+    if constexpr (H == 2) return relu_keep_nan(s + b8) + lds[LM::res0 + n];
     return relu_keep_nan(s + b8) + res0;
+  };
+  auto network_output_hi = [&]() -> float {                               // H = 2: unit 16 + n
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + LM::p5 + (16 + n) * 8);
+    const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + LM::p5 + (16 + n) * 8 + 4);
+    const float s = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]));
+    return relu_keep_nan(s + b8h) + lds[LM::res0 + 16 + n];
   };
 
   // ---- prologue ----
@@ -770,13 +936,21 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     network();
     if constexpr (CLS == 0) {
       // every LDS operand of the chain is requested at once (left to the scheduler the three round trips ran one after the other)
-      const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8);
-      const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + R1Lds::p5 + n * 8 + 4);
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8);
+      const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8 + 4);
       const f32x4 scal = *reinterpret_cast<const f32x4*>(SC + (k % 3) * 4);
-      const float eps = NZ[(k & 1) * 16 + i];                            // drawn during the previous step
+      const float eps = NZ[(k & 1) * MS + i];                            // drawn during the previous step
+      float epsh = 0.f, gvh = 0.f;
+      if constexpr (H == 2) {
+        epsh = NZ[(k & 1) * MS + 16 + i];
+        gvh = network_output_hi();
+        if (is_ou) { pre_b = lds[LM::pb + i]; pre_bh = lds[LM::pb + 16 + i]; }
+        apply_quad_cost();
+      }
+      const float res0v = H == 2 ? lds[LM::res0 + n] : res0;
       __builtin_amdgcn_sched_barrier(0);
       const float dt = scal[0], sq_ldt = scal[1];
-      const float gv = relu_keep_nan((((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + b8) + res0;
+      const float gv = relu_keep_nan((((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + b8) + res0v;
       R1_TICK(12)
       // sigma u = -sigma sigma^T nabla_V: the one product that waits for the network (sigma = I: u = -nabla_V itself); the drift
       // and sigma eps were formed a stage ago (prepare_step)
@@ -790,6 +964,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       }
       const float upd = (pre_b + su) * dt + sq_ldt * pre_se;            // utils.py:45-47
       const float xn = x + stop * upd;                                  // utils.py:48
+      const float updh = H == 2 ? (pre_bh + (okv[H - 1] ? -gvh : 0.f)) * dt + sq_ldt * pre_seh : 0.f;
+      const float xnh = xh + stop * updh;
+      float xeh = xnh;
       float xe = xn, step = dt, stop_new = 1.f;
       if (STOPPING) {                                                   // utils.py:42-44, 49-75; Phi = -x_0
         const float phi_b = -__shfl(x, 0, 16), phi_a = -__shfl(xn, 0, 16);
@@ -797,10 +974,12 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
         const float js = (phi_b > 0.f && phi_a < 0.f) ? 1.f : 0.f;
         const float fr = js * (phi_b / (phi_b - phi_a + 1e-6f) + 1e-6f);
         xe = js * (x + fr * stop * upd) + (1.f - js) * xn;
+        if constexpr (H == 2) xeh = js * (xh + fr * stop * updh) + (1.f - js) * xnh;
         step = js * (fr * fr) * dt + ns * dt;                           // step_fraction squared (utils.py:70-72)
         stop_new = (-__shfl(xe, 0, 16) > 0.f) ? 1.f : 0.f;
       }
       x = lane_ok ? xe : 0.f;
+      if constexpr (H == 2) { xh = okv[1] ? xeh : 0.f; bk_gvh = gvh; bk_epsh = epsh; }
       if (STOPPING) stop = stop_new;
       bk_k = k; bk_gv = gv; bk_step = step; bk_eps = eps;               // costs + stores: see bookkeeping()
       R1_TICK(13)
@@ -817,23 +996,49 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   cur_k = K;                              // (nothing left to prepare)
   if (a.nabla_v) {                        // nabla_V(T, X_K): r1 already holds down_0 [t_K, x_K]
     network();                            // (wave 0 closes the last step's books inside)
+    apply_quad_cost();
     if constexpr (CLS == 0) {
       const float gv = network_output();
       if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
+      if constexpr (H == 2) {
+        const float gvh = network_output_hi();
+        if (store_h) a.nabla_v[(size_t)K * B * d + rowoff + 16] = gvh;
+      }
+    }
+  }
+  if constexpr (H == 2) {
+    if (!a.nabla_v && is_quad) {          // (no terminal evaluation: x_K' P x_K still has to come from wave 3 -- the same code path)
+      if constexpr (CLS == 0) bookkeeping();
+      ou_products();
+      __syncthreads();
+      apply_quad_cost();
     }
   }
   if constexpr (CLS == 0) bookkeeping();  // (no terminal evaluation: the last step's costs and stores)
   if constexpr (CLS == 0) {                                             // terminal cost (utils.py:101)
     float gval = 0.f;
     if (kind == SOCMX_OU_QUADRATIC) {
-      float qx = 0.f;
-      for (int j = 0; j < d; ++j) qx += a.Q[ic * d + j] * __shfl(x, j, 16);
-      gval = row16_sum(lane_ok ? x * qx : 0.f);
+      float qx = 0.f, qxh = 0.f;
+      for (int j = 0; j < d; ++j) {
+        const float xj = comp(x, xh, j);
+        qx += a.Q[ic * d + j] * xj;
+        if constexpr (H == 2) qxh += a.Q[icv[H - 1] * d + j] * xj;
+      }
+      float part = lane_ok ? x * qx : 0.f;
+      if constexpr (H == 2) part += okv[1] ? xh * qxh : 0.f;
+      gval = row16_sum(part);
     } else if (kind == SOCMX_OU_LINEAR) {
-      gval = row16_sum(lane_ok ? a.omega[ic] * x : 0.f);
+      float part = lane_ok ? a.omega[ic] * x : 0.f;
+      if constexpr (H == 2) part += okv[1] ? a.omega[icv[1]] * xh : 0.f;
+      gval = row16_sum(part);
     } else if (kind == SOCMX_DOUBLE_WELL) {
       const float q = x * x - 1.f;
-      gval = row16_sum(lane_ok ? a.nu[ic] * (q * q) : 0.f);
+      float part = lane_ok ? a.nu[ic] * (q * q) : 0.f;
+      if constexpr (H == 2) {
+        const float qh = xh * xh - 1.f;
+        part += okv[1] ? a.nu[icv[1]] * (qh * qh) : 0.f;
+      }
+      gval = row16_sum(part);
     }
     if (lane == 0) {
       a.lpd[grow] = lpd;
@@ -849,14 +1054,28 @@ __global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutAr
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int e = tid; e < R1Lds::bias; e += kR1Waves * 64) lds[e] = 0.f;
-  unet_load_biases_at(a.packed, NET::desc(), lds + R1Lds::bias, tid, kR1Waves * 64);
+  typedef typename R1LdsOf<(NET::outp >> 4)>::type LM;
+  for (int e = tid; e < LM::bias; e += kR1Waves * 64) lds[e] = 0.f;
+  unet_load_biases_at(a.packed, NET::desc(), lds + LM::bias, tid, kR1Waves * 64);
   __syncthreads();
   if (wave == 0) r1_wave<0, MODE, NET, DMAX>(a, lds, 0, lane);
   else r1_wave<1, MODE, NET, DMAX>(a, lds, wave, lane);
 }
 
 bool rollout1_available() { return r1_supported<DefaultNet>(); }
+// 16 <= d <= 31 with sigma = I: the 32-wide input / output network (soc.yaml's default d = 20)
+bool rollout1_wide_available() { return r1_supported<Wide32Net>(); }
+int rollout1_wide_launch(const RolloutArgs& a, bool stopping, void* stream) {
+  if constexpr (r1_supported<Wide32Net>()) {
+    const bool ou = a.kind == SOCMX_OU_QUADRATIC || a.kind == SOCMX_OU_LINEAR;
+    if (!a.sigma_identity) return SOCMX_E_DIM;
+    void (*k)(const RolloutArgs) = stopping ? rollout1_kernel<1, Wide32Net, 31> : ou ? rollout1_kernel<2, Wide32Net, 31> : rollout1_kernel<0, Wide32Net, 31>;
+    if (const int err = ensure_max_lds(k)) return err;
+    return launch(k, dim3((unsigned)a.B), dim3(kR1Waves * 64), (size_t)kLdsBytesPerCU, stream, a);
+  } else {
+    return SOCMX_E_DIM;
+  }
+}
 
 int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream) {
   if constexpr (r1_supported<DefaultNet>()) {

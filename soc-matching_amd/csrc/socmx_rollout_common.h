@@ -88,6 +88,8 @@ typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... a
 //  variant's calls bound to the DEFAULT library's definitions, i.e. to kernels compiled for other widths)
 __attribute__((visibility("hidden"))) bool rollout1_available();
 __attribute__((visibility("hidden"))) int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream);
+__attribute__((visibility("hidden"))) bool rollout1_wide_available();     // ... its 16 <= d <= 31 form (sigma = I)
+__attribute__((visibility("hidden"))) int rollout1_wide_launch(const RolloutArgs& a, bool stopping, void* stream);
 // socmx_rollout32.hip: two 16-row tiles per workgroup (evaluation bursts, more tiles than CUs: d <= 15, or 16 <= d <= 31 with sigma = I)
 __attribute__((visibility("hidden"))) bool rollout32_available(int in0p);
 __attribute__((visibility("hidden"))) int rollout32_launch(const RolloutArgs& a, bool stopping, void* stream);
