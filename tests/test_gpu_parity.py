@@ -1558,7 +1558,9 @@ def test_both_rollout_tile_shapes_pass_the_reference_fixtures():
 
 
 @pytest.mark.parametrize("K", [1, 2, 3])
-@pytest.mark.parametrize("name", ["cfg3_double_well_d10_K200", "cfg1_ou_quadratic_easy_d2_K50", "md_default_d1_K150_B64_stopping"])
+@pytest.mark.parametrize("name", ["cfg3_double_well_d10_K200", "cfg1_ou_quadratic_easy_d2_K50", "md_default_d1_K150_B64_stopping",
+                                  # d = 20: the 16 <= d <= 31 form (two components per lane, down_0 as a stage, OU products off wave 0)
+                                  "ouq20_ou_quadratic_easy_d20_K12"])
 def test_one_row_rollout_on_the_shortest_grids(name, K):
     """One, two and three steps (the noise / scalar / bookkeeping pipeline of the one-row kernel runs one to two steps ahead of
     the integrator: its prologue and its flush are the whole launch here), with and without the terminal nabla_V evaluation,
@@ -1584,12 +1586,14 @@ def test_one_row_rollout_on_the_shortest_grids(name, K):
             np.testing.assert_allclose(_np(got[8]), ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
 
 
-def test_one_row_and_four_row_rollouts_agree_row_by_row():
+@pytest.mark.parametrize("name,steps", [("cfg3_double_well_d10_K200", 40), ("ouq20_ou_quadratic_easy_d20_K12", 12)])
+def test_one_row_and_four_row_rollouts_agree_row_by_row(name, steps):
     """The same Philox rows through the one-row kernel (B = 256: one workgroup per row) and inside a B = 1024 launch (4-row
-    tiles): identical noise, trajectories equal up to fp32 summation order in the network."""
+    tiles): identical noise, trajectories equal up to fp32 summation order in the network -- at d = 10 and at d = 20 (the
+    one-row kernel's 16 <= d <= 31 form against the 4-row general step)."""
     from SOC_matching import utils
-    sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
-    ts = aux["ts"][:41]
+    sde, aux = build_sde(name, DEV)
+    ts = aux["ts"][:steps + 1]
     torch.manual_seed(5)
     x0 = torch.randn(1024, aux["x0"].shape[-1], device=DEV) * 0.5
     one = utils.stochastic_trajectories(sde, x0[:256], ts, aux["lmbd"], seed=11, offset=3)
