@@ -1250,7 +1250,7 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
 #define SOCMX_STR(x) SOCMX_STR2(x)
   static const char msg[] =
       "socmx 0.1.5; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
-      "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches; one row per workgroup on v_fmac_f32_dpp for B <= 256, sigma = I, d <= 15); "
+      "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches; one row per workgroup on v_fmac_f32_dpp for B <= 256 at d <= 15 and, with sigma = I, 17 <= d <= 31; two 16-row tiles per workgroup for bursts beyond 4096 rows at d <= 31); "
       "Philox4x32-10 noise; static_hdims=" SOCMX_STR(SOCMX_H0P) "," SOCMX_STR(SOCMX_H1P) "," SOCMX_STR(SOCMX_H2P) "; "
       "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target; "
       // what the hand-written kernels take (outside these ranges the entry points return SOCMX_E_LDS / SOCMX_E_DIM and the
@@ -1450,7 +1450,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   if (is_default && one_row_form && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
       (B <= 256 || (force_rows == 1 && B <= 1024)))
     return rollout1_launch(a, stopping, stream);
-  // ... and 16 <= d <= 31 with sigma = I at the default widths (soc.yaml's default d = 20): the same kernel with two components
+  // ... and 17 <= d <= 31 with sigma = I at the default widths (soc.yaml's default d = 20): the same kernel with two components
   // per lane and down_0 / res_0 as a stage of their own on all eight waves
   if (is_wide32 && !force_slow && a.sigma_identity && d >= 16 && d <= 31 && r1_prof_ok && !prof && rollout1_wide_available() &&
       (force_rows == 0 || force_rows == 1) && (B <= 256 || (force_rows == 1 && B <= 1024)))

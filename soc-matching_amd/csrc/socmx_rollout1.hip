@@ -50,7 +50,7 @@ __host__ __device__ constexpr char r1_src(int cls, int dmx, int b) {
   constexpr char plan0_3[kR1Blocks + 1] = "RSSLRLSLLSLSLSLSLRLS", plan0_3d[kR1Blocks + 1] = "RSSLRLSLLSLSSSLSSRLS";
   constexpr char plan0_11[kR1Blocks + 1] = "RSSSRLSLLSLRLSLSLRLS", plan0_11d[kR1Blocks + 1] = "RSSSRLSLLSLRSSLSSRLS";
   constexpr char plan0_15[kR1Blocks + 1] = "RSSSRLSLLSLSLSLSLSLS", plan0_15d[kR1Blocks + 1] = "RSSSRLSLLSLSSSLSSSLS";
-  // 16 <= d <= 31 (dm = 31; the 32-wide input / output network): down_0 runs on all eight waves (two resident fragments pairs per
+  // 17 <= d <= 31 (dm = 31; the 32-wide input / output network): down_0 runs on all eight waves (two resident fragments pairs per
   // wave) instead of from wave 0's registers -- wave 0 keeps five blocks resident; the others two fewer than at d <= 15 (the
   // down_0 fragments and the second up_0 block take their registers); A, P (32 x 32) take the LDS of two blocks
   constexpr char plan0_31[kR1Blocks + 1] = "RSSLRLSRLSRSLSLSLRLS", plan1_31[kR1Blocks + 1] = "RRSLRSRLRSLRSRSSLRSS";
@@ -272,9 +272,9 @@ struct R1Lds {
   static constexpr int bias = 1216;   // the nine layers' padded biases (image order)
   static constexpr int p2 = 1216 + 1248;        // (8, 64)   down_2's per-wave partial sums: wave w's contribution of ITS 16 down_1 outputs to all 64 units
   static constexpr int weights = p2 + 512;      // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
-  static constexpr int xin = 0, res0 = 0, pb = 0, fq = 0;   // (16 <= d <= 31 only: R1LdsW; named here so that the shared code compiles)
+  static constexpr int xin = 0, res0 = 0, pb = 0, fq = 0;   // (17 <= d <= 31 only: R1LdsW; named here so that the shared code compiles)
 };
-// 16 <= d <= 31: 32-wide vectors, 32 x 32 matrices, the network input and res_0's output through LDS
+// 17 <= d <= 31: 32-wide vectors, 32 x 32 matrices, the network input and res_0's output through LDS
 struct R1LdsW {
   static constexpr int r1 = 0;
   static constexpr int r2 = 256;
@@ -293,7 +293,7 @@ struct R1LdsW {
   static constexpr int p2 = 3072 + 1344;
   static constexpr int weights = p2 + 512;
 };
-static_assert((R1LdsW::weights + r1_lds_blocks(31) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit (16 <= d <= 31)");
+static_assert((R1LdsW::weights + r1_lds_blocks(31) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit (17 <= d <= 31)");
 template <int H> struct R1LdsOf { typedef R1Lds type; };
 template <> struct R1LdsOf<2> { typedef R1LdsW type; };
 static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(11) * 1024) * 4 <= 160 * 1024 &&
@@ -325,10 +325,10 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   constexpr int DMAX = DMAX0;                       // state dimensions this instantiation takes
   constexpr int DMX = DMAX0 + (DENSE ? 100 : 0);    // ... as the key of the source plans
   constexpr UnetDesc u = NET::desc();
-  // H: 16-component halves of the row's vectors.  H = 2 (16 <= d <= 31, the 32-wide network input / output): lane n of a row
+  // H: 16-component halves of the row's vectors.  H = 2 (17 <= d <= 31, the 32-wide network input / output): lane n of a row
   // carries components n and 16 + n; down_0 and res_0 run as a stage of their own on all waves (network(): stage 0)
   constexpr int H = NET::outp >> 4;
-  static_assert(H == 1 || (H == 2 && DMAX0 == 31 && !DENSE), "16 <= d <= 31: sigma = I, one instantiation");
+  static_assert(H == 1 || (H == 2 && DMAX0 == 31 && !DENSE), "17 <= d <= 31: sigma = I, one instantiation");
   typedef typename R1LdsOf<H>::type LM;
   constexpr int MS = 16 * H;                        // row stride of A, P in LDS
   constexpr int NRES = r1_count(CLS, DMX, 'R'), NLDS = r1_count(CLS, DMX, 'L'), NSTR = r1_count(CLS, DMX, 'S');
@@ -771,7 +771,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   //  measured and is slower -- 0.626 ms against 0.559: both waves then stall more often than they gain.)
   auto network = [&]() {
     if constexpr (H == 2) {
-      // stage 0 (16 <= d <= 31): r1 = relu(down_0 [t, x] + b), wave w: units 32 w .. 32 w + 31 from its sixteen resident
+      // stage 0 (17 <= d <= 31): r1 = relu(down_0 [t, x] + b), wave w: units 32 w .. 32 w + 31 from its sixteen resident
       // registers; wave 0 also res_0 [t, x] + b.  The input register: row g holds input 16 f + 4 g + i at position 4 f + i.
       const float xin = (lane & 15) < 8 ? lds[LM::xin + 16 * ((lane & 15) >> 2) + 4 * g + (lane & 3)] : 0.f;
       float aA = 0.f, aB = 0.f;
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutAr
 }
 
 bool rollout1_available() { return r1_supported<DefaultNet>(); }
-// 16 <= d <= 31 with sigma = I: the 32-wide input / output network (soc.yaml's default d = 20)
+// 17 <= d <= 31 with sigma = I: the 32-wide input / output network (soc.yaml's default d = 20)
 bool rollout1_wide_available() { return r1_supported<Wide32Net>(); }
 int rollout1_wide_launch(const RolloutArgs& a, bool stopping, void* stream) {
   if constexpr (r1_supported<Wide32Net>()) {

@@ -56,7 +56,7 @@ struct Frags2 {
 };
 
 // The tile layout of socmx_unet.h with the split-K scratch cut to what the last stage writes here (eight waves' partial tiles of
-// up_0 + up to four of res_0): two tiles of the 16 <= d <= 31 network would not fit 160 KiB with the full-size scratch.
+// up_0 + up to four of res_0): two tiles of the 17 <= d <= 31 network would not fit 160 KiB with the full-size scratch.
 constexpr int kB32ScratchFloats = 12 * 256;
 template <class NET>
 __host__ __device__ constexpr TileLayout b32_layout() {
@@ -370,7 +370,7 @@ __device__ __forceinline__ void unet_forward2(const B32Img& Wp, float* lds, Frag
   b32_stage5<NET, TS>(Wp, lds, fr, wave, gv_reg); hook(6);
 }
 
-template <int H>                          // H = 16-component halves of a row: 1 (d <= 15) or 2 (16 <= d <= 31)
+template <int H>                          // H = 16-component halves of a row: 1 (d <= 15) or 2 (17 <= d <= 31)
 struct Burst32Lds {                       // float offsets behind the two tiles
   static constexpr int mat = H == 1 ? 256 : 1024;   // a (d, stride) matrix: stride 17 / 33 (socmx_sde_stride)
   static constexpr int A = 0;             // OU drift
@@ -421,11 +421,11 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
   constexpr TileLayout tl = b32_layout<NET>();
   constexpr UnetDesc ud = NET::desc();
   constexpr int TS = (tl.floats + 3) & ~3;
-  // H: 16-component halves of a row.  16 <= d <= 31 (the 32-wide network input / output): thread (row, i) carries components i
+  // H: 16-component halves of a row.  17 <= d <= 31 (the 32-wide network input / output): thread (row, i) carries components i
   // and 16 + i, so that a row is still one 16-lane group (row sums by DPP) -- every per-component statement below loops over h.
   constexpr int H = NET::outp >> 4, CW = 16 * H;
   typedef Burst32Lds<H> LM;
-  static_assert((NET::outp == 16 && NET::in0p == 16) || (NET::outp == 32 && NET::in0p == 32), "d <= 15 or 16 <= d <= 31");
+  static_assert((NET::outp == 16 && NET::in0p == 16) || (NET::outp == 32 && NET::in0p == 32), "d <= 15 or 17 <= d <= 31");
   static_assert((TS + tl.bias + LM::floats) * 4 <= 160 * 1024, "two tiles in one CU's LDS");
   uint64_t key_seed, key_offset;
   rollout_key(a, key_seed, key_offset);
@@ -687,7 +687,7 @@ static int rollout32_launch_t(const RolloutArgs& a, bool stopping, void* stream)
   }
 }
 
-// in0p = 16: d <= 15 (sigma = I or dense); in0p = 32: 16 <= d <= 31 with sigma = I
+// in0p = 16: d <= 15 (sigma = I or dense); in0p = 32: 17 <= d <= 31 with sigma = I
 bool rollout32_available(int in0p) { return in0p == 16 ? b32_supported<DefaultNet>() : in0p == 32 ? b32_supported<Wide32Net>() : false; }
 int rollout32_launch(const RolloutArgs& a, bool stopping, void* stream) {
   return a.u.in0p == 16 ? rollout32_launch_t<DefaultNet>(a, stopping, stream) : rollout32_launch_t<Wide32Net>(a, stopping, stream);

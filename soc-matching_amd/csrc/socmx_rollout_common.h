@@ -79,7 +79,7 @@ struct DynamicNet { static constexpr int outp = 0; };  // descriptors come from 
 // (SOCMX_H*P: the reference's default arch.hdims = [256,128,64] unless this is a variant build, see socmx_unet.h)
 typedef StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16> DefaultNet;  // d <= 15
 typedef StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64> Wide64Net;   // the same hidden widths at d = 64 (BASELINE configs[4])
-typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... and at 16 <= d <= 31 (soc.yaml's default d = 20)
+typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... and at 17 <= d <= 31 (soc.yaml's default d = 20)
 
 
 // socmx_rollout1.hip: the one-row kernel (B <= 256, sigma = I, d <= 15, default widths); returns false when this build has no
@@ -88,9 +88,9 @@ typedef StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32> Wide32Net;   // ... a
 //  variant's calls bound to the DEFAULT library's definitions, i.e. to kernels compiled for other widths)
 __attribute__((visibility("hidden"))) bool rollout1_available();
 __attribute__((visibility("hidden"))) int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream);
-__attribute__((visibility("hidden"))) bool rollout1_wide_available();     // ... its 16 <= d <= 31 form (sigma = I)
+__attribute__((visibility("hidden"))) bool rollout1_wide_available();     // ... its 17 <= d <= 31 form (sigma = I)
 __attribute__((visibility("hidden"))) int rollout1_wide_launch(const RolloutArgs& a, bool stopping, void* stream);
-// socmx_rollout32.hip: two 16-row tiles per workgroup (evaluation bursts, more tiles than CUs: d <= 15, or 16 <= d <= 31 with sigma = I)
+// socmx_rollout32.hip: two 16-row tiles per workgroup (evaluation bursts, more tiles than CUs: d <= 15, or 17 <= d <= 31 with sigma = I)
 __attribute__((visibility("hidden"))) bool rollout32_available(int in0p);
 __attribute__((visibility("hidden"))) int rollout32_launch(const RolloutArgs& a, bool stopping, void* stream);
 

@@ -566,7 +566,7 @@ def test_dense_sigma_rows_of_the_reference_fixture_in_every_tile_shape():
 
 def test_default_config_rows_of_the_reference_fixture_through_the_two_tile_kernel():
     """ouq20_ou_quadratic_easy_d20_K12 (generated by the reference: soc.yaml's default setting and dimension, default widths):
-    its 8 rows with their injected noise replicated into a 4,168-row launch -- the two-tile kernel's 16 <= d <= 31 form -- and
+    its 8 rows with their injected noise replicated into a 4,168-row launch -- the two-tile kernel's 17 <= d <= 31 form -- and
     into a 2,048-row one (16-row kernel): every copy reproduces the reference's trajectory."""
     from SOC_matching import utils
     name = "ouq20_ou_quadratic_easy_d20_K12"
@@ -625,7 +625,7 @@ def test_two_tile_burst_rollout_equals_the_16_row_kernel():
                                          # a dense sigma (the README's Linear OU): the 16-row launch takes the GENERAL SDE step
                                          # (products through LDS tiles), the two-tile kernel forms them in 16-lane groups
                                          ("OU_linear", 10, 6), ("OU_linear", 15, 3), ("OU_linear", 3, 4),
-                                         # 16 <= d <= 31 with sigma = I (the 32-wide network input / output: soc.yaml's default
+                                         # 17 <= d <= 31 with sigma = I (the 32-wide network input / output: soc.yaml's default
                                          # d = 20): two components per thread; the 16-row launch takes the general SDE step
                                          ("OU_quadratic_easy", 20, 5), ("OU_quadratic_hard", 31, 3), ("OU_quadratic_easy", 16, 4),
                                          ("double_well", 17, 4), ("molecular_dynamics", 24, 8)])
@@ -693,7 +693,7 @@ def test_specialised_and_generic_kernels_agree(tmp_path):
         "    x0, sigma, opt_sde, sde, _ = define_variables(cfg, ts)\n"
         "r = utils.stochastic_trajectories(sde, x0.repeat(40, 1), ts, 1.0, seed=5, offset=2)\n"
         "for i, t in enumerate(r): out[f'ou_linear_d64_{i}'] = t.cpu().numpy()\n"
-        "# d = 20 (soc.yaml's default) and d = 31: the 16 <= d <= 31 instantiation\n"
+        "# d = 20 (soc.yaml's default) and d = 31: the 17 <= d <= 31 instantiation\n"
         "for dd, setting in ((20, 'OU_quadratic_easy'), (31, 'OU_linear')):\n"
         "    cfg = load_config([f'method.setting={setting}', f'method.d={dd}', 'method.num_steps=12'])\n"
         "    cfg.method.device = 'cuda:0'\n"
@@ -1559,7 +1559,7 @@ def test_both_rollout_tile_shapes_pass_the_reference_fixtures():
 
 @pytest.mark.parametrize("K", [1, 2, 3])
 @pytest.mark.parametrize("name", ["cfg3_double_well_d10_K200", "cfg1_ou_quadratic_easy_d2_K50", "md_default_d1_K150_B64_stopping",
-                                  # d = 20: the 16 <= d <= 31 form (two components per lane, down_0 as a stage, OU products off wave 0)
+                                  # d = 20: the 17 <= d <= 31 form (two components per lane, down_0 as a stage, OU products off wave 0)
                                   "ouq20_ou_quadratic_easy_d20_K12"])
 def test_one_row_rollout_on_the_shortest_grids(name, K):
     """One, two and three steps (the noise / scalar / bookkeeping pipeline of the one-row kernel runs one to two steps ahead of
@@ -1590,7 +1590,7 @@ def test_one_row_rollout_on_the_shortest_grids(name, K):
 def test_one_row_and_four_row_rollouts_agree_row_by_row(name, steps):
     """The same Philox rows through the one-row kernel (B = 256: one workgroup per row) and inside a B = 1024 launch (4-row
     tiles): identical noise, trajectories equal up to fp32 summation order in the network -- at d = 10 and at d = 20 (the
-    one-row kernel's 16 <= d <= 31 form against the 4-row general step)."""
+    one-row kernel's 17 <= d <= 31 form against the 4-row general step)."""
     from SOC_matching import utils
     sde, aux = build_sde(name, DEV)
     ts = aux["ts"][:steps + 1]
