@@ -160,8 +160,9 @@ int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d
  * on 2 Np rows (z = 0 on the first Np, 1 on the rest).  z may be NULL when n_in = 2.
  * d*d outputs beyond an LDS tile (d > 26 with 128-wide hidden layers; BASELINE configs[4]: d = 64) take the WIDE kernels:
  * the last layer's outputs leave the forward kernel from the accumulators, the backward reads g_net / g_dnet from HBM as
- * MFMA operands (split-K over the waves) and forms the last layer's weight gradient in its own kernel; this needs
- * d % 4 == 0 and h1 <= 128, otherwise SOCMX_E_LDS (callers keep library autograd).
+ * MFMA operands (split-K over the waves) and forms the last layer's weight gradient in its own kernel; any d (rows of d*d
+ * floats that are not whole 16-byte pieces are read shifted back into the row and stored element by element); this needs
+ * h1 <= 128, otherwise SOCMX_E_LDS (callers keep library autograd).
  */
 size_t socmx_mnet_packed_floats(int32_t d, const int32_t hdims_M[2]);
 int socmx_mnet_pack_f32(int32_t d, const int32_t hdims_M[2], int32_t n_in, const float* w0, const float* b0,

@@ -334,14 +334,34 @@ __device__ __forceinline__ f32x4 uload4(const float* ubase, int float_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, 0));
 }
 
+// the first N of them (N = 1, 3: a 4- / 12-byte load -- the vector memory pipe's time follows the bytes per lane)
+template <int N>
+__device__ __forceinline__ f32x4 uloadn(const float* ubase, int float_off) {
+  const __amdgpu_buffer_rsrc_t r =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(reinterpret_cast<const float*>(scalar_ptr(ubase))), 0, 0x7FFFFFFF, 0x00020000);
+  if constexpr (N == 4) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, 0));
+  } else if constexpr (N == 3) {
+    // (the whole vector is cast at once: element-wise casts of the integer vector make this compiler narrow the load to one dword)
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    const f32x3 t = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, float_off * 4, 0, 0));
+    return f32x4{t[0], t[1], t[2], 0.f};
+  } else {
+    static_assert(N == 1, "1, 3 or 4 floats");
+    const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(r, float_off * 4, 0, 0);
+    return f32x4{__builtin_bit_cast(float, t), 0.f, 0.f, 0.f};
+  }
+}
+
 constexpr int kTargetWaves = 8;  // waves per workgroup: the (pair, l-block) iterations of a row are dealt round-robin
 
 // CT = 16-column batch tiles per wave: the A fragments (and, for NET, the blend that forms them) are built once
 // per (pair, l-block) and multiplied into CT accumulators, so the per-iteration bookkeeping (~300 issue cycles)
-// is amortised over 8*CT MFMAs.  NLB1 = (d <= 16): a single l-block, no division in the iteration -> pair map.
-template <bool NET, int CT, bool NLB1>
+// is amortised over 2*NS*CT MFMAs.  NS != 0 (d <= 16): a single l-block of NS MFMAs, no division in the iteration -> pair map.
+template <bool NET, int CT, int NS>
 __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(const TargetArgs a) {
   __shared__ f32x4 part[kTargetWaves][CT][64];
+  constexpr bool NLB1 = NS != 0;
   const int d = a.d, K = a.K, B = a.B;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -357,6 +377,10 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
   const int nlb = NLB1 ? 1 : (d + 15) >> 4;  // 16-wide l-blocks
   const int nlb_shift = (nlb & (nlb - 1)) == 0 ? __builtin_ctz(nlb) : -1;
   const int dd = d * d;
+  // d <= 12 (one l-block): lane group g4 takes l = ns*g4 .. ns*g4 + ns-1 with ns = ceil(d / 4), so that the l-block is ns MFMAs
+  // instead of four (d = 10: three; d <= 4: one) -- the 16-byte reads stay, their tail is masked at consumption
+  // (NS = 1: d <= 4; 3: d <= 12; 4: d <= 16; 0: several l-blocks of four MFMAs)
+  constexpr int ns = NLB1 ? NS : 4;
   const float gam = NET ? a.gamma[0] : 0.f;
   for (int rep = 0; rep < 2; ++rep) {
     const int i = rep == 0 ? (int)blockIdx.x : K - (int)blockIdx.x;
@@ -374,8 +398,8 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       jr = NLB1 ? t : (nlb_shift >= 0 ? t >> nlb_shift : t / nlb);   // a runtime integer division is ~30 instructions
       const int lb = NLB1 ? 0 : (t - jr * nlb) * 16;
       j = i + jr;
-      l0 = min(lb + 4 * g4, d - 1);                 // this lane's four l: l0 .. l0+3 (clamped into the row)
-      nl = max(0, min(4, d - (lb + 4 * g4)));       // how many of them exist
+      l0 = min(lb + ns * g4, d - 1);                // this lane's l: l0 .. l0+ns-1 (clamped into the row)
+      nl = max(0, min(ns, d - (lb + ns * g4)));     // how many of them exist
     };
     auto load = [&](int t, Slot& sl, auto fast_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
@@ -389,12 +413,12 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       // a 16-byte read can cross the end of a buffer only in the last pair matrix / the last operand rows:
       // those iterations (j + 1 >= K: the row's last two pairs) take clamped scalar reads -- in a loop of their own (below)
       if (FAST) {
-        sl.nt = uload4(Ap, aoff);
-        sl.dn = uload4(Dp, aoff);
+        sl.nt = uloadn<ns>(Ap, aoff);
+        sl.dn = uloadn<ns>(Dp, aoff);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          sl.q[c] = uload4(qs, boff0[c] + l0);
-          sl.v[c] = uload4(vs, boff0[c] + l0);
+          sl.q[c] = uloadn<ns>(qs, boff0[c] + l0);
+          sl.v[c] = uloadn<ns>(vs, boff0[c] + l0);
         }
       } else {
         sl.nt = load4<false>(Ap, aoff, dd);
@@ -414,6 +438,7 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
       const float e = NET ? expf(-gam * sl.dl) : 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (s >= ns) break;
         float xm, xd;
         if (NET) {
           const float eye = (krow == l0 + s) ? 1.f : 0.f;
@@ -2211,17 +2236,21 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   const dim3 blk(64 * kTargetWaves);
 #define SOCMX_TARGET_LAUNCH(NETV, CTV, N1V) \
   lerr = launch(socm_target_mfma_kernel<NETV, CTV, N1V>, grid, blk, 0, stream, a)
-  const bool nlb1 = d <= 16;
+  const int nsv = d <= 4 ? 1 : (d <= 12 ? 3 : (d <= 16 ? 4 : 0));      // MFMAs per l-block (0: several l-blocks)
+#define SOCMX_TARGET_NS(NETV, CTV) \
+  do { if (nsv == 1) SOCMX_TARGET_LAUNCH(NETV, CTV, 1); else if (nsv == 3) SOCMX_TARGET_LAUNCH(NETV, CTV, 3); \
+       else if (nsv == 4) SOCMX_TARGET_LAUNCH(NETV, CTV, 4); else SOCMX_TARGET_LAUNCH(NETV, CTV, 0); } while (0)
   if (launched) {
   } else if (delta) {
-    if (ct == 4)      { if (nlb1) SOCMX_TARGET_LAUNCH(true, 4, true); else SOCMX_TARGET_LAUNCH(true, 4, false); }
-    else if (ct == 2) { if (nlb1) SOCMX_TARGET_LAUNCH(true, 2, true); else SOCMX_TARGET_LAUNCH(true, 2, false); }
-    else              { if (nlb1) SOCMX_TARGET_LAUNCH(true, 1, true); else SOCMX_TARGET_LAUNCH(true, 1, false); }
+    if (ct == 4)      SOCMX_TARGET_NS(true, 4);
+    else if (ct == 2) SOCMX_TARGET_NS(true, 2);
+    else              SOCMX_TARGET_NS(true, 1);
   } else {
-    if (ct == 4)      { if (nlb1) SOCMX_TARGET_LAUNCH(false, 4, true); else SOCMX_TARGET_LAUNCH(false, 4, false); }
-    else if (ct == 2) { if (nlb1) SOCMX_TARGET_LAUNCH(false, 2, true); else SOCMX_TARGET_LAUNCH(false, 2, false); }
-    else              { if (nlb1) SOCMX_TARGET_LAUNCH(false, 1, true); else SOCMX_TARGET_LAUNCH(false, 1, false); }
+    if (ct == 4)      SOCMX_TARGET_NS(false, 4);
+    else if (ct == 2) SOCMX_TARGET_NS(false, 2);
+    else              SOCMX_TARGET_NS(false, 1);
   }
+#undef SOCMX_TARGET_NS
 #undef SOCMX_TARGET_LAUNCH
   if (lerr) return lerr;
   return launch_residual(a, stream);

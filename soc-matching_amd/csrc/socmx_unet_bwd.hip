@@ -968,7 +968,9 @@ struct MDesc {
   // WIDE form (the (d*d)-wide tile does not fit LDS -- BASELINE configs[4]: d = 64, 4096 outputs): the last layer's outputs
   // leave the forward kernel straight from the accumulators, the backward kernel reads g_net / g_dnet rows from HBM as
   // the MFMA B operand (split-K over the waves) and the last layer's weight gradient has its own kernel
-  // (mnet_wgrad_wide_kernel); no GOUT tile, no GOUT slab.  Needs d % 4 == 0 (16-byte pieces of a row) and h1p <= 128.
+  // (mnet_wgrad_wide_kernel); no GOUT tile, no GOUT slab.  Needs h1p <= 128.  The kernels move 16-byte pieces of a row of
+  // d*d floats; where d*d is not a multiple of 16 (d % 4 != 0) the row's last piece is read shifted back into the row and
+  // stored element by element (rows start at any 4-byte address then: global accesses need no more).
   int wide;
   int wscratch;            // wide backward kernel: float offset of the split-K combine scratch (aliases the forward tiles)
   int lds_fwd_floats;      // LDS of the forward kernel (wide: without the backward kernel's tiles and combine scratch)
@@ -1013,7 +1015,7 @@ inline MDesc make_mdesc(int d, int h0, int h1, int nwaves) {
   m.lds_floats = o;
   m.lds_fwd_floats = m.lds_floats;
   m.wide = 0;
-  if ((size_t)m.lds_floats * sizeof(float) > (size_t)160 * 1024 && d % 4 == 0 && m.h1p <= 128) {
+  if ((size_t)m.lds_floats * sizeof(float) > (size_t)160 * 1024 && m.h1p <= 128) {
     // wide layout: [x | hh1 | hh2] | gz2 | m1 | m2 | bias (L0, L1, then L2: forward only) | small scratch.  The backward
     // kernel's split-K combine of the wide stage ALIASES the bracketed forward tiles (dead by then): wscratch = 0.
     m.wide = 1;
@@ -1231,6 +1233,8 @@ __device__ __forceinline__ void m_forward_hidden(const MArgs& a, float* lds, int
 // three chunks whose requests are asm statements with written-out waits and run on ACROSS the group boundaries (the generic
 // stage restarts its ring for every group of blocks: a full L2 round trip per 256 MFMAs); the activation quads come from
 // LDS; every accumulator quad leaves with one 16-byte store.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a quad at any 4-byte address
+
 template <int NW>
 __device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* lds, int tile) {
   // (h1p = 128, i.e. eight chunks per block -- the caller checks: narrower last layers take the generic stage)
@@ -1318,9 +1322,14 @@ __device__ __forceinline__ void m_wide_out_stage(const MArgs& a, const float* ld
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int b = wave + NW * (4 * grp + j);
-        if (b < NBLK && b * 16 + 4 * g < m.d2) {
-          *reinterpret_cast<f32x4*>(orow_n + b * 16) = acc[0][j];
-          *reinterpret_cast<f32x4*>(orow_d + b * 16) = acc[1][j];
+        const int left = m.d2 - (b * 16 + 4 * g);           // floats of the row from this quad on
+        if (b < NBLK && left >= 4) {
+          *reinterpret_cast<f32x4u*>(orow_n + b * 16) = acc[0][j];
+          *reinterpret_cast<f32x4u*>(orow_d + b * 16) = acc[1][j];
+        } else if (b < NBLK && left > 0) {                  // (d % 2 == 1: the row ends inside the quad)
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            if (i < left) { orow_n[b * 16 + i] = acc[0][j][i]; orow_d[b * 16 + i] = acc[1][j][i]; }
         }
       }
     }
@@ -1337,7 +1346,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void mnet_forward_kernel(
   // (wide form: the forward kernel's split-K scratch sits behind all three biases)
   const int sc = m.wide ? m.bias + m.bias_floats : m.scratch;
   m_forward_hidden<NW>(a, lds, tile, 0, 3, sc);
-  if (m.wide && m.h1p == 128) {                   // (d % 4 == 0: whole 16-byte quads; eight chunks per block)
+  if (m.wide && m.h1p == 128) {                   // (eight chunks per block)
     m_wide_out_stage<NW>(a, lds, tile);
     return;
   }
@@ -1382,6 +1391,18 @@ __global__ __launch_bounds__(NW * 64) void mnet_backward_kernel(const MArgs a) {
 // order) stream from L2.  Three chunks (8 A + 2 B requests each) in flight, asm loads with written-out wait counts (see
 // wgrad_body).  Four waves per workgroup, two workgroups per CU (their prologues, combines and barriers interleave); the
 // combine and the masked epilogue are described in the kernel.  Then L1^T as above.
+// q read `sh` floats in front of where it belongs: element i := element i + sh of the read, zero past its end (sh <= 0: unchanged)
+__device__ __forceinline__ f32x4 quad_shift(f32x4 q, int sh) {
+  if (sh <= 0) return q;
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = i + sh;
+    r[i] = k == 1 ? q[1] : (k == 2 ? q[2] : (k == 3 ? q[3] : 0.f));
+  }
+  return r;
+}
+
 template <int NW, int NOB>
 __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MArgs a) {   // (two workgroups per CU = two waves per SIMD: the full register budget, no AGPR copies)
   static_assert(NW == 4, "the combine below is written for four waves");
@@ -1393,7 +1414,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
   const int64_t p0 = (int64_t)tile * 16;
   m_forward_hidden<NW>(a, lds, tile, tile_rows, 2);
   const int row = lane & 15, g = lane >> 4;
-  const int KC = m.d2p >> 4;                              // chunks of the reduction (d2p = d2: d % 4 == 0)
+  const int KC = m.d2p >> 4;                              // chunks of the reduction (the last one may end past the row)
   const int kc0 = (wave * KC) / NW, kc1 = ((wave + 1) * KC) / NW;
   f32x4 acc[2][NOB];
 #pragma unroll
@@ -1403,6 +1424,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
     const int64_t prow = min(p0 + row, a.Np - 1);
     const float* bv = a.gnet + (size_t)prow * m.d2 + 4 * g;
     const float* bt = a.gdnet + (size_t)prow * m.d2 + 4 * g;
+    // the row's last quads: read from at most d2 - 4 on (inside the row, hence inside the buffer) and shifted into place below
+    const int klim = m.d2 - 4 - 4 * g;
+    const bool ragged = (m.d2 & 15) != 0;
     const f32x4* wl = reinterpret_cast<const f32x4*>(a.packedT + m.LT[0].w_off) + lane;   // fragment (block j, chunk kc): (j KC + kc) 64
     constexpr int PD = 3, NL = NOB + 2;
     const int nobm1 = (m.h1p >> 4) - 1;
@@ -1412,8 +1436,9 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
 #pragma unroll
       for (int j = 0; j < NOB; ++j)      // (blocks past h1p / 16 re-read the last one: their accumulators are never used)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[sl][j]) : "v"(wl + (size_t)(min(j, nobm1) * KC + k) * 64) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][0]) : "v"(bv + (size_t)k * 16) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][1]) : "v"(bt + (size_t)k * 16) : "memory");
+      const int ko = min(k * 16, klim);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][0]) : "v"(bv + ko) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][1]) : "v"(bt + ko) : "memory");
     };
     auto wait_slot = [&](int sl) {                 // the two younger chunks may stay in flight
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
@@ -1430,6 +1455,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
         if (kc + sl < kc1) {
           f32x4 bq[2] = {fb[sl][0], fb[sl][1]};
           if (!rowok) { bq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; bq[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          if (ragged && kc + sl == KC - 1) {      // (wave-uniform) quads read `sh` floats early: element i is element i + sh of the read
+            const int sh = (kc + sl) * 16 - klim;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) bq[x] = quad_shift(bq[x], sh);
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1504,7 +1534,7 @@ struct MWgradWideArgs {
   int cell_off, bias_off;    // float offsets of layer 2's cells / bias partial inside a slab of partials
 };
 
-template <int NCB>
+template <int NCB, bool RAG>   // RAG: d*d is odd -- a row may end inside a 16-byte piece
 __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWideArgs a) {
   __shared__ __attribute__((aligned(16))) float T[2][2][64][20];   // [stage][g_net, g_dnet][n][pair row]
   const int lane = threadIdx.x & 63;
@@ -1523,7 +1553,8 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
   const int rg = lane & 3, pc = lane >> 2;
   const float* src = lx == 0 ? a.gnet : a.gdnet;
   const bool colok = n0 + 4 * pc < a.d2;
-  const int ncol = colok ? n0 + 4 * pc : 0;
+  const int ncol = colok ? min(n0 + 4 * pc, a.d2 - 4) : 0;        // (RAG: the row's last piece is read shifted back into the row)
+  const int csh = RAG ? n0 + 4 * pc - ncol : 0;
   // B operand: H2 slab, value tile 2t (with g_net), tangent tile 2t + 1 (with g_dnet)
   const int cb0 = wave * NCB;
   f32x4 acc[4][NCB];
@@ -1566,8 +1597,14 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float2 col;
-        col.x = ok0 ? (sl == 0 ? tl[0][0][e] : tl[1][0][e]) : 0.f;
-        col.y = ok1 ? (sl == 0 ? tl[0][1][e] : tl[1][1][e]) : 0.f;
+        if (RAG) {
+          const f32x4 q0 = quad_shift(sl == 0 ? tl[0][0] : tl[1][0], csh), q1 = quad_shift(sl == 0 ? tl[0][1] : tl[1][1], csh);
+          col.x = ok0 ? q0[e] : 0.f;
+          col.y = ok1 ? q1[e] : 0.f;
+        } else {
+          col.x = ok0 ? (sl == 0 ? tl[0][0][e] : tl[1][0][e]) : 0.f;
+          col.y = ok1 ? (sl == 0 ? tl[0][1][e] : tl[1][1][e]) : 0.f;
+        }
         *reinterpret_cast<float2*>(&T[st][lx][4 * pc + e][4 * rg + 2 * lh]) = col;
       }
     };
@@ -1643,7 +1680,7 @@ __global__ __launch_bounds__(256, 2) void mnet_wgrad_wide_kernel(const MWgradWid
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   float* out = a.part + (size_t)slab * a.slab_floats;
-  const int OB = a.d2 >> 4;                                // d2 % 16 == 0 in the wide form
+  const int OB = (a.d2 + 15) >> 4;                         // (the last block's cells past d*d are zero: zero operand columns)
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2065,8 +2102,11 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
     ga.Np = Np; ga.slab_floats = p.slab_floats; ga.d2 = p.m.d2; ga.h1p = p.m.h1p; ga.ntiles = p.ntiles; ga.S = p.S;
     ga.NG = (p.m.d2 + 63) / 64; ga.IB = p.IB[2]; ga.cell_off = p.w_cell_off[2]; ga.bias_off = p.b_part_off[2];
     const unsigned wgrid = (unsigned)(ga.NG * 8 * ((p.S + 7) / 8));
-    const int err = ga.IB > 4 ? launch(mnet_wgrad_wide_kernel<2>, dim3(wgrid), dim3(256), 0, stream, ga)
-                              : launch(mnet_wgrad_wide_kernel<1>, dim3(wgrid), dim3(256), 0, stream, ga);
+    const bool rag = (p.m.d2 & 3) != 0;
+    const int err = ga.IB > 4 ? (rag ? launch(mnet_wgrad_wide_kernel<2, true>, dim3(wgrid), dim3(256), 0, stream, ga)
+                                     : launch(mnet_wgrad_wide_kernel<2, false>, dim3(wgrid), dim3(256), 0, stream, ga))
+                              : (rag ? launch(mnet_wgrad_wide_kernel<1, true>, dim3(wgrid), dim3(256), 0, stream, ga)
+                                     : launch(mnet_wgrad_wide_kernel<1, false>, dim3(wgrid), dim3(256), 0, stream, ga));
     if (err) return err;
   } else {
     if (const int err = ensure_max_lds(mnet_backward_kernel<kK2Waves>)) return err;

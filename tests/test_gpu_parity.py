@@ -849,8 +849,8 @@ def test_readme_double_well_command_line_prints_the_fast_iteration(tmp_path):
 
 
 def test_configurations_outside_the_kernels_ranges_warn_once_and_stay_on_the_gpu():
-    """arch.hdims_M / d combinations the pair-grid-network kernels do not take (d = 30: neither d*d <= 26*26 nor d % 4 == 0)
-    run torch autograd + library GEMMs ON THE GPU and say so once per process; objective and gradients are finite and the
+    """arch.hdims_M / d combinations the pair-grid-network kernels do not take (hidden widths beyond 128 once d*d outputs no
+    longer fit an LDS tile: [256, 256] at d = 30) run torch autograd + library GEMMs ON THE GPU and say so once per process; objective and gradients are finite and the
     run continues (the routing is explicit, never a CPU or oracle path)."""
     import contextlib, io, warnings
     from socmx.config import load_config
@@ -858,7 +858,7 @@ def test_configurations_outside_the_kernels_ranges_warn_once_and_stay_on_the_gpu
     from socmx import nets
     from SOC_matching.method import SOC_Solver
     cfg = load_config(["method.setting=OU_linear", "method.d=30", "method.num_steps=6", "method.gamma=2.0",
-                       "method.scaling_factor_M=0.1"])          # default arch.hdims_M = [128,128]
+                       "method.scaling_factor_M=0.1", "arch.hdims_M=[256,256]"])
     cfg.method.device = DEV
     torch.manual_seed(0)
     ts = torch.linspace(0, 1.0, 7).to(DEV)
@@ -874,6 +874,44 @@ def test_configurations_outside_the_kernels_ranges_warn_once_and_stay_on_the_gpu
     with warnings.catch_warnings():
         warnings.simplefilter("error")          # second call: no second warning
         solver.loss(16, algorithm="SOCM", use_warm_start=False, use_stopping_time=False)
+
+
+@pytest.mark.parametrize("d", [30, 23])
+def test_socm_iteration_at_dimensions_with_ragged_pair_matrix_rows(d):
+    """d % 4 != 0 beyond d = 22 (default arch.hdims_M): the pair-grid-network kernels' WIDE form with rows of d*d floats that are
+    not whole 16-wide blocks.  The SOCM objective and every gradient with the HIP pair-net kernels against the same iteration
+    with the library path of the same module (torch GEMMs + analytic tangent), same injected noise."""
+    import contextlib, io, warnings
+    from socmx.config import load_config
+    from socmx.settings import define_variables
+    from SOC_matching.method import SOC_Solver
+    K, B = 7, 24
+    cfg = load_config(["method.setting=OU_linear", f"method.d={d}", f"method.num_steps={K}", "method.gamma=2.0",
+                       "method.scaling_factor_M=0.1"])
+    cfg.method.device = DEV
+    torch.manual_seed(0)
+    ts = torch.linspace(0, 1.0, K + 1).to(DEV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        x0, sigma, _, sde, _ = define_variables(cfg, ts)
+    solver = SOC_Solver(sde, x0, None, T=1.0, num_steps=K, lmbd=1.0, d=d, sigma=sigma)
+    noise = torch.randn(K, B, d, generator=torch.Generator().manual_seed(3)).to(DEV)
+    res = []
+    for fused in (True, False):
+        sde.M.fused_pair_net = fused
+        solver.noise_in = noise                             # (consumed by the call)
+        for p_ in sde.parameters():
+            p_.grad = None
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                  # no library fall-back warning: the kernels take these shapes
+            out = solver.loss(B, algorithm="SOCM", use_warm_start=False, use_stopping_time=False)
+        out[0].backward()
+        res.append((out[0].item(), {n: p_.grad.double().cpu().clone() for n, p_ in sde.named_parameters() if p_.grad is not None}))
+    (o1, g1), (o0, g0) = res
+    np.testing.assert_allclose(o1, o0, rtol=1e-5)
+    assert set(g1) == set(g0) and any(n.startswith("M.") for n in g1)
+    for n in g0:
+        e = float(((g1[n] - g0[n]) ** 2).sum()) ** 0.5
+        assert e <= 2e-4 * float((g0[n] ** 2).sum()) ** 0.5 + 1e-7, (n, e)
 
 
 def test_the_integration_stub_in_the_docs_runs(monkeypatch):

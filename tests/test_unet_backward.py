@@ -129,9 +129,13 @@ def test_pair_network_kernels_vs_library_autograd(name, extra):
 
 
 @pytest.mark.parametrize("d,hdims,K", [(28, (128, 128), 9), (32, (128, 128), 30), (36, (64, 32), 12), (64, (128, 128), 45),
-                                       (64, (16, 16), 7), (40, (128, 64), 20), (48, (48, 80), 17)])
+                                       (64, (16, 16), 7), (40, (128, 64), 20), (48, (48, 80), 17),
+                                       # d % 4 != 0: rows of d*d floats that end inside a 16-wide block (d even) or inside a
+                                       # 16-byte piece at any 4-byte address (d odd)
+                                       (30, (128, 128), 9), (26, (128, 128), 14), (23, (128, 128), 8), (31, (128, 128), 6),
+                                       (65, (128, 128), 5), (27, (64, 32), 7), (45, (128, 64), 6), (33, (16, 16), 11)])
 def test_wide_pair_network_kernels_vs_fp64(d, hdims, K):
-    """The WIDE pair-grid-network kernels (d*d outputs beyond an LDS tile; d % 4 == 0) on random modules of several hidden
+    """The WIDE pair-grid-network kernels (d*d outputs beyond an LDS tile; any d) on random modules of several hidden
     widths and ragged pair counts, against the same module evaluated in fp64 by torch (values, s-tangents and all six
     parameter gradients for random upstream gradients), and additivity of the gradients over the pairs."""
     from socmx import loss as L, nets
