@@ -162,7 +162,8 @@ int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d
  * the last layer's outputs leave the forward kernel from the accumulators, the backward reads g_net / g_dnet from HBM as
  * MFMA operands (split-K over the waves) and forms the last layer's weight gradient in its own kernel; any d (rows of d*d
  * floats that are not whole 16-byte pieces are read shifted back into the row and stored element by element); this needs
- * h1 <= 128, otherwise SOCMX_E_LDS (callers keep library autograd).
+ * h1 <= 256 (beyond 128 units the backward kernel passes over the gradient rows twice), otherwise SOCMX_E_LDS (callers keep
+ * library autograd).
  */
 size_t socmx_mnet_packed_floats(int32_t d, const int32_t hdims_M[2]);
 int socmx_mnet_pack_f32(int32_t d, const int32_t hdims_M[2], int32_t n_in, const float* w0, const float* b0,

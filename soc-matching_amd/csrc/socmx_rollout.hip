@@ -1257,7 +1257,7 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
       // Python layer routes to torch autograd + library GEMMs on the GPU, with a warning -- never to the CPU)
       "ranges: rollout any arch.hdims, d <= 64 (OU_quadratic) .. 96 (double_well) at the default widths; "
       "control-network backward: architectures whose 16-row tiles fit 160 KiB of LDS (h0 <= 256 at the default depth); "
-      "pair-grid network: every d with hdims_M[1] <= 128 (d*d beyond an LDS tile: wide form), hdims_M up to [256,256] while d*d fits the tile (d <= 25); "
+      "pair-grid network: every d with hdims_M up to [256,256] (d*d beyond an LDS tile: wide form); "
       "stopping-time SOCM kernels: d <= 16; costate (SOCM_adjoint) kernel: d <= 64";
   const int need = (int)sizeof(msg);
   if (buf && cap > 0) {

@@ -968,7 +968,7 @@ struct MDesc {
   // WIDE form (the (d*d)-wide tile does not fit LDS -- BASELINE configs[4]: d = 64, 4096 outputs): the last layer's outputs
   // leave the forward kernel straight from the accumulators, the backward kernel reads g_net / g_dnet rows from HBM as
   // the MFMA B operand (split-K over the waves) and the last layer's weight gradient has its own kernel
-  // (mnet_wgrad_wide_kernel); no GOUT tile, no GOUT slab.  Needs h1p <= 128.  The kernels move 16-byte pieces of a row of
+  // (mnet_wgrad_wide_kernel); no GOUT tile, no GOUT slab.  Needs h1p <= 256.  The kernels move 16-byte pieces of a row of
   // d*d floats; where d*d is not a multiple of 16 (d % 4 != 0) the row's last piece is read shifted back into the row and
   // stored element by element (rows start at any 4-byte address then: global accesses need no more).
   int wide;
@@ -1015,7 +1015,7 @@ inline MDesc make_mdesc(int d, int h0, int h1, int nwaves) {
   m.lds_floats = o;
   m.lds_fwd_floats = m.lds_floats;
   m.wide = 0;
-  if ((size_t)m.lds_floats * sizeof(float) > (size_t)160 * 1024 && m.h1p <= 128) {
+  if ((size_t)m.lds_floats * sizeof(float) > (size_t)160 * 1024 && m.h1p <= 256) {
     // wide layout: [x | hh1 | hh2] | gz2 | m1 | m2 | bias (L0, L1, then L2: forward only) | small scratch.  The backward
     // kernel's split-K combine of the wide stage ALIASES the bracketed forward tiles (dead by then): wscratch = 0.
     m.wide = 1;
@@ -1025,7 +1025,7 @@ inline MDesc make_mdesc(int d, int h0, int h1, int nwaves) {
     m.hh2 = o; o += 32 * m.s2;
     m.gout = -1;
     // one half of the combine: four waves' quads of half the output blocks, value and tangent
-    const int nob_t = (m.h1p >> 4) <= 2 ? 2 : ((m.h1p >> 4) <= 4 ? 4 : 8);   // the kernel's NOB instantiation
+    const int nob_t = (m.h1p >> 4) <= 2 ? 2 : ((m.h1p >> 4) <= 4 ? 4 : 8);   // the kernel's NOB instantiation (129 .. 256 units: two passes of 8)
     const int combine_half = 4 * 2 * (nob_t / 2) * 256;
     m.wscratch = 0;
     if (combine_half > o) o = combine_half;
@@ -1416,6 +1416,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
   const int row = lane & 15, g = lane >> 4;
   const int KC = m.d2p >> 4;                              // chunks of the reduction (the last one may end past the row)
   const int kc0 = (wave * KC) / NW, kc1 = ((wave + 1) * KC) / NW;
+  // A last hidden layer beyond NOB = 8 blocks (129 .. 256 units) takes two passes of eight blocks over the gradient rows:
+  // sixteen blocks' accumulators and fragment rings do not fit the registers (and a spilled ring register is copied BEFORE
+  // its asm-issued load has landed).
+  const int nob = m.h1p >> 4;
+  float* sc = lds + m.wscratch;
+  constexpr int HB = NOB / 2 > 0 ? NOB / 2 : 1;           // blocks per half
+  MEpi b1{ME_MASK, lds, nullptr, m.gz2, m.s2, m.m2, m.h1p,
+          a.ws + (size_t)tile_rows * m.pre[MT_GZ2] + (size_t)(2 * tile) * m.h1p * 16, m.h1p, nullptr, nullptr, 0, 0, 0};
+  for (int jb = 0; jb < nob; jb += NOB) {
   f32x4 acc[2][NOB];
 #pragma unroll
   for (int j = 0; j < NOB; ++j) { acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1429,19 +1438,19 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
     const bool ragged = (m.d2 & 15) != 0;
     const f32x4* wl = reinterpret_cast<const f32x4*>(a.packedT + m.LT[0].w_off) + lane;   // fragment (block j, chunk kc): (j KC + kc) 64
     constexpr int PD = 3, NL = NOB + 2;
-    const int nobm1 = (m.h1p >> 4) - 1;
+    const int nobm1 = nob - 1;
     f32x4 fa[PD][NOB], fb[PD][2];
     auto load = [&](int kc, int sl) {
       const int k = min(kc, kc1 - 1);
 #pragma unroll
       for (int j = 0; j < NOB; ++j)      // (blocks past h1p / 16 re-read the last one: their accumulators are never used)
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[sl][j]) : "v"(wl + (size_t)(min(j, nobm1) * KC + k) * 64) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[sl][j]) : "v"(wl + (size_t)(min(jb + j, nobm1) * KC + k) * 64) : "memory");
       const int ko = min(k * 16, klim);
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][0]) : "v"(bv + ko) : "memory");
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][1]) : "v"(bt + ko) : "memory");
     };
-    auto wait_slot = [&](int sl) {                 // the two younger chunks may stay in flight
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+    auto wait_slot = [&](int sl) {                 // the PD - 1 younger chunks may stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NL) : "memory");
 #pragma unroll
       for (int j = 0; j < NOB; ++j) asm volatile("" : "+v"(fa[sl][j]));
       asm volatile("" : "+v"(fb[sl][0]), "+v"(fb[sl][1]));
@@ -1478,11 +1487,6 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
   // half: the whole kernel stays under 80 KiB of LDS = two workgroups per CU.  Per half: every wave parks its quads of the
   // half's blocks, barrier, wave w reduces block(s) w, w + 4 of the half (four partials per tile) and runs the masked
   // epilogue (gz2 tile + GZ2 slab), barrier.
-  float* sc = lds + m.wscratch;
-  const int nob = m.h1p >> 4;
-  constexpr int HB = NOB / 2 > 0 ? NOB / 2 : 1;           // blocks per half
-  MEpi b1{ME_MASK, lds, nullptr, m.gz2, m.s2, m.m2, m.h1p,
-          a.ws + (size_t)tile_rows * m.pre[MT_GZ2] + (size_t)(2 * tile) * m.h1p * 16, m.h1p, nullptr, nullptr, 0, 0, 0};
   __syncthreads();                                        // (everyone is done with the forward tiles)
 #pragma unroll
   for (int half = 0; half < (NOB + HB - 1) / HB; ++half) {
@@ -1496,7 +1500,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
     }
     __syncthreads();
     for (int jj = wave; jj < HB; jj += NW) {
-      const int j = half * HB + jj;
+      const int j = jb + half * HB + jj;
       if (j < nob) {
         f32x4 vq = f32x4{0.f, 0.f, 0.f, 0.f}, tq = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1509,6 +1513,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
     }
     __syncthreads();
   }
+  }   // (pass)
   MEpi b2{ME_MASK, lds, nullptr, -1, 0, m.m1, m.h0p,
           a.ws + (size_t)tile_rows * m.pre[MT_GZ1] + (size_t)(2 * tile) * m.h0p * 16, m.h0p, nullptr, nullptr, 0, 0, 0};
   m_stage<NW>(a.packedT, m.LT[1], lds, m.gz2, m.s2, lds + m.scratch, b2);
@@ -2103,7 +2108,9 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
     ga.NG = (p.m.d2 + 63) / 64; ga.IB = p.IB[2]; ga.cell_off = p.w_cell_off[2]; ga.bias_off = p.b_part_off[2];
     const unsigned wgrid = (unsigned)(ga.NG * 8 * ((p.S + 7) / 8));
     const bool rag = (p.m.d2 & 3) != 0;
-    const int err = ga.IB > 4 ? (rag ? launch(mnet_wgrad_wide_kernel<2, true>, dim3(wgrid), dim3(256), 0, stream, ga)
+    const int err = ga.IB > 8 ? (rag ? launch(mnet_wgrad_wide_kernel<4, true>, dim3(wgrid), dim3(256), 0, stream, ga)
+                                     : launch(mnet_wgrad_wide_kernel<4, false>, dim3(wgrid), dim3(256), 0, stream, ga))
+                  : ga.IB > 4 ? (rag ? launch(mnet_wgrad_wide_kernel<2, true>, dim3(wgrid), dim3(256), 0, stream, ga)
                                      : launch(mnet_wgrad_wide_kernel<2, false>, dim3(wgrid), dim3(256), 0, stream, ga))
                               : (rag ? launch(mnet_wgrad_wide_kernel<1, true>, dim3(wgrid), dim3(256), 0, stream, ga)
                                      : launch(mnet_wgrad_wide_kernel<1, false>, dim3(wgrid), dim3(256), 0, stream, ga));

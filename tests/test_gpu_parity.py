@@ -849,8 +849,8 @@ def test_readme_double_well_command_line_prints_the_fast_iteration(tmp_path):
 
 
 def test_configurations_outside_the_kernels_ranges_warn_once_and_stay_on_the_gpu():
-    """arch.hdims_M / d combinations the pair-grid-network kernels do not take (hidden widths beyond 128 once d*d outputs no
-    longer fit an LDS tile: [256, 256] at d = 30) run torch autograd + library GEMMs ON THE GPU and say so once per process; objective and gradients are finite and the
+    """arch.hdims_M / d combinations the pair-grid-network kernels do not take (hidden widths beyond 256 once d*d outputs no
+    longer fit an LDS tile: [512, 512] at d = 30) run torch autograd + library GEMMs ON THE GPU and say so once per process; objective and gradients are finite and the
     run continues (the routing is explicit, never a CPU or oracle path)."""
     import contextlib, io, warnings
     from socmx.config import load_config
@@ -858,7 +858,7 @@ def test_configurations_outside_the_kernels_ranges_warn_once_and_stay_on_the_gpu
     from socmx import nets
     from SOC_matching.method import SOC_Solver
     cfg = load_config(["method.setting=OU_linear", "method.d=30", "method.num_steps=6", "method.gamma=2.0",
-                       "method.scaling_factor_M=0.1", "arch.hdims_M=[256,256]"])
+                       "method.scaling_factor_M=0.1", "arch.hdims_M=[512,512]"])
     cfg.method.device = DEV
     torch.manual_seed(0)
     ts = torch.linspace(0, 1.0, 7).to(DEV)

@@ -133,7 +133,9 @@ def test_pair_network_kernels_vs_library_autograd(name, extra):
                                        # d % 4 != 0: rows of d*d floats that end inside a 16-wide block (d even) or inside a
                                        # 16-byte piece at any 4-byte address (d odd)
                                        (30, (128, 128), 9), (26, (128, 128), 14), (23, (128, 128), 8), (31, (128, 128), 6),
-                                       (65, (128, 128), 5), (27, (64, 32), 7), (45, (128, 64), 6), (33, (16, 16), 11)])
+                                       (65, (128, 128), 5), (27, (64, 32), 7), (45, (128, 64), 6), (33, (16, 16), 11),
+                                       # last hidden layer beyond 128 units (arch.hdims_M = [256, 256] at d >= 26)
+                                       (28, (256, 256), 6), (30, (256, 256), 7), (64, (256, 256), 5), (33, (200, 144), 6)])
 def test_wide_pair_network_kernels_vs_fp64(d, hdims, K):
     """The WIDE pair-grid-network kernels (d*d outputs beyond an LDS tile; any d) on random modules of several hidden
     widths and ragged pair counts, against the same module evaluated in fp64 by torch (values, s-tangents and all six
