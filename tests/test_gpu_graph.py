@@ -59,8 +59,8 @@ def test_graph_replay_equals_the_eager_iteration(name, B):
         #  same rule, last-bit differences in the bias corrections -- a few 1e-7 on parameters of size 1e-2 after 7 steps)
         #  At the headline size (B = 128: 25,728 rows per weight gradient) a handful of entries whose gradient sums nearly
         #  cancel differ by a few 1e-6 after seven Adam steps (eps = 1e-4 divides a last-bit difference of the sum by 1e-4):
-        #  element-wise 1e-5 there, and norm-wise agreement to 2e-6 everywhere.
-        np.testing.assert_allclose(par_g[k], par_e[k], rtol=2e-5, atol=5e-7 if B < 128 else 1e-5, err_msg=k)
+        #  element-wise 1e-5 there (and at K = 100, B = 64: 6,464 rows), and norm-wise agreement to 2e-6 everywhere.
+        np.testing.assert_allclose(par_g[k], par_e[k], rtol=2e-5, atol=5e-7 if B * solver.num_steps < 6000 else 1e-5, err_msg=k)
         assert np.linalg.norm(par_g[k] - par_e[k]) <= 2e-6 * max(np.linalg.norm(par_e[k]), 1e-12) + 1e-9, k
 
 
