@@ -329,6 +329,9 @@ FIXTURES = [
     # d <= 15 -- the dense forms of the one-row rollout kernel (u = -sigma^T nabla_V, sigma u, sigma eps on the serial chain) and,
     # through the tests that re-launch its rows in larger batches, of the 4-row / 16-row / two-tile kernels
     ("oul10_ou_linear_d10_K100_B64", "OU_linear", 10, 100, 64, DEFAULT, 2.0, 0, dict(with_pairs=False)),
+    # (6) d % 4 != 0 beyond d = 22 (default widths): rows of d*d = 900 floats in the pair-grid network's WIDE kernels (56 whole
+    # 16-wide blocks + one quad), several 16-wide blocks per pair matrix in the contraction, the 32-wide rollout instantiation
+    ("oul30_ou_linear_d30_K10_B16", "OU_linear", 30, 10, 16, DEFAULT, 2.0, 0, dict(with_pairs=False)),
 ]
 
 

@@ -354,7 +354,9 @@ def test_contraction_kernels_multi_block_shapes(d, K, B):
                                          # ... and BASELINE configs[1] at ITS size (README.md:15: d = 2, K = 50, B = 128)
                                          "cfg1_full_ou_quadratic_easy_d2_K50_B128",
                                          # ... and the README's Linear OU at its size (dense sigma, d = 10, K = 100, B = 64)
-                                         "oul10_ou_linear_d10_K100_B64"])
+                                         "oul10_ou_linear_d10_K100_B64",
+                                         # d = 30: pair matrices of 900 floats (d % 4 != 0) in the wide pair-grid-network kernels
+                                         "oul30_ou_linear_d30_K10_B16"])
 def test_full_socm_loss_on_gpu_vs_golden(name):
     from SOC_matching.method import SOC_Solver
     sde, aux = build_sde(name, DEV)
@@ -1414,7 +1416,8 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["tiny_double_well_d10", "tiny_ou_linear_d6", "tiny_ou_linear_d20", "tiny_molecular_dynamics_d2",
-                                  "cfg3_double_well_d10_K200", "ouq20_ou_quadratic_easy_d20_K12", "cfg5_ou_linear_d64_K20"])
+                                  "cfg3_double_well_d10_K200", "ouq20_ou_quadratic_easy_d20_K12", "cfg5_ou_linear_d64_K20",
+                                  "oul30_ou_linear_d30_K10_B16"])
 def test_rollout_hands_over_nabla_V_on_all_grid_points(name):
     """socmx_rollout_ex_f32's `nabla_v` (K+1,B,d): the network outputs of the integrator plus the terminal evaluation =
     the forward values of method.py:272-278, against the oracle's network on the oracle's trajectory (same noise);

@@ -81,7 +81,9 @@ def test_socm_loss_and_grads(name, derivative):
                                   "cfg5_ou_linear_d64_K20", "cfg5_ou_linear_d64_B256_K3",
                                   "cfg4_double_well_d10_B512_K6",
                                   # the README's Linear OU at its own size: dense sigma, d = 10, K = 100, B = 64
-                                  "oul10_ou_linear_d10_K100_B64"])
+                                  "oul10_ou_linear_d10_K100_B64",
+                                  # d = 30 (d*d = 900 outputs of the pair-grid network: not a multiple of 16)
+                                  "oul30_ou_linear_d30_K10_B16"])
 def test_socm_loss_default_arch(name):
     torch.set_num_threads(4)
     pb, vp, mp, gamma, aux = O.load_fixture(os.path.join(GOLDEN, name + ".npz"), requires_grad=True)

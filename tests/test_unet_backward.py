@@ -94,7 +94,9 @@ def test_unet_backward_zero_gradient_rows_contribute_nothing():
                                         ("ouq20_ou_quadratic_easy_d20_K12", {}),
                                         # d = 64: the WIDE form (4096 outputs: last layer straight to HBM, split-K backward
                                         # from the row-major gradients, its own weight-gradient kernel) -- 231 pairs / 10 pairs
-                                        ("cfg5_ou_linear_d64_K20", {}), ("cfg5_ou_linear_d64_B256_K3", {})])
+                                        ("cfg5_ou_linear_d64_K20", {}), ("cfg5_ou_linear_d64_B256_K3", {}),
+                                        # ... with rows of 900 floats (d = 30)
+                                        ("oul30_ou_linear_d30_K10_B16", {})])
 def test_pair_network_kernels_vs_library_autograd(name, extra):
     """K3: socmx_mnet_forward_f32 / _backward_f32 (SigmoidMLP.sigmoid_layers and its s-tangent on the pair grid) against
     the library path of the same module (torch GEMMs + analytic tangent, itself pinned by the reference's jacrev fixtures):
