@@ -1403,7 +1403,9 @@ __device__ __forceinline__ f32x4 quad_shift(f32x4 q, int sh) {
   return r;
 }
 
-template <int NW, int NOB>
+// GEN: rows of d*d floats that are not whole 16-wide blocks and / or more than NOB output blocks (the d % 4 = 0, <= 128-unit
+// instantiation -- BASELINE configs[4] -- carries none of that code: it cost 0.36 ms of 1.57 at the slice)
+template <int NW, int NOB, bool GEN>
 __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MArgs a) {   // (two workgroups per CU = two waves per SIMD: the full register budget, no AGPR copies)
   static_assert(NW == 4, "the combine below is written for four waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1424,7 +1426,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
   constexpr int HB = NOB / 2 > 0 ? NOB / 2 : 1;           // blocks per half
   MEpi b1{ME_MASK, lds, nullptr, m.gz2, m.s2, m.m2, m.h1p,
           a.ws + (size_t)tile_rows * m.pre[MT_GZ2] + (size_t)(2 * tile) * m.h1p * 16, m.h1p, nullptr, nullptr, 0, 0, 0};
-  for (int jb = 0; jb < nob; jb += NOB) {
+  for (int jb = 0; jb < (GEN ? nob : 1); jb += NOB) {
   f32x4 acc[2][NOB];
 #pragma unroll
   for (int j = 0; j < NOB; ++j) { acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1435,7 +1437,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
     const float* bt = a.gdnet + (size_t)prow * m.d2 + 4 * g;
     // the row's last quads: read from at most d2 - 4 on (inside the row, hence inside the buffer) and shifted into place below
     const int klim = m.d2 - 4 - 4 * g;
-    const bool ragged = (m.d2 & 15) != 0;
+    const bool ragged = GEN && (m.d2 & 15) != 0;
     const f32x4* wl = reinterpret_cast<const f32x4*>(a.packedT + m.LT[0].w_off) + lane;   // fragment (block j, chunk kc): (j KC + kc) 64
     constexpr int PD = 3, NL = NOB + 2;
     const int nobm1 = nob - 1;
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mnet_backward_wide_kernel(const MA
 #pragma unroll
       for (int j = 0; j < NOB; ++j)      // (blocks past h1p / 16 re-read the last one: their accumulators are never used)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[sl][j]) : "v"(wl + (size_t)(min(jb + j, nobm1) * KC + k) * 64) : "memory");
-      const int ko = min(k * 16, klim);
+      const int ko = GEN ? min(k * 16, klim) : k * 16;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][0]) : "v"(bv + ko) : "memory");
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[sl][1]) : "v"(bt + ko) : "memory");
     };
@@ -2093,10 +2095,11 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
   const size_t lds_bytes = (size_t)p.m.lds_floats * sizeof(float);
   const int nlay_b = p.m.wide ? 2 : 3;                    // layers whose weight gradient kernel B forms from the slabs
   if (p.m.wide) {
-    void (*kern)(const MArgs) = mnet_backward_wide_kernel<kK3WideWaves, 8>;
     const int nob = p.m.h1p >> 4;
-    if (nob <= 2) kern = mnet_backward_wide_kernel<kK3WideWaves, 2>;
-    else if (nob <= 4) kern = mnet_backward_wide_kernel<kK3WideWaves, 4>;
+    const bool gen = (p.m.d2 & 15) != 0 || nob > 8;
+    void (*kern)(const MArgs) = gen ? mnet_backward_wide_kernel<kK3WideWaves, 8, true> : mnet_backward_wide_kernel<kK3WideWaves, 8, false>;
+    if (nob <= 2) kern = gen ? mnet_backward_wide_kernel<kK3WideWaves, 2, true> : mnet_backward_wide_kernel<kK3WideWaves, 2, false>;
+    else if (nob <= 4) kern = gen ? mnet_backward_wide_kernel<kK3WideWaves, 4, true> : mnet_backward_wide_kernel<kK3WideWaves, 4, false>;
     if (const int err = ensure_max_lds(kern)) return err;
     if (const int err = launch(kern, dim3(p.ntiles), dim3(kK3WideWaves * 64), lds_bytes, stream, a)) return err;
     // the last layer's weight / bias gradient partials (its own kernel: A operand transposed through LDS)
