@@ -264,7 +264,10 @@ def test_fused_pair_matrix_kernels_vs_materialised(name):
                                    # d % 4 != 0 at B >= 256: the compiler-scheduled LDS form
                                    (22, 4, 256), (50, 3, 270),
                                    # d <= 16 at B >= 512: two pairs per wave in the backward kernel (ragged batch, odd K)
-                                   (3, 9, 520), (10, 6, 515), (16, 5, 512)])
+                                   (3, 9, 520), (10, 6, 515), (16, 5, 512),
+                                   # d <= 16, small batches: one / three / four MFMAs per l-block (d <= 4, <= 12, <= 16: 4- / 12- /
+                                   # 16-byte operand requests) at one, two and four batch tiles per wave, rows long enough for the ring
+                                   (1, 30, 8), (4, 25, 20), (5, 21, 40), (8, 30, 64), (12, 19, 33), (13, 16, 17), (9, 40, 100)])
 def test_contraction_kernels_multi_block_shapes(d, K, B):
     """d > 16 takes several 16-wide k/l blocks per pair matrix, B > 32 four batch tiles per wave (ragged last tile):
     none of the reference-generated fixtures is that large, so the HIP contraction (materialised and fused forms,
