@@ -332,6 +332,13 @@ FIXTURES = [
     # (6) d % 4 != 0 beyond d = 22 (default widths): rows of d*d = 900 floats in the pair-grid network's WIDE kernels (56 whole
     # 16-wide blocks + one quad), several 16-wide blocks per pair matrix in the contraction, the 32-wide rollout instantiation
     ("oul30_ou_linear_d30_K10_B16", "OU_linear", 30, 10, 16, DEFAULT, 2.0, 0, dict(with_pairs=False)),
+    # (7) the eight other losses at the DEFAULT widths in the README's two other sweep settings (README.md:15-45 run every
+    # algorithm at each setting): Quadratic OU at d = 20 (the 32-wide instantiations, A / P matrices in the costate recursion) and
+    # Linear OU at d = 10 (dense sigma)
+    ("ouq20_algs_ou_quadratic_easy_d20_K12", "OU_quadratic_easy", 20, 12, 8, DEFAULT, 2.0, 0,
+     dict(with_pairs=False, with_loss=False, with_algs=True)),
+    ("oul10_algs_ou_linear_d10_K20", "OU_linear", 10, 20, 8, DEFAULT, 2.0, 0,
+     dict(with_pairs=False, with_loss=False, with_algs=True)),
 ]
 
 

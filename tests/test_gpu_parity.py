@@ -1264,7 +1264,10 @@ OTHER_ALGS = ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-
 @pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10",
                                   # default widths, K = 200: HIP rollout (static kernels) -> socmx_baselines kernels -> static
                                   # control-network backward; SOCM_adjoint's costate recursion over 200 steps
-                                  "cfg3_algs_double_well_d10_K200"])
+                                  "cfg3_algs_double_well_d10_K200",
+                                  # ... and the README's two other sweep settings at default widths: Quadratic OU d = 20 (32-wide
+                                  # instantiations, A / P in the costate recursion), Linear OU d = 10 (dense sigma)
+                                  "ouq20_algs_ou_quadratic_easy_d20_K12", "oul10_algs_ou_linear_d10_K20"])
 @pytest.mark.parametrize("alg", OTHER_ALGS)
 def test_other_losses_on_gpu_match_reference(name, alg, monkeypatch):
     """Row f4 on the GPU: the reference's eight other losses on the HIP rollout's buffers (rel_entropy differentiates

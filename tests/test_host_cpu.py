@@ -150,7 +150,9 @@ OTHER_ALGS = ("SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-
 
 @pytest.mark.parametrize("name", ["tiny_ou_quadratic_hard_d4", "tiny_ou_linear_d6", "tiny_double_well_d10",
                                   # default widths, K = 200 (SOCM_adjoint's costate recursion over 200 steps)
-                                  "cfg3_algs_double_well_d10_K200"])
+                                  "cfg3_algs_double_well_d10_K200",
+                                  # the README's two other sweep settings at default widths (d = 20; dense sigma at d = 10)
+                                  "ouq20_algs_ou_quadratic_easy_d20_K12", "oul10_algs_ou_linear_d10_K20"])
 @pytest.mark.parametrize("alg", OTHER_ALGS)
 def test_other_losses_match_reference(name, alg):
     """Row f4: the reference's eight other losses, objective and nabla_V gradients, same injected noise."""
