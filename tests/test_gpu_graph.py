@@ -41,7 +41,8 @@ def _run(name, graph, steps, B, seed=77):
                                     ("cfg3_full_double_well_d10_K200_B128", 128),
                                     ("cfg1_full_ou_quadratic_easy_d2_K50_B128", 128),
                                     ("oul10_ou_linear_d10_K100_B64", 64),      # dense sigma: the one-row kernel's dense form
-                                    ("ouq20_ou_quadratic_easy_d20_K12", 40), ("tiny_molecular_dynamics_d2_stopping", 48)])
+                                    ("ouq20_ou_quadratic_easy_d20_K12", 40), ("tiny_molecular_dynamics_d2_stopping", 48),
+                                    ("oul30_ou_linear_d30_K10_B16", 16)])      # pair matrices of 900 floats: the wide pair-net kernels
 def test_graph_replay_equals_the_eager_iteration(name, B):
     """7 iterations = 2 eager warm-up + the captured one + 4 replays, fresh Philox noise in every one; the eager Trainer on
     the same device key is the reference: losses, weight statistics, gradient telemetry, normaliser and the final
