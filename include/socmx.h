@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 142 /* 0.1.5: + the two-tile burst kernel (socmx_rollout32.hip); SOCMX_ROLLOUT_ADVANCES_KEY */
+#define SOCMX_VERSION 143 /* 0.1.5: + the two-tile burst kernel (socmx_rollout32.hip); SOCMX_ROLLOUT_ADVANCES_KEY; socmx_unet_backward_scaled_f32 */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -143,6 +143,12 @@ int socmx_unet_backward_sizes(int32_t d, const int32_t hdims[3], int64_t N, int6
 int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
                             const float* x, const float* ts, int32_t rows_per_t, int64_t N, const float* gout,
                             float* workspace, float* grads, socmx_stream_t stream);
+/* The same with gout multiplied by the DEVICE scalar gout_scale[0] as the gradient tiles are read (NULL: 1) -- the
+ * d loss / d objective = 1 / running normaliser of main.py:313-320, which lives on the device: one elementwise launch less on the
+ * iteration's critical path; the products are the fp32 products that launch would have written. */
+int socmx_unet_backward_scaled_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
+                                   const float* x, const float* ts, int32_t rows_per_t, int64_t N, const float* gout,
+                                   const float* gout_scale, float* workspace, float* grads, socmx_stream_t stream);
 
 /*
  * The pair-grid network of the SOCM loss: SigmoidMLP.sigmoid_layers (models.py:245-257: Linear(2,h0) ReLU Linear(h0,h1) ReLU

@@ -241,6 +241,7 @@ struct TileArgs {
   const float* x;         // (N, d) rows
   const float* ts;        // time of row r = ts[r / rows_per_t]
   const float* gout;      // (N, d)  d objective / d nabla_V
+  const float* gscale;    // (1,) device scalar that multiplies gout, or nullptr
   float* ws;              // workspace: T_N tensors, tensor t at ws + 16 * ntiles * prefix(t), each [tile][width][16]
   int64_t N;
   int rows_per_t;
@@ -617,10 +618,11 @@ __global__ __launch_bounds__(NW * 64, 2) void unet_bwd_tile_kernel(const TileArg
     X0[r * t.s0 + c] = v;
     slabX[e] = v;
   }
+  const float gsc = a.gscale ? a.gscale[0] : 1.f;
   for (int e = tid; e < ROWS * outp; e += nthr) {
     const int r16 = e & 15, hc = e >> 4;
     const int h = hc >= outp ? 1 : 0, c = hc - h * outp, r = h * 16 + r16;
-    const float v = (row0 + r < a.N && c < d) ? a.gout[(row0 + r) * d + c] : 0.f;
+    const float v = (row0 + r < a.N && c < d) ? a.gout[(row0 + r) * d + c] * gsc : 0.f;
     G0[r * t.sg + c] = v;
     slabG[e] = v;
   }
@@ -1934,6 +1936,13 @@ extern "C" int socmx_unet_backward_sizes(int32_t d, const int32_t hdims[3], int6
 extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
                                        const float* x, const float* ts, int32_t rows_per_t, int64_t N,
                                        const float* gout, float* workspace, float* grads, socmx_stream_t stream) {
+  return socmx_unet_backward_scaled_f32(packed, packedT, d, hdims, x, ts, rows_per_t, N, gout, nullptr, workspace, grads, stream);
+}
+
+extern "C" int socmx_unet_backward_scaled_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
+                                              const float* x, const float* ts, int32_t rows_per_t, int64_t N,
+                                              const float* gout, const float* gout_scale, float* workspace, float* grads,
+                                              socmx_stream_t stream) {
   if (!packed || !packedT || !x || !ts || !gout || !workspace || !grads) return SOCMX_E_NULL;
   if (rows_per_t < 1) return SOCMX_E_DIM;
   K2Plan p;
@@ -1942,7 +1951,7 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   TileArgs ta;
   ta.u = p.u; ta.bd = p.bd; ta.lay = p.lay;
   for (int si = 0; si < kBwdStages; ++si) ta.prog.st[si] = k2_stage_desc(p.u, p.bd, p.lay, si);
-  ta.packed = packed; ta.packedT = packedT; ta.x = x; ta.ts = ts; ta.gout = gout; ta.ws = workspace;
+  ta.packed = packed; ta.packedT = packedT; ta.x = x; ta.ts = ts; ta.gout = gout; ta.gscale = gout_scale; ta.ws = workspace;
   ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles;
   const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
   void (*kern)(const TileArgs) = unet_bwd_tile_kernel<kK2Waves, void>;

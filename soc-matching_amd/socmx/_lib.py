@@ -65,6 +65,8 @@ PROTOTYPES = {
                                             C.POINTER(C.c_int64)]),
     "socmx_unet_backward_f32": (C.c_int, [_fp, _fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, C.c_int32, C.c_int64,
                                           _fp, _fp, _fp, _fp]),
+    "socmx_unet_backward_scaled_f32": (C.c_int, [_fp, _fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, C.c_int32, C.c_int64,
+                                                 _fp, _fp, _fp, _fp, _fp]),
     "socmx_mnet_packed_floats": (C.c_size_t, [C.c_int32, C.POINTER(C.c_int32)]),
     "socmx_mnet_pack_f32": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32] + [_fp] * 8),
     "socmx_mnet_forward_f32": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp]),

@@ -247,10 +247,12 @@ def unet_backward_supported(net, n_rows):
     return ok
 
 
-def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None, out=None, packed_bwd=None):
+def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None, out=None, packed_bwd=None,
+                      gout_scale=None):
     """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
     x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
-    `net.parameters()` order (views of one flat buffer)."""
+    `net.parameters()` order (views of one flat buffer).  `gout_scale`: a (1,) fp32 device tensor that multiplies gout as
+    the kernel reads it (the iteration's d loss / d objective), instead of an elementwise launch in front of the call."""
     L = net.hip_lib()
     dev = x.device
     N, d = x.shape
@@ -270,12 +272,15 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=No
         # (`packed` / `packed_bwd`: the forward / transposed image of the CURRENT weights when the caller knows they are
         #  fresh -- the one this iteration's rollout just used, the one packed beside it on the second stream -- instead of
         #  re-packing in front of the backward)
-        _lib.check(L.socmx_unet_backward_f32(_lib.ptr(packed if packed is not None else net.packed()),
-                                             _lib.ptr(packed_bwd if packed_bwd is not None else net.packed_bwd()), d,
-                                             _lib.i3(net.hdims),
-                                             _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N, _lib.ptr(gout),
-                                             _lib.ptr(work), _lib.ptr(flat), _lib.stream_ptr(dev)),
-                   "socmx_unet_backward_f32")
+        if gout_scale is not None:
+            assert gout_scale.dtype == torch.float32 and gout_scale.numel() == 1 and gout_scale.device == x.device
+        _lib.check(L.socmx_unet_backward_scaled_f32(_lib.ptr(packed if packed is not None else net.packed()),
+                                                    _lib.ptr(packed_bwd if packed_bwd is not None else net.packed_bwd()), d,
+                                                    _lib.i3(net.hdims),
+                                                    _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N, _lib.ptr(gout),
+                                                    _lib.ptr(gout_scale), _lib.ptr(work), _lib.ptr(flat),
+                                                    _lib.stream_ptr(dev)),
+                   "socmx_unet_backward_scaled_f32")
     # flat is in SOCMX_L_* order (weight, bias per layer); parameters() follows the module construction order = the same
     grads, off = {}, 0
     for name in _lib.UNET_LAYERS:

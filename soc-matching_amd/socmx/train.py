@@ -466,8 +466,9 @@ class Trainer:
             _lib.check(Lh.socmx_unet_backward_sizes(d, _lib.i3(sde.nabla_V.hdims), Kp * B, _lib.C.byref(ws), _lib.C.byref(ng)),
                        "socmx_unet_backward_sizes")
             main_flat = torch.zeros(ng.value + 5, dtype=torch.float32, device=dev)
+        # (G . d loss / d objective: the device scalar multiplies the gradient tiles as the backward kernel reads them)
         vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
-                                               (G * gout).reshape(Kp * B, d), return_flat=True,
+                                               G.reshape(Kp * B, d), gout_scale=gout, return_flat=True,
                                                packed=sde.nabla_V._packed,     # (the image this iteration's rollout packed)
                                                out=main_flat, packed_bwd=packed_bwd)
         vparams = list(sde.nabla_V.parameters())

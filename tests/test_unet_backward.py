@@ -89,6 +89,28 @@ def test_unet_backward_zero_gradient_rows_contribute_nothing():
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", ["cfg3_double_well_d10_K200", "tiny_ou_linear_d6", "ouq20_ou_quadratic_easy_d20_K12",
+                                  "cfg5_ou_linear_d64_K20"])
+def test_unet_backward_scaled_equals_the_premultiplied_gradient(name):
+    """socmx_unet_backward_scaled_f32: the device scalar multiplies gout as the tiles are read -- the same fp32 products an
+    elementwise launch in front of socmx_unet_backward_f32 writes, hence the same gradients bit for bit (constexpr and
+    descriptor-driven instantiations, ragged last tile)."""
+    from socmx import nets
+    sde, aux = build_sde(name, DEV)
+    net, d = sde.nabla_V, aux["d"]
+    g = torch.Generator().manual_seed(11)
+    N = 16 * 9 + 5
+    x = torch.randn(N, d, generator=g).to(DEV)
+    gout = torch.randn(N, d, generator=g).to(DEV)
+    ts = torch.linspace(0, 1, N).to(DEV)
+    scale = torch.tensor([0.3718], device=DEV)
+    a = nets.unet_backward_hip(net, x, ts, 1, gout * scale)
+    b = nets.unet_backward_hip(net, x, ts, 1, gout, gout_scale=scale)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert any(float(u.abs().max()) > 0 for u in a)
+
+
 @pytest.mark.parametrize("name,extra", [("tiny_double_well_d10", {}), ("tiny_ou_linear_d6", {}), ("tiny_ou_linear_d20", {}),
                                         ("cfg1_ou_quadratic_easy_d2_K50", {}), ("cfg3_double_well_d10_K200", {}),
                                         ("ouq20_ou_quadratic_easy_d20_K12", {}),
