@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 143 /* 0.1.5: + the two-tile burst kernel (socmx_rollout32.hip); SOCMX_ROLLOUT_ADVANCES_KEY; socmx_unet_backward_scaled_f32 */
+#define SOCMX_VERSION 143 /* 0.1.5: + the two-tile burst kernel (socmx_rollout32.hip); SOCMX_ROLLOUT_ADVANCES_KEY; socmx_unet_backward_scaled_f32, socmx_adam_step_scalars_f32 */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -459,6 +459,13 @@ typedef struct socmx_adam_tensor {
 int socmx_adam_step_f32(const socmx_adam_tensor* tensors, int32_t ntensors, int64_t total, const float* grad,
                         float* ema_grad, const float* itr, double c_grad, float lr, float beta1, float beta2, float eps,
                         float* scratch, float* sums_out, socmx_stream_t stream);
+/* The same launch followed, in its last workgroup to finish, by phase 1 of socmx_iteration_scalars_f32 with gn = sums_out[0] and
+ * gne = sums_out[1] (both absent when ema_grad is NULL): out[0..6], ema_gn, norm and itr are updated exactly as that call would
+ * -- one launch less at the end of every iteration.  itr is read by the Adam part (EMA coefficients) and advanced afterwards. */
+int socmx_adam_step_scalars_f32(const socmx_adam_tensor* tensors, int32_t ntensors, int64_t total, const float* grad,
+                                float* ema_grad, float* itr, double c_grad, float lr, float beta1, float beta2, float eps,
+                                float* scratch, float* sums_out, float* norm, float* ema_gn, const float* w_mean,
+                                const float* w_std, const float* obj, double c_norm, float* out, socmx_stream_t stream);
 
 /*
  * Column sums of a tall row-major (R, C) matrix: out[c] = sum_r x[r][c].  Bias gradients of the nn.Linear layers

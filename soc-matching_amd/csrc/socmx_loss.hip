@@ -1976,6 +1976,22 @@ __device__ __forceinline__ float ema_update(float v, float ema, float c, float o
   return c * v + omc * ema;
 }
 
+// phase 1 (one thread): the iteration's scalar outputs and the state updates of main.py:313-320, 330-345, 354-359
+__device__ __forceinline__ void iteration_scalars_phase1(const ScalarArgs& a, float itr, bool has_gn, float gn, float gne) {
+  const float norm = a.norm[0];
+  float ema_gn = 0.f;
+  if (has_gn) { ema_gn = ema_update(gn, a.ema_gn[0], a.c_grad, a.one_minus_c_grad, a.warm_grad, itr); a.ema_gn[0] = ema_gn; }
+  a.out[0] = a.obj[0] * (1.f / norm);                      // loss = objective / normaliser   (main.py:313-320)
+  a.out[1] = a.w_mean[0];
+  a.out[2] = a.w_std[0];
+  a.out[3] = has_gn ? gn : 0.f;
+  a.out[4] = ema_gn;
+  a.out[5] = gne;
+  a.out[6] = norm;                                         // the normaliser this iteration used
+  a.norm[0] = ema_update(a.w_mean[0], norm, a.c_norm, a.one_minus_c_norm, a.warm_norm, itr);   // main.py:354-359
+  a.itr[0] = itr + 1.f;
+}
+
 __global__ void iteration_scalars_kernel(const ScalarArgs a) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float itr = a.itr[0];
@@ -1988,19 +2004,7 @@ __global__ void iteration_scalars_kernel(const ScalarArgs a) {
     a.ab[0] = A; a.ab[1] = B;
     return;
   }
-  const float norm = a.norm[0];
-  const float gn = a.gn ? a.gn[0] : 0.f;
-  float ema_gn = 0.f;
-  if (a.gn) { ema_gn = ema_update(gn, a.ema_gn[0], a.c_grad, a.one_minus_c_grad, a.warm_grad, itr); a.ema_gn[0] = ema_gn; }
-  a.out[0] = a.obj[0] * (1.f / norm);                      // loss = objective / normaliser   (main.py:313-320)
-  a.out[1] = a.w_mean[0];
-  a.out[2] = a.w_std[0];
-  a.out[3] = gn;
-  a.out[4] = ema_gn;
-  a.out[5] = a.gne ? a.gne[0] : 0.f;
-  a.out[6] = norm;                                         // the normaliser this iteration used
-  a.norm[0] = ema_update(a.w_mean[0], norm, a.c_norm, a.one_minus_c_norm, a.warm_norm, itr);   // main.py:354-359
-  a.itr[0] = itr + 1.f;
+  iteration_scalars_phase1(a, itr, a.gn != nullptr, a.gn ? a.gn[0] : 0.f, a.gne ? a.gne[0] : 0.f);
 }
 
 // ---- Adam on a flat gradient + gradient telemetry (main.py:174-238, 325-349) ------------------------------------------
@@ -2015,6 +2019,8 @@ struct AdamArgs {
   float lr, beta1, beta2, eps;
   float* scratch;      // [0] = finished-workgroup ticket (as unsigned); [4 + 2 b], [5 + 2 b] = workgroup b's sum g^2, sum ema^2
   float* sums_out;
+  int has_post;        // the last workgroup to finish also runs the iteration's scalar bookkeeping (phase 1 of ScalarArgs post)
+  ScalarArgs post;
 };
 
 constexpr int kAdamPerBlock = 1024;
@@ -2087,9 +2093,13 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
     if ((tid & 63) == 0) { red[0][tid >> 6] = pg; red[1][tid >> 6] = pe; }
     __syncthreads();
     if (tid == 0) {
-      a.sums_out[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-      a.sums_out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      const float sg_all = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      const float se_all = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      a.sums_out[0] = sg_all;
+      a.sums_out[1] = se_all;
       *reinterpret_cast<unsigned*>(a.scratch) = 0u;
+      // (every workgroup read the iteration counter before it took its ticket: advancing it here is ordered behind them)
+      if (a.has_post) iteration_scalars_phase1(a.post, a.post.itr[0], a.ema != nullptr, sg_all, a.ema ? se_all : 0.f);
     }
     if (tid < a.ntensors) tab[tid].step[0] = t;
   }
@@ -2112,6 +2122,30 @@ extern "C" int socmx_adam_step_f32(const socmx_adam_tensor* tensors, int32_t nte
   a.c_grad = (float)c_grad; a.one_minus_c_grad = (float)(1.0 - c_grad);
   a.warm_grad = ema_grad ? (float)(int)floor(1.0 / c_grad) : 0.f;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.scratch = scratch; a.sums_out = sums_out;
+  a.has_post = 0; a.post = ScalarArgs{};
+  const unsigned blocks = (unsigned)((total + kAdamPerBlock - 1) / kAdamPerBlock);
+  return launch(adam_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
+extern "C" int socmx_adam_step_scalars_f32(const socmx_adam_tensor* tensors, int32_t ntensors, int64_t total, const float* grad,
+                                           float* ema_grad, float* itr, double c_grad, float lr, float beta1, float beta2,
+                                           float eps, float* scratch, float* sums_out, float* norm, float* ema_gn,
+                                           const float* w_mean, const float* w_std, const float* obj, double c_norm, float* out,
+                                           socmx_stream_t stream) {
+  if (!tensors || !grad || !scratch || !sums_out || !itr || !norm || !w_mean || !w_std || !obj || !out || (ema_grad && !ema_gn))
+    return SOCMX_E_NULL;
+  if (ntensors < 1 || ntensors > 64 || total < 1 || !(c_grad > 0.0) || !(c_norm > 0.0)) return SOCMX_E_DIM;
+  AdamArgs a;
+  a.tensors = tensors; a.ntensors = ntensors; a.total = total; a.grad = grad; a.ema = ema_grad; a.itr = itr;
+  a.c_grad = (float)c_grad; a.one_minus_c_grad = (float)(1.0 - c_grad);
+  a.warm_grad = ema_grad ? (float)(int)floor(1.0 / c_grad) : 0.f;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.scratch = scratch; a.sums_out = sums_out;
+  a.has_post = 1;
+  ScalarArgs& q = a.post;
+  q = ScalarArgs{};
+  q.phase = 1; q.itr = itr; q.norm = norm; q.ema_gn = ema_gn; q.w_mean = w_mean; q.w_std = w_std; q.obj = obj; q.out = out;
+  q.c_norm = (float)c_norm; q.one_minus_c_norm = (float)(1.0 - c_norm); q.warm_norm = (float)(int)floor(1.0 / c_norm);
+  q.c_grad = (float)c_grad; q.one_minus_c_grad = (float)(1.0 - c_grad); q.warm_grad = (float)(int)floor(1.0 / c_grad);
   const unsigned blocks = (unsigned)((total + kAdamPerBlock - 1) / kAdamPerBlock);
   return launch(adam_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
 }

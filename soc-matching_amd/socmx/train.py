@@ -498,45 +498,43 @@ class Trainer:
                 nsd = tail[4:5]
         gn = gne = None
         adam = self._fused_adam_table(D, vparams, vflat)
+        out = torch.empty(7, dtype=torch.float32, device=dev)
         if adam is not None:
-            # control-network Adam step + gradient telemetry in ONE launch on the flat gradient (socmx_adam_step_f32):
-            # replaces the optimiser's multi-tensor launches, two dot products, the EMA lerp and the coefficient kernel
+            # control-network Adam step + gradient telemetry + the iteration's scalar bookkeeping (loss, EMA normaliser, iteration
+            # counter, telemetry EMAs) in ONE launch on the flat gradient (socmx_adam_step_scalars_f32): replaces the optimiser's
+            # multi-tensor launches, two dot products, the EMA lerp, the coefficient kernel and ~35 elementwise launches
             table, _, sums = adam
             grp = self._groups_main[0]
             b1, b2 = grp["betas"]
             with _lib.on_device(dev):
-                _lib.check(Lh.socmx_adam_step_f32(table.data_ptr(), len(vparams), vflat.numel(), f(vflat),
-                                                  f(D["ema_flat"]) if self.grad_telemetry else None, f(D["itr1"]),
-                                                  0.01, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]),
-                                                  f(D["adam_scratch"]), f(sums), _lib.stream_ptr(dev)),
-                           "socmx_adam_step_f32")
-            if self.grad_telemetry:
-                gn, gne = sums[0:1], sums[1:2]
+                _lib.check(Lh.socmx_adam_step_scalars_f32(
+                    table.data_ptr(), len(vparams), vflat.numel(), f(vflat),
+                    f(D["ema_flat"]) if self.grad_telemetry else None, f(D["itr1"]), 0.01, float(grp["lr"]), float(b1),
+                    float(b2), float(grp["eps"]), f(D["adam_scratch"]), f(sums), f(D["norm1"]),
+                    f(D["ema_gn1"]) if self.grad_telemetry else None, f(w_mean), f(w_std), f(obj), self.coeff, f(out),
+                    _lib.stream_ptr(dev)), "socmx_adam_step_scalars_f32")
         else:
             for p, g in zip(vparams, vgrads):
                 p.grad = g
-        # scalar bookkeeping (loss, EMA normaliser, iteration counter, telemetry EMAs): two one-thread kernels instead of
-        # ~35 elementwise launches (socmx_iteration_scalars_f32)
-        if adam is None and self.grad_telemetry:                         # main.py:325-345
-            # the control-network gradients are views of ONE flat buffer (socmx_unet_backward_f32), and so is their EMA:
-            # squared norms are dot products, the EMA  A ema + B g  (A = 1 - B in every branch of compute_EMA) one lerp
-            gn = torch.dot(vflat, vflat).reshape(1)
-            with _lib.on_device(dev):
-                _lib.check(Lh.socmx_iteration_scalars_f32(0, f(D["itr1"]), None, None, None, None, None, None, None,
-                                                          self.coeff, 0.01, f(D["ab"]), None, _lib.stream_ptr(dev)),
-                           "socmx_iteration_scalars_f32")
-            D["ema_flat"].lerp_(vflat, D["ab"][1])
-            gne = torch.dot(D["ema_flat"], D["ema_flat"]).reshape(1)
-        if adam is None:
+            if self.grad_telemetry:                                      # main.py:325-345
+                # the control-network gradients are views of ONE flat buffer (socmx_unet_backward_f32), and so is their EMA:
+                # squared norms are dot products, the EMA  A ema + B g  (A = 1 - B in every branch of compute_EMA) one lerp
+                gn = torch.dot(vflat, vflat).reshape(1)
+                with _lib.on_device(dev):
+                    _lib.check(Lh.socmx_iteration_scalars_f32(0, f(D["itr1"]), None, None, None, None, None, None, None,
+                                                              self.coeff, 0.01, f(D["ab"]), None, _lib.stream_ptr(dev)),
+                               "socmx_iteration_scalars_f32")
+                D["ema_flat"].lerp_(vflat, D["ab"][1])
+                gne = torch.dot(D["ema_flat"], D["ema_flat"]).reshape(1)
             self._step_groups(self._groups_main)                          # main.py:347-349 (nabla_V: the next rollout needs it)
             for p in vparams:
                 p.grad = None
-        out = torch.empty(7, dtype=torch.float32, device=dev)
-        with _lib.on_device(dev):
-            _lib.check(Lh.socmx_iteration_scalars_f32(
-                1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(w_mean),
-                f(w_std), f(obj), f(gn) if gn is not None else None, f(gne) if gne is not None else None,
-                self.coeff, 0.01, None, f(out), _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
+            # scalar bookkeeping: one one-thread kernel instead of ~35 elementwise launches (socmx_iteration_scalars_f32)
+            with _lib.on_device(dev):
+                _lib.check(Lh.socmx_iteration_scalars_f32(
+                    1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(w_mean),
+                    f(w_std), f(obj), f(gn) if gn is not None else None, f(gne) if gne is not None else None,
+                    self.coeff, 0.01, None, f(out), _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
         self._m_pending = True
         if nsd is not None:
             out = torch.cat([out, nsd.reshape(1)])
