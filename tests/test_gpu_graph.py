@@ -226,6 +226,63 @@ def test_fused_adam_step_matches_torch_adam():
     assert float(scratch[0]) == 0.0              # the ticket is re-armed; the rest holds per-workgroup partial sums
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("telemetry", [True, False])
+def test_adam_step_with_scalars_equals_the_two_launches(telemetry):
+    """socmx_adam_step_scalars_f32 = socmx_adam_step_f32 followed by phase 1 of socmx_iteration_scalars_f32 on its sums: parameters,
+    Adam state, EMA buffers, the seven outputs, the normaliser and the iteration counter bit for bit, over the EMA warm-up branches."""
+    from socmx import _lib
+    dev = torch.device("cuda", 0)
+    L, f = _lib.lib(), _lib.ptr
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 16), (64,), (33, 64), (33,), (5, 33), (5,)]
+    total = sum(int(np.prod(s)) for s in shapes)
+
+    def setup():
+        gg = torch.Generator().manual_seed(9)
+        ps = [torch.randn(*s, generator=gg).to(dev).requires_grad_(True) for s in shapes]
+        opt = torch.optim.Adam(ps, lr=1e-2, eps=1e-4, fused=True)
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=gg).to(dev)
+        opt.step()
+        rows, off = [], 0
+        for p in ps:
+            st = opt.state[p]
+            rows.append([p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel(), off])
+            off += p.numel()
+        z = lambda n, v=0.0: torch.full((n,), v, device=dev)
+        return dict(ps=ps, opt=opt, table=torch.tensor(rows, dtype=torch.int64, device=dev),
+                    scratch=z(4 + 2 * ((total + 1023) // 1024)), sums=z(2), ema=z(total), itr=z(1), norm=z(1, 1.0),
+                    ema_gn=z(1), out=z(7))
+
+    A, B = setup(), setup()
+    for it in range(5):
+        flat = torch.randn(total, generator=g).to(dev)
+        w_mean, w_std, obj = (torch.rand(1, generator=g).to(dev) + 0.5 for _ in range(3))
+        with _lib.on_device(dev):
+            S = A
+            _lib.check(L.socmx_adam_step_f32(S["table"].data_ptr(), len(shapes), total, f(flat), f(S["ema"]) if telemetry else None,
+                                            f(S["itr"]), 0.4, 1e-2, 0.9, 0.999, 1e-4, f(S["scratch"]), f(S["sums"]),
+                                            _lib.stream_ptr(dev)), "socmx_adam_step_f32")
+            _lib.check(L.socmx_iteration_scalars_f32(1, f(S["itr"]), f(S["norm"]), f(S["ema_gn"]) if telemetry else None, f(w_mean),
+                                                    f(w_std), f(obj), f(S["sums"][0:1]) if telemetry else None,
+                                                    f(S["sums"][1:2]) if telemetry else None, 0.3, 0.4, None, f(S["out"]),
+                                                    _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
+            S = B
+            _lib.check(L.socmx_adam_step_scalars_f32(S["table"].data_ptr(), len(shapes), total, f(flat),
+                                                    f(S["ema"]) if telemetry else None, f(S["itr"]), 0.4, 1e-2, 0.9, 0.999, 1e-4,
+                                                    f(S["scratch"]), f(S["sums"]), f(S["norm"]), f(S["ema_gn"]) if telemetry else None,
+                                                    f(w_mean), f(w_std), f(obj), 0.3, f(S["out"]), _lib.stream_ptr(dev)),
+                       "socmx_adam_step_scalars_f32")
+        torch.cuda.synchronize()
+        for k in ("out", "norm", "itr", "ema_gn", "ema", "sums"):
+            assert torch.equal(A[k], B[k]), (it, k, A[k], B[k])
+        for a, b in zip(A["ps"], B["ps"]):
+            assert torch.equal(a, b)
+        assert float(B["itr"]) == it + 1 and float(B["scratch"][0]) == 0.0
+        assert (float(B["out"][3]) > 0) == telemetry
+
+
 @pytest.mark.parametrize("fused_adam", [True, False])
 def test_graph_mode_survives_an_optimizer_reload_and_an_lr_change(fused_adam):
     """the captured iteration bakes in the Adam state's data pointers and the groups' hyper-parameters.  A
