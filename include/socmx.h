@@ -39,7 +39,7 @@
  *   - re-entrant: the only mutable state is a mutex-protected per-process cache of which kernels already had their
  *     dynamic-LDS limit raised (hipFuncSetAttribute once per kernel and device, not per call); a few getenv()
  *     switches for A/B runs are read once per process: SOCMX_GENERIC, SOCMX_NOFAST, SOCMX_WAVES, SOCMX_PROF_WAVE,
- *     SOCMX_TARGET_WIDE_REGS, SOCMX_TARGET_BWD_REGS.
+ *     SOCMX_TARGET_WIDE_REGS, SOCMX_TARGET_BWD_REGS, SOCMX_TARGET_CT, SOCMX_TARGET_FUSE.
  *
  * Reference-side binding: see INTEGRATION.md (ctypes stub).
  */

@@ -287,6 +287,7 @@ struct TargetArgs {
   //   M = e I + (1-e) net,  dM = gamma e (net - I) + (1-e) dnet,  e = exp(-gamma (s-t))       (models.py:263-275)
   // are formed in registers while the A fragments are loaded.
   const float *delta, *gamma;    // (Np,) s-t per pair, (1,) on the device
+  int fuse_residual;             // socm_target_mfma_kernel at d <= 16: the residual (objective, G) leaves with the target rows
 };
 
 __host__ __device__ inline int64_t pair_row_offset(int i, int K) {
@@ -361,8 +362,14 @@ constexpr int kTargetWaves = 8;  // waves per workgroup: the (pair, l-block) ite
 template <bool NET, int CT, int NS>
 __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(const TargetArgs a) {
   __shared__ f32x4 part[kTargetWaves][CT][64];
+  __shared__ float sg[NS != 0 ? 256 : 1];        // sigma (d x d, d <= 16): the fused residual's two products
+  __shared__ float objw[CT];
   constexpr bool NLB1 = NS != 0;
   const int d = a.d, K = a.K, B = a.B;
+  const bool fuse = NLB1 && a.fuse_residual;
+  if (fuse) {                                    // (visible to the epilogue through the barriers of the combine)
+    for (int e = threadIdx.x; e < d * d; e += 64 * kTargetWaves) sg[e] = a.sigma[e];
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
@@ -507,6 +514,47 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
           const int k = kb + 4 * g4 + r;
           if (k < d) a.target[((size_t)i * B + m) * d + k] = tot[r];
         }
+      }
+      if (fuse) {
+        // The residual of method.py:702-720 on the rows this wave just finished (d <= 16: kb = 0, the four lanes m, m + 16,
+        // m + 32, m + 48 hold the row's d components, four each):  R = sigma^T (nabla_V - target),  objective += w |R|^2 inv_norm,
+        // G = 2 w inv_norm sigma R  -- what socm_residual_kernel computes from the stored target, one launch later
+        const int mc = min(m, B - 1);
+        const size_t row = ((size_t)i * B + mc) * d;
+        const float wm = a.w[mc];
+        float df[4], sk[4] = {0.f, 0.f, 0.f, 0.f};
+        int kq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 4 * g4 + r;
+          kq[r] = min(k, d - 1) * d;
+          df[r] = k < d ? a.nablaV[row + k] - tot[r] : 0.f;
+        }
+        float ob = 0.f;
+        for (int c = 0; c < d; ++c) {
+          float rc = (sg[kq[0] + c] * df[0] + sg[kq[1] + c] * df[1]) + (sg[kq[2] + c] * df[2] + sg[kq[3] + c] * df[3]);
+          rc += __shfl_xor(rc, 16, 64);
+          rc += __shfl_xor(rc, 32, 64);                    // every lane group now holds R[c]
+          ob += rc * rc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sk[r] += sg[kq[r] + c] * rc;
+        }
+        if (m < B) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * g4 + r < d) a.G[row + 4 * g4 + r] = 2.f * wm * a.inv_norm * sk[r];
+        }
+        ob = wave_sum((m < B && g4 == 0) ? wm * ob : 0.f);
+        if (lane == 0) objw[wave] = ob;
+      }
+    }
+    if (fuse) {                                           // one atomic per workgroup and row
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float ob = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) ob += objw[c];
+        atomicAdd(a.objective, ob * a.inv_norm);
       }
     }
   }
@@ -2243,6 +2291,7 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.q = q; a.v = v; a.gT = gT;
   a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective;
   a.delta = delta; a.gamma = gamma;
+  a.fuse_residual = 0;
   void* const st0 = stream;
   bool launched = false;
   int lerr = 0;
@@ -2271,6 +2320,10 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
 #define SOCMX_TARGET_LAUNCH(NETV, CTV, N1V) \
   lerr = launch(socm_target_mfma_kernel<NETV, CTV, N1V>, grid, blk, 0, stream, a)
   const int nsv = d <= 4 ? 1 : (d <= 12 ? 3 : (d <= 16 ? 4 : 0));      // MFMAs per l-block (0: several l-blocks)
+  // d <= 16: objective and G leave with the target rows (no socm_residual_kernel launch behind the contraction; developer
+  // override SOCMX_TARGET_FUSE=0, read once)
+  static const int fuse_env = [] { const char* e = getenv("SOCMX_TARGET_FUSE"); return e ? atoi(e) : 1; }();
+  a.fuse_residual = (!launched && nsv != 0 && fuse_env) ? 1 : 0;
 #define SOCMX_TARGET_NS(NETV, CTV) \
   do { if (nsv == 1) SOCMX_TARGET_LAUNCH(NETV, CTV, 1); else if (nsv == 3) SOCMX_TARGET_LAUNCH(NETV, CTV, 3); \
        else if (nsv == 4) SOCMX_TARGET_LAUNCH(NETV, CTV, 4); else SOCMX_TARGET_LAUNCH(NETV, CTV, 0); } while (0)
@@ -2287,6 +2340,7 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
 #undef SOCMX_TARGET_NS
 #undef SOCMX_TARGET_LAUNCH
   if (lerr) return lerr;
+  if (a.fuse_residual) return 0;
   return launch_residual(a, stream);
 }
 
