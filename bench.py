@@ -105,8 +105,7 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
     world = dist.get_world_size() if use_dist else 1
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
     def time_iterations(graph):
-        trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True,
-                          hip_graph=graph)
+        trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, hip_graph=graph)
         for _ in range(max(3, warmup)):                  # (in hipGraph mode: 2 eager warm-ups + the captured iteration)
             trainer.step()
         torch.cuda.synchronize(device)
@@ -117,18 +116,26 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
         trainer.join()
         return 1e3 * (time.perf_counter() - t0) / steps, info
     it_ms_eager, info = time_iterations(False)
+    it_ms_body = None
+    if use_dist:
+        it_ms_body, info_b = time_iterations("nocapture")
     fl = flops_per_traj_step(d, HDIMS) * B * K
     out = {"workload": label, "rollout_ms": roll_ms, "trajectory_steps_per_s": B * K / (roll_ms * 1e-3),
            "socm_ms_per_iter": it_ms_eager, "socm_iters_per_sec": 1e3 / it_ms_eager,
            "iteration_mode": "eager (two HIP streams)" if not use_dist else "eager (one flat all-reduce per iteration)",
-           "socm_ms_per_iter_eager": it_ms_eager, "socm_ms_per_iter_graph": None, "last_loss": float(info["loss"]),
+           "socm_ms_per_iter_eager": it_ms_eager, "socm_ms_per_iter_eager_body": it_ms_body, "socm_ms_per_iter_graph": None,
+           "last_loss": float(info["loss"]),
            "rollout_roofline": {"bound": "mfma", "achieved": fl / (roll_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
                                 "unit": "TFLOP/s", "frac": fl / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                                 "active_workgroups": rollout_workgroups(d, B)}}
 
+    if it_ms_body is not None and it_ms_body < out["socm_ms_per_iter"]:
+        out.update(socm_ms_per_iter=it_ms_body, socm_iters_per_sec=1e3 / it_ms_body, last_loss=float(info_b["loss"]),
+                   iteration_mode="autograd-free body, eager (no RCCL call inside a graph)")
+
     def graph_leg():
         """The same iterations replayed as ONE captured hipGraph (sharded: with the RCCL all-reduces captured inside)."""
-        it_ms_graph, info_g = time_iterations(True)
+        it_ms_graph, info_g = time_iterations("sharded" if world > 1 else True)
         out["socm_ms_per_iter_graph"] = it_ms_graph
         if it_ms_graph < out["socm_ms_per_iter"]:
             out.update(socm_ms_per_iter=it_ms_graph, socm_iters_per_sec=1e3 / it_ms_graph, iteration_mode="hipGraph replay",
@@ -198,12 +205,53 @@ def cpu_baseline(budget_s=12.0):
             note = (f"1 thread; 10-step probes, ms per thread count: 1: {1e3 * p1:.0f}, {shown} "
                     f"(dispatch-bound: no multi-thread leg)")
     torch.set_num_threads(1)
+    it = cpu_iteration_baseline(pb, vp, ts, d, K, B)
     best = dict(value=n * B * K / el, unit="trajectory-steps/s", cores=used, kind="port",
                 sample=f"{n} rollouts of double_well d=10 K=200 B=128 (oracle eager torch-CPU, {el:.1f} s, {note}; the oracle "
                        f"'port' costs 0.86x the reference's own rollout on the same CPU: tests/golden/calibrate_cpu_baseline.py, "
                        f"BASELINE.md section 4)",
-                ms_per_rollout=1e3 * el / n, host_cpus=ncpu)
+                ms_per_rollout=1e3 * el / n, host_cpus=ncpu, **it)
     return best
+
+
+def cpu_iteration_baseline(pb, vp, ts, d, K, B):
+    """Metric 2 beside the GPU's `socm_ms_per_iter`: ONE iteration of the reference's algorithm on the host -- the oracle's
+    faithful dense SOCM loss (the zero-filled (K+1, K+1, B, d, d) einsums of method.py:591-631 and functorch.jacrev for the
+    s-derivative, method.py:510-515: ~10 GB at this size), backward, Adam step (main.py:280-352) -- at configs[2]'s own size
+    when the host has the memory for it, else on a quarter of the rows (said in the sample text).  One timed iteration, no
+    warm-up (it is 10-30 s of CPU work); threads = min(host CPUs, 32): unlike the rollout this path is bandwidth-bound."""
+    from oracle import socm_oracle as O
+    try:
+        avail_gb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")) / 2 ** 20
+    except Exception:
+        avail_gb = 0.0
+    rows = B if avail_gb >= 48 else B // 4
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(threads)
+    try:
+        from socmx.nets import SigmoidMLP
+        torch.manual_seed(0)
+        mnet = SigmoidMLP(d, [128, 128], gamma=GAMMA, scaling_factor=0.1)
+        mp = {k: v.detach().clone().requires_grad_(True) for k, v in mnet.state_dict().items() if k != "gamma"}
+        gamma = torch.tensor([GAMMA], requires_grad=True)
+        vpg = {k: v.detach().clone().requires_grad_(True) for k, v in vp.items()}
+        opt = torch.optim.Adam([{"params": list(vpg.values())}, {"params": list(mp.values()), "lr": 1e-3},
+                                {"params": [gamma], "lr": 1e-3}], lr=1e-4, eps=1e-4)      # main.py:188-230
+        noise = torch.randn(K, rows, d)
+        t0 = time.perf_counter()
+        obj, _, _ = O.socm_loss(pb, vpg, mp, gamma, torch.zeros(d), ts, 1.0, 1.0, rows, noise, derivative="jacrev")
+        (obj / 1.0).backward()
+        opt.step()
+        opt.zero_grad()
+        el = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(1)
+    return dict(socm_ms_per_iter=1e3 * el, socm_iters_per_sec=1.0 / el, socm_cores=threads,
+                socm_sample=f"1 iteration (dense SOCM loss with jacrev + backward + Adam; oracle eager torch-CPU, {threads} threads) of "
+                            f"double_well d=10 K=200 B={rows}" + ("" if rows == B else f" -- a QUARTER of configs[2]'s {B} rows: the "
+                            f"host reports {avail_gb:.0f} GB available, the full size needs ~25 GB with its backward") +
+                            "; the oracle's iteration costs 0.7-1.1x the reference's own on the same CPU "
+                            "(tests/golden/calibrate_cpu_iteration.py, BASELINE.md section 4)")
 
 
 def launch_command(args, port, environ=None):
@@ -334,22 +382,33 @@ def main():
 
     for i in range(args.warmup):
         one_rollout(i)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # the rollout is launched on torch's current stream, so these events bracket exactly that launch (and the ~3 us
-        # weight re-pack that precedes every rollout)
-        ev[i][0].record()
-        one_rollout(args.warmup + i)
-        ev[i][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # One timed BLOCK = exactly `steps` rollouts between two barriers (+ device synchronisation), its time the MAX over ranks.
+    # A 20-step block at this size is ~10 ms, where one host hiccup moves the figure by percent: blocks are repeated until at
+    # least 0.5 s of them have run (at most 64) and the MEDIAN block is reported; `steps` / `warmup` echo the command line.
+    blocks, kernel_blocks, n_done = [], [], args.warmup
+    while True:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            # the rollout is launched on torch's current stream, so these events bracket exactly that launch (and the ~3 us
+            # weight re-pack that precedes every rollout)
+            ev[i][0].record()
+            one_rollout(n_done + i)
+            ev[i][1].record()
+        barrier()
+        el = time.perf_counter() - t0
+        n_done += args.steps
+        t = torch.tensor([el, sum(blocks) + el], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)       # (every rank sees the same block time and takes the same decision)
+        blocks.append(float(t[0].item()))
+        kernel_blocks.append(sum(a.elapsed_time(b) for a, b in ev) / args.steps)
+        if float(t[1].item()) >= 0.5 or len(blocks) >= 64:
+            break
+    order = sorted(range(len(blocks)), key=blocks.__getitem__)
+    mid = order[len(order) // 2]
+    elapsed, kernel_ms = blocks[mid], kernel_blocks[mid]
     value = world * B * K * args.steps / elapsed
 
     # ---- metric 2: full SOCM iterations ----------------------------------------------------------
@@ -359,8 +418,8 @@ def main():
     it_steps, it_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
 
     def time_iterations(graph):
-        trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, gemm_select=True,
-                          hip_graph=graph)
+        # (the shipped defaults of main.py / configs/soc.yaml: backend.gemm_select False)
+        trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, hip_graph=graph)
         for _ in range(it_warm):
             trainer.step()
         barrier()
@@ -375,17 +434,26 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), float(info["loss"])
 
-    # eager schedule (two HIP streams; sharded: ONE flat all-reduce per iteration) and the whole iteration replayed as ONE
-    # captured hipGraph (Trainer(hip_graph=True); sharded: with its all-reduces inside): same arithmetic, no host work between
-    # the launches
+    # Three schedules of the same arithmetic: (1) the eager autograd iteration (two HIP streams; sharded: ONE flat all-reduce per
+    # iteration); (2) sharded runs: the autograd-free body run eagerly -- what main.py does by default over several ranks (its
+    # collectives are ordinary RCCL calls: the flat gradient buffer on the main stream, the pair-grid network's small one on the
+    # second stream); (3) the whole iteration replayed as ONE captured hipGraph (main.py's default on one GPU; sharded:
+    # backend.hip_graph=sharded, with the all-reduces inside, the ranks agreeing on the capture first)
     it_elapsed_eager, last_loss = time_iterations(False)
     it_elapsed = it_elapsed_eager
     it_mode = "eager (two HIP streams)" if not use_dist else "eager (one flat all-reduce per iteration)"
+    it_elapsed_body = None
+    if use_dist:
+        it_elapsed_body, last_loss_b = time_iterations("nocapture")
+        if it_elapsed_body < it_elapsed:
+            it_elapsed, last_loss = it_elapsed_body, last_loss_b
+            it_mode = "autograd-free body, eager (main.py's default over several ranks: no RCCL call inside a graph)"
+    graph_mode = "sharded" if world > 1 else True
     it_elapsed_graph = None
     defer_graph = world > 1 or args.defer_graph  # multi-GPU: every hipGraph leg runs at the end, under the watchdog
     graph_legs = []
     if not defer_graph:
-        it_elapsed_graph, last_loss_g = time_iterations(True)
+        it_elapsed_graph, last_loss_g = time_iterations(graph_mode)
         if it_elapsed_graph < it_elapsed:
             it_elapsed, it_mode, last_loss = it_elapsed_graph, "hipGraph replay", last_loss_g
 
@@ -458,6 +526,7 @@ def main():
             "metric": "trajectory-steps/sec", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "timed_blocks": len(blocks), "block_ms_min_median_max": [1e3 * min(blocks), 1e3 * elapsed, 1e3 * max(blocks)],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
             "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in rank_devices}),
@@ -467,6 +536,7 @@ def main():
             "socm_iters_per_sec": it_steps / it_elapsed, "socm_ms_per_iter": 1e3 * it_elapsed / it_steps,
             "socm_iters_timed": it_steps, "socm_last_loss": last_loss, "socm_iteration_mode": it_mode,
             "socm_ms_per_iter_eager": 1e3 * it_elapsed_eager / it_steps,
+            "socm_ms_per_iter_eager_body": None if it_elapsed_body is None else 1e3 * it_elapsed_body / it_steps,
             "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps,
             "roofline": {"bound": "mfma", "kernel": "socmx::rollout1_kernel<0,StaticNet<16,256,128,64,16>,11>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -512,7 +582,7 @@ def main():
         timer.daemon = True
         timer.start()
         try:
-            g_elapsed, g_loss = time_iterations(True)
+            g_elapsed, g_loss = time_iterations(graph_mode)
             for leg in graph_legs:
                 leg()
             if line is not None:

@@ -28,6 +28,12 @@ from SOC_matching.experiment_settings.settings import define_variables
 from socmx.train import Trainer, compute_EMA, make_optimizer
 
 
+
+def _graph_mode(v):
+    """backend.hip_graph as Trainer takes it: True / False, or the strings "force" (also capture the losses measured faster on the
+    eager iteration: SOCM_const_M, SOCM_exp, SOCM_adjoint) and "sharded" (a multi-rank run captures its RCCL all-reduces too)."""
+    return v if isinstance(v, str) and v in ("force", "sharded") else bool(v)
+
 def run(cfg):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +100,7 @@ def run(cfg):
     trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm,
                       gemm_select=bool(backend.get("gemm_select", False)),
                       tune_new_shapes=bool(backend.get("tune_new_shapes", False)),
-                      hip_graph=bool(backend.get("hip_graph", True)), log=log)
+                      hip_graph=_graph_mode(backend.get("hip_graph", True)), log=log)
 
     solver.algorithm = algorithm
     info = solver.training_info = {k: [] for k in (

@@ -77,6 +77,18 @@ class Shard:
             o += e.numel()
         return out
 
+    def agree(self, ok):
+        """True iff EVERY rank passes ok=True (one tiny all_reduce(MIN), executed eagerly): how the ranks decide together
+        whether a captured iteration may be replayed -- a rank that alone fell back to another body would issue a different
+        sequence of collectives and deadlock the job."""
+        if self.world_size == 1 and not dist.is_initialized():
+            return bool(ok)
+        backend = dist.get_backend(self.group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item())
+
     def allreduce_flat_(self, flat):
         """In-place all_reduce(SUM) of a caller-owned flat fp32 buffer (the hipGraph body owns its buffers: gradients,
         objective and weight statistics are written straight into one)."""

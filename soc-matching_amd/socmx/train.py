@@ -81,6 +81,19 @@ class Trainer:
             # (never silent: `backend.hip_graph` is on by default, so a run that cannot use it says why)
             self._log("backend.hip_graph: running the eager two-stream iteration instead -- " +
                       (f"measured faster for algorithm {algorithm!r}" if solver.x0.is_cuda else "the solver is not on a GPU"))
+        # A sharded run (world size > 1) does NOT capture by default: a captured graph holds the iteration's RCCL all-reduces,
+        # a wedged capture or replay hangs the job, and a rank that alone falls back to another body would issue a different
+        # sequence of collectives.  Such a run takes the same autograd-free body EAGERLY (one flat all-reduce on the main
+        # stream, the pair-grid network's small one beside the next rollout; no gradient copies); `hip_graph="sharded"` (or
+        # "force") opts in to capturing it, and then the ranks agree on the capture's success before any of them replays.
+        shard = getattr(solver, "shard", None)
+        self._multi_rank = shard is not None and shard.world_size > 1
+        # (hip_graph="nocapture": that eager form of the body at any world size -- bench.py times it beside the replayed graph)
+        self.capture_graphs = (self.hip_graph and hip_graph != "nocapture"
+                               and (not self._multi_rank or hip_graph in ("sharded", "force")))
+        if self.hip_graph and not self.capture_graphs and hip_graph != "nocapture":
+            self._log("backend.hip_graph: sharded run -- the autograd-free iteration runs eagerly (no RCCL call inside a captured "
+                      "graph); backend.hip_graph=sharded opts in")
         self.graph_warmup = int(graph_warmup)
         self.fused_adam = bool(fused_adam)    # hipGraph body: control-network Adam + telemetry as one launch (socmx_adam_step_f32)
         self._graphs = {}
@@ -640,7 +653,10 @@ class Trainer:
     def _graph_step(self, loss_kwargs):
         solver = self.solver
         dev = solver.x0.device
-        manual = self._manual_ok(loss_kwargs)
+        if self.sync_timing:
+            torch.cuda.synchronize(dev)
+        start = time.time()              # (the reference starts its timer at the top of the loop body, main.py:280: the host-side
+        manual = self._manual_ok(loss_kwargs)        #  checks below are part of the iteration)
         self._drop_stale_graphs()
         if not manual:
             self._flush_M()
@@ -649,9 +665,6 @@ class Trainer:
         body = (lambda: self._body_manual(loss_kwargs)) if manual else (lambda: self._body_dev(loss_kwargs))
         key = tuple(sorted((k, id(v) if callable(v) else v) for k, v in loss_kwargs.items()))
         key = (("manual",) + key) if manual else key
-        if self.sync_timing:
-            torch.cuda.synchronize(dev)
-        start = time.time()
         entry = self._graphs.get(key)
         if entry is None:
             self._graph_state()
@@ -660,7 +673,9 @@ class Trainer:
             n = self._graphs.setdefault(("warm",) + key, 0)
             # (the manual body needs two eager iterations: the second one is the first to run the pair-grid network's
             #  update, which creates that group's Adam state -- it must exist before a capture)
-            if n < (max(2, self.graph_warmup) if manual else self.graph_warmup) or (manual and not self._m_pending):
+            if not self.capture_graphs:
+                vals = body()           # (sharded default: the same body, never captured -- on the current stream)
+            elif n < (max(2, self.graph_warmup) if manual else self.graph_warmup) or (manual and not self._m_pending):
                 self._graphs[("warm",) + key] = n + 1
                 side = torch.cuda.Stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
@@ -674,11 +689,17 @@ class Trainer:
                 #  captures -- under the default "global" error mode that invalidates the capture now and then; the
                 #  collectives themselves are enqueued by this thread)
                 mode = "thread_local" if solver.shard is not None else "global"
+                err = None
                 try:
                     with torch.cuda.graph(g, capture_error_mode=mode):
                         static_vals = body()
                 except Exception as e:                       # noqa: BLE001 -- whatever the capture choked on, training goes on
-                    return self._capture_failed(e, loss_kwargs)
+                    err = e
+                if self._multi_rank and not solver.shard.agree(err is None) and err is None:
+                    # (a capture records, it does not execute: every rank is here, none has issued a collective of this iteration)
+                    err = RuntimeError("another rank could not capture the iteration")
+                if err is not None:
+                    return self._capture_failed(err, loss_kwargs)
                 self._graphs[key] = entry = (g, static_vals)
                 self._graphs_sig = self._optimizer_signature()
                 g.replay()                                   # capture does not execute: this replay IS the iteration
