@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsocmx.so")
+# (SOCMX_LIB: a developer build of the same ABI elsewhere -- `make PROF=1`, plan sweeps -- instead of the shipped library)
+LIB_PATH = os.environ.get("SOCMX_LIB") or os.path.join(_HERE, "libsocmx.so")
 
 OU_QUADRATIC, OU_LINEAR, DOUBLE_WELL, MOLECULAR_DYNAMICS = 0, 1, 2, 3
 SIGMA_IDENTITY = 1

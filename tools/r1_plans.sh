@@ -1,9 +1,22 @@
 #!/bin/bash
-# Developer sweep of the one-row kernel's class-1 source plans: objects prebuilt under tools/ubench/_bin/plans/ (CHANGELOG, round 4 notes),
-# relinked into the library one at a time on the GPU box and timed with tools/quick_bench.py.
-cd $GRAFT_REPO_ROOT/soc-matching_amd/csrc
-for o in ../../tools/ubench/_bin/plans/r1_*.o; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../socmx/libsocmx.so socmx_baselines.o socmx_loss.o socmx_rollout.o $o socmx_rollout_ctrl.o socmx_stopping.o socmx_unet_bwd.o || exit 1
-  echo "== $(basename $o .o)"
-  (cd ../.. && python3 tools/quick_bench.py cfg3 cfg2 2>&1 | grep -E "parity|rollout")
-done
+# Developer sweep of the packed-fma one-row kernel's source plans (csrc/socmx_rollout1p.hip: SOCMX_R1P_PLAN0 / 1 / 2): each plan is
+# compiled into ITS OWN library under tools/ubench/_bin/plans/ -- only socmx_rollout1p.o differs, the other objects are the shipped
+# build's; the shipped soc-matching_amd/socmx/libsocmx.so is never touched -- and loaded through SOCMX_LIB (socmx/_lib.py).
+#   prebuild (no GPU needed):  bash tools/r1_plans.sh build NAME CHAIN_PLAN BOOKS_PLAN SKIP_PLAN [extra compiler flags]
+#   on the GPU box:            bash tools/r1_plans.sh run
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+P=$ROOT/tools/ubench/_bin/plans
+C=$ROOT/soc-matching_amd/csrc
+mkdir -p $P
+if [ "$1" = build ]; then
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -c $C/socmx_rollout1p.hip -o $P/r1p_$2.o \
+     "-DSOCMX_R1P_PLAN0=\"$3\"" "-DSOCMX_R1P_PLAN1=\"$4\"" "-DSOCMX_R1P_PLAN2=\"$5\"" $6 -Rpass-analysis=kernel-resource-usage 2>&1 \
+     | grep -E "error|VGPRs Spill" | sed 's/.*VGPRs Spill: //; s/\[-R.*//' | tr '\n' ' '
+  echo " <- VGPR spills per instantiation ($2)"
+  OBJS=$(ls $C/*.o | grep -v socmx_rollout1p.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libsocmx_$2.so $OBJS $P/r1p_$2.o && rm -f $P/r1p_$2.o
+else
+  for l in $P/libsocmx_*.so; do
+    echo "== $(basename $l .so): $(cd $ROOT && SOCMX_LIB=$l python3 tools/r1p_check.py time-only 2>/dev/null | tail -1) ms"
+  done
+fi

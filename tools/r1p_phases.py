@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase cycles of the one-row rollout kernel (needs a library built with -DSOCMX_R1_PROF:
-   make -C soc-matching_amd/csrc PROF=1 and SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so SOCMX_R1_FORM=dpp).  Prints, per wave of workgroup 0, the average cycles per step
+"""Per-phase cycles of the PACKED-FMA one-row rollout kernel, csrc/socmx_rollout1p.hip (needs the developer library:
+   make -C soc-matching_amd/csrc PROF=1, then SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so python3 tools/r1p_phases.py).  Prints, per wave of workgroup 0, the average cycles per step
    between the kernel's marks (s_memtime: 100 MHz ticks on this part are converted with the measured kernel time)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,7 +32,7 @@ cyc = torch.zeros(8 * 16 + 64 * 64, dtype=torch.int64, device=dev)
 rollout.hip_trajectories(sde, state0, ts, 1.0, seed=0, phase_cycles=cyc)
 torch.cuda.synchronize()
 c = cyc[:128].double().cpu().numpy().reshape(8, 16) / K
-names = ["-", "S1+S2", "bar", "(S2)", "(bar)", "S3", "bar", "S4end", "S5p", "bar", "serial/noise", "bar", "out", "sde", "S4pairs135", "S4pairs246"]
+names = ["-", "B1", "P1", "B2", "P2", "B3", "P3", "B4", "P4", "B5", "sde|idle", "-", "-", "-", "-", "-"]; names[0] = "P0"
 tot = c.sum(1)
 print(f"rollout {ms:.3f} ms = {ms*1e3/K:.3f} us/step; ticks per step per wave (sum {tot.mean():.1f}) -> one tick = {ms*1e6/K/tot.mean():.2f} ns")
 scale = ms * 1e6 / K / tot.mean() * 2.4   # cycles at 2.4 GHz per tick
