@@ -17,7 +17,6 @@
 #include "../../include/socmx.h"
 #include "socmx_unet.h"
 #include "socmx_launch.h"
-#include "socmx_rollout1p.h"
 #include "socmx_philox.h"
 #include "socmx_rollout_common.h"
 
@@ -1272,9 +1271,7 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
 extern "C" size_t socmx_unet_packed_floats(int32_t d, const int32_t hdims[3]) {
   if (!hdims || !dims_ok(d, hdims)) return 0;
   const int h[3] = {hdims[0], hdims[1], hdims[2]};
-  // (the default widths at d <= 15 carry a second part behind the fragment-ordered image: the wave-major blocks of the
-  //  packed-fma one-row rollout kernel, socmx_rollout1p.h)
-  return (size_t)make_unet_desc(d, h).total_floats + (r1p_image_wanted(d, h) ? (size_t)r1p_image_floats() : 0);
+  return (size_t)make_unet_desc(d, h).total_floats;
 }
 
 extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_stream_t stream) {
@@ -1291,9 +1288,7 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
   }
   a.packed = packed;
   const int threads = 256, blocks = (a.u.total_floats + threads - 1) / threads;
-  if (const int err = launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a)) return err;
-  if (r1p_image_wanted(net->d, h)) return rollout1p_pack(net, packed + a.u.total_floats, stream);
-  return 0;
+  return launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a);
 }
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)
@@ -1452,14 +1447,9 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   // (a dense sigma at d <= 15 -- the README's Linear OU, d = 10 -- takes the same kernel: sigma u = -(sigma sigma^T) nabla_V is the
   //  one extra product on its serial chain; not with a stopping time, which is built for sigma = I)
   const bool one_row_form = fast || (!force_slow && !a.sigma_identity && d <= 15 && !stopping);
-  // sigma = I: the packed-fma form of that kernel (socmx_rollout1p.hip: v_pk_fma_f32 on replicated activations, chain waves and
-  // skip-GEMM waves).  SOCMX_R1_FORM=dpp keeps the v_fmac_f32_dpp form (developer A/B switch, tests).
-  static const bool r1_dpp = [] { const char* e = getenv("SOCMX_R1_FORM"); return e && e[0] == 'd'; }();
-  const bool one_row_ok = is_default && one_row_form && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
-                          (B <= 256 || (force_rows == 1 && B <= 1024));
-  if (one_row_ok && r1_prof_ok && !r1_dpp && a.sigma_identity && rollout1p_available() && r1p_image_wanted(d, h))
-    return rollout1p_launch(a, stopping, stream);
-  if (one_row_ok && r1_prof_ok) return rollout1_launch(a, stopping, stream);
+  if (is_default && one_row_form && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
+      (B <= 256 || (force_rows == 1 && B <= 1024)))
+    return rollout1_launch(a, stopping, stream);
   // ... and 17 <= d <= 31 with sigma = I at the default widths (soc.yaml's default d = 20): the same kernel with two components
   // per lane and down_0 / res_0 as a stage of their own on all eight waves
   if (is_wide32 && !force_slow && a.sigma_identity && d >= 16 && d <= 31 && r1_prof_ok && !prof && rollout1_wide_available() &&

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Source plans for csrc/socmx_rollout1p.hip (SOCMX_R1P_PLAN0 / 1 / 2): spreads a role's stream (S) and LDS (L) blocks evenly over
 its program, keeps the DPP-form blocks resident, at most one LDS block per unit (pair of blocks), checks the LDS budget.
-    python3 tools/r1p_mkplan.py  Rc Lc Sc   Rb Lb Sb   Rs Ls Ss      (chain | books incl. res_0 | skip; counts of R, L, S blocks)"""
+    python3 tools/r1p_mkplan.py  R L S   Rb Lb Sb      (waves 0..6 | wave 7, the books, incl. res_0; counts of R, L, S blocks)"""
 import sys
 
 def spread(n, counts):
@@ -23,13 +23,12 @@ def spread(n, counts):
     return out
 
 def units(role):
-    if role == 0:
-        return [(1, 2), (3, 4), (5, 6), (7, 8), (9,), (10,), (11, 12), (13, 14), (15, 16), (17, 18), (19, 20)]
-    return [(0, 1, 2, 3), (4, 5), (6, 7), (8, 9, 10, 11), (12, 13, 14, 15), (16, 17, 18, 19)]
+    # blocks in consumption order (csrc/socmx_rollout1p.h): units = sets of blocks multiplied together (one LDS landing block per unit)
+    return [(1, 2), (3, 4), (5, 6), (7,), (8, 9), (10, 11), (12,), (13, 14), (15, 16), (17, 18), (19, 20)]
 
 def make(role, R, L, S):
-    n = 22 if role == 0 else (21 if role == 1 else 20)
-    fixed = {0: [0, 21], 1: [20], 2: []}[role]
+    n = 22 if role == 0 else 23
+    fixed = {0: [0, 21], 1: [0, 21, 22]}[role]
     free = [b for b in range(n) if b not in fixed]
     assert R + L + S == n and R >= len(fixed), (role, R, L, S, n)
     assert S % 2 == 0 and S >= 2
@@ -56,10 +55,10 @@ def make(role, R, L, S):
     return p
 
 if __name__ == "__main__":
-    v = [int(x) for x in sys.argv[1:10]]
-    ps = [make(r, *v[3 * r:3 * r + 3]) for r in range(3)]
-    lds = 4 * v[1] + v[4] + 3 * v[7]
-    stream = 4 * v[2] + v[5] + 3 * v[8]
-    assert lds <= 33, f"LDS blocks {lds} > 33"
+    v = [int(x) for x in sys.argv[1:7]]
+    ps = [make(r, *v[3 * r:3 * r + 3]) for r in range(2)]
+    lds = 7 * v[1] + v[4]
+    stream = 7 * v[2] + v[5]
+    assert lds <= 31, f"LDS blocks {lds} > 31"
     print(' '.join(ps))
     print(f"# LDS {lds} blocks (<= 33), stream {stream} blocks = {stream * 4} KB per step", file=sys.stderr)

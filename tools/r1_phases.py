@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycles of the one-row rollout kernel (needs a library built with -DSOCMX_R1_PROF:
-   make -C soc-matching_amd/csrc PROF=1 and SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so SOCMX_R1_FORM=dpp).  Prints, per wave of workgroup 0, the average cycles per step
+   make -C soc-matching_amd/csrc PROF=1 and SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so).  Prints, per wave of workgroup 0, the average cycles per step
    between the kernel's marks (s_memtime: 100 MHz ticks on this part are converted with the measured kernel time)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
