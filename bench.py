@@ -541,11 +541,15 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "socmx::rollout1_kernel<0,StaticNet<16,256,128,64,16>,11>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU, v_fmac_f32_dpp: 64 "
-                                 "MACs per instruction at ~5 cycles per SIMD, a quarter of the packed-fp32 / MFMA rate the peak "
-                                 "is quoted at): 128 of 256 CUs work, frac <= 128/256/4 = 0.125 by construction; "
-                                 "peak = 157.3 TF is the fp32 MFMA = packed-vector figure; see roofline_full_chip for the "
-                                 "MFMA kernel with the chip full (2,048 workgroups of two 16-row tiles)",
+                         "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU): 128 of 256 CUs work, and a "
+                                 "v_fmac_f32_dpp (64 MACs) issues at 4.54 cycles per SIMD with two waves on it -- measured, "
+                                 "tools/ubench/valu_banks.hip, profiles/r5/valu_banks.txt -- i.e. 28.2 flop/clk/SIMD of the 64 the "
+                                 "peak is quoted at: frac <= 0.5 x 0.44 = 0.22 for this form; the step's 2,645 fmacs are 3.0k of its "
+                                 "~6.4k cycles (the rest: five barriers, the integrating wave's serial section, 870 other VALU "
+                                 "instructions, the 200 KB/step weight stream).  Three packed-fma rewrites (v_pk_fma_f32, 4.42 cycles per "
+                                 "128 MACs) were built and measured in round 5 and are not faster: tools/experiments/r1p/README.md.  "
+                                 "peak = 157.3 TF is the fp32 MFMA = packed-vector figure; see roofline_full_chip for the MFMA kernel with "
+                                 "the chip full (2,048 workgroups of two 16-row tiles)",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": byts,
                          "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,

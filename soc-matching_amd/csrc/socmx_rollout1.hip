@@ -181,7 +181,15 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   constexpr int NRES = r1_count(CLS, DMX, 'R'), NLDS = r1_count(CLS, DMX, 'L'), NSTR = r1_count(CLS, DMX, 'S');
   const float* __restrict__ Wp = a.packed;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
-  const int grow = blockIdx.x;
+  // Which row this workgroup integrates.  Workgroup b runs on XCD b % 8 (observed placement, used for speed only: any mapping is
+  // correct), and a row's per-step stores are 4 d bytes -- 40 at d = 10, a third of a 128-byte line of the (K, B, d) tensors.
+  // With row = b, the rows sharing a line belong to workgroups on DIFFERENT XCDs: each XCD's L2 holds its fragment of the line
+  // and writes its sectors back on its own (rocprofv3 WRITE_SIZE 2.3x the bytes stored, profiles/r4/pmc_summary.json).  Rows
+  // are therefore dealt out XCD by XCD -- XCD x takes the contiguous rows [row0(x), row0(x + 1)) -- so that a line's fragments
+  // meet in ONE L2 before they leave it.
+  const int xcd = blockIdx.x & 7, in_xcd = blockIdx.x >> 3;
+  const int rows_base = a.B >> 3, rows_rem = a.B & 7;
+  const int grow = xcd * rows_base + min(xcd, rows_rem) + in_xcd;       // (blocks b = x mod 8: ceil((B - x) / 8) = base + (x < rem) of them)
   const int g = lane >> 4, n = lane & 15;
   const uint32_t loff = lane * 16;
   uint64_t key_seed, key_offset;
