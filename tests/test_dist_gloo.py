@@ -176,3 +176,51 @@ def test_shifted_weight_sums_pool_exactly():
     mean, std = mean_std_from_shifted_sums(total, shift)
     np.testing.assert_allclose(mean.item(), w.double().mean().item(), rtol=1e-6)
     np.testing.assert_allclose(std.item(), w.double().std().item(), rtol=1e-4)
+
+
+def _agree_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from socmx.dist import Shard
+    sh = Shard()
+    # every rank ok -> True; one rank not ok -> False on EVERY rank (the ranks then take the same fall-back together)
+    ret[rank] = (sh.agree(True), sh.agree(rank != 1), sh.agree(False))
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_capture_before_anyone_replays():
+    """train.py: a sharded run that opts in to capturing its iteration (hip_graph="sharded") replays only if EVERY rank
+    captured -- `Shard.agree` is the one all_reduce(MIN) that decides it (world size 2, gloo)."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_agree_worker, args=(2, port, ret), nprocs=2, join=True)
+        ret = dict(ret)
+    assert ret[0] == (True, False, False) and ret[1] == (True, False, False)
+
+
+def test_a_sharded_run_does_not_capture_collectives_unless_asked():
+    """The rule of Trainer.__init__ (no GPU needed: the flags are decided before anything is captured): over several ranks
+    backend.hip_graph=True keeps the iteration eager; "sharded" / "force" opt in; one rank captures as before."""
+    from types import SimpleNamespace
+    from socmx.train import Trainer
+
+    class FakeShard:
+        def __init__(self, w): self.world_size = w
+
+    def flags(hip_graph, world, cuda=True):
+        logs = []
+        solver = SimpleNamespace(x0=SimpleNamespace(is_cuda=cuda), shard=FakeShard(world) if world else None,
+                                 neural_sde=SimpleNamespace(use_stopping_time=False))
+        tr = Trainer(solver, None, 8, hip_graph=hip_graph, log=logs.append)
+        return tr.hip_graph, tr.capture_graphs, logs
+
+    assert flags(True, 0)[:2] == (True, True)
+    assert flags(True, 1)[:2] == (True, True)                       # RCCL initialised at world size 1: nobody to disagree with
+    hg, cap, logs = flags(True, 8)
+    assert (hg, cap) == (True, False) and any("sharded run" in m for m in logs)   # said, never silent
+    assert flags("sharded", 8)[:2] == (True, True)
+    assert flags("force", 8)[:2] == (True, True)
+    assert flags("nocapture", 0)[:2] == (True, False)
+    assert flags(True, 8, cuda=False)[:2] == (False, False)

@@ -115,6 +115,22 @@ def test_philox_noise_contract_and_moments():
     np.testing.assert_allclose(_np(r[0]), want[0].numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B", [1, 7, 13, 100])
+def test_one_row_kernel_rows_do_not_depend_on_the_batch_they_ride_in(B):
+    """The one-row kernel deals its rows out XCD by XCD (csrc/socmx_rollout1.hip: workgroup b integrates row
+    (b % 8) * (B / 8) + ... -- any bijection is correct, this one keeps a cache line's row fragments in one L2).  Rows are
+    independent and the Philox stream is keyed by the GLOBAL row: the first B rows of a 128-row launch must be the rows of a
+    B-row launch bit for bit, for batch sizes that do not divide by eight too."""
+    from SOC_matching import utils
+    sde, aux = build_sde("cfg3_double_well_d10_K200", DEV)
+    x0 = aux["x0"]
+    big = utils.stochastic_trajectories(sde, x0.repeat(128, 1), aux["ts"], aux["lmbd"], seed=77, offset=3)
+    small = utils.stochastic_trajectories(sde, x0.repeat(B, 1), aux["ts"], aux["lmbd"], seed=77, offset=3)
+    for a, b in zip(small, big):
+        a, b = _np(a), _np(b)
+        assert np.array_equal(a, b[:, :B] if a.ndim >= 2 else b[:B]), a.shape
+
+
 @pytest.mark.parametrize("name", ["tiny_ou_linear_d20", "tiny_ou_linear_d64", "tiny_ou_linear_d6"])
 def test_philox_contract_on_the_general_sde_path(name):
     """Dense sigma (and d >= 16: one Philox block feeds four components): the documented draw
