@@ -200,9 +200,15 @@ int socmx_mnet_backward_f32(const float* packed, int32_t d, const int32_t hdims_
  *   Costs-only launch: states, noises, controls, stop_indicators and fractional_timesteps may ALL be NULL; then only
  *   lpd / lps / ltw are written (what the evaluation bursts utils.py:131-231 and method.py:185-221 consume; at
  *   d = 64, K = 400 the trajectory of 65,536 rows would be 20 GB).  Any other mix of NULLs is SOCMX_E_NULL.
- *   Tile shape (internal; a row's result does not depend on it beyond fp32 summation order in the network): a workgroup owns
- *   16 rows (v_mfma_f32_16x16x4_f32); for B <= 1024, d <= 64 and the library's constexpr-specialised hidden widths it owns 4
- *   rows (v_mfma_f32_4x4x1_16b_f32 on the same packed image, B / 4 workgroups) -- csrc/socmx_rollout.hip, rollout_launch.
+ *   Tile shape (internal; a row's result does not depend on it beyond fp32 summation order in the network), chosen by
+ *   rollout_launch (csrc/socmx_rollout.hip) from B, d, sigma and the library's constexpr-specialised hidden widths:
+ *     ONE row per workgroup   B <= 256 at d <= 15 (any sigma without a stopping time) and at 17 <= d <= 31 with sigma = I:
+ *                             matrix-vector stages on v_fmac_f32_dpp, weights resident in registers / LDS
+ *                             (csrc/socmx_rollout1.hip) -- the default for training batches: BASELINE configs[1], [2]
+ *     4 rows                  up to 64 tiles of 16 rows otherwise (B <= 1024; B <= 256 at d >= 32), d <= 64:
+ *                             v_mfma_f32_4x4x1_16b_f32 on the same packed image, B / 4 workgroups
+ *     16 rows                 everything else (v_mfma_f32_16x16x4_f32); more than 256 tiles at d <= 31: two tiles per
+ *                             workgroup (csrc/socmx_rollout32.hip: the evaluation bursts)
  */
 int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
                       const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,

@@ -310,7 +310,7 @@ FIXTURES = [
     ("cfg4_double_well_d10_B512_K6", "double_well", 10, 6, 512, DEFAULT, 6.0, 0, dict(with_pairs=False, T=0.06)),
     # FULL-SIZE PINS (round 4).  (1) The headline config at its own size -- README.md:51 / BASELINE configs[2]: double_well
     # d = 10, K = 200, B = 128, default widths (the reference holds ~10.6 GB of (Kp,Kp,B,d,d) intermediates and needs a few
-    # minutes on one thread): the 32-workgroup launch bench.py times faces the reference itself.
+    # minutes on one thread): the 128-workgroup launch (one row per workgroup) bench.py times faces the reference itself.
     ("cfg3_full_double_well_d10_K200_B128", "double_well", 10, 200, 128, DEFAULT, 6.0, 0, dict(with_pairs=False)),
     # (2) README.md:60's molecular_dynamics run as written: d = 1, K = 150, B = 64, default control-network widths,
     # arch.hdims_M=[64,64], gamma = 2 (gamma2 = gamma3 = 1: MolecularDynamics does not forward them, method.py:29-30),

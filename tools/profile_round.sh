@@ -64,3 +64,9 @@ python3 tools/burst_settings.py 2>&1 | grep -v amdgpu.ids > $R/burst_settings.tx
 rm -rf gpurun_out/pmc_b32
 rm -rf $OUT gpurun_out/k2prof gpurun_out/iterprof gpurun_out/prof gpurun_out/pmc_k3
 ls -la $R
+# round 5: what a multiply-add costs on this chip's VALU form by form (explicit registers: VGPR banks, accumulator counts, waves
+# per SIMD), and one unit of a packed-fma matrix-vector kernel with its activations by v_readlane_b32 / broadcast LDS reads
+(hipcc -O3 --offload-arch=gfx950 -Wno-unused-result -o /tmp/vb tools/ubench/valu_banks.hip 2>/dev/null && timeout 120 /tmp/vb) > $R/valu_banks.txt 2>&1
+(hipcc -O3 --offload-arch=gfx950 -Wno-unused-result -o /tmp/pku tools/ubench/pk_unit.hip 2>/dev/null && timeout 60 /tmp/pku) > $R/pk_unit.txt 2>&1
+# the sharded default (several ranks: the autograd-free body eagerly, no RCCL call inside a graph) timed at world size 1
+python3 bench.py --gpus 1 --spawn --no-dist-graph --steps 20 --warmup 5 --no-cpu-baseline --no-burst > $R/bench_sharded_world1_eager.json 2> $R/bench_sharded_world1_eager.err
