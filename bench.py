@@ -498,6 +498,8 @@ def main():
 
     if rank == 0:
         flops = flops_per_traj_step(d, HDIMS) * B * K
+        # (what the one-row kernel executes: the 256 x 256 skip product replaced by the folded d x 256 one -- socmx.h)
+        flops_exec = flops - 2 * (HDIMS[0] * HDIMS[0] - d * HDIMS[0]) * B * K if rollout_workgroups(d, B) == B else flops
         byts = bytes_per_traj_step(d) * B * K
         achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/):
@@ -544,12 +546,19 @@ def main():
                          "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU): 128 of 256 CUs work, and a "
                                  "v_fmac_f32_dpp (64 MACs) issues at 4.54 cycles per SIMD with two waves on it -- measured, "
                                  "tools/ubench/valu_banks.hip, profiles/r5/valu_banks.txt -- i.e. 28.2 flop/clk/SIMD of the 64 the "
-                                 "peak is quoted at: frac <= 0.5 x 0.44 = 0.22 for this form; the step's 2,645 fmacs are 3.0k of its "
-                                 "~6.4k cycles (the rest: five barriers, the integrating wave's serial section, 870 other VALU "
-                                 "instructions, the 200 KB/step weight stream).  Three packed-fma rewrites (v_pk_fma_f32, 4.42 cycles per "
-                                 "128 MACs) were built and measured in round 5 and are not faster: tools/experiments/r1p/README.md.  "
-                                 "peak = 157.3 TF is the fp32 MFMA = packed-vector figure; see roofline_full_chip for the MFMA kernel with "
-                                 "the chip full (2,048 workgroups of two 16-row tiles)",
+                                 "peak is quoted at: frac <= 0.5 x 0.44 = 0.22 for executed flops in this form.  `achieved` counts the "
+                                 "REFERENCE network's flops (BASELINE.md section 5); the kernel executes fewer: the skip res_1 r1 + b "
+                                 "reaches the output's ReLU only through the linear up_0 (models.py:239-240), so the pack kernel folds "
+                                 "up_0 res_1 into a d x 256 matrix and the 256 x 256 product (39 % of the MACs, 256 KB of the 677 KB "
+                                 "of weights) is never formed -- executed_flops_per_launch / executed_frac below.  With it every "
+                                 "weight is register- or LDS-resident (no L2 stream) and the step is 1,685 fmacs = 1.9k of its "
+                                 "~4.65k cycles; the rest is latency: four barriers with an LDS round trip each, the cross-row "
+                                 "reductions, the integrating wave's serial section (profiles/r5/r1_phases.txt).  Three packed-fma "
+                                 "rewrites (v_pk_fma_f32, 4.42 cycles per 128 MACs) were built and measured in round 5 and are not "
+                                 "faster: tools/experiments/r1p/README.md.  peak = 157.3 TF is the fp32 MFMA = packed-vector figure; "
+                                 "see roofline_full_chip for the MFMA kernel with the chip full (2,048 workgroups of two 16-row tiles)",
+                         "executed_flops_per_launch": flops_exec,
+                         "executed_frac": flops_exec / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": byts,
                          "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,

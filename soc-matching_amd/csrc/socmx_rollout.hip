@@ -1221,6 +1221,32 @@ __global__ void unet_pack_kernel(const PackArgs a) {
   a.packed[idx] = v;
 }
 
+// The fold behind the nine layers (UnetDesc::fold): F = up_0 res_1 (outp x h0, fragment-ordered like a layer) and f = up_0 b4.
+// One thread per element, fp64 accumulation (the products are exact in fp64, the 256-term sum is rounded once to fp32).
+__global__ void unet_fold_kernel(const PackArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const LayerDesc F = a.u.fold;
+  const int nw = F.in_pad * F.out_pad;
+  if (idx >= nw + F.out_pad) return;
+  const int h0 = a.fout[4], dout = a.fout[8];           // res_1: h0 x h0 (row-major [out][in]); up_0: d x h0
+  const float* up0 = a.w[8];
+  const float* res1 = a.w[4];
+  double acc = 0.0;
+  if (idx >= nw) {                                      // f[n] = sum_m up_0[n][m] b4[m]
+    const int n = idx - nw;
+    if (n < dout)
+      for (int m = 0; m < h0; ++m) acc += (double)up0[(size_t)n * h0 + m] * (double)a.b[4][m];
+  } else {
+    const int i = idx & 3, lane = (idx >> 2) & 63, chunk = idx >> 8;     // chunk = nb * KC + kc
+    const int KC = F.in_pad >> 4;
+    const int nb = chunk / KC, kc = chunk - nb * KC;
+    const int n = nb * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + i;
+    if (n < dout && kk < h0)
+      for (int m = 0; m < h0; ++m) acc += (double)up0[(size_t)n * h0 + m] * (double)res1[(size_t)m * h0 + kk];
+  }
+  a.packed[F.w_off + idx] = (float)acc;
+}
+
 // key[1] += inc: the Philox offset of the next keyed rollout (its own tiny node so that every workgroup of the rollout
 // before it has read the old value: same-stream order)
 __global__ void philox_advance_kernel(uint64_t* key, uint64_t inc) {
@@ -1271,7 +1297,7 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
 extern "C" size_t socmx_unet_packed_floats(int32_t d, const int32_t hdims[3]) {
   if (!hdims || !dims_ok(d, hdims)) return 0;
   const int h[3] = {hdims[0], hdims[1], hdims[2]};
-  return (size_t)make_unet_desc(d, h).total_floats;
+  return (size_t)make_unet_desc(d, h).image_floats;
 }
 
 extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_stream_t stream) {
@@ -1288,7 +1314,9 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
   }
   a.packed = packed;
   const int threads = 256, blocks = (a.u.total_floats + threads - 1) / threads;
-  return launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+  if (const int err = launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a)) return err;
+  const int nfold = a.u.fold.in_pad * a.u.fold.out_pad + a.u.fold.out_pad;
+  return launch(unet_fold_kernel, dim3((nfold + threads - 1) / threads), dim3(threads), 0, stream, a);
 }
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)

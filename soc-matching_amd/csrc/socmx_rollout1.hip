@@ -39,32 +39,42 @@ constexpr int kR1Waves = 8;
 constexpr int kR1Blocks = 20;   // main-program blocks per wave and step
 constexpr int kR1PD = 2;        // ring depth (blocks)
 
-// Where block b of a wave's program comes from: 'R' registers, 'L' LDS, 'S' L2 stream.  Class 0 = wave 0, class 1 = waves 1..7.
-//   blocks in the order a wave consumes them: 0-3 down_1 (chunks 0..3), 4 down_2 over the wave's own outputs (always resident) | 5-6 res_2, 7 up_2 | 8-15 res_1 (R0c0 R1c0 R0c1 ...),
-//   16-19 up_1 (U0c0 U1c0 U0c1 U1c1) -- in a two-GEMM stage the skip GEMM runs first: its input is in registers since an earlier
-//   stage, so its fmacs cover the LDS round trip of the stage's other input
+// Where block b of a wave's program comes from: 'R' registers, 'L' LDS, 'S' L2 stream, 'X' not part of the program.
+// Class 0 = wave 0, class 1 = waves 1..7.
+//   blocks in the order a wave consumes them: 0-3 down_1 (chunks 0..3), 4 down_2 over the wave's own outputs (always resident) | 5-6 res_2, 7 up_2 |
+//   16-19 up_1 (U0c0 U1c0 U0c1 U1c1).  Blocks 8-15 were res_1 (256 x 256: 39 % of the network) until round 5: res_1 r1 reaches the
+//   next ReLU only through the linear map up_0, so the kernel multiplies r1 by the FOLDED (outp x 256) matrix up_0 res_1 instead
+//   (UnetDesc::fold, formed by the pack kernel) -- eight fmacs per wave and step where there were 128, and with 256 KB of weights
+//   gone the remaining twelve blocks per wave fit registers + LDS: NOTHING streams from L2 any more.
 __host__ __device__ constexpr char r1_src(int cls, int dmx, int b) {
   // wave 0 also holds 4 (1 + DMAX) + (1 + DMAX) registers of down_0 / res_0: fewer resident blocks at larger d
-  // dmx = DMAX (+ 100 for a dense sigma: sigma and sigma sigma^T take the LDS of two blocks, which wave 0 streams instead)
-  const bool dense = dmx >= 100;
+  // dmx = DMAX (+ 100 for a dense sigma: sigma and sigma sigma^T sit behind the LDS blocks)
   const int dm = dmx % 100;
-  constexpr char plan0_3[kR1Blocks + 1] = "RSSLRLSLLSLSLSLSLRLS", plan0_3d[kR1Blocks + 1] = "RSSLRLSLLSLSSSLSSRLS";
-  constexpr char plan0_11[kR1Blocks + 1] = "RSSSRLSLLSLRLSLSLRLS", plan0_11d[kR1Blocks + 1] = "RSSSRLSLLSLRSSLSSRLS";
-  constexpr char plan0_15[kR1Blocks + 1] = "RSSSRLSLLSLSLSLSLSLS", plan0_15d[kR1Blocks + 1] = "RSSSRLSLLSLSSSLSSSLS";
-  // 17 <= d <= 31 (dm = 31; the 32-wide input / output network): down_0 runs on all eight waves (two resident fragments pairs per
-  // wave) instead of from wave 0's registers -- wave 0 keeps five blocks resident; the others two fewer than at d <= 15 (the
-  // down_0 fragments and the second up_0 block take their registers); A, P (32 x 32) take the LDS of two blocks
-  constexpr char plan0_31[kR1Blocks + 1] = "RSSLRLSRLSRSLSLSLRLS", plan1_31[kR1Blocks + 1] = "RRSLRSRLRSLRSRSSLRSS";
-  // (stream blocks spread over the step's TIME, two blocks of lead each: S1 ~1.1k cycles, S2 ~0.5k, S3 ~0.9k, S4 ~2.6k, then wave
-  //  0's serial section ~1.2k with no consumption)
-#ifdef SOCMX_R1_PLAN1
-  constexpr char plan1[kR1Blocks + 1] = SOCMX_R1_PLAN1;     // (developer sweeps: tools/r1_plans.sh)
-#else
-  constexpr char plan1[kR1Blocks + 1] = "RRSLRSRLRSLRSRRSLRSR";
+#ifndef SOCMX_R1_PLAN0_3
+#define SOCMX_R1_PLAN0_3 "RLRLRLRLXXXXXXXXLRLR"
 #endif
+#ifndef SOCMX_R1_PLAN0_11
+#define SOCMX_R1_PLAN0_11 "RLRLRLLLXXXXXXXXLRLR"
+#endif
+#ifndef SOCMX_R1_PLAN0_15
+#define SOCMX_R1_PLAN0_15 "RLLLRLLLXXXXXXXXLRLR"
+#endif
+#ifndef SOCMX_R1_PLAN0_31
+#define SOCMX_R1_PLAN0_31 "RLLLRLLLXXXXXXXXLRLR"
+#endif
+#ifndef SOCMX_R1_PLAN1_31
+#define SOCMX_R1_PLAN1_31 "RRRLRRRLXXXXXXXXRLRR"
+#endif
+#ifndef SOCMX_R1_PLAN1
+#define SOCMX_R1_PLAN1 "RRRRRRRLXXXXXXXXRRRR"
+#endif
+  constexpr char plan0_3[kR1Blocks + 1] = SOCMX_R1_PLAN0_3, plan0_11[kR1Blocks + 1] = SOCMX_R1_PLAN0_11, plan0_15[kR1Blocks + 1] = SOCMX_R1_PLAN0_15;
+  // 17 <= d <= 31 (dm = 31; the 32-wide input / output network): down_0 runs on all eight waves (two resident fragments pairs per
+  // wave) instead of from wave 0's registers; the down_0 fragments, the second up_0 block and the second fold block take registers
+  constexpr char plan0_31[kR1Blocks + 1] = SOCMX_R1_PLAN0_31, plan1_31[kR1Blocks + 1] = SOCMX_R1_PLAN1_31;
+  constexpr char plan1[kR1Blocks + 1] = SOCMX_R1_PLAN1;     // (developer sweeps: -DSOCMX_R1_PLAN1=...)
   if (dm > 15) return cls == 1 ? plan1_31[b] : plan0_31[b];
   if (cls == 1) return plan1[b];
-  if (dense) return dm <= 3 ? plan0_3d[b] : dm <= 11 ? plan0_11d[b] : plan0_15d[b];
   return dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
 }
 __host__ __device__ constexpr int r1_count(int cls, int dm, char s, int upto = kR1Blocks) {
@@ -118,7 +128,9 @@ struct R1Lds {
   static constexpr int sc = 1204;     // (3, 4) per-step scalars of steps k - 1, k, k + 1 (dt, sqrt(lambda dt), dt / lambda, its root): the unused tail of pmat
   static constexpr int bias = 1216;   // the nine layers' padded biases (image order)
   static constexpr int p2 = 1216 + 1248;        // (8, 64)   down_2's per-wave partial sums: wave w's contribution of ITS 16 down_1 outputs to all 64 units
-  static constexpr int weights = p2 + 512;      // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
+  static constexpr int nzb = p2 + 512;          // (24, 16)  the noise of 24 steps: drawn in batches of eight steps, one batch ahead (wave 2)
+  static constexpr int scb = nzb + 384;         // (32, 4)   per-step scalars of 32 steps: batches of sixteen (wave 3)
+  static constexpr int weights = p2 + 1024;     // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
   static constexpr int xin = 0, res0 = 0, pb = 0, fq = 0;   // (17 <= d <= 31 only: R1LdsW; named here so that the shared code compiles)
 };
 // 17 <= d <= 31: 32-wide vectors, 32 x 32 matrices, the network input and res_0's output through LDS
@@ -138,7 +150,9 @@ struct R1LdsW {
   static constexpr int pmat = 2048;
   static constexpr int bias = 3072;
   static constexpr int p2 = 3072 + 1344;
-  static constexpr int weights = p2 + 512;
+  static constexpr int nzb = p2 + 512;          // (12, 32)  the noise of 12 steps: batches of four steps
+  static constexpr int scb = nzb + 384;         // (32, 4)
+  static constexpr int weights = p2 + 1024;
 };
 static_assert((R1LdsW::weights + r1_lds_blocks(31) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit (17 <= d <= 31)");
 template <int H> struct R1LdsOf { typedef R1Lds type; };
@@ -178,6 +192,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   static_assert(H == 1 || (H == 2 && DMAX0 == 31 && !DENSE), "17 <= d <= 31: sigma = I, one instantiation");
   typedef typename R1LdsOf<H>::type LM;
   constexpr int MS = 16 * H;                        // row stride of A, P in LDS
+  constexpr int NBS = 8 / H;                        // steps per noise batch (noise_batch below); its ring holds three batches: slot = step % (3 NBS)
   constexpr int NRES = r1_count(CLS, DMX, 'R'), NLDS = r1_count(CLS, DMX, 'L'), NSTR = r1_count(CLS, DMX, 'S');
   const float* __restrict__ Wp = a.packed;
   const int d = a.d, B = a.B, K = a.K, kind = a.kind;
@@ -221,6 +236,16 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       const int k = 32 * wave + 16 * (g & 1) + 8 * (g >> 1) + j;           // (output block h: KC = 16 fragments further on)
       w5[h][j] = Wp[u.L[8].w_off + (((h * 16 + (k >> 4)) * 64) + ((k & 15) >> 2) * 16 + n) * 4 + (k & 3)];
     }
+  // the FOLD's share of this wave (UnetDesc::fold = up_0 res_1, fragment-ordered): r1 inputs 32 w .. 32 w + 31 = positions
+  // 8 (w & 1) .. 8 (w & 1) + 7 of the activation register of chunk w >> 1 -- the fragments (h, 4 (w >> 1) + 2 (w & 1) + f), f < 2
+  float wf[H][8];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kc = 4 * (wave >> 1) + 2 * (wave & 1) + (j >> 2);
+      wf[h][j] = Wp[u.fold.w_off + ((h * 16 + kc) * 64 + lane) * 4 + (j & 3)];
+    }
   // H = 2: this wave's two unit blocks of down_0 (blocks 2 w, 2 w + 1; two 16-input fragments each: register 4 kc + i <->
   // broadcast position 4 kc + i of the input register) and, on wave 0, res_0's two blocks
   float wd0[H == 2 ? 2 : 1][8], w3f[H == 2 ? 2 : 1][8];
@@ -240,7 +265,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   const float* BL = lds + LM::bias;          // (copied by the kernel's prologue; read where a layer ends)
   // LDS-resident blocks: copied once, read back with ds_read_b128 at lane * 16 + fragment * 1 KiB
   constexpr int lds_first = CLS == 0 ? 0 : r1_count(0, DMX, 'L');
-  static_assert(r1_count(CLS, DMX, 'S') % kR1PD == 0 && r1_count(CLS, DMX, 'S') >= kR1PD, "static ring slots across steps");
+  static_assert(r1_count(CLS, DMX, 'S') == 0 || (r1_count(CLS, DMX, 'S') % kR1PD == 0 && r1_count(CLS, DMX, 'S') >= kR1PD), "static ring slots across steps");
+  static_assert(r1_count(CLS, DMX, 'X') == 8 && r1_src(CLS, DMX, 8) == 'X' && r1_src(CLS, DMX, 15) == 'X', "blocks 8-15 (res_1) are folded into up_0");
   float* LW = lds + LM::weights + (lds_first + (CLS == 0 ? 0 : (wave - 1) * NLDS)) * 1024;
 #pragma unroll
   for (int r = 0; r < NLDS; ++r) {
@@ -383,7 +409,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     if constexpr (H == 2) {
       xh = okv[1] ? a.x0[(size_t)grow * d + 16 + i] : 0.f;
       kaph = (okv[1] && !is_ou) ? a.kappa[16 + i] : 0.f;
-      b8h = Wp[u.L[8].b_off + 16 + n];
+      b8h = Wp[u.L[8].b_off + 16 + n] + Wp[u.fold.b_off + 16 + n];     // (+ up_0 b4: the fold's constant term)
     } else {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -396,7 +422,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #pragma unroll
       for (int kk = 0; kk <= DMAX; ++kk) w3[kk] = Wp[u.L[3].w_off + ((kk >> 2) * 16 + n) * 4 + (kk & 3)];
     }
-    b8 = Wp[u.L[8].b_off + n];
+    b8 = Wp[u.L[8].b_off + n] + Wp[u.fold.b_off + n];                    // (+ up_0 b4: the fold's constant term)
     b3 = Wp[u.L[3].b_off + n];
     for (int e = lane; e < d * d; e += 64) {
       const int r = e / d, c = e - r * d;
@@ -428,8 +454,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   // what the coming step's chain needs besides nabla_V, from values known a stage earlier: b(x_k) and sigma eps_k
   auto prepare_step = [&](int k) {
     if (k >= K) return;
-    const float eps = lds[LM::nz + (k & 1) * MS + i];
-    if constexpr (H == 2) pre_seh = lds[LM::nz + (k & 1) * MS + 16 + i];
+    const float eps = lds[LM::nzb + (k % (3 * NBS)) * MS + i];
+    if constexpr (H == 2) pre_seh = lds[LM::nzb + (k % (3 * NBS)) * MS + 16 + i];
     if (is_ou) {                                                        // b = A x   (OU_quadratic.py:51-52, OU_linear.py:43-44)
       if constexpr (H == 1) {
         float bi = 0.f;
@@ -481,42 +507,45 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     *reinterpret_cast<f32x4*>(lds + LM::r1 + r1_perm(lane) * 4) = y;
   };
 
-  // ---- noise one step ahead: wave 1 the Philox words of step k + 2, wave 2 Box-Muller on the words of step k + 1 ----
-  float* NZ = lds + LM::nz;
-  uint32_t* WZ = reinterpret_cast<uint32_t*>(lds + LM::wz);
-  const bool w_words = CLS == 1 && wave == 1 && lane < 8 * H && !a.noise_in, w_draws = CLS == 1 && wave == 2 && lane < 8 * H;
-  auto words = [&](int k) {
-    if (!w_words || k >= K) return;
-    uint32_t wa, wb;
-    philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + grow), (uint32_t)k, lane >> 1, lane & 1, wa, wb);
-    WZ[((k & 1) * 8 * H + lane) * 2] = wa;
-    WZ[((k & 1) * 8 * H + lane) * 2 + 1] = wb;
-  };
-  auto draws = [&](int k) {
-    if (!w_draws || k >= K) return;
+  // ---- noise and scalars in BATCHES: wave 2 draws eight steps' noise (four at 17 <= d <= 31) with all 64 lanes once every eight
+  // steps, one batch ahead; wave 3 forms sixteen steps' scalars once every sixteen steps.  Per step that is ~40 instructions
+  // instead of ~300 (Philox4x32-10 + Box-Muller per step ran ~1.2k cycles on the drawing wave: hidden behind the long stage 4
+  // until round 5, on the step's critical path once res_1 had left it).  Draws as documented in include/socmx.h: lane = (step,
+  // pair), the same words, the same pair arithmetic -- bit-identical to the other tile shapes.
+  float* NZ = lds + LM::nzb;
+  auto noise_batch = [&](int nb) {
+    if (!(CLS == 1 && wave == 2)) return;
+    const int k = NBS * nb + lane / (8 * H), pr = lane % (8 * H), c0 = 2 * pr;
+    if (k >= K) return;
     float z0 = 0.f, z1 = 0.f;
-    const int c0 = 2 * lane;
     if (a.noise_in) {
       const float* src = a.noise_in + ((size_t)k * B + grow) * d;
       if (c0 < d) z0 = src[c0];
       if (c0 + 1 < d) z1 = src[c0 + 1];
     } else {
-      box_muller_pair(WZ[((k & 1) * 8 * H + lane) * 2], WZ[((k & 1) * 8 * H + lane) * 2 + 1], z0, z1);
+      uint32_t wa, wb;
+      philox_pair_words(key_seed, key_offset, (uint32_t)(a.row0 + grow), (uint32_t)k, pr >> 1, pr & 1, wa, wb);
+      box_muller_pair(wa, wb, z0, z1);
     }
-    NZ[(k & 1) * MS + c0] = c0 < d ? z0 : 0.f;
-    NZ[(k & 1) * MS + c0 + 1] = c0 + 1 < d ? z1 : 0.f;
+    NZ[(k % (3 * NBS)) * MS + c0] = c0 < d ? z0 : 0.f;
+    NZ[(k % (3 * NBS)) * MS + c0 + 1] = c0 + 1 < d ? z1 : 0.f;
   };
-
   // The step's scalars -- dt (utils.py:38), sqrt(lambda dt) (utils.py:47), dt / lambda and its root -- are an IEEE division and
-  // two square roots, ~40 dependent instructions: wave 3 (idle while wave 0 integrates) forms those of step k + 1 during
-  // step k and leaves them in LDS; on wave 0 they would sit on the step's serial chain or in front of its first stage.
-  float* SC = lds + LM::sc;
-  auto step_scalars = [&](int k) {
-    if (CLS == 1 && wave == 3 && lane == 0 && k < K) {
-      const float dt = a.ts[k + 1] - a.ts[k];
-      const float dol = dt / a.lmbd;
-      *reinterpret_cast<f32x4*>(SC + (k % 3) * 4) = f32x4{dt, sqrtf(a.lmbd * dt), dol, sqrtf(dol)};
-    }
+  // two square roots, ~40 dependent instructions per step: lane l of wave 3 forms those of step 16 nb + l
+  float* SC = lds + LM::scb;
+  auto scalar_batch = [&](int nb) {
+    if (!(CLS == 1 && wave == 3 && lane < 16)) return;
+    const int k = 16 * nb + lane;
+    if (k >= K) return;
+    const float dt = a.ts[k + 1] - a.ts[k];
+    const float dol = dt / a.lmbd;
+    *reinterpret_cast<f32x4*>(SC + (k & 31) * 4) = f32x4{dt, sqrtf(a.lmbd * dt), dol, sqrtf(dol)};
+  };
+  // (a batch is drawn while the step 8 nb is integrated -- its slots were last read three batches ago -- and first read eight
+  //  steps later; the scalars of steps 16 nb + 16 .. while step 16 nb + 1 is integrated: the other half of their ring)
+  auto batches = [&](int k) {
+    if (k % NBS == 0) noise_batch(k / NBS + 1);
+    if ((k & 15) == 1) scalar_batch((k >> 4) + 1);
   };
   // ---- what a step leaves behind for later (wave 0): only x_{k+1} -> down_0 -> r1 is on the path to the next evaluation;
   // the running costs (two row sums), the trajectory stores and nabla_V's hand-over are issued at the end of the NEXT
@@ -562,7 +591,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     if (bk_k < 0) return;
     const int k = bk_k;
     bk_k = -1;
-    const f32x4 scal = *reinterpret_cast<const f32x4*>(lds + LM::sc + (k % 3) * 4);
+    const f32x4 scal = *reinterpret_cast<const f32x4*>(lds + LM::scb + (k & 31) * 4);
     const float eps = bk_eps;
     float uc = lane_ok ? -bk_gv : 0.f;                                  // u = -sigma^T nabla_V (method.py:58-80)
     if constexpr (DENSE) {
@@ -685,7 +714,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     for (int w8 = 0; w8 < 4; ++w8) p2b[w8] = lds[LM::p2 + (4 + w8) * 64 + pk];
     blk(R1B(6), R1NX(7, 1), q0, q1, xr2.y);
     const float xr3 = relu_keep_nan((p2lo + ((p2b[0] + p2b[1]) + (p2b[2] + p2b[3]))) + bias2);
-    blk(R1B(7), R1NX(8, 2), u0, u1, xr3);
+    blk(R1B(7), R1NX(16, 2), u0, u1, xr3);
     {
       const float t = r1_reduce4(u0 + u1, q0 + q1, 0.f, 0.f);     // rows 0: up_2's totals, rows 2: res_2's
       float up, rs;
@@ -696,42 +725,45 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     R1_TICK(5)
     __syncthreads();
     R1_TICK(6)
-    // stage 4: o1 = relu(up_1 o2 + b) + res_1 r1 + b   wave w: units 32 w .. 32 w + 31 (two neuron blocks; res_1 first)
+    // stage 4: o1' = relu(up_1 o2 + b)   wave w: units 32 w .. 32 w + 31 (two neuron blocks).  The skip term res_1 r1 + b of
+    // models.py:239 is not formed: it reaches the output only through up_0, as (up_0 res_1) r1 + up_0 b -- the FOLD, whose share of
+    // this wave (r1 inputs 32 w .. 32 w + 31, in registers since stage 1) runs first and covers part of o2's LDS round trip
     const float2 xo2 = *reinterpret_cast<const float2*>(lds + LM::o2 + lane * 2);
-    const float bu4 = BL[u.L[7].b_lds + 32 * wave + 16 * (g & 1) + n], br4 = BL[u.L[4].b_lds + 32 * wave + 16 * (g & 1) + n];
-    // (the two accumulators of a block pair are the two neuron blocks': eight live accumulators did not fit beside the
-    //  resident weights, and consecutive fmacs still never depend on each other -- blocks of the same chunk run as a pair)
-    float ua = 0.f, ub = 0.f, ra = 0.f, rb = 0.f;
-    blk2(R1B(8), R1B(9), R1NX(10, 2), ra, rb, xr1[0]);
-    R1_TICK(14)
-    blk2(R1B(10), R1B(11), R1NX(12, 2), ra, rb, xr1[1]);
-    R1_TICK(15)
-    blk2(R1B(12), R1B(13), R1NX(14, 2), ra, rb, xr1[2]);
-    R1_TICK(14)
-    blk2(R1B(14), R1B(15), R1NX(16, 2), ra, rb, xr1[3]);
-    R1_TICK(15)
+    const float bu4 = BL[u.L[7].b_lds + 32 * wave + 16 * (g & 1) + n];
+    float p0 = 0.f, p1 = 0.f, q0_ = 0.f, q1_ = 0.f;
+    {
+      const int C = wave >> 1;
+      const float xc = C == 0 ? xr1[0] : C == 1 ? xr1[1] : C == 2 ? xr1[2] : xr1[3];
+      if (wave & 1) {
+        r1_fmac8<1>(p0, p1, xc, wf[0]);
+        if constexpr (H == 2) r1_fmac8<1>(q0_, q1_, xc, wf[H - 1]);
+      } else {
+        r1_fmac8<0>(p0, p1, xc, wf[0]);
+        if constexpr (H == 2) r1_fmac8<0>(q0_, q1_, xc, wf[H - 1]);
+      }
+    }
+    // (the two accumulators of a block pair are the two neuron blocks': consecutive fmacs never depend on each other)
+    float ua = 0.f, ub = 0.f;
     blk2(R1B(16), R1B(17), R1NX(18, 2), ua, ub, xo2.x);
     R1_TICK(14)
     blk2(R1B(18), R1B(19), std::integral_constant<int, kR1Blocks>{}, ua, ub, xo2.y);
     R1_TICK(15)
     float o1;
     {
-      // rows 0: up_1 block 2w, 1: up_1 block 2w + 1, 2: res_1 block 2w, 3: res_1 block 2w + 1
-      const float t = r1_reduce4(ua, ra, ub, rb);
+      // rows 0: up_1 block 2w, 1: up_1 block 2w + 1
+      const float t = r1_reduce4(ua, 0.f, ub, 0.f);
       float up, rs;
       r1_halves(t, up, rs);
       R1_TICK(7)
-      o1 = relu_keep_nan(up + bu4) + (rs + br4);          // lane (g, n): unit 32 w + 16 (g & 1) + n, both halves alike
+      o1 = relu_keep_nan(up + bu4);                       // lane (g, n): unit 32 w + 16 (g & 1) + n, both halves alike
     }
-    // stage 5, this wave's share: up_0 over the wave's own 32 outputs (no barrier in between)
+    // stage 5, this wave's share: up_0 over the wave's own 32 outputs (no barrier in between), on top of the fold's share
     {
       const float x5 = r1_ror8_upper(o1);
-      float p0 = 0.f, p1 = 0.f;
       r1_fmac8<0>(p0, p1, x5, w5[0]);
       const float y = r1_rows_sum(p0 + p1);
       if (lane < 16) lds[LM::p5 + n * 8 + wave] = y;
       if constexpr (H == 2) {                                              // the second 16-unit block of up_0's outputs
-        float q0_ = 0.f, q1_ = 0.f;
         r1_fmac8<0>(q0_, q1_, x5, w5[1]);
         const float yh = r1_rows_sum(q0_ + q1_);
         if (lane < 16) lds[LM::p5 + (16 + n) * 8 + wave] = yh;
@@ -742,13 +774,13 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     // next steps' noise and scalars -- none of it is left for the serial section behind the barrier.
     // (at the lowest issue priority: the SIMD's other wave is still inside stage 4 and everybody waits for IT)
     __builtin_amdgcn_s_setprio(0);
+    // (closing the books in stage 3's slack instead was measured: 0.454 ms against 0.437 -- at the lowest priority the
+    //  ~450-cycle chain of LDS reads and row sums outlasts that slack, and wave 0 becomes the wave stage 3 waits for)
     if constexpr (CLS == 0) {
       bookkeeping();
       prepare_step(cur_k);
     } else {
-      words(cur_k + 2);
-      draws(cur_k + 1);
-      step_scalars(cur_k + 1);
+      batches(cur_k);
       ou_products();
     }
     __builtin_amdgcn_s_setprio(2);
@@ -773,13 +805,11 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 
   // ---- prologue ----
   __builtin_amdgcn_s_setprio(2);
-  words(0);
+  noise_batch(0);
+  scalar_batch(0);
   if constexpr (CLS == 0) first_layer(a.ts[0]);
   __syncthreads();
   if constexpr (CLS == 0) rollout_key_advance(a, key_offset);     // (every wave read the key in front of this barrier)
-  draws(0);
-  words(1);
-  step_scalars(0);
   __syncthreads();
   if constexpr (CLS == 0) prepare_step(0);
   for (int k = 0; k < K; ++k) {
@@ -793,11 +823,11 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       // every LDS operand of the chain is requested at once (left to the scheduler the three round trips ran one after the other)
       const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8);
       const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8 + 4);
-      const f32x4 scal = *reinterpret_cast<const f32x4*>(SC + (k % 3) * 4);
-      const float eps = NZ[(k & 1) * MS + i];                            // drawn during the previous step
+      const f32x4 scal = *reinterpret_cast<const f32x4*>(SC + (k & 31) * 4);
+      const float eps = NZ[(k % (3 * NBS)) * MS + i];                    // drawn a batch ago
       float epsh = 0.f, gvh = 0.f;
       if constexpr (H == 2) {
-        epsh = NZ[(k & 1) * MS + 16 + i];
+        epsh = NZ[(k % (3 * NBS)) * MS + 16 + i];
         gvh = network_output_hi();
         if (is_ou) { pre_b = lds[LM::pb + i]; pre_bh = lds[LM::pb + 16 + i]; }
         apply_quad_cost();

@@ -48,8 +48,14 @@ struct UnetDesc {
   int h[3];   // hdims
   int hp[3];  // padded hdims
   LayerDesc L[9];
-  int total_floats;
+  int total_floats; // the nine layers' fragments and biases (the part every kernel reads)
   int bias_floats;  // sum of padded fan-outs
+  // Behind them, the FOLD: o1 = relu(up_1 o2 + b) + res_1 r1 + b reaches the next ReLU only through the LINEAR map up_0
+  // (models.py:239-242), so   up_0 o1 = up_0 relu(up_1 o2 + b7) + (up_0 res_1) r1 + up_0 b4   exactly -- a forward-only kernel
+  // that multiplies r1 by the (outp x h0) matrix  up_0 res_1  never needs res_1's h0 x h0 weights (39 % of the network's MACs and
+  // bytes at the default widths).  The pack kernel forms it (fp64 accumulation, rounded once) whenever it re-lays the weights.
+  LayerDesc fold;   // fragment-ordered like a layer: in_pad = hp[0], out_pad = outp; b_off: up_0 b4 (outp floats); b_lds unused
+  int image_floats; // total_floats + the fold: the size of the packed image
 };
 
 __host__ __device__ constexpr int pad16(int x) { return (x + 15) & ~15; }
@@ -87,6 +93,10 @@ __host__ __device__ constexpr UnetDesc make_unet_desc_padded(int d, int in0p, in
   }
   u.total_floats = off;
   u.bias_floats = boff;
+  u.fold.in_pad = h0p; u.fold.out_pad = outp; u.fold.b_lds = 0;
+  u.fold.w_off = off; off += h0p * outp;
+  u.fold.b_off = off; off += outp;
+  u.image_floats = off;
   return u;
 }
 
