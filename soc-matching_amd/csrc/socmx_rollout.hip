@@ -1222,29 +1222,44 @@ __global__ void unet_pack_kernel(const PackArgs a) {
 }
 
 // The fold behind the nine layers (UnetDesc::fold): F = up_0 res_1 (outp x h0, fragment-ordered like a layer) and f = up_0 b4.
-// One thread per element, fp64 accumulation (the products are exact in fp64, the 256-term sum is rounded once to fp32).
-__global__ void unet_fold_kernel(const PackArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// It sits in front of every rollout, so it is laid out for latency, not for work: one workgroup per (output unit n, 64 input
+// columns), 16 waves that split res_1's rows sixteen ways -- wave p: rows p, p + 16, ... (a coalesced 256-byte read each, all of
+// a thread's loads independent), up_0[n][m] a broadcast -- and one LDS pass adds the sixteen partial sums in a fixed order.
+// fp64 accumulation: the products are exact, the h0-term sum is rounded once to fp32.  (One thread per element with an
+// h0-iteration loop -- the first form -- took 96 us at the default widths: as long as the backward kernel's tail.)
+constexpr int kFoldCols = 64, kFoldParts = 16;
+__global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const PackArgs a) {
+  __shared__ double red[kFoldParts][kFoldCols];
   const LayerDesc F = a.u.fold;
-  const int nw = F.in_pad * F.out_pad;
-  if (idx >= nw + F.out_pad) return;
   const int h0 = a.fout[4], dout = a.fout[8];           // res_1: h0 x h0 (row-major [out][in]); up_0: d x h0
   const float* up0 = a.w[8];
   const float* res1 = a.w[4];
+  const int n = blockIdx.x, col = threadIdx.x & (kFoldCols - 1), part = threadIdx.x / kFoldCols;
+  const int kk = blockIdx.y * kFoldCols + col;
   double acc = 0.0;
-  if (idx >= nw) {                                      // f[n] = sum_m up_0[n][m] b4[m]
-    const int n = idx - nw;
-    if (n < dout)
-      for (int m = 0; m < h0; ++m) acc += (double)up0[(size_t)n * h0 + m] * (double)a.b[4][m];
-  } else {
-    const int i = idx & 3, lane = (idx >> 2) & 63, chunk = idx >> 8;     // chunk = nb * KC + kc
-    const int KC = F.in_pad >> 4;
-    const int nb = chunk / KC, kc = chunk - nb * KC;
-    const int n = nb * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + i;
-    if (n < dout && kk < h0)
-      for (int m = 0; m < h0; ++m) acc += (double)up0[(size_t)n * h0 + m] * (double)res1[(size_t)m * h0 + kk];
+  if (n < dout && kk < h0) {
+    const float* u = up0 + (size_t)n * h0;
+#pragma unroll 8
+    for (int m = part; m < h0; m += kFoldParts) acc = fma((double)u[m], (double)res1[(size_t)m * h0 + kk], acc);
   }
-  a.packed[F.w_off + idx] = (float)acc;
+  red[part][col] = acc;
+  __syncthreads();
+  if (part == 0 && kk < F.in_pad) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < kFoldParts; ++q) t += red[q][col];
+    const int KC = F.in_pad >> 4;
+    const int chunk = (n >> 4) * KC + (kk >> 4), lane = (n & 15) + 16 * ((kk & 15) >> 2);
+    a.packed[F.w_off + (chunk * 64 + lane) * 4 + (kk & 3)] = (float)t;
+  }
+  if (blockIdx.y == 0 && part == 1) {                   // f[n] = sum_m up_0[n][m] b4[m] (one wave, lanes along m)
+    double t = 0.0;
+    if (n < dout)
+      for (int m = col; m < h0; m += kFoldCols) t = fma((double)up0[(size_t)n * h0 + m], (double)a.b[4][m], t);
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) t += __shfl_xor(t, sh);
+    if (col == 0) a.packed[F.b_off + n] = (float)t;
+  }
 }
 
 // key[1] += inc: the Philox offset of the next keyed rollout (its own tiny node so that every workgroup of the rollout
@@ -1315,8 +1330,8 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
   a.packed = packed;
   const int threads = 256, blocks = (a.u.total_floats + threads - 1) / threads;
   if (const int err = launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a)) return err;
-  const int nfold = a.u.fold.in_pad * a.u.fold.out_pad + a.u.fold.out_pad;
-  return launch(unet_fold_kernel, dim3((nfold + threads - 1) / threads), dim3(threads), 0, stream, a);
+  return launch(unet_fold_kernel, dim3(a.u.fold.out_pad, (a.u.fold.in_pad + kFoldCols - 1) / kFoldCols),
+                dim3(kFoldCols * kFoldParts), 0, stream, a);
 }
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)
