@@ -121,8 +121,7 @@ struct R1Lds {
   static constexpr int r2 = 256;      // (64, 2)   down_1's output
   static constexpr int o2 = 384;      // (64, 2)   stage 3's output
   static constexpr int p5 = 512;      // (16, 8)   up_0's per-wave partial sums, neuron-major
-  static constexpr int nz = 640;      // (2, 16)   the row's noise of steps k, k + 1
-  static constexpr int wz = 672;      // (2, 8, 2) Philox words of steps k + 1, k + 2
+  static constexpr int tsr = 640;     // (32)      t_{k+1} of 32 steps: written with the scalars (wave 3), read by wave 0 in the step
   static constexpr int amat = 704;    // (16, 16)  A, P of the OU settings (wave 0's drift / running cost)
   static constexpr int pmat = 960;
   static constexpr int sc = 1204;     // (3, 4) per-step scalars of steps k - 1, k, k + 1 (dt, sqrt(lambda dt), dt / lambda, its root): the unused tail of pmat
@@ -139,8 +138,7 @@ struct R1LdsW {
   static constexpr int r2 = 256;
   static constexpr int o2 = 384;
   static constexpr int p5 = 512;      // (32, 8)
-  static constexpr int nz = 768;      // (2, 32)
-  static constexpr int wz = 832;      // (2, 16, 2)
+  static constexpr int tsr = 768;     // (32)
   static constexpr int xin = 896;     // (32)   the network input [t, x, 0..] of the coming evaluation (wave 0 writes it)
   static constexpr int res0 = 928;    // (32)   res_0 [t, x] + b of the evaluation under way
   static constexpr int sc = 960;      // (3, 4)
@@ -540,6 +538,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     const float dt = a.ts[k + 1] - a.ts[k];
     const float dol = dt / a.lmbd;
     *reinterpret_cast<f32x4*>(SC + (k & 31) * 4) = f32x4{dt, sqrtf(a.lmbd * dt), dol, sqrtf(dol)};
+    lds[LM::tsr + (k & 31)] = a.ts[k + 1];
   };
   // (a batch is drawn while the step 8 nb is integrated -- its slots were last read three batches ago -- and first read eight
   //  steps later; the scalars of steps 16 nb + 16 .. while step 16 nb + 1 is integrated: the other half of their ring)
@@ -816,7 +815,6 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #ifdef SOCMX_R1_PROF
     if (k == 0) prof_last = __builtin_readcyclecounter();
 #endif
-    const float t1 = a.ts[k + 1];             // (a scalar load: requested here, long before wave 0 needs it)
     cur_k = k;
     network();
     if constexpr (CLS == 0) {
@@ -825,6 +823,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8 + 4);
       const f32x4 scal = *reinterpret_cast<const f32x4*>(SC + (k & 31) * 4);
       const float eps = NZ[(k % (3 * NBS)) * MS + i];                    // drawn a batch ago
+      // t_{k+1} from the scalars' ring, not from memory: the kernel stores, so the compiler loads a.ts[] through the vector path,
+      // and the one vmcnt counter made this read wait for the books' stores of the stage before (s_waitcnt vmcnt(0) on the chain)
+      const float t1 = lds[LM::tsr + (k & 31)];
       float epsh = 0.f, gvh = 0.f;
       if constexpr (H == 2) {
         epsh = NZ[(k % (3 * NBS)) * MS + 16 + i];
