@@ -1227,39 +1227,60 @@ __global__ void unet_pack_kernel(const PackArgs a) {
 // a thread's loads independent), up_0[n][m] a broadcast -- and one LDS pass adds the sixteen partial sums in a fixed order.
 // fp64 accumulation: the products are exact, the h0-term sum is rounded once to fp32.  (One thread per element with an
 // h0-iteration loop -- the first form -- took 96 us at the default widths: as long as the backward kernel's tail.)
+// transposed: the image of F^T as a layer (h0 outputs, outp inputs) -- what the backward chain multiplies dL/d(pre-activation of
+// up_0) by in place of res_1^T up_0^T (socmx_unet_bwd.hip); no bias.
 constexpr int kFoldCols = 64, kFoldParts = 16;
-__global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const PackArgs a) {
+struct FoldArgs {
+  const float* up0;        // (dout, h0) row-major (torch layout)
+  const float* res1;       // (h0, h0)
+  const float* b4;         // (h0,) res_1's bias; unused when out_b is null
+  int h0, dout, in_pad, out_pad;     // F: out_pad x in_pad after padding
+  float* out_w;
+  float* out_b;            // out_pad floats, or null
+  int transposed;
+};
+__global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const FoldArgs a) {
   __shared__ double red[kFoldParts][kFoldCols];
-  const LayerDesc F = a.u.fold;
-  const int h0 = a.fout[4], dout = a.fout[8];           // res_1: h0 x h0 (row-major [out][in]); up_0: d x h0
-  const float* up0 = a.w[8];
-  const float* res1 = a.w[4];
+  const int h0 = a.h0, dout = a.dout;
   const int n = blockIdx.x, col = threadIdx.x & (kFoldCols - 1), part = threadIdx.x / kFoldCols;
   const int kk = blockIdx.y * kFoldCols + col;
   double acc = 0.0;
   if (n < dout && kk < h0) {
-    const float* u = up0 + (size_t)n * h0;
+    const float* u = a.up0 + (size_t)n * h0;
 #pragma unroll 8
-    for (int m = part; m < h0; m += kFoldParts) acc = fma((double)u[m], (double)res1[(size_t)m * h0 + kk], acc);
+    for (int m = part; m < h0; m += kFoldParts) acc = fma((double)u[m], (double)a.res1[(size_t)m * h0 + kk], acc);
   }
   red[part][col] = acc;
   __syncthreads();
-  if (part == 0 && kk < F.in_pad) {
+  if (part == 0 && kk < a.in_pad) {
     double t = 0.0;
 #pragma unroll
     for (int q = 0; q < kFoldParts; ++q) t += red[q][col];
-    const int KC = F.in_pad >> 4;
-    const int chunk = (n >> 4) * KC + (kk >> 4), lane = (n & 15) + 16 * ((kk & 15) >> 2);
-    a.packed[F.w_off + (chunk * 64 + lane) * 4 + (kk & 3)] = (float)t;
+    if (a.transposed) {          // layer F^T: unit kk, input n -- fragment ((kk >> 4) KC + (n >> 4)), KC = out_pad / 16
+      const int KC = a.out_pad >> 4;
+      const int chunk = (kk >> 4) * KC + (n >> 4), lane = (kk & 15) + 16 * ((n & 15) >> 2);
+      a.out_w[(chunk * 64 + lane) * 4 + (n & 3)] = (float)t;
+    } else {
+      const int KC = a.in_pad >> 4;
+      const int chunk = (n >> 4) * KC + (kk >> 4), lane = (n & 15) + 16 * ((kk & 15) >> 2);
+      a.out_w[(chunk * 64 + lane) * 4 + (kk & 3)] = (float)t;
+    }
   }
-  if (blockIdx.y == 0 && part == 1) {                   // f[n] = sum_m up_0[n][m] b4[m] (one wave, lanes along m)
+  if (a.out_b && blockIdx.y == 0 && part == 1) {        // f[n] = sum_m up_0[n][m] b4[m] (one wave, lanes along m)
     double t = 0.0;
     if (n < dout)
-      for (int m = col; m < h0; m += kFoldCols) t = fma((double)up0[(size_t)n * h0 + m], (double)a.b[4][m], t);
+      for (int m = col; m < h0; m += kFoldCols) t = fma((double)a.up0[(size_t)n * h0 + m], (double)a.b4[m], t);
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) t += __shfl_xor(t, sh);
-    if (col == 0) a.packed[F.b_off + n] = (float)t;
+    if (col == 0) a.out_b[n] = (float)t;
   }
+}
+
+// (shared with socmx_unet_bwd.hip: socmx_rollout_common.h declares it)
+int unet_fold_launch(const float* up0, const float* res1, const float* b4, int h0, int dout, int in_pad, int out_pad,
+                     float* out_w, float* out_b, int transposed, void* stream) {
+  FoldArgs f{up0, res1, b4, h0, dout, in_pad, out_pad, out_w, out_b, transposed};
+  return launch(unet_fold_kernel, dim3(out_pad, (in_pad + kFoldCols - 1) / kFoldCols), dim3(kFoldCols * kFoldParts), 0, stream, f);
 }
 
 // key[1] += inc: the Philox offset of the next keyed rollout (its own tiny node so that every workgroup of the rollout
@@ -1330,8 +1351,8 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
   a.packed = packed;
   const int threads = 256, blocks = (a.u.total_floats + threads - 1) / threads;
   if (const int err = launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a)) return err;
-  return launch(unet_fold_kernel, dim3(a.u.fold.out_pad, (a.u.fold.in_pad + kFoldCols - 1) / kFoldCols),
-                dim3(kFoldCols * kFoldParts), 0, stream, a);
+  return unet_fold_launch(a.w[8], a.w[4], a.b[4], a.fout[4], a.fout[8], a.u.fold.in_pad, a.u.fold.out_pad,
+                          packed + a.u.fold.w_off, packed + a.u.fold.b_off, 0, stream);
 }
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)

@@ -61,6 +61,12 @@ struct UnetDesc {
 __host__ __device__ constexpr int pad16(int x) { return (x + 15) & ~15; }
 
 // layer (fan_in, fan_out) in SOCMX_L_* order
+// socmx_rollout.hip: F = up_0 res_1 (and f = up_0 b4 when out_b is given) in MFMA fragment order; transposed: the image of F^T
+// as a layer of h0 outputs and outp inputs (the backward chain, socmx_unet_bwd.hip).  Raw torch-layout weights in.
+__attribute__((visibility("hidden"))) int unet_fold_launch(const float* up0, const float* res1, const float* b4, int h0, int dout,
+                                                           int in_pad, int out_pad, float* out_w, float* out_b, int transposed,
+                                                           void* stream);
+
 inline void unet_layer_dims(int d, const int h[3], int fin[9], int fout[9]) {
   const int i0 = d + 1;
   fin[0] = i0;   fout[0] = h[0];  // down_0

@@ -13,6 +13,8 @@
 //                              of 16x16 blocks of one layer and a slab of row tiles (split-K), operands straight from
 //                              global memory as 16-byte loads, bias gradients as row sums of the same A fragments.
 //   C  unet_wgrad_finish_kernel  adds the slabs in a fixed order (deterministic) and scatters into torch layout.
+//   D  unet_unfold_kernel      the skip res_1 is FOLDED through up_0 in all of the above (see "the fold" below): this kernel
+//                              turns G' = ZU0^T R1 (d x h0) into dW_res_1, db_res_1 and the skip's share of dW_up_0.
 // Bound: fp32 MFMA (A: forward + activation-gradient GEMMs = 2 x 2 x MACs per row; B: 2 x MACs per row).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,7 +46,8 @@ __host__ __device__ constexpr BwdDesc make_bwd_desc(const UnetDesc& u) {
   BwdDesc b{};
   int off = 0;
   for (int t = 0; t < KT_N; ++t) {
-    const LayerDesc& f = u.L[kt_source(t)];
+    // (KT_R1: not res_1^T but F^T = (up_0 res_1)^T -- the fold: outp inputs instead of h0)
+    const LayerDesc& f = t == KT_R1 ? u.fold : u.L[kt_source(t)];
     b.L[t].in_pad = f.out_pad;
     b.L[t].out_pad = f.in_pad;
     b.L[t].w_off = off;
@@ -75,7 +78,7 @@ __host__ __device__ constexpr int tensor_prefix(const UnetDesc& u, int t) {   //
 }
 // (gradient tensor, activation tensor) of forward layer l: dW_l = grad^T . act
 __host__ __device__ constexpr int layer_grad_tensor(int l) {
-  constexpr int g[9] = {T_ZD0, T_ZD1, T_ZD2, T_G0, T_GO1, T_GO2, T_ZU2, T_ZU1, T_ZU0};
+  constexpr int g[9] = {T_ZD0, T_ZD1, T_ZD2, T_G0, T_ZU0 /* the fold: G' = ZU0^T R1, see unet_unfold_kernel */, T_GO2, T_ZU2, T_ZU1, T_ZU0};
   return g[l];
 }
 __host__ __device__ constexpr int layer_act_tensor(int l) {
@@ -133,11 +136,17 @@ __host__ __device__ constexpr BwdLayout make_bwd_layout(const UnetDesc& u, int n
 
 // ---- the eleven stages of kernel A ------------------------------------------------------------------------------------
 //  forward   0: R1 = relu(d0 X + b)      1: R2 = relu(d1 R1 + b)     2: R3 = relu(d2 R2 + b)
-//            3: O2 = relu(u2 R3 + b) + r2 R2 + b   [mask MU2]        4: O1 = relu(u1 O2 + b) + r1 R1 + b   [mask MU1]
-//            5: MU0 = (u0 O1 + b > 0);  ZU0 = G (.) MU0              (the output itself is not needed: res_0 is skipped)
+//            3: O2 = relu(u2 R3 + b) + r2 R2 + b   [mask MU2]        4: A1 = relu(u1 O2 + b)               [mask MU1]
+//            5: MU0 = (u0 A1 + F R1 + f + b > 0);  ZU0 = G (.) MU0   (the output itself is not needed: res_0 is skipped)
 //  backward  6: GO1 = u0^T ZU0;  ZU1 = GO1 (.) MU1                   7: GO2 = u1^T ZU1;  ZU2 = GO2 (.) MU2
 //            8: ZD2 = (u2^T ZU2) (.) [R3 > 0]                         9: ZD1 = (d2^T ZD2 + r2^T GO2) (.) [R2 > 0]
-//           10: ZD0 = (d1^T ZD1 + r1^T GO1) (.) [R1 > 0]
+//           10: ZD0 = (d1^T ZD1 + F^T ZU0) (.) [R1 > 0]
+// THE FOLD (round 5).  models.py:239-240: o1 = relu(u1 o2 + b) + r1 R1 + b4 enters the output's ReLU only through the linear u0, so
+// with F = u0 r1 (outp x h0) and f = u0 b4:  u0 o1 = u0 A1 + F R1 + f.  The 256 x 256 skip product disappears from the forward
+// (stage 4), from the backward chain (r1^T GO1 = r1^T u0^T ZU0 = F^T ZU0: stage 10 multiplies a 16-wide tile) and from the weight
+// gradients: dW_r1 = GO1^T R1 = u0^T (ZU0^T R1) and the skip's share of dW_u0 = ZU0^T o1 is (ZU0^T R1) r1^T + (sum ZU0) b4^T --
+// kernel B forms G' = ZU0^T R1 (outp x h0) in layer 4's slot, kernel D the three small products.  39 % of the network's
+// multiply-adds at the default widths, and the GO1 slab (h0 floats per row) is not exported any more.
 constexpr int kBwdStages = 11;
 enum { EPI_RELU = 0, EPI_RES, EPI_MASK0, EPI_DUAL, EPI_ACTMASK };
 
@@ -170,18 +179,18 @@ __host__ __device__ constexpr K2Stage make_k2_stage(const UnetDesc& u, const Bwd
     case 1: fwd(1, t.r1, t.s1, 0, 1, t.r1, t.s1, t.r2, t.s2); s.epi = EPI_RELU; s.mask = b.mr2; s.ex1 = T_R2; break;
     case 2: fwd(2, t.r2, t.s2, 0, 2, t.r2, t.s2, t.r3, t.s3); s.epi = EPI_RELU; s.mask = b.mr3; s.ex1 = T_R3; break;
     case 3: fwd(6, t.r3, t.s3, 1, 5, t.r2, t.s2, t.o2, t.s2); s.epi = EPI_RES; s.mask = b.mu2; s.ex1 = T_O2; break;
-    case 4: fwd(7, t.o2, t.s2, 1, 4, t.r1, t.s1, t.o1, t.s1); s.epi = EPI_RES; s.mask = b.mu1; s.ex1 = T_O1; break;
-    case 5: fwd(8, t.o1, t.s1, 0, 8, t.o1, t.s1, -1, 0); s.epi = EPI_MASK0; s.aux = t.gv; s.saux = t.sg;
+    case 4: fwd(7, t.o2, t.s2, 0, 7, t.o2, t.s2, t.o1, t.s1); s.epi = EPI_RELU; s.mask = b.mu1; s.ex1 = T_O1; break;   // (T_O1 carries A1)
+    case 5: fwd(8, t.o1, t.s1, 1, 8, t.r1, t.s1, -1, 0); s.sd.L2 = u.fold; s.epi = EPI_MASK0; s.aux = t.gv; s.saux = t.sg;
             s.y2 = b.zu0; s.sy2 = t.sg; s.ex2 = T_ZU0; break;
     case 6: bwd(KT_U0, b.zu0, t.sg, 0, KT_U0, b.zu0, t.sg, b.go1, t.s1); s.epi = EPI_DUAL; s.mask = b.mu1;
-            s.y2 = b.zu1; s.sy2 = t.s1; s.ex1 = T_GO1; s.ex2 = T_ZU1; break;
+            s.y2 = b.zu1; s.sy2 = t.s1; s.ex1 = -1 /* GO1 stays in LDS: nobody downstream reads its slab */; s.ex2 = T_ZU1; break;
     case 7: bwd(KT_U1, b.zu1, t.s1, 0, KT_U1, b.zu1, t.s1, b.go2, t.s2); s.epi = EPI_DUAL; s.mask = b.mu2;
             s.y2 = b.zu2; s.sy2 = t.s2; s.ex1 = T_GO2; s.ex2 = T_ZU2; break;
     case 8: bwd(KT_U2, b.zu2, t.s2, 0, KT_U2, b.zu2, t.s2, b.zd2, t.s3); s.epi = EPI_ACTMASK; s.mask = b.mr3;
             s.ex1 = T_ZD2; break;
     case 9: bwd(KT_D2, b.zd2, t.s3, 1, KT_R2, b.go2, t.s2, b.zd1, t.s2); s.epi = EPI_ACTMASK; s.mask = b.mr2;
             s.ex1 = T_ZD1; break;
-    default: bwd(KT_D1, b.zd1, t.s2, 1, KT_R1, b.go1, t.s1, -1, 0); s.epi = EPI_ACTMASK; s.mask = b.mr1;
+    default: bwd(KT_D1, b.zd1, t.s2, 1, KT_R1 /* F^T */, b.zu0, t.sg, -1, 0); s.epi = EPI_ACTMASK; s.mask = b.mr1;
             s.ex1 = T_ZD0; break;
   }
   s.w1 = s.ex1 >= 0 ? tensor_width(u, s.ex1) : 0;
@@ -207,7 +216,7 @@ __host__ __device__ constexpr int k2_scratch_floats(const UnetDesc& u, int nwave
   const int outs[kBwdStages] = {u.hp[0], u.hp[1], u.hp[2], u.hp[1], u.hp[0], u.outp,
                                 bd.L[KT_U0].out_pad, bd.L[KT_U1].out_pad, bd.L[KT_U2].out_pad, bd.L[KT_D2].out_pad,
                                 bd.L[KT_D1].out_pad};
-  const int two[kBwdStages] = {0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1};
+  const int two[kBwdStages] = {0, 0, 0, 1, 0, 0 /* stage 5: GEMM 2 adds into GEMM 1's partial sums */, 0, 0, 0, 1, 1};
   int need = 0;
   for (int si = 0; si < kBwdStages; ++si) {
     const int nblk = outs[si] >> 4;
@@ -287,6 +296,7 @@ struct EpiCtx {
   const float* bias_lds;
   int64_t tile_rows;       // 16 * ntiles
   int tile;                // first 16-row tile of this workgroup (row r of the LDS tiles belongs to tile + r / 16)
+  const float* fold_bias;  // f = up_0 b_res_1 (global memory, the forward image): added to stage 5's pre-activation
 };
 
 template <int EPI>
@@ -305,8 +315,11 @@ struct Epi {
       export4(slab(prefix, width, r), r, n0, v);
     }
   }
+  // EPI_MASK0: only the sign of L1 X1 + L2 X2 + biases matters -- a split stage adds GEMM 2's partial sums to GEMM 1's
+  static constexpr bool kFuse2 = EPI == EPI_MASK0;
   __device__ __forceinline__ f32x4 init(int n0) const {
-    if constexpr (EPI == EPI_RELU || EPI == EPI_RES || EPI == EPI_MASK0) return lds4(c.bias_lds + s.sd.L1.b_lds + n0);
+    if constexpr (EPI == EPI_MASK0) return lds4(c.bias_lds + s.sd.L1.b_lds + n0) + *reinterpret_cast<const f32x4*>(c.fold_bias + n0);
+    if constexpr (EPI == EPI_RELU || EPI == EPI_RES) return lds4(c.bias_lds + s.sd.L1.b_lds + n0);
     return f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // between GEMM 1 and GEMM 2
@@ -344,7 +357,7 @@ struct Epi {
       for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
       *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
       *reinterpret_cast<f32x4*>(c.lds + s.y2 + r * s.sy2 + n0) = z;
-      put(s.p1, s.w1, r, n0, v, h, nblk);
+      if (s.ex1 >= 0) put(s.p1, s.w1, r, n0, v, h, nblk);
       put(s.p2, s.w2, r, n0, z, h, nblk);
     } else {   // EPI_ACTMASK: the sign of the forward activation, saved as a nibble by that stage's EPI_RELU
       const unsigned m = reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
@@ -484,10 +497,13 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
 #pragma unroll
       for (int h = 0; h < RT; ++h) acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (w1) k2_gemm_run<1, RT, false>(acc, r1, p1, 16 * sd.s1);
+      if constexpr (EPI::kFuse2) {
+        if (w2) k2_gemm_run<1, RT, false>(acc, r2, p2, 16 * sd.s2);
+      }
 #pragma unroll
       for (int h = 0; h < RT; ++h)
         *reinterpret_cast<f32x4*>(P1 + (part * ROWS + h * 16 + row) * outp + blk * 16 + 4 * g) = acc[h][0];
-      if (has2) {
+      if (has2 && !EPI::kFuse2) {
         f32x4 acc2[RT][1];
 #pragma unroll
         for (int h = 0; h < RT; ++h) acc2[h][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -507,7 +523,7 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
       f32x4 v = epi.init(n0);
       for (int p = 0; p < parts; ++p) v += lds4(P1 + (p * ROWS + r) * outp + n0);
       epi.mid(v, r, n0);
-      if (has2)
+      if (has2 && !EPI::kFuse2)
         for (int p = 0; p < parts; ++p) v += lds4(P2 + (p * ROWS + r) * outp + n0);
       epi.fin(v, r, n0, u);
     }
@@ -627,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, 2) void unet_bwd_tile_kernel(const TileArg
     slabG[e] = v;
   }
   unet_load_biases(a.packed, u, t, lds, tid, nthr);
-  EpiCtx ctx{lds, a.ws, lds + t.bias, tile_rows, tile};
+  EpiCtx ctx{lds, a.ws, lds + t.bias, tile_rows, tile, a.packed + u.fold.b_off};
   // first ring of stage 0 (GEMM 1 = down_0 of the forward image)
   Pre carry;
   {
@@ -860,6 +876,9 @@ struct FinishArgs {
   int scheduled;           // 1: block group i of kernel B's schedule wrote 8 n[i] partials (else S for every cell)
   int item0[10];
   uint8_t n[kWgMaxItems + 1];
+  float* fold_g;           // control network: layer 4's slot holds G' = ZU0^T R1 (fout[4] x fin[4]) and s = sum ZU0 -- they go
+                           // here ([fout][fin], then fout sums) for unet_unfold_kernel, not into `grads`; null: no such layer
+  int fold_fout;           // ... G' rows (= d); fout[4] stays res_1's fan-out for nobody: the finish kernel reads this one
 };
 
 __device__ __forceinline__ int finish_partials(const FinishArgs& a, int l, int ob, int ib) {
@@ -907,15 +926,76 @@ __global__ __launch_bounds__(256) void unet_wgrad_finish_kernel(const FinishArgs
   __syncthreads();
   if (y != 0 || S == 0) return;
   const f32x4 v = (quarter[0][xl] + quarter[1][xl]) + (quarter[2][xl] + quarter[3][xl]);
+  const bool folded = a.fold_g && l == 4;
+  const int fo = folded ? a.fold_fout : a.fout[l];
+  float* gw = folded ? a.fold_g : a.grads + a.gw_off[l];
+  float* gb = folded ? a.fold_g + (size_t)a.fold_fout * a.fin[l] : a.grads + a.gb_off[l];
   if (cells) {
     if (i < a.fin[l])
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
-        if (o + rr < a.fout[l]) a.grads[a.gw_off[l] + (int64_t)(o + rr) * a.fin[l] + i] = v[rr];
+        if (o + rr < fo) gw[(int64_t)(o + rr) * a.fin[l] + i] = v[rr];
   } else {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
-      if (o + rr < a.fout[l]) a.grads[a.gb_off[l] + o + rr] = v[rr];
+      if (o + rr < fo) gb[o + rr] = v[rr];
+  }
+}
+
+// ---- kernel D: the fold undone on the gradients --------------------------------------------------------------------------
+// In: G' = ZU0^T R1 (d x h0) and s = sum_rows ZU0 (d) from kernel C (fold_g); u0 (d x h0), r1 (h0 x h0), b4 from the forward image.
+//   dW_r1[m][k]  = sum_n u0[n][m] G'[n][k]              (= GO1^T R1 with GO1 = ZU0 u0)
+//   db_r1[m]     = sum_n u0[n][m] s[n]
+//   dW_u0[n][m] += sum_k G'[n][k] r1[m][k] + s[n] b4[m]  (kernel C wrote ZU0^T A1 there: the skip's share of ZU0^T o1 is added)
+// Latency layout like unet_fold_kernel: block (y = 0: 64 columns k of dW_r1 x 4 rows m per thread group | y = 1: dW_u0).
+struct UnfoldArgs {
+  UnetDesc u;
+  int d, h0;
+  const float* packed;     // forward image
+  const float* fold_g;     // [d][h0] G', then d sums
+  float* grads;
+  int64_t gw4, gb4, gw8;   // offsets of dW_r1, db_r1, dW_u0 in `grads`
+};
+// element [n][k] of layer L of the forward image (socmx_unet.h fragment order)
+__device__ __forceinline__ float image_w(const float* packed, const LayerDesc& L, int n, int k) {
+  const int KC = L.in_pad >> 4;
+  return packed[L.w_off + (((n >> 4) * KC + (k >> 4)) * 64 + (n & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)];
+}
+__global__ __launch_bounds__(256) void unet_unfold_kernel(const UnfoldArgs a) {
+  __shared__ float red[16][17];
+  const int d = a.d, h0 = a.h0;
+  const float* G = a.fold_g;
+  const float* sv = a.fold_g + (size_t)d * h0;
+  const int nb1 = (h0 + 3) / 4 * ((h0 + 63) / 64);          // dW_r1: blocks of (4 rows m, 64 columns k)
+  if ((int)blockIdx.x < nb1) {
+    const int kb = blockIdx.x % ((h0 + 63) / 64), mb = blockIdx.x / ((h0 + 63) / 64);
+    const int k = kb * 64 + (threadIdx.x & 63), m = mb * 4 + (threadIdx.x >> 6);
+    if (k < h0 && m < h0) {
+      float acc = 0.f;
+      for (int n = 0; n < d; ++n) acc = fmaf(image_w(a.packed, a.u.L[8], n, m), G[(size_t)n * h0 + k], acc);
+      a.grads[a.gw4 + (int64_t)m * h0 + k] = acc;
+    }
+    if (kb == 0 && (threadIdx.x & 63) == 0 && m < h0) {
+      float acc = 0.f;
+      for (int n = 0; n < d; ++n) acc = fmaf(image_w(a.packed, a.u.L[8], n, m), sv[n], acc);
+      a.grads[a.gb4 + m] = acc;
+    }
+    return;
+  }
+  // dW_u0: block = (n, 16 units m), thread (m = tid & 15, part = tid >> 4) adds the terms k = part, part + 16, ...
+  const int b = blockIdx.x - nb1, mblocks = (h0 + 15) / 16;
+  const int n = b / mblocks, m = (b % mblocks) * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+  float acc = 0.f;
+  if (m < h0)
+    for (int k = part; k < h0; k += 16) acc = fmaf(G[(size_t)n * h0 + k], image_w(a.packed, a.u.L[4], m, k), acc);
+  red[part][threadIdx.x & 15] = acc;
+  __syncthreads();
+  if (part == 0 && m < h0) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x & 15];
+    t = fmaf(sv[n], a.packed[a.u.L[4].b_off + m], t);
+    a.grads[a.gw8 + (int64_t)n * h0 + m] += t;
   }
 }
 
@@ -932,6 +1012,7 @@ __global__ void unet_pack_bwd_kernel(const PackTArgs a) {
   if (idx >= a.bd.total_floats) return;
   int t = KT_N - 1;
   while (t > 0 && idx < a.bd.L[t].w_off) --t;
+  if (t == KT_R1) return;                 // F^T: unet_fold_launch(transposed) writes this slot
   const LayerDesc L = a.bd.L[t];
   const int rel = idx - L.w_off;
   const int i = rel & 3, lane = (rel >> 2) & 63, chunk = rel >> 8;
@@ -1838,6 +1919,7 @@ struct K2Plan {
   int total_cells_floats, total_bias;
   int fin[9], fout[9];
   int64_t gw_off[9], gb_off[9], grad_floats;
+  int64_t fold_floats;     // G' and s behind the partials (kernel C -> kernel D)
 };
 
 static const int kK2Waves = 8;
@@ -1866,7 +1948,8 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   int off = 0, items = 0;
   int64_t goff = 0;
   for (int l = 0; l < 9; ++l) {
-    p.OB[l] = p.u.L[l].out_pad >> 4;
+    // (layer 4's slot: not dW_res_1 = GO1^T R1 but G' = ZU0^T R1 -- outp x h0, the fold; kernel D makes dW_res_1 of it)
+    p.OB[l] = (l == 4 ? p.u.fold.out_pad : p.u.L[l].out_pad) >> 4;
     p.IB[l] = p.u.L[l].in_pad >> 4;
     p.w_cell_off[l] = off;
     off += p.OB[l] * p.IB[l] * 256;
@@ -1876,10 +1959,11 @@ static int k2_plan(int32_t d, const int32_t hdims[3], int64_t N, K2Plan& p) {
   }
   p.grad_floats = goff;
   p.total_cells_floats = off;
-  for (int l = 0; l < 9; ++l) { p.b_part_off[l] = off; off += p.u.L[l].out_pad; }
+  for (int l = 0; l < 9; ++l) { p.b_part_off[l] = off; off += l == 4 ? p.u.fold.out_pad : p.u.L[l].out_pad; }
   p.total_bias = off - p.total_cells_floats;
   p.slab_floats = off;
   p.n_items = items;
+  p.fold_floats = ((int64_t)d * h[0] + d + 63) & ~(int64_t)63;
   // Slabs of row tiles for kernel B's UNIFORM grid (small inputs, and nets the wave schedule's table cannot describe): one
   // wave per (block group, slab), four slabs per workgroup; the slab GROUPS must divide evenly over the 8 XCDs -- kernel B
   // numbers them onto XCDs -- so S is a multiple of 32; at least 4 tiles per slab.
@@ -1920,7 +2004,10 @@ extern "C" int socmx_unet_pack_bwd_f32(const socmx_unet* net, float* packedT, so
   }
   a.packedT = packedT;
   const int threads = 256, blocks = (a.bd.total_floats + threads - 1) / threads;
-  return launch(unet_pack_bwd_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+  if (const int err = launch(unet_pack_bwd_kernel, dim3(blocks), dim3(threads), 0, stream, a)) return err;
+  // the KT_R1 slot: F^T = (up_0 res_1)^T as a layer of h0 outputs and outp inputs (the fold: see the stage table)
+  return unet_fold_launch(net->weight[8], net->weight[4], nullptr, h[0], net->d, u.fold.in_pad, u.fold.out_pad,
+                          packedT + a.bd.L[KT_R1].w_off, nullptr, 1, stream);
 }
 
 extern "C" int socmx_unet_backward_sizes(int32_t d, const int32_t hdims[3], int64_t N, int64_t* workspace_floats,
@@ -1928,7 +2015,7 @@ extern "C" int socmx_unet_backward_sizes(int32_t d, const int32_t hdims[3], int6
   K2Plan p;
   const int rc = k2_plan(d, hdims, N, p);
   if (rc) return rc;
-  if (workspace_floats) *workspace_floats = p.ws_floats + p.part_floats;
+  if (workspace_floats) *workspace_floats = p.ws_floats + p.part_floats + p.fold_floats;
   if (grad_floats) *grad_floats = p.grad_floats;
   return 0;
 }
@@ -1989,8 +2076,16 @@ extern "C" int socmx_unet_backward_scaled_f32(const float* packed, const float* 
   }
   fa.total_cells_floats = p.total_cells_floats; fa.total_bias = p.total_bias; fa.S = p.S; fa.slab_floats = p.slab_floats;
   fa.part = wa.part; fa.grads = grads;
+  fa.fold_g = workspace + p.ws_floats + p.part_floats; fa.fold_fout = d;
   const int nthreads = p.total_cells_floats + p.total_bias;
-  return launch(unet_wgrad_finish_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, stream, fa);
+  if (const int err = launch(unet_wgrad_finish_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, stream, fa)) return err;
+  // ---- kernel D ----
+  UnfoldArgs ua;
+  ua.u = p.u; ua.d = d; ua.h0 = hdims[0]; ua.packed = packed; ua.fold_g = fa.fold_g; ua.grads = grads;
+  ua.gw4 = p.gw_off[4]; ua.gb4 = p.gb_off[4]; ua.gw8 = p.gw_off[8];
+  const int h0 = hdims[0];
+  const unsigned nb1 = (unsigned)((h0 + 3) / 4 * ((h0 + 63) / 64)), nb2 = (unsigned)(d * ((h0 + 15) / 16));
+  return launch(unet_unfold_kernel, dim3(nb1 + nb2), dim3(256), 0, stream, ua);
 }
 
 // ---- K3: the pair-grid network ---------------------------------------------------------------------------------------
