@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) void rollout_kernel(const RolloutArgs a) {
     if (is_quad) P_l[r * ds + c] = a.P[e];
   }
   if (!is_ou) for (int e = tid; e < d; e += nthr) KAP[e] = a.kappa[e];
-  unet_load_biases(a.packed, ud, tl, lds, tid, nthr);
+  unet_load_biases(a.packed, ud, tl, lds, tid, nthr, ud.folded != 0);
   Pre carry;
   if constexpr (kStatic) carry = unet_carry_init_static<NW, NET>(a.packed);
   else carry = unet_carry_init(a.packed, a.prog);
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(NW * 64) void rollout4_kernel(const RolloutArgs a) 
     if (is_ou) A_l[r * ds + c] = a.A[e];
     if (is_quad) P_l[r * ds + c] = a.P[e];
   }
-  unet_load_biases(a.packed, ud, tl, lds, tid, nthr);
+  unet_load_biases(a.packed, ud, tl, lds, tid, nthr, ud.folded != 0);
   Pre carry = unet_carry_init_static<NW, NET>(a.packed);
 
   const bool act = tid < 64;
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(NW * 64) void rollout4g_kernel(const RolloutArgs a)
     if (is_ou) A_l[r * ds + c] = a.A[e];
     if (is_quad) P_l[r * ds + c] = a.P[e];
   }
-  unet_load_biases(a.packed, ud, tl, lds, tid, nthr);
+  unet_load_biases(a.packed, ud, tl, lds, tid, nthr, ud.folded != 0);
   Pre carry = unet_carry_init_static<NW, NET>(a.packed);
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = tid & 63;
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(NW * 64) void unet_forward_kernel(const ForwardArgs
     const int64_t grow = min(row0 + r, a.N - 1);
     X0[r * a.t.s0 + c] = (c < in0) ? a.tx[grow * in0 + c] : 0.f;
   }
-  unet_load_biases(a.packed, a.u, a.t, lds, tid, nthr);
+  unet_load_biases(a.packed, a.u, a.t, lds, tid, nthr, a.u.folded != 0);
   Pre carry = unet_carry_init(a.packed, a.prog);
   __syncthreads();
   unet_tile_forward<NW>(a.packed, a.prog, a.t, lds, carry, [](int) {});
@@ -1202,7 +1202,20 @@ struct PackArgs {
 
 __global__ void unet_pack_kernel(const PackArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.u.total_floats) return;
+  if (idx >= a.u.total_floats) {
+    // behind the nine layers: up_0 once more, as the second half of cat = [up_0 res_1 | up_0] (UnetDesc::cat; the fold kernel
+    // writes the first half) -- fragment (nb, kc) of up_0 is fragment (nb, KC + kc) of cat
+    const int rel = idx - a.u.total_floats;
+    if (rel >= a.u.L[8].in_pad * a.u.L[8].out_pad) return;
+    const int i = rel & 3, lane = (rel >> 2) & 63, chunk = rel >> 8;
+    const int KC = a.u.L[8].in_pad >> 4;
+    const int nb = chunk / KC, kc = chunk - nb * KC;
+    const int n = nb * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + i;
+    float v = 0.f;
+    if (n < a.fout[8] && kk < a.fin[8]) v = a.w[8][(size_t)n * a.fin[8] + kk];
+    a.packed[a.u.cat.w_off + ((nb * 2 * KC + KC + kc) * 64 + lane) * 4 + i] = v;
+    return;
+  }
   int l = 8;
   while (l > 0 && idx < a.u.L[l].w_off) --l;
   const LayerDesc L = a.u.L[l];
@@ -1238,6 +1251,7 @@ struct FoldArgs {
   float* out_w;
   float* out_b;            // out_pad floats, or null
   int transposed;
+  float* out_cat;          // null, or the image of [F | up_0] (UnetDesc::cat): F's fragment (nb, kc) goes to (nb, kc) of 2 KC
 };
 __global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const FoldArgs a) {
   __shared__ double red[kFoldParts][kFoldCols];
@@ -1264,6 +1278,7 @@ __global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const
       const int KC = a.in_pad >> 4;
       const int chunk = (n >> 4) * KC + (kk >> 4), lane = (n & 15) + 16 * ((kk & 15) >> 2);
       a.out_w[(chunk * 64 + lane) * 4 + (kk & 3)] = (float)t;
+      if (a.out_cat) a.out_cat[((chunk + (n >> 4) * KC) * 64 + lane) * 4 + (kk & 3)] = (float)t;
     }
   }
   if (a.out_b && blockIdx.y == 0 && part == 1) {        // f[n] = sum_m up_0[n][m] b4[m] (one wave, lanes along m)
@@ -1278,8 +1293,8 @@ __global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const
 
 // (shared with socmx_unet_bwd.hip: socmx_rollout_common.h declares it)
 int unet_fold_launch(const float* up0, const float* res1, const float* b4, int h0, int dout, int in_pad, int out_pad,
-                     float* out_w, float* out_b, int transposed, void* stream) {
-  FoldArgs f{up0, res1, b4, h0, dout, in_pad, out_pad, out_w, out_b, transposed};
+                     float* out_w, float* out_b, int transposed, void* stream, float* out_cat) {
+  FoldArgs f{up0, res1, b4, h0, dout, in_pad, out_pad, out_w, out_b, transposed, out_cat};
   return launch(unet_fold_kernel, dim3(out_pad, (in_pad + kFoldCols - 1) / kFoldCols), dim3(kFoldCols * kFoldParts), 0, stream, f);
 }
 
@@ -1349,10 +1364,10 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
     a.b[l] = net->bias[l];
   }
   a.packed = packed;
-  const int threads = 256, blocks = (a.u.total_floats + threads - 1) / threads;
+  const int threads = 256, blocks = (a.u.total_floats + a.u.L[8].in_pad * a.u.L[8].out_pad + threads - 1) / threads;
   if (const int err = launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a)) return err;
   return unet_fold_launch(a.w[8], a.w[4], a.b[4], a.fout[4], a.fout[8], a.u.fold.in_pad, a.u.fold.out_pad,
-                          packed + a.u.fold.w_off, packed + a.u.fold.b_off, 0, stream);
+                          packed + a.u.fold.w_off, packed + a.u.fold.b_off, 0, stream, packed + a.u.cat.w_off);
 }
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)

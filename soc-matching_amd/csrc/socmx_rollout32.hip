@@ -448,8 +448,8 @@ __global__ __launch_bounds__(kB32Waves * 64) void rollout32_kernel(const Rollout
     if (is_quad) P_l[rr * ds + cc] = a.P[e];
     if (dense) SIG[rr * ds + cc] = a.sigma[e];
   }
-  unet_load_biases(a.packed, ud, tl, lds, tid, NW * 64);
-  const B32Img img = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, ud.total_floats * 4, 0x00020000), (tid & 63) * 16};
+  unet_load_biases(a.packed, ud, tl, lds, tid, NW * 64, ud.folded != 0);
+  const B32Img img = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, ud.image_floats * 4, 0x00020000), (tid & 63) * 16};
   Frags2 carry;
   b32_frags_init<NET>(img, carry, __builtin_amdgcn_readfirstlane(tid >> 6));
 

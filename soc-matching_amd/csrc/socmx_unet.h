@@ -55,7 +55,14 @@ struct UnetDesc {
   // that multiplies r1 by the (outp x h0) matrix  up_0 res_1  never needs res_1's h0 x h0 weights (39 % of the network's MACs and
   // bytes at the default widths).  The pack kernel forms it (fp64 accumulation, rounded once) whenever it re-lays the weights.
   LayerDesc fold;   // fragment-ordered like a layer: in_pad = hp[0], out_pad = outp; b_off: up_0 b4 (outp floats); b_lds unused
-  int image_floats; // total_floats + the fold: the size of the packed image
+  // ... and for the MFMA tile kernels the CONCATENATED last layer  cat = [up_0 res_1 | up_0]  (outp x 2 hp[0]): with the R1 and O1
+  // tiles side by side in LDS (TileLayout: one tile of row stride 2 hp[0] + 4) the last stage is ONE split-K GEMM over [r1 | o1']
+  // (o1' = relu(up_1 o2 + b): stage 4 loses its 256 x 256 second GEMM) -- unet_stage_desc.  b_off = the fold's, b_lds = up_0's:
+  // the kernels that run the folded program load b_up0 + up_0 b4 into that slot (unet_load_biases(..., fold_bias = true)).
+  LayerDesc cat;
+  int folded;       // 1: unet_stage_desc returns the folded program (16-wide outputs, or >= 64: the last stage's split / direct
+                    // forms take any K; 32- and 48-wide outputs keep the plain program -- their slim split holds eight fragments)
+  int image_floats; // total_floats + the fold + cat: the size of the packed image
 };
 
 __host__ __device__ constexpr int pad16(int x) { return (x + 15) & ~15; }
@@ -65,7 +72,7 @@ __host__ __device__ constexpr int pad16(int x) { return (x + 15) & ~15; }
 // as a layer of h0 outputs and outp inputs (the backward chain, socmx_unet_bwd.hip).  Raw torch-layout weights in.
 __attribute__((visibility("hidden"))) int unet_fold_launch(const float* up0, const float* res1, const float* b4, int h0, int dout,
                                                            int in_pad, int out_pad, float* out_w, float* out_b, int transposed,
-                                                           void* stream);
+                                                           void* stream, float* out_cat = nullptr);
 
 inline void unet_layer_dims(int d, const int h[3], int fin[9], int fout[9]) {
   const int i0 = d + 1;
@@ -102,6 +109,9 @@ __host__ __device__ constexpr UnetDesc make_unet_desc_padded(int d, int in0p, in
   u.fold.in_pad = h0p; u.fold.out_pad = outp; u.fold.b_lds = 0;
   u.fold.w_off = off; off += h0p * outp;
   u.fold.b_off = off; off += outp;
+  u.cat.in_pad = 2 * h0p; u.cat.out_pad = outp; u.cat.b_lds = u.L[8].b_lds; u.cat.b_off = u.fold.b_off;
+  u.cat.w_off = off; off += 2 * h0p * outp;
+  u.folded = (outp == 16 || outp >= 64) ? 1 : 0;
   u.image_floats = off;
   return u;
 }
@@ -133,13 +143,14 @@ __host__ __device__ constexpr TileLayout make_tile_layout(const UnetDesc& u, int
     t.s0 = r4_stride(u.in0p); t.s1 = r4_stride(u.hp[0]); t.s2 = r4_stride(u.hp[1]); t.s3 = r4_stride(u.hp[2]);
     t.sg = r4_stride(u.outp);
   }
+  // R1 and O1 share ONE tile: row = [r1 (hp0) | o1 (hp0) | 4] -- the folded last stage reads the row as a 2 hp0-wide operand
+  t.s1 = rows == 4 ? r4_stride(2 * u.hp[0]) : 2 * u.hp[0] + 4;
   int off = 0;
   t.x0 = off; off += rows * t.s0;
-  t.r1 = off; off += rows * t.s1;
+  t.r1 = off; t.o1 = off + u.hp[0]; off += rows * t.s1;
   t.r2 = off; off += rows * t.s2;
   t.r3 = off; off += rows * t.s3;
   t.o2 = off; off += rows * t.s2;
-  t.o1 = off; off += rows * t.s1;
   t.gv = off; off += rows * t.sg;
   t.scratch = off; off += 2 * rows * 16 * nwaves;  // split-K partials: 2 GEMMs x (parts*out_pad <= 16*nwaves) x rows
   t.bias = off; off += u.bias_floats;
@@ -187,6 +198,17 @@ __host__ __device__ constexpr StageDesc make_stage(const UnetDesc& u, int l1, in
 
 // stage i of the network (0..5); constexpr so the specialised kernels see immediates
 __host__ __device__ constexpr StageDesc unet_stage_desc(const UnetDesc& u, const TileLayout& t, int i) {
+  if (u.folded && i >= 4) {
+    // THE FOLD (UnetDesc::cat): stage 4 is o1' = relu(up_1 o2 + b) alone; stage 5 multiplies [r1 | o1'] by [up_0 res_1 | up_0]
+    if (i == 4) {
+      StageDesc d = make_stage(u, 7, t.o2, t.s2, 0, 7, t.o2, t.s2, t.o1, t.s1, 8);
+      d.Ln = u.cat;
+      return d;
+    }
+    StageDesc d = make_stage(u, 8, t.r1, t.s1, 1, 3, t.x0, t.s0, t.gv, t.sg, 0);
+    d.L1 = u.cat;
+    return d;
+  }
   switch (i) {
     case 0: return make_stage(u, 0, t.x0, t.s0, 0, 0, t.x0, t.s0, t.r1, t.s1, 1);   // r1 = relu(down_0 x)
     case 1: return make_stage(u, 1, t.r1, t.s1, 0, 1, t.r1, t.s1, t.r2, t.s2, 2);   // r2 = relu(down_1 r1)
@@ -292,12 +314,17 @@ __device__ __forceinline__ void relu4_keep_nan(f32x4& v) {
 }
 
 // all threads: copy the padded biases of the nine layers from the packed image into LDS (once per kernel)
+// fold_bias: up_0's slot gets b_up0 + up_0 b_res1 (the kernels that run the folded program of unet_stage_desc)
 __device__ __forceinline__ void unet_load_biases(const float* __restrict__ Wp, const UnetDesc& u, const TileLayout& t,
-                                                 float* lds, int tid, int nthr) {
+                                                 float* lds, int tid, int nthr, bool fold_bias = false) {
   // (unrolled: a runtime index into u.L[] would put the whole descriptor into scratch memory)
 #pragma unroll
   for (int l = 0; l < 9; ++l)
-    for (int e = tid; e < u.L[l].out_pad; e += nthr) lds[t.bias + u.L[l].b_lds + e] = Wp[u.L[l].b_off + e];
+    for (int e = tid; e < u.L[l].out_pad; e += nthr) {
+      float v = Wp[u.L[l].b_off + e];
+      if (l == 8 && fold_bias) v += Wp[u.fold.b_off + e];
+      lds[t.bias + u.L[l].b_lds + e] = v;
+    }
 }
 
 // the same copy to an explicit LDS address (bias of layer l at dst + u.L[l].b_lds)
@@ -911,7 +938,7 @@ __host__ __device__ constexpr int r4_resident_stage() {
   const StageDesc sd = unet_stage_desc(NET::desc(), NET::layout4(NW), 4);
   const int NBLK = sd.L1.out_pad >> 4;
   const bool uniform = (NBLK >= NW && NBLK % NW == 0 && NBLK / NW <= 4 && NBLK / NW != 3) || (NBLK < NW && NBLK >= kSimds);
-  return (uniform && sd.has2 && sd.L1.in_pad * sd.L1.out_pad <= 33 * 1024) ? 4 : -1;
+  return (uniform && sd.L1.in_pad * sd.L1.out_pad <= 33 * 1024) ? 4 : -1;     // (with or without a second GEMM: the folded stage 4 has none)
 }
 template <int NW, class NET>
 __host__ __device__ constexpr int r4_resident_floats() {
@@ -944,7 +971,7 @@ __device__ __forceinline__ void stage_direct4(const float* __restrict__ Wp, cons
   typedef Ring4<NB, R4Frags<NW>::value> RingT;
   RingT r1, r2;
   if constexpr (W1LDS) {
-    ring_fill<NB, true, RingT>(r2, p2, pre);
+    if (has2) ring_fill<NB, true, RingT>(r2, p2, pre);
   } else {
     ring_fill<NB, true, RingT>(r1, p1, pre);
     if (has2) ring_fill<NB, false, RingT>(r2, p2, pre);   // the residual GEMM's first chunks fly while GEMM 1 runs
@@ -1016,9 +1043,11 @@ __device__ __forceinline__ void unet_stage_static4(const float* __restrict__ Wp,
   asm volatile("" : "+v"(c.f[4]), "+v"(c.f[5]), "+v"(c.f[6]), "+v"(c.f[7]));
   // first ring of the next stage's GEMM 1 (requested before this stage's closing barrier)
   constexpr bool res_here = SI == RES_SI, res_next = (SI + 1) % 6 == RES_SI;
-  static_assert(!res_here || (uniform && sd.has2), "the resident layer is GEMM 1 of a uniform two-GEMM stage");
+  static_assert(!res_here || uniform, "the resident layer is GEMM 1 of a uniform stage");
   auto prefetch_next = [&]() {
-    if constexpr (uniform_next) {
+    if constexpr (res_next && !sdn.has2) {
+      // (next stage's only GEMM is resident in LDS: nothing to request)
+    } else if constexpr (uniform_next) {
       // (next stage's GEMM 1 resident in LDS: the first ring of its GEMM 2 instead)
       constexpr int nbn = NBLKn >= NW ? NBLKn / NW : 1;
       constexpr int KCx = res_next ? KC2n : KCn;
