@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 144 /* 0.1.6: the packed U-Net image carries the folded skip (up_0 res_1, up_0 b_res_1) behind the nine layers: socmx_unet_packed_floats grew */
+#define SOCMX_VERSION 145 /* 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -112,11 +112,13 @@ int socmx_capabilities(char* buf, int cap);
 
 /* ---- control network --------------------------------------------------- */
 
-/* Number of floats of the MFMA-fragment-ordered image of a U-Net: the nine layers of models.py:212-228, then the FOLD --
- * F = W_up_0 W_res_1 (out_pad x h0) in the same fragment order and f = W_up_0 b_res_1.  models.py:239-240 reads
- * out = relu(up_0 (relu(up_1 o2 + b) + res_1 r1 + b) + b) + ...: the skip res_1 r1 + b reaches the ReLU only through the
- * linear up_0, so a forward-only evaluation may use F r1 + f in its place (a d x 256 product instead of a 256 x 256 one).
- * The one-row rollout kernel does; the pack kernel forms F with fp64 accumulation. */
+/* Number of floats of the MFMA-fragment-ordered image of a U-Net: the nine layers of models.py:212-228, then THE FOLD --
+ * F = W_up_0 W_res_1 (out_pad x h0) in the same fragment order, f = W_up_0 b_res_1, and cat = [F | W_up_0] (out_pad x 2 h0).
+ * models.py:239-240 reads out = relu(up_0 (relu(up_1 o2 + b) + res_1 r1 + b) + b) + ...: the skip res_1 r1 + b reaches the ReLU
+ * only through the linear up_0, so every kernel uses F r1 + f in its place (a d x 256 product instead of a 256 x 256 one):
+ * the one-row rollout multiplies r1 by F, the MFMA tile kernels multiply the LDS row [r1 | relu(up_1 o2 + b)] by cat in ONE
+ * split-K GEMM, the backward kernels use F and F^T (socmx_unet_pack_bwd_f32) and recover dW_res_1, db_res_1 and the skip's share
+ * of dW_up_0 from the d x h0 product ZU0^T R1.  The pack kernels form F with fp64 accumulation. */
 size_t socmx_unet_packed_floats(int32_t d, const int32_t hdims[3]);
 
 /* packed (device, socmx_unet_packed_floats floats) <- net. Re-run after every optimizer step. */
