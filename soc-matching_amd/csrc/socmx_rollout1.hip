@@ -65,8 +65,10 @@ __host__ __device__ constexpr char r1_src(int cls, int dmx, int b) {
 #ifndef SOCMX_R1_PLAN1_31
 #define SOCMX_R1_PLAN1_31 "RRRLRRRLXXXXXXXXRLRR"
 #endif
+// (all twelve blocks of waves 1..7 resident: one register of the sigma = I instantiations spills -- outside the step loop -- and the
+//  ~70-cycle stall stage 3 paid for the LDS block's second half is gone: 0.414 -> 0.405 ms at configs[2], A/B on one box)
 #ifndef SOCMX_R1_PLAN1
-#define SOCMX_R1_PLAN1 "RRRRRRRLXXXXXXXXRRRR"
+#define SOCMX_R1_PLAN1 "RRRRRRRRXXXXXXXXRRRR"
 #endif
   constexpr char plan0_3[kR1Blocks + 1] = SOCMX_R1_PLAN0_3, plan0_11[kR1Blocks + 1] = SOCMX_R1_PLAN0_11, plan0_15[kR1Blocks + 1] = SOCMX_R1_PLAN0_15;
   // 17 <= d <= 31 (dm = 31; the 32-wide input / output network): down_0 runs on all eight waves (two resident fragments pairs per
