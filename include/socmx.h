@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 145 /* 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
+#define SOCMX_VERSION 146 /* 0.1.8: + socmx_weights_stats_scalars_f32; 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -307,6 +307,15 @@ int socmx_rollout_phase_cycles_f32(const socmx_problem* problem, const float* pa
  * with Chan's parallel-variance rule on the host. */
 int socmx_weights_stats_f32(const float* lpd, const float* lps, const float* ltw, int32_t B,
                             float* w, float* stats, socmx_stream_t stream);
+/* The same launch also forms the three device scalars the loss side of an iteration starts from (each pointer may be NULL):
+ *   gam_out[0]  = gamma[0]        the exponent of models.py:265-275 as THIS iteration's contraction reads it (the deferred backward
+ *                                 of the same iteration reads this copy after gamma itself may have been stepped),
+ *   gout_out[0] = 1 / norm[0]     d loss / d objective of main.py:313-320 (the running normaliser lives in device memory),
+ *   obj_zero[0] = 0               the objective's accumulator (socmx_socm_target_fwd_net_f32 adds into it).
+ * Three one-element launches on the iteration's critical path otherwise. */
+int socmx_weights_stats_scalars_f32(const float* lpd, const float* lps, const float* ltw, int32_t B, float* w, float* stats,
+                                    const float* gamma, float* gam_out, const float* norm, float* gout_out, float* obj_zero,
+                                    socmx_stream_t stream);
 
 /* The same statistics for a batch SHARD (one rank of a data-parallel run; no reference counterpart -- the reference is
  * single-process), in a form that ONE all_reduce(SUM) combines, so they travel in the flat gradient buffer:

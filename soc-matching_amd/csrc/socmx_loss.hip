@@ -43,10 +43,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // ---- importance weights: method.py:258-262, 903-904 -------------------------------------------
+struct StatScalars {       // socmx_weights_stats_scalars_f32: all optional
+  const float* gamma; float* gam_out; const float* norm; float* gout_out; float* obj_zero;
+};
 __global__ __launch_bounds__(256) void weights_stats_kernel(const float* __restrict__ lpd, const float* __restrict__ lps,
                                                             const float* __restrict__ ltw, int B, float* __restrict__ w,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, const StatScalars sc) {
   __shared__ float red[32];
+  if (threadIdx.x == 0) {
+    if (sc.gam_out) sc.gam_out[0] = sc.gamma[0];
+    if (sc.gout_out) sc.gout_out[0] = 1.f / sc.norm[0];
+    if (sc.obj_zero) sc.obj_zero[0] = 0.f;
+  }
   float s = 0.f;
   for (int m = threadIdx.x; m < B; m += blockDim.x) {
     const float x = expf(lpd[m] + lps[m] + ltw[m]);
@@ -2216,7 +2224,16 @@ extern "C" int socmx_weights_stats_f32(const float* lpd, const float* lps, const
                                        float* stats, socmx_stream_t stream) {
   if (!lpd || !lps || !ltw || !w || !stats) return SOCMX_E_NULL;
   if (B < 1) return SOCMX_E_DIM;
-  return launch(weights_stats_kernel, dim3(1), dim3(256), 0, stream, lpd, lps, ltw, (int)B, w, stats);
+  return launch(weights_stats_kernel, dim3(1), dim3(256), 0, stream, lpd, lps, ltw, (int)B, w, stats, StatScalars{});
+}
+
+extern "C" int socmx_weights_stats_scalars_f32(const float* lpd, const float* lps, const float* ltw, int32_t B, float* w,
+                                               float* stats, const float* gamma, float* gam_out, const float* norm,
+                                               float* gout_out, float* obj_zero, socmx_stream_t stream) {
+  if (!lpd || !lps || !ltw || !w || !stats || (gam_out && !gamma) || (gout_out && !norm)) return SOCMX_E_NULL;
+  if (B < 1) return SOCMX_E_DIM;
+  return launch(weights_stats_kernel, dim3(1), dim3(256), 0, stream, lpd, lps, ltw, (int)B, w, stats,
+                StatScalars{gamma, gam_out, norm, gout_out, obj_zero});
 }
 
 extern "C" int socmx_shard_stats_f32(int32_t phase, const float* w, int32_t B, const float* shift, const float* obj,

@@ -89,6 +89,7 @@ PROTOTYPES = {
                                                  C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, _fp,
                                                  _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "socmx_weights_stats_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp]),
+    "socmx_weights_stats_scalars_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "socmx_shard_stats_f32": (C.c_int, [C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "socmx_num_pairs": (C.c_int64, [C.c_int32]),
     "socmx_matching_target_f32": (C.c_int, [C.c_int32, C.POINTER(Problem), C.c_int32, C.c_int32, _fp, C.c_float, C.c_float,

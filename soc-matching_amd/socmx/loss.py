@@ -334,18 +334,26 @@ def socm_objective(pb, ts, lmbd, K, states, noises, controls, M_all, dM_all, nab
 # importance weights
 # --------------------------------------------------------------------------------------
 
-def weights_and_stats(lpd, lps, ltw):
+def weights_and_stats(lpd, lps, ltw, scalars=None):
     """w = exp(lpd+lps+ltw) (method.py:258-262) and stats = (sum w, sum (w-mean_local)^2, n[, mean, std]): mean
-    and unbiased std (method.py:903-904) follow from the first three, and shards combine with Chan's formula."""
+    and unbiased std (method.py:903-904) follow from the first three, and shards combine with Chan's formula.
+    `scalars` (GPU only): (gamma, gam_out, norm, gout_out, obj_zero) one-element tensors or None each -- the same launch copies
+    gamma, forms 1 / norm and clears the objective's accumulator (socmx_weights_stats_scalars_f32)."""
     if lpd.is_cuda:
         L = _lib.lib()
         B = lpd.shape[0]
         w = torch.empty_like(lpd)
         stats = torch.empty(5, dtype=torch.float32, device=lpd.device)
         with _lib.on_device(lpd.device):
-            _lib.check(L.socmx_weights_stats_f32(_lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), B, _lib.ptr(w),
-                                                 _lib.ptr(stats), _lib.stream_ptr(lpd.device)),
-                       "socmx_weights_stats_f32")
+            if scalars is not None:
+                _lib.check(L.socmx_weights_stats_scalars_f32(_lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), B, _lib.ptr(w),
+                                                             _lib.ptr(stats), *[_lib.ptr(x) for x in scalars],
+                                                             _lib.stream_ptr(lpd.device)),
+                           "socmx_weights_stats_scalars_f32")
+            else:
+                _lib.check(L.socmx_weights_stats_f32(_lib.ptr(lpd), _lib.ptr(lps), _lib.ptr(ltw), B, _lib.ptr(w),
+                                                     _lib.ptr(stats), _lib.stream_ptr(lpd.device)),
+                           "socmx_weights_stats_f32")
         return w, stats
     w = torch.exp(lpd + lps + ltw)
     return w, torch.stack([w.sum(), ((w - w.mean()) ** 2).sum(), torch.tensor(float(w.shape[0]))])

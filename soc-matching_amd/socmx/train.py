@@ -333,7 +333,31 @@ class Trainer:
         solver = self.solver
         _, _, part = L.target_bwd_net(solver.dim, solver.num_steps, D["q"].shape[1], D["G"], D, D["gout"], D["net"], D["dnet"],
                                       D["delta"], D["gam"], g_net=D["g_net"], g_dnet=D["g_dnet"])
-        torch.sum(part, dim=0, keepdim=True, out=D["g_gamma"])
+        side = self._fused_side_table(D, params + [sde.gamma])
+        if side is not None:
+            torch.sum(part, dim=0, keepdim=True, out=D["m_flat"][side[4]:])      # gamma's gradient: straight into the flat buffer's tail
+        else:
+            torch.sum(part, dim=0, keepdim=True, out=D["g_gamma"])
+        if side is not None:
+            # The pair-grid network's gradients and gamma's in ONE flat buffer (the buffer a sharded run all-reduces), then ONE
+            # Adam launch over the seven tensors (socmx_adam_step_f32) instead of torch's four multi-tensor launches: this
+            # branch runs on the second stream beside the rollout and, since the rollout got shorter than it, IS the iteration's
+            # critical path up to the point where the main stream joins it
+            from . import _lib
+            table, grp, sums, scratch, n = side
+            flat = D["m_flat"]
+            nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
+                                   D["g_net"], D["g_dnet"], out=flat)
+            if shard is not None:
+                shard.allreduce_flat_(flat)
+            b1, b2 = grp["betas"]
+            dev = flat.device
+            with _lib.on_device(dev):
+                _lib.check(_lib.lib().socmx_adam_step_f32(table.data_ptr(), len(params) + 1, n + 1, _lib.ptr(flat), None,
+                                                         _lib.ptr(D["itr1"]), 0.01, float(grp["lr"]), float(b1), float(b2),
+                                                         float(grp["eps"]), _lib.ptr(scratch), _lib.ptr(sums),
+                                                         _lib.stream_ptr(dev)), "socmx_adam_step_f32")
+            return
         if shard is None:
             grads = nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
                                            D["g_net"], D["g_dnet"])
@@ -356,6 +380,52 @@ class Trainer:
         self._step_groups(self._groups_side)
         for p in params + [sde.gamma]:
             p.grad = None
+        # (torch's step has created the Adam state by now: build the fused step's table here, outside any capture, so that the
+        #  next update -- possibly the captured one -- finds it)
+        if self.fused_adam and D is not None and not torch.cuda.is_current_stream_capturing():
+            self._fused_side_table(D, params + [sde.gamma])
+
+    def _fused_side_table(self, D, tensors):
+        """Device table for socmx_adam_step_f32 over the pair-grid network's six tensors + gamma, or None while the fused step does
+        not apply: every side group must be a torch.optim.Adam group with the SAME float lr / betas / eps, no weight decay /
+        amsgrad / maximize, covering exactly these tensors, with device-resident fp32 state that torch's own step created (the
+        eager warm-up iterations) and equal step counts.  Rebuilt whenever a data pointer or a hyper-parameter changed."""
+        if not self.fused_adam or "itr1" not in D:
+            return None
+        opt, groups = self.optimizer, self._groups_side
+        if type(opt) is not torch.optim.Adam or not groups:
+            return None
+        g0 = groups[0]
+        hyper = lambda g: (g["lr"], tuple(g["betas"]), g["eps"])
+        if any(torch.is_tensor(g["lr"]) or g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False)
+               or hyper(g) != hyper(g0) for g in groups):
+            return None
+        if sorted(id(p) for g in groups for p in g["params"]) != sorted(id(p) for p in tensors):
+            return None
+        st = opt.state
+        for p in tensors:
+            q = st.get(p)
+            if (not q or not torch.is_tensor(q.get("step")) or q["step"].device != p.device or q["step"].dtype != torch.float32
+                    or p.dtype != torch.float32 or not p.is_contiguous()):
+                return None
+        sig = (tuple(x.data_ptr() for p in tensors for x in (p, st[p]["exp_avg"], st[p]["exp_avg_sq"], st[p]["step"])),
+               float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"]))
+        if D.get("adam_side_sig") != sig:
+            if torch.cuda.is_current_stream_capturing():
+                return None              # (the table is a host-to-device copy: built by an eager iteration, see _m_update's tail)
+            rows, off = [], 0
+            for p in tensors:
+                rows.append([p.data_ptr(), st[p]["exp_avg"].data_ptr(), st[p]["exp_avg_sq"].data_ptr(), st[p]["step"].data_ptr(),
+                             p.numel(), off])
+                off += p.numel()
+            dev = tensors[0].device
+            n = off - tensors[-1].numel()
+            if "m_flat" not in D or D["m_flat"].numel() != off:
+                D["m_flat"] = torch.empty(off, dtype=torch.float32, device=dev)
+            D["adam_side"] = (torch.tensor(rows, dtype=torch.int64, device=dev), g0, torch.zeros(2, dtype=torch.float32, device=dev),
+                              torch.zeros(4 + 2 * ((off + 1023) // 1024), dtype=torch.float32, device=dev), n)
+            D["adam_side_sig"] = sig
+        return D["adam_side"]
 
     def _flush_M(self):
         """Apply the outstanding pair-grid-network update now (before anything outside the replayed graph reads or
@@ -414,16 +484,19 @@ class Trainer:
         layers = [M.sigmoid_layers[i] for i in (0, 2, 4)]
         mparams = [p.detach() for l in layers for p in (l.weight, l.bias)]
 
-        def m_branch():
+        def m_branch(gout_free=None):
             if self._m_pending:
                 self._m_update(t_vec, s_vec)
+            if gout_free is not None:
+                gout_free.record(torch.cuda.current_stream(dev))      # the deferred backward has read the previous d loss / d objective
             net, dnet, _ = nets.pair_net_forward(d, M.hdims, mparams, t_vec, s_vec, packed=D["packed"],
                                                  out=(D["net"], D["dnet"]))
             # two scalars the main stream needs only behind the rollout: gamma (final once the deferred update above ran) and
             # 1 / running normaliser = d loss / d objective (main.py:313-320) -- formed here, off the critical path
-            D["gam"].copy_(sde.gamma.detach().reshape(1))
-            torch.reciprocal(D["norm1"], out=D["gout"])
-            D["obj"].zero_()           # (the objective's accumulator: cleared here instead of in front of the contraction)
+            if side is None:
+                D["gam"].copy_(sde.gamma.detach().reshape(1))
+                torch.reciprocal(D["norm1"], out=D["gout"])
+                D["obj"].zero_()       # (the objective's accumulator: cleared here instead of in front of the contraction)
             return net, dnet
 
         main = torch.cuda.current_stream(dev)
@@ -450,20 +523,32 @@ class Trainer:
             sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0,
             shares_chip=True)        # (the second stream's branch -- deferred contraction backward, pair-grid network -- runs beside it)
         packed_bwd = None
+        scal3 = None
         if side is not None:
+            gout_free = torch.cuda.Event()
             with torch.cuda.stream(side):
                 side.wait_event(fork)
                 # (the transposed weight image the control-network backward reads: packed here, beside the rollout, instead of
                 #  in front of the backward on the critical path -- the weights do not change in between)
                 packed_bwd = sde.nabla_V.packed_bwd()
-                net, dnet = m_branch()
+                net, dnet = m_branch(gout_free)
+            # two scalars of the main stream's own chain, enqueued behind the rollout where this stream waits for the second one
+            # anyway (on the second stream they were 20 us at the end of what has become the longer branch): 1 / running
+            # normaliser = d loss / d objective (main.py:313-320) -- once the deferred backward has read the previous one -- and
+            # the objective's cleared accumulator
+            main.wait_event(gout_free)
+            # (gamma is final once the deferred update ran; the three scalars ride in the weights' launch below)
+            scal3 = (sde.gamma.detach().reshape(1), D["gam"], D["norm1"], D["gout"], D["obj"])
+        # (the weights and the contraction's operands need the rollout only -- and, for the operand buffers the deferred backward
+        #  of the previous iteration read, the event above: formed BEFORE the join, while the second stream finishes the
+        #  pair-grid network's forward)
+        weight, stats = L.weights_and_stats(lpd, lps, ltw, scalars=scal3)
+        w_mean, w_std = L.mean_std_from_stats(stats)
+        ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls, out=D)
         if side is not None:
             main.wait_stream(side)
             net.record_stream(main)
             dnet.record_stream(main)
-        weight, stats = L.weights_and_stats(lpd, lps, ltw)
-        w_mean, w_std = L.mean_std_from_stats(stats)
-        ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls, out=D)
         gam = D["gam"]                                                     # (filled in m_branch)
         obj, G, _ = L.target_fwd_net(pb, K, net, dnet, delta, gam, ops, nabla_v, weight, 1.0 / (Kp * B_global), G=D["G"],
                                      obj=D["obj"])
@@ -635,7 +720,7 @@ class Trainer:
         if getattr(self, "_graphs_sig", None) != self._optimizer_signature():
             self._graphs = {}
             if self._dev is not None:
-                for k in ("adam_table", "adam_sig", "adam_scratch"):
+                for k in ("adam_table", "adam_sig", "adam_scratch", "adam_side", "adam_side_sig"):
                     self._dev.pop(k, None)
             self._make_capturable()
 
@@ -645,7 +730,7 @@ class Trainer:
             return
         vparams = list(self.solver.neural_sde.nabla_V.parameters())
         if len(self._groups_main) != 1 or self._adam_signature(self._groups_main[0], vparams) != D["adam_sig"]:
-            for k in ("adam_table", "adam_sig", "adam_scratch"):
+            for k in ("adam_table", "adam_sig", "adam_scratch", "adam_side", "adam_side_sig"):
                 D.pop(k, None)
             self._graphs = {}          # warm-up iterations run eagerly again (they rebuild the table), then a new capture
             self._make_capturable()

@@ -62,7 +62,11 @@ def test_graph_replay_equals_the_eager_iteration(name, B):
         #  cancel differ by a few 1e-6 after seven Adam steps (eps = 1e-4 divides a last-bit difference of the sum by 1e-4):
         #  element-wise 1e-5 there (and at K = 100, B = 64: 6,464 rows), and norm-wise agreement to 2e-6 everywhere.
         np.testing.assert_allclose(par_g[k], par_e[k], rtol=2e-5, atol=5e-7 if B * solver.num_steps < 6000 else 1e-5, err_msg=k)
-        assert np.linalg.norm(par_g[k] - par_e[k]) <= 2e-6 * max(np.linalg.norm(par_e[k]), 1e-12) + 1e-9, k
+        # (the pair-grid network and gamma are stepped by socmx_adam_step_f32 in the replayed body too -- one launch on the second
+        #  stream instead of torch's four -- at M_lr = 1e-2, a hundred times the control network's rate: the same last-bit
+        #  differences in the bias corrections weigh a hundred times more in the update; 4e-6 norm-wise there)
+        nw = 4e-6 if (k.startswith("M.") or "gamma" in k) else 2e-6
+        assert np.linalg.norm(par_g[k] - par_e[k]) <= nw * max(np.linalg.norm(par_e[k]), 1e-12) + 1e-9, k
 
 
 @pytest.mark.parametrize("alg", ["SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-variance", "variance",
