@@ -1200,8 +1200,7 @@ struct PackArgs {
   float* packed;
 };
 
-__global__ void unet_pack_kernel(const PackArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void unet_pack_element(const PackArgs& a, const int idx) {
   if (idx >= a.u.total_floats) {
     // behind the nine layers: up_0 once more, as the second half of cat = [up_0 res_1 | up_0] (UnetDesc::cat; the fold kernel
     // writes the first half) -- fragment (nb, kc) of up_0 is fragment (nb, KC + kc) of cat
@@ -1233,6 +1232,7 @@ __global__ void unet_pack_kernel(const PackArgs a) {
   }
   a.packed[idx] = v;
 }
+__global__ void unet_pack_kernel(const PackArgs a) { unet_pack_element(a, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // The fold behind the nine layers (UnetDesc::fold): F = up_0 res_1 (outp x h0, fragment-ordered like a layer) and f = up_0 b4.
 // It sits in front of every rollout, so it is laid out for latency, not for work: one workgroup per (output unit n, 64 input
@@ -1253,11 +1253,10 @@ struct FoldArgs {
   int transposed;
   float* out_cat;          // null, or the image of [F | up_0] (UnetDesc::cat): F's fragment (nb, kc) goes to (nb, kc) of 2 KC
 };
-__global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const FoldArgs a) {
-  __shared__ double red[kFoldParts][kFoldCols];
+__device__ __forceinline__ void unet_fold_block(const FoldArgs& a, const int bx, const int by, double (*red)[kFoldCols]) {
   const int h0 = a.h0, dout = a.dout;
-  const int n = blockIdx.x, col = threadIdx.x & (kFoldCols - 1), part = threadIdx.x / kFoldCols;
-  const int kk = blockIdx.y * kFoldCols + col;
+  const int n = bx, col = threadIdx.x & (kFoldCols - 1), part = threadIdx.x / kFoldCols;
+  const int kk = by * kFoldCols + col;
   double acc = 0.0;
   if (n < dout && kk < h0) {
     const float* u = a.up0 + (size_t)n * h0;
@@ -1281,7 +1280,7 @@ __global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const
       if (a.out_cat) a.out_cat[((chunk + (n >> 4) * KC) * 64 + lane) * 4 + (kk & 3)] = (float)t;
     }
   }
-  if (a.out_b && blockIdx.y == 0 && part == 1) {        // f[n] = sum_m up_0[n][m] b4[m] (one wave, lanes along m)
+  if (a.out_b && by == 0 && part == 1) {                // f[n] = sum_m up_0[n][m] b4[m] (one wave, lanes along m)
     double t = 0.0;
     if (n < dout)
       for (int m = col; m < h0; m += kFoldCols) t = fma((double)a.up0[(size_t)n * h0 + m], (double)a.b4[m], t);
@@ -1289,6 +1288,22 @@ __global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const
     for (int sh = 32; sh >= 1; sh >>= 1) t += __shfl_xor(t, sh);
     if (col == 0) a.out_b[n] = (float)t;
   }
+}
+__global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_fold_kernel(const FoldArgs a) {
+  __shared__ double red[kFoldParts][kFoldCols];
+  unet_fold_block(a, blockIdx.x, blockIdx.y, red);
+}
+// The re-lay and the fold in ONE launch (they read the raw weights only and write disjoint parts of the image): blocks
+// [0, pack_blocks) re-lay 1,024 elements each, the rest are the fold's (output unit, 64 columns) blocks.  One launch less in front
+// of every rollout (~6 us of its ~0.4 ms at configs[2]).
+__global__ __launch_bounds__(kFoldCols * kFoldParts) void unet_pack_fold_kernel(const PackArgs a, const FoldArgs f, const int pack_blocks) {
+  __shared__ double red[kFoldParts][kFoldCols];
+  if ((int)blockIdx.x < pack_blocks) {
+    unet_pack_element(a, blockIdx.x * (kFoldCols * kFoldParts) + threadIdx.x);
+    return;
+  }
+  const int b = blockIdx.x - pack_blocks;
+  unet_fold_block(f, b % f.out_pad, b / f.out_pad, red);
 }
 
 // (shared with socmx_unet_bwd.hip: socmx_rollout_common.h declares it)
@@ -1364,10 +1379,12 @@ extern "C" int socmx_unet_pack_f32(const socmx_unet* net, float* packed, socmx_s
     a.b[l] = net->bias[l];
   }
   a.packed = packed;
-  const int threads = 256, blocks = (a.u.total_floats + a.u.L[8].in_pad * a.u.L[8].out_pad + threads - 1) / threads;
-  if (const int err = launch(unet_pack_kernel, dim3(blocks), dim3(threads), 0, stream, a)) return err;
-  return unet_fold_launch(a.w[8], a.w[4], a.b[4], a.fout[4], a.fout[8], a.u.fold.in_pad, a.u.fold.out_pad,
-                          packed + a.u.fold.w_off, packed + a.u.fold.b_off, 0, stream, packed + a.u.cat.w_off);
+  const int threads = kFoldCols * kFoldParts;
+  const int pack_blocks = (a.u.total_floats + a.u.L[8].in_pad * a.u.L[8].out_pad + threads - 1) / threads;
+  const FoldArgs f{a.w[8], a.w[4], a.b[4], a.fout[4], a.fout[8], a.u.fold.in_pad, a.u.fold.out_pad,
+                   packed + a.u.fold.w_off, packed + a.u.fold.b_off, 0, packed + a.u.cat.w_off};
+  const int fold_blocks = f.out_pad * ((f.in_pad + kFoldCols - 1) / kFoldCols);
+  return launch(unet_pack_fold_kernel, dim3(pack_blocks + fold_blocks), dim3(threads), 0, stream, a, f, pack_blocks);
 }
 
 static const int kWaves = 8;  // waves per 16-row tile workgroup (2 per SIMD)

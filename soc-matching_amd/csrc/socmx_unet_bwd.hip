@@ -2170,7 +2170,11 @@ static int mnet_bwd_plan(int32_t d, const int32_t hdims[2], int32_t n_in, int64_
   p.slab_floats = off;
   const int nt16 = 2 * p.ntiles;
   // (wide form: the last layer's partials are 2 MB per slab at d = 64 -- 32 slabs keep kernel C's reduction at 70 MB)
-  int S = p.m.wide ? 32 : 64;
+  // (developer A/B switch, read once: SOCMX_K3_SLABS)
+  static const int env_slabs = [] { const char* e = getenv("SOCMX_K3_SLABS"); return e ? atoi(e) : 0; }();
+  // (96 slabs once there are enough tiles: this kernel runs on the second stream beside the rollout, i.e. on the half of the chip
+  //  the one-row workgroups leave free -- 240 workgroups of shorter waves fill it in one round: 80 -> 61 us at configs[2])
+  int S = p.m.wide ? 32 : (env_slabs > 0 ? env_slabs : (nt16 >= 1536 ? 96 : 64));
   if (S > nt16 / 4) S = nt16 / 4 >= 32 ? 32 : nt16 / 4;
   p.S = S < 1 ? 1 : S;
   p.part_floats = (int64_t)p.S * p.slab_floats;

@@ -94,6 +94,12 @@ class Shard:
         objective and weight statistics are written straight into one)."""
         if self.world_size == 1 and not dist.is_initialized():
             return flat
+        if self.world_size == 1 and flat.is_cuda and torch.cuda.is_current_stream_capturing():
+            # One rank: the sum is the identity -- and it is NOT put into a graph under capture.  A captured RCCL call leaves an
+            # event "last recorded in a capturing stream" behind, and torch's process-group watchdog thread, which polls its
+            # events on its own schedule, dies on it (hipErrorCapturedEvent -> the whole process): seen in one of three full runs
+            # of the GPU test suite.  Eager calls at world size 1 still go through RCCL (the path a multi-rank run takes by default).
+            return flat
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 

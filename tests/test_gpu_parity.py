@@ -1409,7 +1409,8 @@ tr2.join(); torch.cuda.synchronize()
 num = sum(float(((a - b) ** 2).sum()) for a, b in zip(sde.state_dict().values(), sde2.state_dict().values()))
 den = sum(float((b ** 2).sum()) for b in sde2.state_dict().values())
 res['param_rel_diff'] = (num / den) ** 0.5
-# hipGraph mode WITH a shard: the autograd-free body, its two RCCL all-reduces captured inside the graph -- 2 eager warm-ups,
+# hipGraph mode WITH a shard: the autograd-free body -- its two all-reduces are RCCL calls in the 2 eager warm-ups and, at world
+# size 1, identities inside the capture (socmx/dist.py: a captured RCCL call can take torch's watchdog thread down) --,
 # the capture, 3 replays, fresh Philox noise each; against the unsharded hipGraph Trainer on the same device key
 from socmx.rollout import PhiloxKey
 runs = []
@@ -1445,7 +1446,7 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
     """The sharded code path with the real RCCL backend (torch.distributed 'nccl', world_size 1) in a fresh child
     process: Shard(), the 3-float all-gather of a direct `.loss()` call, the flat gradient all-reduce -- objective, weight
     statistics and every gradient against the reference-generated fixture --, then sharded Trainer iterations, eager (ONE
-    all-reduce per iteration) and as a replayed hipGraph with the collectives captured inside."""
+    all-reduce per iteration) and as a replayed hipGraph (one rank: the sums are identities there, not captured RCCL calls)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gpath = str(tmp_path / "grads.npz")
