@@ -265,7 +265,7 @@ def launch_command(args, port, environ=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup",
            str(args.warmup)]
-    for flag in ("no_cpu_baseline", "no_burst", "no_secondary", "no_dist_graph", "defer_graph"):
+    for flag in ("no_cpu_baseline", "no_burst", "no_secondary", "no_dist_graph", "dist_graph", "defer_graph"):
         if getattr(args, flag):
             cmd.append("--" + flag.replace("_", "-"))
     if args.force_dist or args.spawn:
@@ -303,10 +303,14 @@ def make_parser():
                     "torch.distributed.run; implies --force-dist in the child)")
     ap.add_argument("--defer-graph", action="store_true", help="take the multi-GPU ordering of the hipGraph legs (last, under the "
                     "watchdog) at any world size: how that path is exercised on one GPU")
+    ap.add_argument("--dist-graph", action="store_true", help="world size > 1: also run the hipGraph legs with the RCCL all-reduces "
+                    "captured inside (backend.hip_graph=sharded: experimental, see --no-dist-graph); off by default")
     ap.add_argument("--no-dist-graph", action="store_true", help="world size > 1: skip the hipGraph legs (the iteration "
                     "replayed with its RCCL all-reduces captured inside).  They run LAST, after every eager number is in the "
-                    "line, under a watchdog that prints the line and exits if they do not finish -- this builder could "
-                    "validate the capture at world size 1 only")
+                    "line, under a watchdog that prints the line and exits if they do not finish -- EXPERIMENTAL: no "
+                    "multi-GPU node was available to this builder, and at world size 1 a captured RCCL call took torch's "
+                    "process-group watchdog thread (and the process) down in one of three full test runs, so one rank no longer "
+                    "captures any (socmx/dist.py)")
     return ap
 
 
@@ -580,7 +584,10 @@ def main():
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
     else:
         line = None
-    if defer_graph and not args.no_dist_graph:
+    # (world > 1: the captured-RCCL legs are opt-in -- `--dist-graph` -- since a captured RCCL call can make torch's process-group
+    #  watchdog thread abort the process, and an aborted rank prints no line; what such a run ships by default, the eager body, is
+    #  already in the line)
+    if defer_graph and not args.no_dist_graph and (world == 1 or args.dist_graph):
         # Multi-GPU hipGraph legs (the iteration replayed with its RCCL all-reduces captured inside), LAST and under a watchdog:
         # every eager number is already in the line; if a capture or a replay does not come back, every rank prints /
         # exits on its own timer and the run still delivers its line.
@@ -608,7 +615,9 @@ def main():
                 line["socm_ms_per_iter_graph"] = 1e3 * g_elapsed / it_steps
                 if g_elapsed < it_elapsed:
                     line.update(socm_iters_per_sec=it_steps / g_elapsed, socm_ms_per_iter=1e3 * g_elapsed / it_steps,
-                                socm_iteration_mode="hipGraph replay (RCCL all-reduces captured)", socm_last_loss=g_loss)
+                                socm_iteration_mode=("hipGraph replay (RCCL all-reduces captured)" if world > 1 else
+                                                     "hipGraph replay (one rank: the sums are identities under capture, no RCCL "
+                                                     "call in the graph -- socmx/dist.py)"), socm_last_loss=g_loss)
                 line["dist_graph"] = "ok"
         except Exception as e:  # noqa: BLE001
             if line is not None:
