@@ -77,6 +77,9 @@ __host__ __device__ constexpr char r1_src(int cls, int dmx, int b) {
   constexpr char plan1[kR1Blocks + 1] = SOCMX_R1_PLAN1;     // (developer sweeps: -DSOCMX_R1_PLAN1=...)
   if (dm > 15) return cls == 1 ? plan1_31[b] : plan0_31[b];
   if (cls == 1) return plan1[b];
+  // (a dense sigma adds row i of sigma sigma^T to wave 0's registers: at d <= 11 it takes the four-resident-block plan of d <= 15 --
+  //  with the five-block one 3-5 registers of the step loop spilled to scratch)
+  if (dmx >= 100 && dm > 3) return plan0_15[b];
   return dm <= 3 ? plan0_3[b] : dm <= 11 ? plan0_11[b] : plan0_15[b];
 }
 __host__ __device__ constexpr int r1_count(int cls, int dm, char s, int upto = kR1Blocks) {
