@@ -163,8 +163,8 @@ template <> struct R1LdsOf<2> { typedef R1LdsW type; };
 static_assert((R1Lds::weights + r1_lds_blocks(3) * 1024) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(11) * 1024) * 4 <= 160 * 1024 &&
               (R1Lds::weights + r1_lds_blocks(15) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit");
 // dense sigma: sigma and S = sigma sigma^T (16 x 16 each) behind the weight blocks
-static_assert((R1Lds::weights + r1_lds_blocks(103) * 1024 + 512) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(111) * 1024 + 512) * 4 <= 160 * 1024 &&
-              (R1Lds::weights + r1_lds_blocks(115) * 1024 + 512) * 4 <= 160 * 1024, "dense sigma: no room for sigma, sigma sigma^T");
+static_assert((R1Lds::weights + r1_lds_blocks(103) * 1024 + 768) * 4 <= 160 * 1024 && (R1Lds::weights + r1_lds_blocks(111) * 1024 + 768) * 4 <= 160 * 1024 &&
+              (R1Lds::weights + r1_lds_blocks(115) * 1024 + 768) * 4 <= 160 * 1024, "dense sigma: no room for sigma, sigma sigma^T");
 
 // Developer instrumentation (-DSOCMX_R1_PROF): per-wave s_memtime deltas between the marks of a step, summed over the launch,
 // written by workgroup 0 to a.prof[wave * 16 + slot] (socmx_rollout_phase_cycles_f32; tools/r1_phases.py).
@@ -404,6 +404,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   float* P_l = lds + LM::pmat;
   float* S_l = lds + LM::weights + r1_lds_blocks(DMX) * 1024;   // dense sigma: sigma, then S = sigma sigma^T (stride 16)
   float* SS_l = S_l + 256;
+  float* ST_l = S_l + 512;                              // ... and sigma^T (the control u = -sigma^T nabla_V reads its rows)
   float srow[DENSE ? DMAX : 1];                           // row i of S: sigma u = -S nabla_V is on the step's serial chain
   float pre_b = 0.f, pre_se = 0.f;                        // drift b(x_k) and (sigma eps_k)_i of the coming step, formed in the slack
   if constexpr (CLS == 0) {
@@ -433,7 +434,10 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       if (is_quad) P_l[H == 2 ? c * MS + r : r * MS + c] = a.P[e];
     }
     if constexpr (DENSE) {
-      for (int e = lane; e < 256; e += 64) S_l[e] = ((e >> 4) < d && (e & 15) < d) ? a.sigma[(e >> 4) * d + (e & 15)] : 0.f;
+      for (int e = lane; e < 256; e += 64) {
+        S_l[e] = ((e >> 4) < d && (e & 15) < d) ? a.sigma[(e >> 4) * d + (e & 15)] : 0.f;
+        ST_l[e] = ((e >> 4) < d && (e & 15) < d) ? a.sigma[(e & 15) * d + (e >> 4)] : 0.f;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-private LDS traffic: no barrier needed)
       for (int e = lane; e < 256; e += 64) {
         float acc = 0.f;
@@ -454,6 +458,23 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     if constexpr (H == 2) { const float t1 = __shfl(hi, j & 15, 16); return (j & 16) ? t1 : t0; }
     return t0;
   };
+  // y_i = sum_j M[i][j] v_j for the component i this lane carries: row i of a 16 x 16 LDS matrix (zero past d) as four 16-byte
+  // reads, v_j by DPP row broadcast inside the multiply-adds (H = 1: v holds component j at position j of every row, zero past
+  // d).  A `for (j < d) .. __shfl(v, j, 16)` loop was d ds_bpermute round trips: at OU_linear d = 10 (dense sigma) the three such
+  // products per step outlasted the slack wave 0 has for them -- 3.5 us per step against 2.0 for the elementwise drift.
+  auto row_dot = [&](const float* M16, float v) -> float {
+    float w[16];
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(M16 + ic * 16);
+#pragma unroll
+    for (int q = 0; q < (DMAX + 3) / 4; ++q) {
+      const f32x4 t = r4[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[4 * q + e] = t[e];
+    }
+    float a0 = 0.f, a1 = 0.f;
+    r1_state_one<DMAX>(a0, a1, v, w);
+    return a0 + a1;
+  };
   // what the coming step's chain needs besides nabla_V, from values known a stage earlier: b(x_k) and sigma eps_k
   auto prepare_step = [&](int k) {
     if (k >= K) return;
@@ -461,18 +482,14 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     if constexpr (H == 2) pre_seh = lds[LM::nzb + (k % (3 * NBS)) * MS + 16 + i];
     if (is_ou) {                                                        // b = A x   (OU_quadratic.py:51-52, OU_linear.py:43-44)
       if constexpr (H == 1) {
-        float bi = 0.f;
-        for (int j = 0; j < d; ++j) bi += A_l[ic * MS + j] * comp(x, xh, j);
-        pre_b = lane_ok ? bi : 0.f;
+        pre_b = lane_ok ? row_dot(A_l, x) : 0.f;
       }                                                                 // (H = 2: wave 2 forms it, ou_products(); read behind the barrier)
     } else {
       pre_b = -2.f * kap * (x * x - 1.f) * 2.f * x;                     // double_well.py:44-48
       if constexpr (H == 2) pre_bh = -2.f * kaph * (xh * xh - 1.f) * 2.f * xh;
     }
     if constexpr (DENSE) {
-      float se = 0.f;
-      for (int j = 0; j < d; ++j) se += S_l[ic * 16 + j] * __shfl(eps, j, 16);
-      pre_se = lane_ok ? se : 0.f;
+      pre_se = lane_ok ? row_dot(S_l, lane_ok ? eps : 0.f) : 0.f;
     } else {
       pre_se = eps;
     }
@@ -599,18 +616,14 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     const float eps = bk_eps;
     float uc = lane_ok ? -bk_gv : 0.f;                                  // u = -sigma^T nabla_V (method.py:58-80)
     if constexpr (DENSE) {
-      float t = 0.f;
-      for (int j = 0; j < d; ++j) t += S_l[j * 16 + ic] * __shfl(bk_gv, j, 16);
-      uc = lane_ok ? -t : 0.f;
+      uc = lane_ok ? -row_dot(ST_l, lane_ok ? bk_gv : 0.f) : 0.f;
     }
     const float xe = x;                                                 // x_{k+1}
     const float uch = (H == 2 && okv[H - 1]) ? -bk_gvh : 0.f;
     float f = 0.f;                                                      // f at the NEW state, OLD time (utils.py:92-96)
     if (is_quad) {
       if constexpr (H == 1) {
-        float px = 0.f;
-        for (int j = 0; j < d; ++j) px += P_l[ic * MS + j] * comp(xe, xh, j);
-        f = row16_sum(lane_ok ? xe * px : 0.f);
+        f = row16_sum(lane_ok ? xe * row_dot(P_l, xe) : 0.f);
       }                                       // (H = 2: x'Px comes from wave 3 behind the barrier -- apply_quad_cost())
     } else if (kind == SOCMX_MOLECULAR_DYNAMICS) {
       f = 1.f;
