@@ -483,7 +483,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     if (is_ou) {                                                        // b = A x   (OU_quadratic.py:51-52, OU_linear.py:43-44)
       if constexpr (H == 1) {
         pre_b = lane_ok ? row_dot(A_l, x) : 0.f;
-      }                                                                 // (H = 2: wave 2 forms it, ou_products(); read behind the barrier)
+      }                                                                 // (H = 2: wave 1 forms it, ou_products(); read behind the barrier)
     } else {
       pre_b = -2.f * kap * (x * x - 1.f) * 2.f * x;                     // double_well.py:44-48
       if constexpr (H == 2) pre_bh = -2.f * kaph * (xh * xh - 1.f) * 2.f * xh;
@@ -576,22 +576,23 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   int bk_k = -1;                       // the step whose bookkeeping is outstanding
   float bk_gv = 0.f, bk_step = 0.f, bk_eps = 0.f, bk_gvh = 0.f, bk_epsh = 0.f;
   float bk_sol = 0.f;                  // H = 2, OU_quadratic: step / lambda of the step whose -f x'Px term is outstanding
-  // H = 2, OU settings: the d x d products of the state leave wave 0.  Waves 2 and 3 read the evaluation's input vector from LDS
+  // H = 2, OU settings: the d x d products of the state leave wave 0.  Waves 1 and 3 read the evaluation's input vector from LDS
   // (xin = [t_k, x_k]) in the slack behind stage 4 -- lane (i = lane & 31, half = lane >> 5) adds the terms j = half, half + 2, ..
-  // of row i from the TRANSPOSED matrix (lanes along i: one LDS pass per term, x_j a broadcast) -- and leave b = A x_k (wave 2) and
+  // of row i from the TRANSPOSED matrix (lanes along i: one LDS pass per term, x_j a broadcast) -- and leave b = A x_k (wave 1) and
   // x_k' P x_k (wave 3) in LDS; wave 0 picks them up behind the barrier.  (On wave 0 they were forty ds_bpermute + eighty
   // multiply-adds per step at d = 20: 6.5 us per step against 3.7 for the elementwise drift.)
   auto ou_products = [&]() {
     if constexpr (H == 2 && is_ou && CLS == 1) {
-      if (wave == 2 || (wave == 3 && is_quad)) {
-        const float* Mt = wave == 2 ? A_l : P_l;
+      // (wave 1 for A x: wave 2 draws the noise batches and wave 3 the scalars in the same slack)
+      if (wave == 1 || (wave == 3 && is_quad)) {
+        const float* Mt = wave == 1 ? A_l : P_l;
         const int ii = lane & 31, hf = lane >> 5;
         // (a rolled loop on purpose: all sixteen terms unrolled -- thirty-two LDS reads in flight beside the other waves' weight
         //  blocks -- measured slower, 4.96 against 4.49 us per step at d = 20)
         float acc = 0.f;
         for (int j = hf; j < d; j += 2) acc = fmaf(Mt[j * MS + ii], lds[LM::xin + 1 + j], acc);
         acc = __fadd_rn(acc, __shfl_xor(acc, 32));
-        if (wave == 2) {
+        if (wave == 1) {
           if (lane < 32) lds[LM::pb + lane] = ii < d ? acc : 0.f;
         } else {
           float t = (lane < 32 && ii < d) ? __fmul_rn(lds[LM::xin + 1 + ii], acc) : 0.f;
