@@ -134,7 +134,10 @@ struct R1Lds {
   static constexpr int p2 = 1216 + 1248;        // (8, 64)   down_2's per-wave partial sums: wave w's contribution of ITS 16 down_1 outputs to all 64 units
   static constexpr int nzb = p2 + 512;          // (24, 16)  the noise of 24 steps: drawn in batches of eight steps, one batch ahead (wave 2)
   static constexpr int scb = nzb + 384;         // (32, 4)   per-step scalars of 32 steps: batches of sixteen (wave 3)
-  static constexpr int weights = p2 + 1024;     // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
+  static constexpr int xk = p2 + 1024;          // (16)  x_k, written by wave 0 when it has integrated: wave 1 forms the d x d products of the
+  static constexpr int pbx = xk + 16;           // (16)  OU / dense-sigma settings from it in its slack -- b = A x_k here,
+  static constexpr int psx = pbx + 16;          // (16)  sigma eps_k here -- and wave 0 picks them up behind the barrier
+  static constexpr int weights = p2 + 1024 + 64;     // LDS-resident blocks: wave 0's, then waves 1..7's, 1024 floats each
   static constexpr int xin = 0, res0 = 0, pb = 0, fq = 0;   // (17 <= d <= 31 only: R1LdsW; named here so that the shared code compiles)
 };
 // 17 <= d <= 31: 32-wide vectors, 32 x 32 matrices, the network input and res_0's output through LDS
@@ -156,6 +159,7 @@ struct R1LdsW {
   static constexpr int nzb = p2 + 512;          // (12, 32)  the noise of 12 steps: batches of four steps
   static constexpr int scb = nzb + 384;         // (32, 4)
   static constexpr int weights = p2 + 1024;
+  static constexpr int xk = 0, pbx = 0, psx = 0;   // (d <= 15 only: named so that the shared code compiles)
 };
 static_assert((R1LdsW::weights + r1_lds_blocks(31) * 1024) * 4 <= 160 * 1024, "LDS-resident weight blocks do not fit (17 <= d <= 31)");
 template <int H> struct R1LdsOf { typedef R1Lds type; };
@@ -388,6 +392,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   const int ic = icv[0];
   const bool lane_ok = okv[0];
   constexpr bool STOPPING = MODE == 1, is_ou = (MODE & 2) != 0;
+  constexpr bool OFF = H == 1 && (is_ou || DENSE);      // d <= 15: b = A x and sigma eps are formed by wave 1 (h1_products)
   static_assert(!(STOPPING && DENSE), "the stopping-time step is built for sigma = I");
   const bool is_quad = is_ou && kind == SOCMX_OU_QUADRATIC;
   const bool traj = a.states != nullptr;
@@ -449,6 +454,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       for (int j = 0; j < DMAX; ++j) srow[j] = SS_l[n * 16 + j];
     }
     if (store) a.states[rowoff] = x;
+    if constexpr (OFF) {
+      if (lane < 16) lds[LM::xk + i] = x;
+    }
     if (H == 2 && store_h) a.states[rowoff + 16] = xh;
     if (store0) a.stop_ind[grow] = 1.f;
   }
@@ -481,7 +489,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     const float eps = lds[LM::nzb + (k % (3 * NBS)) * MS + i];
     if constexpr (H == 2) pre_seh = lds[LM::nzb + (k % (3 * NBS)) * MS + 16 + i];
     if (is_ou) {                                                        // b = A x   (OU_quadratic.py:51-52, OU_linear.py:43-44)
-      if constexpr (H == 1) {
+      if constexpr (H == 1 && !OFF) {
         pre_b = lane_ok ? row_dot(A_l, x) : 0.f;
       }                                                                 // (H = 2: wave 1 forms it, ou_products(); read behind the barrier)
     } else {
@@ -489,7 +497,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       if constexpr (H == 2) pre_bh = -2.f * kaph * (xh * xh - 1.f) * 2.f * xh;
     }
     if constexpr (DENSE) {
-      pre_se = lane_ok ? row_dot(S_l, lane_ok ? eps : 0.f) : 0.f;
+      if constexpr (!OFF) pre_se = lane_ok ? row_dot(S_l, lane_ok ? eps : 0.f) : 0.f;
     } else {
       pre_se = eps;
     }
@@ -599,6 +607,24 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
           t = row16_sum(t);
           t = __fadd_rn(t, __shfl_xor(t, 16));
           if (lane == 0) lds[LM::fq] = t;
+        }
+      }
+    }
+  };
+  // d <= 15, OU drift and / or dense sigma: wave 1 forms b = A x_k and sigma eps_k in its slack behind stage 4 (x_k from LDS, where
+  // wave 0 left it when it integrated; eps_k from the noise ring) -- on wave 0 the two products stood between its books and the
+  // barrier everybody waits at (1.5k cycles of "slack" work against 0.5k on the other waves)
+  auto h1_products = [&]() {
+    if constexpr (OFF && CLS == 1) {
+      if (wave == 1 && cur_k < K) {
+        if constexpr (is_ou) {
+          const float pbv = row_dot(A_l, lds[LM::xk + i]);
+          if (lane < 16) lds[LM::pbx + i] = lane_ok ? pbv : 0.f;
+        }
+        if constexpr (DENSE) {
+          const float e = lds[LM::nzb + (cur_k % (3 * NBS)) * MS + i];
+          const float psv = row_dot(S_l, lane_ok ? e : 0.f);
+          if (lane < 16) lds[LM::psx + i] = lane_ok ? psv : 0.f;
         }
       }
     }
@@ -800,6 +826,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     } else {
       batches(cur_k);
       ou_products();
+      h1_products();
     }
     __builtin_amdgcn_s_setprio(2);
     R1_TICK(8)
@@ -853,6 +880,10 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
         apply_quad_cost();
       }
       const float res0v = H == 2 ? lds[LM::res0 + n] : res0;
+      if constexpr (OFF) {
+        if constexpr (is_ou) pre_b = lds[LM::pbx + i];
+        if constexpr (DENSE) pre_se = lds[LM::psx + i];
+      }
       __builtin_amdgcn_sched_barrier(0);
       const float dt = scal[0], sq_ldt = scal[1];
       const float gv = relu_keep_nan((((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + b8) + res0v;
@@ -884,6 +915,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
         stop_new = (-__shfl(xe, 0, 16) > 0.f) ? 1.f : 0.f;
       }
       x = lane_ok ? xe : 0.f;
+      if constexpr (OFF) {
+        if (lane < 16) lds[LM::xk + i] = x;
+      }
       if constexpr (H == 2) { xh = okv[1] ? xeh : 0.f; bk_gvh = gvh; bk_epsh = epsh; }
       if (STOPPING) stop = stop_new;
       bk_k = k; bk_gv = gv; bk_step = step; bk_eps = eps;               // costs + stores: see bookkeeping()

@@ -10,7 +10,10 @@ from socmx.config import load_config
 from socmx.settings import define_variables
 from socmx import rollout
 dev = torch.device("cuda:0")
+# python tools/r1_phases.py [B [setting d K]]     e.g. 128 OU_quadratic_easy 20 50
 setting, d, K, B, gamma = ("double_well", 10, 200, int(sys.argv[1]) if len(sys.argv) > 1 else 128, 6.0)
+if len(sys.argv) > 4:
+    setting, d, K = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 cfg = load_config([f"method.setting={setting}", f"method.d={d}", f"method.num_steps={K}", f"method.gamma={gamma}",
                    "method.scaling_factor_M=0.1", "optim.M_lr=1e-3", f"optim.batch_size={B}"])
 cfg.method.device = "cuda:0"
