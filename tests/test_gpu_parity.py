@@ -228,6 +228,25 @@ def test_weights_stats_kernel():
         np.testing.assert_allclose(std.item(), wref.std().item(), rtol=1e-4)
 
 
+def test_weights_stats_kernel_forms_the_iteration_scalars():
+    """socmx_weights_stats_scalars_f32: the same weights and statistics, plus gamma's copy, 1 / normaliser (main.py:313-320: bit-equal
+    to torch.reciprocal) and the cleared accumulator -- each optional."""
+    from socmx import loss as L
+    g = torch.Generator().manual_seed(3)
+    lpd, lps, ltw = [(0.3 * torch.randn(128, generator=g) - 1).to(DEV) for _ in range(3)]
+    w0, st0 = L.weights_and_stats(lpd, lps, ltw)
+    gamma = torch.tensor([1.7], device=DEV)
+    norm = torch.tensor([0.0371], device=DEV)
+    gam, gout, obj = [torch.full((1,), 9.0, device=DEV) for _ in range(3)]
+    w1, st1 = L.weights_and_stats(lpd, lps, ltw, scalars=(gamma, gam, norm, gout, obj))
+    assert torch.equal(w0, w1) and torch.equal(st0, st1)
+    assert gam.item() == gamma.item() and obj.item() == 0.0
+    assert torch.equal(gout, torch.reciprocal(norm))
+    gam2 = torch.full((1,), 9.0, device=DEV)
+    L.weights_and_stats(lpd, lps, ltw, scalars=(gamma, gam2, None, None, None))
+    assert gam2.item() == gamma.item()
+
+
 @pytest.mark.parametrize("name", LOSS)
 def test_target_kernels_vs_oracle(name):
     """prep + target_fwd + target_bwd against the oracle's dense einsum form, same inputs."""
