@@ -1548,7 +1548,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
     return rollout1_launch(a, stopping, stream);
   // ... and 17 <= d <= 31 with sigma = I at the default widths (soc.yaml's default d = 20): the same kernel with two components
   // per lane and down_0 / res_0 as a stage of their own on all eight waves
-  if (is_wide32 && !force_slow && a.sigma_identity && d >= 16 && d <= 31 && r1_prof_ok && !prof && rollout1_wide_available() &&
+  if (is_wide32 && !force_slow && a.sigma_identity && d >= 16 && d <= 31 && r1_prof_ok && rollout1_wide_available() &&
       (force_rows == 0 || force_rows == 1) && (B <= 256 || (force_rows == 1 && B <= 1024)))
     return rollout1_wide_launch(a, stopping, stream);
   // (... unless the launch is stand-alone -- no SOCMX_ROLLOUT_SHARES_CHIP: nothing beside it to starve -- then the shorter

@@ -150,12 +150,12 @@ struct R1LdsW {
   static constexpr int xin = 896;     // (32)   the network input [t, x, 0..] of the coming evaluation (wave 0 writes it)
   static constexpr int res0 = 928;    // (32)   res_0 [t, x] + b of the evaluation under way
   static constexpr int sc = 960;      // (3, 4)
-  static constexpr int pb = 976;      // (32)   b = A x of the evaluation's state (OU settings: formed by wave 2 in the slack)
+  static constexpr int pb = 976;      // (32)   b = A x of the evaluation's state (OU settings: formed by wave 1 in the slack)
   static constexpr int fq = 1008;     // (1)    x' P x of the same state (OU_quadratic: wave 3)
-  static constexpr int amat = 1024;   // (32, 32), TRANSPOSED: amat[j * 32 + i] = A[i][j] (lanes along i: conflict-free)
-  static constexpr int pmat = 2048;
-  static constexpr int bias = 3072;
-  static constexpr int p2 = 3072 + 1344;
+  static constexpr int amat = 1024;   // (32, 36): row-major, rows padded to 36 floats (16-byte reads of eight row entries by the
+  static constexpr int pmat = 2176;   //           16 lanes of a DPP row land on distinct banks)
+  static constexpr int bias = 3328;
+  static constexpr int p2 = 3328 + 1344;
   static constexpr int nzb = p2 + 512;          // (12, 32)  the noise of 12 steps: batches of four steps
   static constexpr int scb = nzb + 384;         // (32, 4)
   static constexpr int weights = p2 + 1024;
@@ -198,7 +198,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   constexpr int H = NET::outp >> 4;
   static_assert(H == 1 || (H == 2 && DMAX0 == 31 && !DENSE), "17 <= d <= 31: sigma = I, one instantiation");
   typedef typename R1LdsOf<H>::type LM;
-  constexpr int MS = 16 * H;                        // row stride of A, P in LDS
+  constexpr int MS = 16 * H;                        // row stride of the noise ring (and of A, P at d <= 15)
+  constexpr int MSA = H == 2 ? 36 : 16;             // row stride of A, P in LDS
   constexpr int NBS = 8 / H;                        // steps per noise batch (noise_batch below); its ring holds three batches: slot = step % (3 NBS)
   constexpr int NRES = r1_count(CLS, DMX, 'R'), NLDS = r1_count(CLS, DMX, 'L'), NSTR = r1_count(CLS, DMX, 'S');
   const float* __restrict__ Wp = a.packed;
@@ -435,8 +436,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     b3 = Wp[u.L[3].b_off + n];
     for (int e = lane; e < d * d; e += 64) {
       const int r = e / d, c = e - r * d;
-      if (is_ou) A_l[H == 2 ? c * MS + r : r * MS + c] = a.A[e];
-      if (is_quad) P_l[H == 2 ? c * MS + r : r * MS + c] = a.P[e];
+      if (is_ou) A_l[r * MSA + c] = a.A[e];
+      if (is_quad) P_l[r * MSA + c] = a.P[e];
     }
     if constexpr (DENSE) {
       for (int e = lane; e < 256; e += 64) {
@@ -585,27 +586,42 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   float bk_gv = 0.f, bk_step = 0.f, bk_eps = 0.f, bk_gvh = 0.f, bk_epsh = 0.f;
   float bk_sol = 0.f;                  // H = 2, OU_quadratic: step / lambda of the step whose -f x'Px term is outstanding
   // H = 2, OU settings: the d x d products of the state leave wave 0.  Waves 1 and 3 read the evaluation's input vector from LDS
-  // (xin = [t_k, x_k]) in the slack behind stage 4 -- lane (i = lane & 31, half = lane >> 5) adds the terms j = half, half + 2, ..
-  // of row i from the TRANSPOSED matrix (lanes along i: one LDS pass per term, x_j a broadcast) -- and leave b = A x_k (wave 1) and
+  // (xin = [t_k, x_k]) in the slack behind stage 4, form y = M x_k as DPP multiply-adds (below) and leave b = A x_k (wave 1) and
   // x_k' P x_k (wave 3) in LDS; wave 0 picks them up behind the barrier.  (On wave 0 they were forty ds_bpermute + eighty
   // multiply-adds per step at d = 20: 6.5 us per step against 3.7 for the elementwise drift.)
   auto ou_products = [&]() {
     if constexpr (H == 2 && is_ou && CLS == 1) {
       // (wave 1 for A x: wave 2 draws the noise batches and wave 3 the scalars in the same slack)
       if (wave == 1 || (wave == 3 && is_quad)) {
-        const float* Mt = wave == 1 ? A_l : P_l;
-        const int ii = lane & 31, hf = lane >> 5;
-        // (a rolled loop on purpose: all sixteen terms unrolled -- thirty-two LDS reads in flight beside the other waves' weight
-        //  blocks -- measured slower, 4.96 against 4.49 us per step at d = 20)
-        float acc = 0.f;
-        for (int j = hf; j < d; j += 2) acc = fmaf(Mt[j * MS + ii], lds[LM::xin + 1 + j], acc);
-        acc = __fadd_rn(acc, __shfl_xor(acc, 32));
+        // y = M x for the 32-wide vector as DPP multiply-adds: row g of the wave takes the eight terms j = 8 g .. 8 g + 7 of both
+        // outputs of its lane (i = n and 16 + n) -- operand register: rows 0, 1 hold x_0 .. x_15 (row 1 rotated by eight), rows 2, 3
+        // x_16 .. x_31 likewise, so that position e of row g is x_{8 g + e}; the eight matrix entries M[i][8 g ..] are two 16-byte
+        // LDS reads -- and the four rows' partial sums meet in r1_rows_sum.  (The first form -- one LDS pass per term in a rolled
+        // loop, lanes along i -- took ~2,000 cycles of these waves' ~800-cycle slack: everybody waited for them, 7.0k cycles per
+        // step at d = 20 against 6.0k for the elementwise drift.)
+        const float* M = wave == 1 ? A_l : P_l;
+        const float xlo = lds[LM::xin + 1 + n], xhi = n < 15 ? lds[LM::xin + 17 + n] : 0.f;
+        const float xs = r1_ror8_odd_rows(g < 2 ? xlo : xhi);
+        float wl[8], wh[8];
+        {
+          const f32x4* rl = reinterpret_cast<const f32x4*>(M + n * MSA + 8 * g);
+          const f32x4* rh = reinterpret_cast<const f32x4*>(M + (16 + n) * MSA + 8 * g);
+          const f32x4 l0 = rl[0], l1 = rl[1], h0 = rh[0], h1 = rh[1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { wl[e] = l0[e]; wl[4 + e] = l1[e]; wh[e] = h0[e]; wh[4 + e] = h1[e]; }
+        }
+        float al0 = 0.f, al1 = 0.f, ah0 = 0.f, ah1 = 0.f;
+        r1_fmac8<0>(al0, al1, xs, wl);
+        r1_fmac8<0>(ah0, ah1, xs, wh);
+        const float ylo = r1_rows_sum(al0 + al1), yhi = r1_rows_sum(ah0 + ah1);
         if (wave == 1) {
-          if (lane < 32) lds[LM::pb + lane] = ii < d ? acc : 0.f;
+          if (lane < 16) {
+            lds[LM::pb + n] = n < d ? ylo : 0.f;
+            lds[LM::pb + 16 + n] = 16 + n < d ? yhi : 0.f;
+          }
         } else {
-          float t = (lane < 32 && ii < d) ? __fmul_rn(lds[LM::xin + 1 + ii], acc) : 0.f;
+          float t = lane < 16 ? fmaf(xhi, yhi, __fmul_rn(xlo, ylo)) : 0.f;    // (x is zero past d)
           t = row16_sum(t);
-          t = __fadd_rn(t, __shfl_xor(t, 16));
           if (lane == 0) lds[LM::fq] = t;
         }
       }

@@ -147,6 +147,13 @@ __device__ __forceinline__ float r1_ror8_upper(float v) {
   return r;
 }
 
+// rows 1, 3 <- the row rotated by eight positions; rows 0, 2 unchanged
+__device__ __forceinline__ float r1_ror8_odd_rows(float v) {
+  float r = v;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xa bank_mask:0xf" : "+v"(r) : "v"(v));
+  return r;
+}
+
 // One streamed fragment as a raw buffer load: descriptor of the packed image (four SGPRs, once per wave) + the lane's 32-bit
 // byte offset + the block's byte offset in an SGPR + the fragment as an immediate -- no 64-bit VGPR address per request.
 // Compiler-visible loads on purpose: with asm requests and written-out vmcnt the compiler does not know that a register
