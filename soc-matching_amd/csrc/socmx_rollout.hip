@@ -1341,7 +1341,7 @@ extern "C" int socmx_capabilities(char* buf, int cap) {
 #define SOCMX_STR2(x) #x
 #define SOCMX_STR(x) SOCMX_STR2(x)
   static const char msg[] =
-      "socmx 0.1.5; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network "
+      "socmx 0.1.8; target gfx950 (MI355X, CDNA4); wave64; fp32 v_mfma_f32_16x16x4_f32 control network with the skip res_1 folded through up_0 "
       "(v_mfma_f32_4x4x1_16b_f32 on 4-row tiles for small batches; one row per workgroup on v_fmac_f32_dpp for B <= 256 at d <= 15 and, with sigma = I, 17 <= d <= 31; two 16-row tiles per workgroup for bursts beyond 4096 rows at d <= 31); "
       "Philox4x32-10 noise; static_hdims=" SOCMX_STR(SOCMX_H0P) "," SOCMX_STR(SOCMX_H1P) "," SOCMX_STR(SOCMX_H2P) "; "
       "kernels: rollout, unet_forward, unet_pack, weights_stats, mpairs, socm_target; "

@@ -70,3 +70,11 @@ ls -la $R
 (hipcc -O3 --offload-arch=gfx950 -Wno-unused-result -o /tmp/pku tools/ubench/pk_unit.hip 2>/dev/null && timeout 60 /tmp/pku) > $R/pk_unit.txt 2>&1
 # the sharded default (several ranks: the autograd-free body eagerly, no RCCL call inside a graph) timed at world size 1
 python3 bench.py --gpus 1 --spawn --no-dist-graph --steps 20 --warmup 5 --no-cpu-baseline --no-burst > $R/bench_sharded_world1_eager.json 2> $R/bench_sharded_world1_eager.err
+# the one-row kernel's phase tables (needs the instrumented library: make -C soc-matching_amd/csrc PROF=1) at configs[2], soc.yaml's default
+# d = 20 and the README's Linear OU (dense sigma), and the run-to-run determinism check
+if [ -f soc-matching_amd/socmx/libsocmx_prof.so ]; then
+  SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so python3 tools/r1_phases.py 128 > $R/r1_phases.txt 2>&1
+  SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so python3 tools/r1_phases.py 128 OU_quadratic_easy 20 50 > $R/r1_phases_d20.txt 2>&1
+  SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so python3 tools/r1_phases.py 64 OU_linear 10 100 > $R/r1_phases_oul10.txt 2>&1
+fi
+python3 tools/determinism_check.py cfg3_double_well_d10_K200 > $R/determinism_check.txt 2>&1
