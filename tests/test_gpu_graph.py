@@ -69,6 +69,24 @@ def test_graph_replay_equals_the_eager_iteration(name, B):
         assert np.linalg.norm(par_g[k] - par_e[k]) <= nw * max(np.linalg.norm(par_e[k]), 1e-12) + 1e-9, k
 
 
+@pytest.mark.parametrize("name,B", [("cfg3_double_well_d10_K200", 64), ("oul10_ou_linear_d10_K100_B64", 64),
+                                    ("ouq20_ou_quadratic_easy_d20_K12", 40)])
+def test_training_is_bit_reproducible_run_to_run(name, B):
+    """Two runs of the replayed iteration from the same device key, with other work on the chip in between (dirty LDS, caches):
+    weight statistics, gradient telemetry and the final parameters are BIT-identical -- no float atomics anywhere on the path
+    that feeds the update (rollout, loss gradients, backward, Adam: fixed summation orders).  Only the reported loss value may
+    move in its last bits (one float atomicAdd per workgroup of the contraction; it feeds nothing back)."""
+    rec_a, par_a, _, _ = _run(name, True, 5, B)
+    junk = torch.randn(2048, 2048, device=DEV)
+    (junk @ junk).sum().item()
+    _run("tiny_double_well_d10", True, 3, 16)
+    rec_b, par_b, _, _ = _run(name, True, 5, B)
+    assert np.array_equal(rec_a[:, 1:], rec_b[:, 1:])
+    np.testing.assert_allclose(rec_a[:, 0], rec_b[:, 0], rtol=2e-6)
+    for k in par_a:
+        assert np.array_equal(par_a[k], par_b[k]), k
+
+
 @pytest.mark.parametrize("alg", ["SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy", "log-variance", "variance",
                                  "moment", "rel_entropy"])
 def test_graph_replay_of_the_other_losses_equals_the_eager_iteration(alg):
