@@ -774,6 +774,14 @@ class Trainer:
                 #  captures -- under the default "global" error mode that invalidates the capture now and then; the
                 #  collectives themselves are enqueued by this thread)
                 mode = "thread_local" if solver.shard is not None else "global"
+                if solver.shard is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+                    # Let the process group's watchdog thread reap every finished collective BEFORE a stream starts capturing: it
+                    # polls the end events of the works it still lists (every ~100 ms), and an event whose stream -- one of
+                    # torch's pooled streams, the same pool the capture stream comes from -- is capturing at that moment answers
+                    # hipErrorCapturedEvent, which the watchdog turns into std::terminate (seen in ~1 of 5 full GPU test runs).
+                    # Nothing is in flight after the synchronisation, nothing is listed after a few polling periods.
+                    torch.cuda.synchronize(dev)
+                    time.sleep(0.35)
                 err = None
                 try:
                     with torch.cuda.graph(g, capture_error_mode=mode):
