@@ -131,11 +131,11 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
 
     if it_ms_body is not None and it_ms_body < out["socm_ms_per_iter"]:
         out.update(socm_ms_per_iter=it_ms_body, socm_iters_per_sec=1e3 / it_ms_body, last_loss=float(info_b["loss"]),
-                   iteration_mode="autograd-free body, eager (no RCCL call inside a graph)")
+                   iteration_mode="autograd-free body, eager (nothing captured)")
 
     def graph_leg():
         """The same iterations replayed as ONE captured hipGraph (sharded: with the RCCL all-reduces captured inside)."""
-        it_ms_graph, info_g = time_iterations("sharded" if world > 1 else True)
+        it_ms_graph, info_g = time_iterations(True)
         out["socm_ms_per_iter_graph"] = it_ms_graph
         if it_ms_graph < out["socm_ms_per_iter"]:
             out.update(socm_ms_per_iter=it_ms_graph, socm_iters_per_sec=1e3 / it_ms_graph, iteration_mode="hipGraph replay",
@@ -303,14 +303,13 @@ def make_parser():
                     "torch.distributed.run; implies --force-dist in the child)")
     ap.add_argument("--defer-graph", action="store_true", help="take the multi-GPU ordering of the hipGraph legs (last, under the "
                     "watchdog) at any world size: how that path is exercised on one GPU")
-    ap.add_argument("--dist-graph", action="store_true", help="world size > 1: also run the hipGraph legs with the RCCL all-reduces "
-                    "captured inside (backend.hip_graph=sharded: experimental, see --no-dist-graph); off by default")
+    ap.add_argument("--dist-graph", action="store_true", help="(accepted for compatibility: the hipGraph legs of a sharded run are "
+                    "on by default since the shard owns its RCCL communicators)")
     ap.add_argument("--no-dist-graph", action="store_true", help="world size > 1: skip the hipGraph legs (the iteration "
-                    "replayed with its RCCL all-reduces captured inside).  They run LAST, after every eager number is in the "
-                    "line, under a watchdog that prints the line and exits if they do not finish -- EXPERIMENTAL: no "
-                    "multi-GPU node was available to this builder, and at world size 1 a captured RCCL call took torch's "
-                    "process-group watchdog thread (and the process) down in one of three full test runs, so one rank no longer "
-                    "captures any (socmx/dist.py)")
+                    "replayed with the ncclAllReduce launches of the shard's own communicators captured inside: main.py's default "
+                    "over several ranks).  They run LAST, after every eager number is in the line, under a watchdog that prints the "
+                    "line and exits if they do not finish: no multi-GPU node was available to this builder, the captured "
+                    "collectives have run at world size 1 only")
     return ap
 
 
@@ -439,10 +438,10 @@ def main():
         return float(t.item()), float(info["loss"])
 
     # Three schedules of the same arithmetic: (1) the eager autograd iteration (two HIP streams; sharded: ONE flat all-reduce per
-    # iteration); (2) sharded runs: the autograd-free body run eagerly -- what main.py does by default over several ranks (its
-    # collectives are ordinary RCCL calls: the flat gradient buffer on the main stream, the pair-grid network's small one on the
-    # second stream); (3) the whole iteration replayed as ONE captured hipGraph (main.py's default on one GPU; sharded:
-    # backend.hip_graph=sharded, with the all-reduces inside, the ranks agreeing on the capture first)
+    # iteration); (2) sharded runs: the autograd-free body run eagerly (its collectives: the flat gradient buffer on the main
+    # stream, the pair-grid network's small one on the second stream); (3) the whole iteration replayed as ONE captured hipGraph
+    # -- main.py's default on one GPU and, with the all-reduces of the shard's own RCCL communicators inside and the ranks
+    # agreeing on the capture first, over several
     it_elapsed_eager, last_loss = time_iterations(False)
     it_elapsed = it_elapsed_eager
     it_mode = "eager (two HIP streams)" if not use_dist else "eager (one flat all-reduce per iteration)"
@@ -451,8 +450,8 @@ def main():
         it_elapsed_body, last_loss_b = time_iterations("nocapture")
         if it_elapsed_body < it_elapsed:
             it_elapsed, last_loss = it_elapsed_body, last_loss_b
-            it_mode = "autograd-free body, eager (main.py's default over several ranks: no RCCL call inside a graph)"
-    graph_mode = "sharded" if world > 1 else True
+            it_mode = "autograd-free body, eager (what a sharded run falls back to when nothing may be captured)"
+    graph_mode = True
     it_elapsed_graph = None
     defer_graph = world > 1 or args.defer_graph  # multi-GPU: every hipGraph leg runs at the end, under the watchdog
     graph_legs = []
@@ -584,10 +583,11 @@ def main():
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
     else:
         line = None
-    # (world > 1: the captured-RCCL legs are opt-in -- `--dist-graph` -- since a captured RCCL call can make torch's process-group
-    #  watchdog thread abort the process, and an aborted rank prints no line; what such a run ships by default, the eager body, is
-    #  already in the line)
-    if defer_graph and not args.no_dist_graph and (world == 1 or args.dist_graph):
+    # (world > 1: the hipGraph legs replay the iteration with the all-reduces of the shard's OWN RCCL communicators captured inside
+    #  -- socmx/rccl.py: launches on the iteration's streams, nothing of torch's process group under capture -- which is what
+    #  main.py does by default over several ranks; over torch's process group (SOCMX_RCCL=0) a multi-rank run never captures and
+    #  these legs would only repeat the eager body)
+    if defer_graph and not args.no_dist_graph and (world == 1 or solver.shard is None or solver.shard.capturable):
         # Multi-GPU hipGraph legs (the iteration replayed with its RCCL all-reduces captured inside), LAST and under a watchdog:
         # every eager number is already in the line; if a capture or a replay does not come back, every rank prints /
         # exits on its own timer and the run still delivers its line.
@@ -615,9 +615,8 @@ def main():
                 line["socm_ms_per_iter_graph"] = 1e3 * g_elapsed / it_steps
                 if g_elapsed < it_elapsed:
                     line.update(socm_iters_per_sec=it_steps / g_elapsed, socm_ms_per_iter=1e3 * g_elapsed / it_steps,
-                                socm_iteration_mode=("hipGraph replay (RCCL all-reduces captured)" if world > 1 else
-                                                     "hipGraph replay (one rank: the sums are identities under capture, no RCCL "
-                                                     "call in the graph -- socmx/dist.py)"), socm_last_loss=g_loss)
+                                socm_iteration_mode="hipGraph replay (ncclAllReduce launches of the shard's own communicators "
+                                                    "captured inside)" if use_dist else "hipGraph replay", socm_last_loss=g_loss)
                 line["dist_graph"] = "ok"
         except Exception as e:  # noqa: BLE001
             if line is not None:

@@ -31,8 +31,10 @@ from socmx.train import Trainer, compute_EMA, make_optimizer
 
 def _graph_mode(v):
     """backend.hip_graph as Trainer takes it: True / False, or the strings "force" (also capture the losses measured faster on the
-    eager iteration: SOCM_const_M, SOCM_exp, SOCM_adjoint) and "sharded" (a multi-rank run captures its RCCL all-reduces too)."""
-    return v if isinstance(v, str) and v in ("force", "sharded") else bool(v)
+    eager iteration: SOCM_const_M, SOCM_exp, SOCM_adjoint).  ("sharded", rounds 4-5's opt-in for capturing a multi-rank iteration,
+    is accepted and means True: a sharded run captures by default now -- its all-reduces are launches of the shard's own RCCL
+    communicators, socmx/rccl.py.)"""
+    return v if isinstance(v, str) and v in ("force", "nocapture") else bool(v)
 
 def run(cfg):
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -80,7 +80,9 @@ class SOC_Solver(nn.Module):
             return None
         streams = self.__dict__.setdefault("_side_streams", {})
         if (device, which) not in streams:
-            streams[(device, which)] = torch.cuda.Stream(device)
+            # (a stream of this package's own, never one of torch's pooled ones: it joins hipGraph captures -- socmx/streams.py)
+            from .streams import private_stream
+            streams[(device, which)] = private_stream(device, f"solver{which}")
         return streams[(device, which)]
 
     def control_objective(self, batch_size, total_n_samples=65536, noise_in=None):

@@ -81,19 +81,21 @@ class Trainer:
             # (never silent: `backend.hip_graph` is on by default, so a run that cannot use it says why)
             self._log("backend.hip_graph: running the eager two-stream iteration instead -- " +
                       (f"measured faster for algorithm {algorithm!r}" if solver.x0.is_cuda else "the solver is not on a GPU"))
-        # A sharded run (world size > 1) does NOT capture by default: a captured graph holds the iteration's RCCL all-reduces,
-        # a wedged capture or replay hangs the job, and a rank that alone falls back to another body would issue a different
-        # sequence of collectives.  Such a run takes the same autograd-free body EAGERLY (one flat all-reduce on the main
-        # stream, the pair-grid network's small one beside the next rollout; no gradient copies); `hip_graph="sharded"` (or
-        # "force") opts in to capturing it, and then the ranks agree on the capture's success before any of them replays.
+        # A sharded run (world size > 1) captures its iteration WITH the collectives inside when the shard's transport is the
+        # package's own RCCL communicators (socmx/dist.py "rccl": a collective is one launch on the caller's stream) -- the ranks
+        # agree on the capture's success before any of them replays (Shard.agree), so that none falls back alone and waits in a
+        # different sequence of collectives.  Over torch's process group (SOCMX_RCCL=0, a communicator that did not come up) or
+        # the host-staged test transport nothing is captured: the same autograd-free body runs EAGERLY (one flat all-reduce on
+        # the main stream, the pair-grid network's small one beside the next rollout; no gradient copies).
         shard = getattr(solver, "shard", None)
         self._multi_rank = shard is not None and shard.world_size > 1
+        capturable = not self._multi_rank or bool(getattr(shard, "capturable", False))
         # (hip_graph="nocapture": that eager form of the body at any world size -- bench.py times it beside the replayed graph)
-        self.capture_graphs = (self.hip_graph and hip_graph != "nocapture"
-                               and (not self._multi_rank or hip_graph in ("sharded", "force")))
+        self.capture_graphs = self.hip_graph and hip_graph != "nocapture" and capturable
         if self.hip_graph and not self.capture_graphs and hip_graph != "nocapture":
-            self._log("backend.hip_graph: sharded run -- the autograd-free iteration runs eagerly (no RCCL call inside a captured "
-                      "graph); backend.hip_graph=sharded opts in")
+            self._log("backend.hip_graph: sharded run over transport " + repr(getattr(shard, "transport", "?")) + " -- the "
+                      "autograd-free iteration runs eagerly (collectives of torch's process group are never captured); the "
+                      "package's own RCCL communicators (backend nccl, SOCMX_RCCL unset) capture it")
         self.graph_warmup = int(graph_warmup)
         self.fused_adam = bool(fused_adam)    # hipGraph body: control-network Adam + telemetry as one launch (socmx_adam_step_f32)
         self._graphs = {}
@@ -349,7 +351,7 @@ class Trainer:
             nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
                                    D["g_net"], D["g_dnet"], out=flat)
             if shard is not None:
-                shard.allreduce_flat_(flat)
+                shard.allreduce_flat_(flat, slot="side")
             b1, b2 = grp["betas"]
             dev = flat.device
             with _lib.on_device(dev):
@@ -372,7 +374,7 @@ class Trainer:
             grads = nets.pair_net_backward(sde.M.dim, sde.M.hdims, [p.shape for p in params], D["packed"], t_vec, s_vec,
                                            D["g_net"], D["g_dnet"], out=D["m_flat"])
             D["m_flat"][n:].copy_(D["g_gamma"])
-            shard.allreduce_flat_(D["m_flat"])
+            shard.allreduce_flat_(D["m_flat"], slot="side")
             g_gamma = D["m_flat"][n:].reshape(sde.gamma.shape).clone()
         for p, g in zip(params, grads):
             p.grad = g
@@ -736,6 +738,7 @@ class Trainer:
             self._make_capturable()
 
     def _graph_step(self, loss_kwargs):
+        from .streams import private_stream
         solver = self.solver
         dev = solver.x0.device
         if self.sync_timing:
@@ -762,7 +765,7 @@ class Trainer:
                 vals = body()           # (sharded default: the same body, never captured -- on the current stream)
             elif n < (max(2, self.graph_warmup) if manual else self.graph_warmup) or (manual and not self._m_pending):
                 self._graphs[("warm",) + key] = n + 1
-                side = torch.cuda.Stream(dev)
+                side = private_stream(dev, "capture")        # (the stream the capture will run on: socmx/streams.py)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     vals = body()
@@ -770,21 +773,16 @@ class Trainer:
                 vals.record_stream(torch.cuda.current_stream(dev))
             else:
                 g = torch.cuda.CUDAGraph()
-                # (sharded: the process group's watchdog thread polls its events with hipEventQuery while this thread
-                #  captures -- under the default "global" error mode that invalidates the capture now and then; the
-                #  collectives themselves are enqueued by this thread)
+                # Every stream that joins this capture -- the capture stream itself, the solver's second stream -- is a stream of
+                # this package's own (socmx/streams.py), and a sharded body's collectives are launches of the shard's own RCCL
+                # communicators on those streams (socmx/rccl.py): torch's process group, its pooled streams and its watchdog thread
+                # -- which polls the events of earlier eager calls with hipEventQuery while this thread captures -- never meet the
+                # capture.  (Rounds 4-5 captured ProcessGroupNCCL calls, drew the capture stream from torch's pool and slept 0.35 s
+                # in front of the capture to let the watchdog drain; all three are gone.)
                 mode = "thread_local" if solver.shard is not None else "global"
-                if solver.shard is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
-                    # Let the process group's watchdog thread reap every finished collective BEFORE a stream starts capturing: it
-                    # polls the end events of the works it still lists (every ~100 ms), and an event whose stream -- one of
-                    # torch's pooled streams, the same pool the capture stream comes from -- is capturing at that moment answers
-                    # hipErrorCapturedEvent, which the watchdog turns into std::terminate (seen in ~1 of 5 full GPU test runs).
-                    # Nothing is in flight after the synchronisation, nothing is listed after a few polling periods.
-                    torch.cuda.synchronize(dev)
-                    time.sleep(0.35)
                 err = None
                 try:
-                    with torch.cuda.graph(g, capture_error_mode=mode):
+                    with torch.cuda.graph(g, stream=private_stream(dev, "capture"), capture_error_mode=mode):
                         static_vals = body()
                 except Exception as e:                       # noqa: BLE001 -- whatever the capture choked on, training goes on
                     err = e

@@ -200,27 +200,41 @@ def test_ranks_agree_on_a_capture_before_anyone_replays():
     assert ret[0] == (True, False, False) and ret[1] == (True, False, False)
 
 
-def test_a_sharded_run_does_not_capture_collectives_unless_asked():
-    """The rule of Trainer.__init__ (no GPU needed: the flags are decided before anything is captured): over several ranks
-    backend.hip_graph=True keeps the iteration eager; "sharded" / "force" opt in; one rank captures as before."""
+def test_a_sharded_run_captures_only_over_its_own_communicators():
+    """The rule of Trainer.__init__ (no GPU needed: the flags are decided before anything is captured): several ranks capture
+    their iteration iff the shard's transport is the package's own RCCL communicators (`Shard.capturable`); over torch's process
+    group or the host-staged transport the autograd-free body runs eagerly whatever the config key says -- and says so."""
     from types import SimpleNamespace
     from socmx.train import Trainer
 
     class FakeShard:
-        def __init__(self, w): self.world_size = w
+        def __init__(self, w, transport):
+            self.world_size, self.transport = w, transport
+            self.capturable = w == 1 or transport == "rccl"
 
-    def flags(hip_graph, world, cuda=True):
+    def flags(hip_graph, world, cuda=True, transport="rccl"):
         logs = []
-        solver = SimpleNamespace(x0=SimpleNamespace(is_cuda=cuda), shard=FakeShard(world) if world else None,
+        solver = SimpleNamespace(x0=SimpleNamespace(is_cuda=cuda), shard=FakeShard(world, transport) if world else None,
                                  neural_sde=SimpleNamespace(use_stopping_time=False))
         tr = Trainer(solver, None, 8, hip_graph=hip_graph, log=logs.append)
         return tr.hip_graph, tr.capture_graphs, logs
 
     assert flags(True, 0)[:2] == (True, True)
-    assert flags(True, 1)[:2] == (True, True)                       # RCCL initialised at world size 1: nobody to disagree with
-    hg, cap, logs = flags(True, 8)
-    assert (hg, cap) == (True, False) and any("sharded run" in m for m in logs)   # said, never silent
-    assert flags("sharded", 8)[:2] == (True, True)
-    assert flags("force", 8)[:2] == (True, True)
+    assert flags(True, 1, transport="group")[:2] == (True, True)    # one rank: nobody to disagree with
+    assert flags(True, 8)[:2] == (True, True)                       # own communicators: the default captures
+    for mode in (True, "sharded", "force"):
+        for transport in ("group", "staged"):
+            hg, cap, logs = flags(mode, 8, transport=transport)
+            assert (hg, cap) == (True, False) and any("sharded run" in m and transport in m for m in logs)   # said, never silent
     assert flags("nocapture", 0)[:2] == (True, False)
+    assert flags("nocapture", 8)[:2] == (True, False)
     assert flags(True, 8, cuda=False)[:2] == (False, False)
+
+
+def test_shard_transport_follows_the_process_group():
+    """socmx/dist.py: an un-initialised process (rank / world given by hand) and a gloo group on CPU tensors use the group's own
+    calls; only backend nccl brings up the package's communicators (GPU tests), only gloo + a CUDA device stages through the host."""
+    from socmx.dist import Shard
+    sh = Shard(rank=1, world_size=4)
+    assert sh.transport == "group" and not sh.capturable and sh.local_rows(10) == (3, 3)
+    assert Shard(rank=0, world_size=1).capturable

@@ -1399,6 +1399,8 @@ sde, aux = build_sde(name, 'cuda:0')
 solver = SOC_Solver(sde, aux['x0'], None, T=aux['T'], num_steps=aux['K'], lmbd=aux['lmbd'], d=aux['d'], sigma=sde.sigma)
 solver.shard = Shard()
 assert dist.get_backend() == 'nccl'
+want_transport = 'group' if os.environ.get('SOCMX_RCCL') == '0' else 'rccl'
+assert solver.shard.transport == want_transport, (solver.shard.transport, solver.shard.transport_note)
 solver.noise_in = aux['noise']
 out = solver.loss(aux['B'], algorithm='SOCM', use_warm_start=False)
 out[0].backward()
@@ -1428,16 +1430,20 @@ tr2.join(); torch.cuda.synchronize()
 num = sum(float(((a - b) ** 2).sum()) for a, b in zip(sde.state_dict().values(), sde2.state_dict().values()))
 den = sum(float((b ** 2).sum()) for b in sde2.state_dict().values())
 res['param_rel_diff'] = (num / den) ** 0.5
-# hipGraph mode WITH a shard: the autograd-free body -- its two all-reduces are RCCL calls in the 2 eager warm-ups and, at world
-# size 1, identities inside the capture (socmx/dist.py: a captured RCCL call can take torch's watchdog thread down) --,
-# the capture, 3 replays, fresh Philox noise each; against the unsharded hipGraph Trainer on the same device key
+# hipGraph mode WITH a shard: the autograd-free body -- its two all-reduces are launches of the shard's OWN RCCL communicators
+# (socmx/rccl.py) on the iteration's two streams, eagerly in the 2 warm-ups and CAPTURED into the graph with everything else
+# (over torch's process group, SOCMX_RCCL=0: identities under capture at world size 1) --, the capture, 3 replays, fresh Philox
+# noise each, an eager process-group collective in between (its Work is what the group's watchdog thread polls while the
+# next capture runs); against the unsharded hipGraph Trainer on the same device key
 from socmx.rollout import PhiloxKey
 runs = []
 for sharded in (True, False):
     sde3, aux3 = build_sde(name, 'cuda:0')
     solver3 = SOC_Solver(sde3, aux3['x0'], None, T=aux3['T'], num_steps=aux3['K'], lmbd=aux3['lmbd'], d=aux3['d'], sigma=sde3.sigma)
     if sharded:
-        solver3.shard = Shard()
+        solver3.shard = solver.shard
+        calls0 = sum(c.calls for c in solver3.shard._comms.values())
+        dist.all_reduce(torch.zeros(4, device='cuda:0'))
     solver3.philox_key = PhiloxKey(torch.device('cuda', 0), seed=9, offset=0)
     # (normalization_const: what main.py:119-130 estimates before training -- E[w], here 0.02..0.04 -- and what the sharded
     #  statistics kernel shifts the weights by before it sums them, socmx_loss.hip shard_stats_kernel; a constant far from the
@@ -1451,6 +1457,11 @@ for sharded in (True, False):
     captured = [k for k in tr3._graphs if isinstance(k, tuple) and k and k[0] == 'manual']
     runs.append((rec, [v.detach().cpu().numpy() for v in sde3.state_dict().values()], len(captured)))
 res['graph_captured'] = [r[2] for r in runs]
+res['transport'] = solver.shard.transport
+# (6 iterations: the 2 eager warm-ups and the capture enqueue / record the main-stream collective and -- from the second iteration
+#  on -- the second stream's one for the deferred pair-grid-network update: 1 + 2 + 2; the 3 replays re-run the captured launches
+#  without passing through Python; join() applies the last outstanding update eagerly: + 1)
+res['rccl_calls_graph_run'] = sum(c.calls for c in solver.shard._comms.values()) - calls0
 res['graph_rec_sharded'], res['graph_rec_plain'] = runs[0][0], runs[1][0]
 num = sum(float(((a - b) ** 2).sum()) for a, b in zip(runs[0][1], runs[1][1]))
 den = sum(float((b ** 2).sum()) for b in runs[1][1])
@@ -1460,12 +1471,14 @@ dist.barrier(); dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("name", ["tiny_double_well_d10", "cfg3_double_well_d10_K200"])
-def test_rccl_shard_path_on_the_gpu(name, tmp_path):
+@pytest.mark.parametrize("name,own", [("tiny_double_well_d10", "1"), ("cfg3_double_well_d10_K200", "1"), ("tiny_double_well_d10", "0")])
+def test_rccl_shard_path_on_the_gpu(name, own, tmp_path):
     """The sharded code path with the real RCCL backend (torch.distributed 'nccl', world_size 1) in a fresh child
-    process: Shard(), the 3-float all-gather of a direct `.loss()` call, the flat gradient all-reduce -- objective, weight
-    statistics and every gradient against the reference-generated fixture --, then sharded Trainer iterations, eager (ONE
-    all-reduce per iteration) and as a replayed hipGraph (one rank: the sums are identities there, not captured RCCL calls)."""
+    process: Shard() -- which brings up the package's own two communicators (socmx/rccl.py; own = "0": SOCMX_RCCL=0, torch's
+    process group carries the collectives instead) --, the 3-float all-gather of a direct `.loss()` call, the flat gradient
+    all-reduce -- objective, weight statistics and every gradient against the reference-generated fixture --, then sharded
+    Trainer iterations, eager (ONE all-reduce per iteration) and as a replayed hipGraph with the ncclAllReduce launches
+    captured inside."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gpath = str(tmp_path / "grads.npz")
@@ -1475,7 +1488,7 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
         res = subprocess.run([sys.executable, "-c", _RCCL_CHILD, root, port, name, gpath], capture_output=True, text=True,
-                             timeout=900)
+                             timeout=900, env=dict(os.environ, SOCMX_RCCL=own))
         # (the rendezvous / communicator bring-up alone gets a second try -- the port picked above is free only until somebody
         #  else binds it; an arithmetic or capture failure of the child is never retried)
         bringup = any(t in res.stderr for t in ("EADDRINUSE", "Address already in use", "ncclSystemError", "ncclUnhandledCudaError",
@@ -1501,6 +1514,8 @@ def test_rccl_shard_path_on_the_gpu(name, tmp_path):
     #  one defers it to the second stream: same arithmetic, same update order per parameter)
     assert r["deferred_M"] and r["param_rel_diff"] < 2e-6, r
     assert r["graph_captured"] == [1, 1], r["graph_captured"]
+    assert r["transport"] == ("rccl" if own == "1" else "group")
+    assert r["rccl_calls_graph_run"] == (6 if own == "1" else 0), r["rccl_calls_graph_run"]
     np.testing.assert_allclose(r["graph_rec_sharded"], r["graph_rec_plain"], rtol=2e-5, atol=1e-7)
     assert r["graph_param_rel_diff"] < 2e-6, r["graph_param_rel_diff"]
     np.testing.assert_allclose(r["losses"][0], float(z["loss_objective"]), rtol=2e-4)   # normalisation constant 1.0
