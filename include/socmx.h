@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 146 /* 0.1.8: + socmx_weights_stats_scalars_f32; 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
+#define SOCMX_VERSION 147 /* 0.1.9: the objective is summed without float atomics -- socmx_socm_target_fwd_f32 / _fwd_net_f32 / socmx_socm_residual_f32 take a caller-owned workspace (socmx_socm_objective_workspace_floats); socmx_shard_stats_f32 carries per-rank (n, mean, M2) slots instead of shifted sums; 0.1.8: + socmx_weights_stats_scalars_f32; 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -318,13 +318,13 @@ int socmx_weights_stats_scalars_f32(const float* lpd, const float* lps, const fl
                                     socmx_stream_t stream);
 
 /* The same statistics for a batch SHARD (one rank of a data-parallel run; no reference counterpart -- the reference is
- * single-process), in a form that ONE all_reduce(SUM) combines, so they travel in the flat gradient buffer:
- *   phase 0: tail[0..3] = (obj[0] (0 if obj is NULL), sum_m (w[m] - c), sum_m (w[m] - c)^2, B) with c = shift[0] read from
- *            DEVICE memory -- the running normalisation constant (main.py:354-359), identical on every rank and close to
- *            mean(w), which keeps the shifted sums well conditioned in fp32;
- *   phase 1: mean_std[0..1] = (c + S1/N, sqrt((S2 - S1^2/N) / (N - 1))) from the reduced tail = torch.mean / torch.std of
- *            method.py:903-904 over the GLOBAL batch. */
-int socmx_shard_stats_f32(int32_t phase, const float* w, int32_t B, const float* shift, const float* obj, float* tail,
+ * single-process), in a form that ONE all_reduce(SUM) combines EXACTLY, so they travel in the flat gradient buffer:
+ *   phase 0: tail (1 + 3 world floats): tail[0] = obj[0] (0 if obj is NULL); tail[1 + 3 rank ..] = (B, mean, sum (w - mean)^2) of
+ *            this rank's rows (two passes), every other rank's slot = 0 -- summing zeros is exact, so behind the all-reduce
+ *            every rank holds every rank's triple bit for bit;
+ *   phase 1: mean_std[0..1] = Chan's pooling of the world triples in rank order, in fp64 = torch.mean / torch.std of
+ *            method.py:903-904 over the GLOBAL batch, at the accuracy of the one-process statistics whatever the weights' scale. */
+int socmx_shard_stats_f32(int32_t phase, const float* w, int32_t B, int32_t rank, int32_t world, const float* obj, float* tail,
                           float* mean_std, socmx_stream_t stream);
 
 /* Number of (t_i <= s_j) pairs: (K+1)(K+2)/2, ordered i-major, j ascending (method.py:533-547).
@@ -352,13 +352,18 @@ int socmx_socm_prep_f32(const socmx_problem* problem, const float* ts, int32_t K
  * r[i,m,:]      = sigma^T ( nablaV[i,m] - target[i,m] )
  * objective    += inv_norm * sum_{i,m} w[m] |r[i,m]|^2             (inv_norm = 1/((K+1) B_global))
  * G[i,m,:]      = d objective / d nablaV[i,m,:] = 2 w[m] inv_norm sigma r[i,m]   ( = - d objective/d target )
- * objective (1,) is ACCUMULATED with one atomic per workgroup: zero it first.
+ * objective (1,) is ADDED TO (zero it first) -- once per launch, by the last contributor to finish, with the launch's total:
+ * every workgroup leaves its partial sum in a slot of `workspace` and the slots are added in a fixed order, so the value is
+ * bit-reproducible run to run like the reference's torch.sum (method.py:717-720); no float atomics.
+ * workspace: socmx_socm_objective_workspace_floats(K, B) floats of device memory, ZERO before its first use; every launch leaves
+ * its ticket word zero again, so one buffer serves all launches of a stream (never two launches that may run concurrently).
  * target, nablaV, G: (K+1,B,d); target is an output (written by the MFMA contraction, read by the residual pass).
  */
+int64_t socmx_socm_objective_workspace_floats(int32_t K, int32_t B);
 int socmx_socm_target_fwd_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* M_all,
                               const float* dM_all, const float* q, const float* v, const float* gT,
                               const float* nablaV, const float* w, float inv_norm, float* target,
-                              float* G, float* objective, socmx_stream_t stream);
+                              float* G, float* objective, float* workspace, socmx_stream_t stream);
 
 /* gM[p] = -sum_m G[i,m] (x) qx[j,m],  gdM[p] = +sum_m G[i,m] (x) v[j,m]   (p = pair (i,j); qx = q for j<K,
  * gT for j=K; gdM at j=K is 0).  Overwrites gM, gdM (Np,d,d). */
@@ -377,7 +382,7 @@ int socmx_socm_target_bwd_f32(int32_t d, int32_t K, int32_t B, const float* G, c
 int socmx_socm_target_fwd_net_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* net,
                                   const float* dnet, const float* delta, const float* gamma, const float* q,
                                   const float* v, const float* gT, const float* nablaV, const float* w,
-                                  float inv_norm, float* target, float* G, float* objective,
+                                  float inv_norm, float* target, float* G, float* objective, float* workspace,
                                   socmx_stream_t stream);
 
 /* g_net = d obj/d net, g_dnet = d obj/d dnet (Np,d,d), scaled by gout[0] (upstream gradient of the objective on
@@ -398,7 +403,7 @@ int socmx_socm_target_bwd_net_f32(int32_t d, int32_t K, int32_t B, const float* 
  *           + ((nabla_b_i + nabla_b_{i+1}) / 2)^T a_{i+1}) with the constant step dt = T / K (method.py:722-749): all K steps
  *           inside one kernel (d <= 64)
  * q, v (K,B,d), gT (B,d) from socmx_socm_prep_f32; states (K+1,B,d) for kind 2; unused pointers may be NULL.
- * socmx_socm_residual_f32 then gives objective = sum w |sigma^T (nabla_V - target)|^2 inv_norm (ADDED to objective[0]) and
+ * socmx_socm_residual_f32 then gives objective = sum w |sigma^T (nabla_V - target)|^2 inv_norm (ADDED to objective[0]; workspace as for socmx_socm_target_fwd_f32) and
  * G = d objective / d nabla_V for ANY target in HBM (method.py:702-720's form, shared by the three).
  * Girsanov family (method.py:751-856: cross_entropy, variance, log-variance, moment): c (K,B) with
  *   c[i,m] = stop[i,m] ( dt (-<l,u>/lmbd + |l|^2/(2 lmbd) - [with_f] f(X_i)/lmbd) - sqrt(dt/lmbd) <l,eps> ),  l = -sigma^T nabla_V,
@@ -409,7 +414,8 @@ int socmx_matching_target_f32(int32_t kind, const socmx_problem* problem, int32_
                               float dt, const float* gamma, const float* q, const float* v, const float* gT,
                               const float* states, float* target, float* dtarget, socmx_stream_t stream);
 int socmx_socm_residual_f32(const socmx_problem* problem, int32_t K, int32_t B, const float* target, const float* nablaV,
-                            const float* w, float inv_norm, float* G, float* objective, socmx_stream_t stream);
+                            const float* w, float inv_norm, float* G, float* objective, float* workspace,
+                            socmx_stream_t stream);
 int socmx_girsanov_fwd_f32(const socmx_problem* problem, int32_t K, int32_t B, float lmbd, int32_t with_f, const float* ts,
                            const float* nablaV, const float* noises, const float* controls, const float* states,
                            const float* frac, const float* stop, float* c, socmx_stream_t stream);

@@ -78,34 +78,47 @@ __global__ __launch_bounds__(256) void weights_stats_kernel(const float* __restr
   }
 }
 
-// ---- importance-weight statistics of a batch SHARD, in a form ONE all_reduce(SUM) can combine --------------------
-// phase 0: tail = (objective, sum (w - c), sum (w - c)^2, n) with the shift c read from device memory (the running
-//          normalisation constant: identical on every rank and close to mean(w), so the sums stay well conditioned);
-// phase 1: from the REDUCED tail: mean = c + S1 / N, unbiased std = sqrt((S2 - S1^2 / N) / (N - 1))  (method.py:903-904).
-__global__ __launch_bounds__(256) void shard_stats_kernel(int phase, const float* __restrict__ w, int B,
-                                                          const float* __restrict__ shift, const float* __restrict__ obj,
-                                                          float* __restrict__ tail, float* __restrict__ mean_std) {
+// ---- importance-weight statistics of a batch SHARD, in a form ONE all_reduce(SUM) combines EXACTLY ----------------
+// phase 0: tail[0] = objective; rank r's slot tail[1 + 3 r ..] = (n_r, mean_r, M2_r = sum (w - mean_r)^2) of ITS rows (two
+//          passes: well conditioned whatever the weights' scale), every other rank's slot = 0.  Summing zeros is exact, so the
+//          all-reduce hands every rank all world triples bit for bit (an all-gather riding in the iteration's one collective);
+// phase 1: Chan's pooling rule over the slots in rank order, in fp64: mean = sum n_r mean_r / N,
+//          M2 = sum M2_r + sum n_r (mean_r - mean)^2, unbiased std = sqrt(M2 / (N - 1))                 (method.py:903-904).
+// (Rounds 4-5 summed (w - c), (w - c)^2 against the running normaliser c: with c far from mean(w) -- bench.py's 1.0 against
+//  0.03 -- the fp32 sums cancelled to 1e-4 of the std.)
+__global__ __launch_bounds__(256) void shard_stats_kernel(int phase, const float* __restrict__ w, int B, int rank, int world,
+                                                          const float* __restrict__ obj, float* __restrict__ tail,
+                                                          float* __restrict__ mean_std) {
   __shared__ float red[32];
-  const float c = shift[0];
   if (phase == 0) {
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f;
+    for (int m = threadIdx.x; m < B; m += blockDim.x) s1 += w[m];
+    const float mean = block_sum(s1, red) / (float)B;
+    float m2 = 0.f;
     for (int m = threadIdx.x; m < B; m += blockDim.x) {
-      const float x = w[m] - c;
-      s1 += x;
-      s2 += x * x;
+      const float x = w[m] - mean;
+      m2 += x * x;
     }
-    s1 = block_sum(s1, red);
-    s2 = block_sum(s2, red);
-    if (threadIdx.x == 0) {
-      tail[0] = obj ? obj[0] : 0.f;
-      tail[1] = s1;
-      tail[2] = s2;
-      tail[3] = (float)B;
+    m2 = block_sum(m2, red);
+    for (int e = threadIdx.x; e < 3 * world; e += blockDim.x) {
+      const int r = e / 3, c = e - 3 * r;
+      tail[1 + e] = r != rank ? 0.f : (c == 0 ? (float)B : (c == 1 ? mean : m2));
     }
+    if (threadIdx.x == 0) tail[0] = obj ? obj[0] : 0.f;
   } else if (threadIdx.x == 0) {
-    const float s1 = tail[1], s2 = tail[2], n = tail[3];
-    mean_std[0] = c + s1 / n;
-    mean_std[1] = sqrtf(fmaxf(s2 - s1 * s1 / n, 0.f) / (n - 1.f));
+    double n = 0.0, s = 0.0;
+    for (int r = 0; r < world; ++r) {
+      n += (double)tail[1 + 3 * r];
+      s += (double)tail[1 + 3 * r] * (double)tail[2 + 3 * r];
+    }
+    const double mean = s / n;
+    double m2 = 0.0;
+    for (int r = 0; r < world; ++r) {
+      const double dm = (double)tail[2 + 3 * r] - mean;
+      m2 += (double)tail[3 + 3 * r] + (double)tail[1 + 3 * r] * dm * dm;
+    }
+    mean_std[0] = (float)mean;
+    mean_std[1] = (float)sqrt(m2 / (n - 1.0));
   }
 }
 
@@ -291,12 +304,40 @@ struct TargetArgs {
   const float *q, *v, *gT;       // (K,B,d), (K,B,d), (B,d)   batch-major
   const float *nablaV, *w;       // (Kp,B,d), (B,)
   float *target, *G, *objective; // (Kp,B,d) or NULL, (Kp,B,d), (1,)
+  float *ws;                     // objective workspace: [0] ticket (as unsigned; zero between launches), [2 ..] one slot per contributor
   // NET variant: M_all / dM_all hold the raw network outputs net, d(net)/ds and the pair matrices
   //   M = e I + (1-e) net,  dM = gamma e (net - I) + (1-e) dnet,  e = exp(-gamma (s-t))       (models.py:263-275)
   // are formed in registers while the A fragments are loaded.
   const float *delta, *gamma;    // (Np,) s-t per pair, (1,) on the device
   int fuse_residual;             // socm_target_mfma_kernel at d <= 16: the residual (objective, G) leaves with the target rows
 };
+
+// The objective of a launch without float atomics (method.py:717-720 is one torch.sum: the reference's loss value is reproducible
+// run to run, and so is this one).  Every contributor -- a (workgroup, row) of the fused contraction, a workgroup or a wave of the
+// residual kernels -- stores its partial sum into ITS slot of the caller's workspace and draws a ticket; the wave that draws the
+// last one adds the slots up in a fixed order (lane-strided partial sums, then the wave butterfly), adds the total to
+// objective[0] and re-arms the ticket.  Called by a WHOLE wave; `v` is read from lane 0.
+__device__ __forceinline__ void objective_commit(const TargetArgs& a, unsigned slot, unsigned nslots, float v) {
+  const int lane = threadIdx.x & 63;
+  unsigned* const ticket = reinterpret_cast<unsigned*>(a.ws);
+  float* const slots = a.ws + 2;
+  unsigned last = 0u;
+  if (lane == 0) {
+    slots[slot] = v;
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == nslots - 1 ? 1u : 0u;
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  __threadfence();
+  float s = 0.f;
+  for (unsigned k = lane; k < nslots; k += 64) s += __builtin_nontemporal_load(&slots[k]);
+  s = wave_sum(s);
+  if (lane == 0) {
+    a.objective[0] += s;
+    *ticket = 0u;
+  }
+}
 
 __host__ __device__ inline int64_t pair_row_offset(int i, int K) {
   return (int64_t)i * (K + 1) - (int64_t)i * (i - 1) / 2;
@@ -556,13 +597,13 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
         if (lane == 0) objw[wave] = ob;
       }
     }
-    if (fuse) {                                           // one atomic per workgroup and row
+    if (fuse) {                                           // one slot per (row, workgroup of the row): objective_commit
       __syncthreads();
-      if (threadIdx.x == 0) {
+      if (wave == 0) {
         float ob = 0.f;
 #pragma unroll
         for (int c = 0; c < CT; ++c) ob += objw[c];
-        atomicAdd(a.objective, ob * a.inv_norm);
+        objective_commit(a, (unsigned)i * gridDim.y + blockIdx.y, (unsigned)(K + 1) * gridDim.y, ob * a.inv_norm);
       }
     }
   }
@@ -1064,7 +1105,7 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
 }
 
 // r = sigma^T (nablaV - target), objective += inv_norm * sum w |r|^2, G = 2 w inv_norm sigma r.
-// Workgroup = one row i x 64 batch lanes; wave shuffle -> LDS -> one atomic per workgroup.
+// Workgroup = one row i x 64 batch lanes; wave shuffle -> one workspace slot per workgroup (objective_commit).
 __global__ __launch_bounds__(64) void socm_residual_kernel(const TargetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int d = a.d, B = a.B;
@@ -1093,7 +1134,7 @@ __global__ __launch_bounds__(64) void socm_residual_kernel(const TargetArgs a) {
     }
   }
   obj = wave_sum(obj);
-  if (ml == 0) atomicAdd(a.objective, obj * a.inv_norm);
+  objective_commit(a, blockIdx.x * gridDim.y + blockIdx.y, gridDim.x * gridDim.y, obj * a.inv_norm);
 }
 
 // The same residual for d % 4 == 0, d <= 64 on the MFMA: with S = sigma sigma^T (formed once per workgroup in LDS, its 16
@@ -1180,7 +1221,7 @@ __global__ __launch_bounds__(256) void socm_residual_mfma_kernel(const TargetArg
     if (valid) obj += wm * dot;
   }
   obj = wave_sum(obj);
-  if (lane == 0) atomicAdd(a.objective, obj * a.inv_norm);
+  objective_commit(a, blockIdx.x * 4 + wave, gridDim.x * 4, obj * a.inv_norm);
 }
 
 // The operands v, q for d % 4 == 0, d <= 64 on the MFMA (same orientation as socm_residual_mfma_kernel: a lane (row m, group g)
@@ -2236,11 +2277,11 @@ extern "C" int socmx_weights_stats_scalars_f32(const float* lpd, const float* lp
                 StatScalars{gamma, gam_out, norm, gout_out, obj_zero});
 }
 
-extern "C" int socmx_shard_stats_f32(int32_t phase, const float* w, int32_t B, const float* shift, const float* obj,
+extern "C" int socmx_shard_stats_f32(int32_t phase, const float* w, int32_t B, int32_t rank, int32_t world, const float* obj,
                                      float* tail, float* mean_std, socmx_stream_t stream) {
-  if (!shift || !tail || (phase == 0 ? !w : !mean_std)) return SOCMX_E_NULL;
-  if ((phase != 0 && phase != 1) || (phase == 0 && B < 1)) return SOCMX_E_DIM;
-  return launch(shard_stats_kernel, dim3(1), dim3(256), 0, stream, (int)phase, w, (int)B, shift, obj, tail, mean_std);
+  if (!tail || (phase == 0 && !w) || (phase != 0 && !mean_std)) return SOCMX_E_NULL;
+  if (world < 1 || world > 4096 || rank < 0 || rank >= world || (phase == 0 && B < 1)) return SOCMX_E_DIM;
+  return launch(shard_stats_kernel, dim3(1), dim3(256), 0, stream, (int)phase, w, (int)B, (int)rank, (int)world, obj, tail, mean_std);
 }
 
 extern "C" int64_t socmx_num_pairs(int32_t K) { return K < 0 ? 0 : (int64_t)(K + 1) * (K + 2) / 2; }
@@ -2298,15 +2339,15 @@ static int launch_residual(const TargetArgs& a, socmx_stream_t stream) {
 static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all, const float* dM_all,
                              const float* delta, const float* gamma, const float* q, const float* v,
                              const float* gT, const float* nablaV, const float* w, float inv_norm, float* target,
-                             float* G, float* objective, socmx_stream_t stream) {
-  if (!pb || !M_all || !dM_all || !q || !v || !gT || !nablaV || !w || !G || !objective || !target || !pb->sigma)
+                             float* G, float* objective, float* workspace, socmx_stream_t stream) {
+  if (!pb || !M_all || !dM_all || !q || !v || !gT || !nablaV || !w || !G || !objective || !target || !pb->sigma || !workspace)
     return SOCMX_E_NULL;
   const int d = pb->d;
   if (d < 1 || d > 1024 || K < 1 || B < 1) return SOCMX_E_DIM;
   TargetArgs a;
   a.d = d; a.K = K; a.B = B; a.KG = 0; a.inv_norm = inv_norm;
   a.sigma = pb->sigma; a.M_all = M_all; a.dM_all = dM_all; a.q = q; a.v = v; a.gT = gT;
-  a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective;
+  a.nablaV = nablaV; a.w = w; a.target = target; a.G = G; a.objective = objective; a.ws = workspace;
   a.delta = delta; a.gamma = gamma;
   a.fuse_residual = 0;
   void* const st0 = stream;
@@ -2364,33 +2405,40 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
 // objective = sum w |sigma^T (nabla_V - target)|^2 inv_norm and G = d objective / d nabla_V from a target that is already in
 // HBM: the residual kernels of the SOCM loss, for the matching-family baselines (socmx_matching_target_f32) whose targets
 // come from other kernels (method.py:289-478, 722-749 end in the same least-squares form as method.py:702-720)
+// floats of the objective workspace (ticket + one slot per contributor of whichever kernel the sizes select: the fused contraction
+// has (K+1) * ceil(B/16) at most, the residual kernels (K+1) * ceil(B/64) or 4 * 1024)
+extern "C" int64_t socmx_socm_objective_workspace_floats(int32_t K, int32_t B) {
+  if (K < 1 || B < 1) return 0;
+  return 2 + std::max<int64_t>((int64_t)(K + 1) * ((B + 15) / 16), 4096);
+}
+
 extern "C" int socmx_socm_residual_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* target,
                                        const float* nablaV, const float* w, float inv_norm, float* G, float* objective,
-                                       socmx_stream_t stream) {
-  if (!pb || !target || !nablaV || !w || !G || !objective || !pb->sigma) return SOCMX_E_NULL;
+                                       float* workspace, socmx_stream_t stream) {
+  if (!pb || !target || !nablaV || !w || !G || !objective || !pb->sigma || !workspace) return SOCMX_E_NULL;
   if (pb->d < 1 || pb->d > 1024 || K < 1 || B < 1) return SOCMX_E_DIM;
   TargetArgs a{};
   a.d = pb->d; a.K = K; a.B = B; a.inv_norm = inv_norm; a.sigma = pb->sigma; a.nablaV = nablaV; a.w = w;
-  a.target = const_cast<float*>(target); a.G = G; a.objective = objective;
+  a.target = const_cast<float*>(target); a.G = G; a.objective = objective; a.ws = workspace;
   return launch_residual(a, stream);
 }
 
 extern "C" int socmx_socm_target_fwd_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* M_all,
                                          const float* dM_all, const float* q, const float* v, const float* gT,
                                          const float* nablaV, const float* w, float inv_norm, float* target,
-                                         float* G, float* objective, socmx_stream_t stream) {
+                                         float* G, float* objective, float* workspace, socmx_stream_t stream) {
   return launch_target_fwd(pb, K, B, M_all, dM_all, nullptr, nullptr, q, v, gT, nablaV, w, inv_norm, target, G,
-                           objective, stream);
+                           objective, workspace, stream);
 }
 
 extern "C" int socmx_socm_target_fwd_net_f32(const socmx_problem* pb, int32_t K, int32_t B, const float* net,
                                              const float* dnet, const float* delta, const float* gamma,
                                              const float* q, const float* v, const float* gT,
                                              const float* nablaV, const float* w, float inv_norm, float* target,
-                                             float* G, float* objective, socmx_stream_t stream) {
+                                             float* G, float* objective, float* workspace, socmx_stream_t stream) {
   if (!delta || !gamma) return SOCMX_E_NULL;
   return launch_target_fwd(pb, K, B, net, dnet, delta, gamma, q, v, gT, nablaV, w, inv_norm, target, G,
-                           objective, stream);
+                           objective, workspace, stream);
 }
 
 static int launch_target_bwd(int32_t d, int32_t K, int32_t B, const float* G, const float* q, const float* v,

@@ -110,6 +110,7 @@ def run(cfg):
         "weight_mean", "EMA_weight_mean", "weight_std", "EMA_weight_std", "grad_norm_sqd", "EMA_grad_norm_sqd",
         "sqd_norm_EMA_grad", "control_objective_mean", "control_objective_std_err", "control_objective_itr",
         "trajectories")}
+    info["iteration_mode"] = []      # (not in the reference: which schedule each iteration took -- Trainer.step's `mode`)
     info["cfg"] = cfg
     compute_L2_error = ground_truth_control is not None
     every = cfg.method.compute_control_objective_every
@@ -122,6 +123,7 @@ def run(cfg):
                             compute_control_objective=checkpoint, total_n_samples=cfg.method.n_samples_control,
                             verbose=(itr == 0 and rank == 0))
         out = step["out"]
+        info["iteration_mode"].append(step.get("mode"))
         vals = dict(time_per_iteration=step["time_per_iteration"], loss=step["loss"], weight_mean=step["weight_mean"],
                     weight_std=step["weight_std"])
         if compute_L2_error:
@@ -165,8 +167,12 @@ def run(cfg):
               if i >= min(10, n_it // 2) and not (i == 0 or i % every == every - 1 or i == n_it - 1)]
     if steady:
         steady.sort()
+        modes = {}
+        for i, m in enumerate(info["iteration_mode"]):
+            if i >= min(10, n_it // 2) and not (i == 0 or i % every == every - 1 or i == n_it - 1):
+                modes[m] = modes.get(m, 0) + 1
         log(f"time_per_iteration: median {1e3 * steady[len(steady) // 2]:.3f} ms over {len(steady)} steady-state iterations "
-            f"({'hipGraph replay' if trainer.hip_graph else 'eager two-stream'} iteration)")
+            f"(modes: {', '.join(f'{k} x{v}' for k, v in sorted(modes.items(), key=lambda kv: -kv[1]))})")
     return solver
 
 

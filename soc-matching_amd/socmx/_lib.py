@@ -90,17 +90,18 @@ PROTOTYPES = {
                                                  _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "socmx_weights_stats_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp]),
     "socmx_weights_stats_scalars_f32": (C.c_int, [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "socmx_shard_stats_f32": (C.c_int, [C.c_int32, _fp, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_shard_stats_f32": (C.c_int, [C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp]),
     "socmx_num_pairs": (C.c_int64, [C.c_int32]),
     "socmx_matching_target_f32": (C.c_int, [C.c_int32, C.POINTER(Problem), C.c_int32, C.c_int32, _fp, C.c_float, C.c_float,
                                             _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "socmx_socm_residual_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp]),
+    "socmx_socm_residual_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp]),
+    "socmx_socm_objective_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "socmx_girsanov_fwd_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, C.c_float, C.c_int32] + [_fp] * 9),
     "socmx_girsanov_bwd_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, C.c_float] + [_fp] * 9),
     "socmx_socm_prep_f32": (C.c_int, [C.POINTER(Problem), _fp, C.c_int32, C.c_int32, C.c_float,
                                       _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "socmx_socm_target_fwd_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, _fp,
-                                            _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp]),
+                                            _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "socmx_socm_target_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
                                             _fp]),
     "socmx_socm_stopping_target_fwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, C.c_float]
@@ -117,7 +118,7 @@ PROTOTYPES = {
     "socmx_linear_bwd_finish_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_int32, C.c_int32, _fp, _fp]),
     "socmx_relu_bwd_colsum_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp]),
     "socmx_socm_target_fwd_net_f32": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp,
-                                                _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp]),
+                                                _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, _fp, _fp]),
     "socmx_socm_target_bwd_net_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                                 _fp, _fp, _fp, _fp, _fp, _fp]),
 }
@@ -308,6 +309,26 @@ class on_device:
 
 def stream_ptr(device=None):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+_objective_ws = {}
+
+
+def objective_workspace(device, K, B):
+    """The workspace of the objective's ordered sum (include/socmx.h: socmx_socm_objective_workspace_floats) for launches on
+    the CURRENT stream of `device`: zeroed once, re-armed by every launch, one per (device, stream, size) -- launches of one
+    stream never overlap, and a buffer is never re-allocated (a captured graph keeps using the address it recorded)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    n = int(lib().socmx_socm_objective_workspace_floats(int(K), int(B)))
+    key = (idx, torch.cuda.current_stream(dev).cuda_stream, n)
+    ws = _objective_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(n, dtype=torch.float32, device=torch.device("cuda", idx))
+        if torch.cuda.is_current_stream_capturing():
+            return ws            # (memory of the graph's own pool: lives and dies with that graph, never cached)
+        _objective_ws[key] = ws
+    return ws
 
 
 def i3(v):

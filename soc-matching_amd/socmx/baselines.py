@@ -45,7 +45,8 @@ class _MatchingHip(torch.autograd.Function):
                                                     f(ops["q"]), f(ops["v"]), f(ops["gT"]), f(c(states)), f(target),
                                                     f(dtarget), _lib.stream_ptr(dev)), "socmx_matching_target_f32")
             _lib.check(Lh.socmx_socm_residual_f32(pb.c_struct(), K, B, f(target), f(nv), f(w), 1.0 / (Kp * B), f(G), f(obj),
-                                                  _lib.stream_ptr(dev)), "socmx_socm_residual_f32")
+                                                  f(_lib.objective_workspace(dev, K, B)), _lib.stream_ptr(dev)),
+                       "socmx_socm_residual_f32")
         ctx.save_for_backward(G, *([dtarget] if kind == 1 else []))
         ctx.gamma_shape = gamma.shape if kind == 1 else None
         return obj[0]

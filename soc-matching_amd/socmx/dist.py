@@ -5,9 +5,9 @@ Trajectories are independent (utils.py:37-101 has no cross-sample term) and the 
 sum over samples (method.py:717-720), so rank r simulates rows [row0, row0+B_r) of the global batch
 with the Philox stream keyed by the GLOBAL row index, and the only communication per iteration is
 ONE all_reduce(SUM) (stopping-time SOCM: one more, a scalar -- the loss normaliser sum(stop_indicators) scales every
-gradient and is needed before the backward pass, solver._stop_normaliser) of a flat fp32 buffer holding every gradient, the objective value, the shifted
-sums (sum (w - c), sum (w - c)^2, n) that give mean/std of w (c = the running normalisation constant,
-identical on every rank) and, when computed, this rank's share of the weighted L2 error --
+gradient and is needed before the backward pass, solver._stop_normaliser) of a flat fp32 buffer holding every gradient, the objective value, one
+(n, mean, M2) slot per rank (each rank fills its own, the sum of zeros elsewhere is exact: mean/std of w pooled by Chan's
+rule at one-process accuracy) and, when computed, this rank's share of the weighted L2 error --
 over RCCL (torch.distributed backend "nccl") on xGMI; "gloo" on CPU for tests.  The buffer is
 0.7-3 MB, i.e. latency-bound: it must stay a single collective, never one call per parameter.
 (hipGraph mode, train.py: the pair-grid network's gradients -- produced one iteration later on the
@@ -188,21 +188,25 @@ class Shard:
         return self._reduce(flat, "sum", slot)
 
 
-def shifted_weight_sums(weight, shift):
-    """(sum (w - c), sum (w - c)^2, n) of this shard's importance weights: summable across ranks (one all_reduce), and
-    well conditioned when c is close to mean(w) -- Trainer passes the running normalisation constant."""
-    wc = weight.double() - shift.double() if torch.is_tensor(shift) else weight.double() - float(shift)
-    # (accumulated in fp64, handed to the fp32 all-reduce buffer rounded once)
-    return torch.stack([wc.sum(), (wc * wc).sum(), torch.tensor(float(weight.numel()), device=weight.device,
-                                                                dtype=torch.float64)]).to(torch.float32)
+def weight_stat_slots(weight, rank, world_size):
+    """(3 world,) fp32: this rank's (n, mean, M2 = sum (w - mean)^2) in ITS slot, zeros in every other rank's.  Summing zeros is
+    exact, so ONE all_reduce(SUM) hands every rank all the triples bit for bit -- an all-gather riding inside the iteration's flat
+    gradient all-reduce -- and `mean_std_from_slots` pools them with Chan's rule in fp64: the accuracy of the one-process
+    statistics whatever the weights' scale.  (Rounds 4-5 summed (w - c), (w - c)^2 against the running normaliser c, which
+    cancelled in fp32 when c was far from mean(w).)"""
+    w = weight.detach().double()
+    mean = w.mean()
+    slots = torch.zeros(3 * world_size, dtype=torch.float32, device=weight.device)
+    slots[3 * rank:3 * rank + 3] = torch.stack([torch.tensor(float(w.numel()), dtype=torch.float64, device=w.device), mean,
+                                               ((w - mean) ** 2).sum()]).to(torch.float32)
+    return slots
 
 
-def mean_std_from_shifted_sums(sums, shift):
-    """Pooled mean / unbiased std from the reduced sums.  The subtraction S2 - S1^2 / n runs in fp64; what remains is the
-    fp32 rounding of the TRANSMITTED sums, a relative error of about 6e-8 (1 + ((mean - c) / std)^2) in the variance --
-    below 1e-5 while the running normaliser c is within ten standard deviations of the batch mean."""
-    s1, s2, n = sums[0].double(), sums[1].double(), sums[2].double()
-    sh = shift.double() if torch.is_tensor(shift) else float(shift)
-    mean = sh + s1 / n
-    std = torch.sqrt(torch.clamp(s2 - s1 * s1 / n, min=0.0) / (n - 1))
-    return mean.to(torch.float32), std.to(torch.float32)
+def mean_std_from_slots(slots):
+    """Pooled mean / unbiased std (method.py:903-904 over the GLOBAL batch) from the reduced slots."""
+    t = slots.double().reshape(-1, 3)
+    n, mean_r, m2_r = t[:, 0], t[:, 1], t[:, 2]
+    N = n.sum()
+    mean = (n * mean_r).sum() / N
+    m2 = m2_r.sum() + (n * (mean_r - mean) ** 2).sum()
+    return mean.to(torch.float32), torch.sqrt(m2 / (N - 1)).to(torch.float32)

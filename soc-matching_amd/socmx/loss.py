@@ -135,7 +135,8 @@ class _TargetResidualHip(torch.autograd.Function):
             _lib.check(L.socmx_socm_target_fwd_f32(
                 pb.c_struct(), K, B, _lib.ptr(M_all), _lib.ptr(dM_all), _lib.ptr(ops["q"]), _lib.ptr(ops["v"]),
                 _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm), _lib.ptr(target),
-                _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_f32")
+                _lib.ptr(G), _lib.ptr(obj), _lib.ptr(_lib.objective_workspace(dev, K, B)), _lib.stream_ptr(dev)),
+                "socmx_socm_target_fwd_f32")
         ctx.save_for_backward(G, ops["q"], ops["v"], ops["gT"])
         ctx.dims = (d, K, B, M_all.shape[0])
         if want_target:
@@ -178,7 +179,8 @@ def target_fwd_net(pb, K, net, dnet, delta, gam, ops, nablaV, w, inv_norm, G=Non
         _lib.check(L.socmx_socm_target_fwd_net_f32(
             pb.c_struct(), K, B, _lib.ptr(net), _lib.ptr(dnet), _lib.ptr(delta), _lib.ptr(gam), _lib.ptr(ops["q"]),
             _lib.ptr(ops["v"]), _lib.ptr(ops["gT"]), _lib.ptr(nablaV), _lib.ptr(w), float(inv_norm),
-            _lib.ptr(target), _lib.ptr(G), _lib.ptr(obj), _lib.stream_ptr(dev)), "socmx_socm_target_fwd_net_f32")
+            _lib.ptr(target), _lib.ptr(G), _lib.ptr(obj), _lib.ptr(_lib.objective_workspace(dev, K, B)),
+            _lib.stream_ptr(dev)), "socmx_socm_target_fwd_net_f32")
     return obj, G, target
 
 
@@ -289,7 +291,8 @@ class _ResidualHip(torch.autograd.Function):
         obj = torch.zeros(1, dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             _lib.check(Lh.socmx_socm_residual_f32(pb.c_struct(), K, B, f(tg), f(nv), f(w), float(inv_norm), f(G), f(obj),
-                                                  _lib.stream_ptr(dev)), "socmx_socm_residual_f32")
+                                                  f(_lib.objective_workspace(dev, K, B)), _lib.stream_ptr(dev)),
+                       "socmx_socm_residual_f32")
         ctx.save_for_backward(G)
         return obj[0]
 

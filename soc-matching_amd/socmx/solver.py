@@ -235,12 +235,11 @@ class SOC_Solver(nn.Module):
             return (objective, norm_sqd_diff, cm, ce, traj, torch.mean(weight), torch.std(weight), stop_indicators)
 
         weight, stats = L.weights_and_stats(lpd, lps, ltw)
-        shift = getattr(self, "defer_weight_stats", None)
-        if shard is not None and shift is not None:
-            # Trainer carries the statistics in its ONE flat all-reduce (socmx.dist): leave the shard's shifted sums for
+        if shard is not None and getattr(self, "defer_weight_stats", False):
+            # Trainer carries the statistics in its ONE flat all-reduce (socmx.dist): leave this shard's (n, mean, M2) slot for
             # it; the mean / std returned below are this shard's own until Trainer replaces them
-            from .dist import shifted_weight_sums
-            self._local_w_sums = shifted_weight_sums(weight, shift)
+            from .dist import weight_stat_slots
+            self._local_w_sums = weight_stat_slots(weight, shard.rank, shard.world_size)
         elif shard is not None:
             stats = shard.combine_weight_stats(stats)
         w_mean, w_std = L.mean_std_from_stats(stats)

@@ -355,7 +355,7 @@ class Trainer:
             b1, b2 = grp["betas"]
             dev = flat.device
             with _lib.on_device(dev):
-                _lib.check(_lib.lib().socmx_adam_step_f32(table.data_ptr(), len(params) + 1, n + 1, _lib.ptr(flat), None,
+                _lib.check(_lib.lib().socmx_adam_step_f32(table.data_ptr(), len(params) + 1, flat.numel(), _lib.ptr(flat), None,
                                                          _lib.ptr(D["itr1"]), 0.01, float(grp["lr"]), float(b1), float(b2),
                                                          float(grp["eps"]), _lib.ptr(scratch), _lib.ptr(sums),
                                                          _lib.stream_ptr(dev)), "socmx_adam_step_f32")
@@ -390,8 +390,9 @@ class Trainer:
     def _fused_side_table(self, D, tensors):
         """Device table for socmx_adam_step_f32 over the pair-grid network's six tensors + gamma, or None while the fused step does
         not apply: every side group must be a torch.optim.Adam group with the SAME float lr / betas / eps, no weight decay /
-        amsgrad / maximize, covering exactly these tensors, with device-resident fp32 state that torch's own step created (the
-        eager warm-up iterations) and equal step counts.  Rebuilt whenever a data pointer or a hyper-parameter changed."""
+        amsgrad / maximize, covering exactly these tensors (contiguous fp32, gamma a single element), with device-resident fp32
+        state that torch's own step created (the eager warm-up iterations) and EQUAL step counts -- checked when the table is
+        built.  Rebuilt whenever a data pointer or a hyper-parameter changed."""
         if not self.fused_adam or "itr1" not in D:
             return None
         opt, groups = self.optimizer, self._groups_side
@@ -404,6 +405,8 @@ class Trainer:
             return None
         if sorted(id(p) for g in groups for p in g["params"]) != sorted(id(p) for p in tensors):
             return None
+        if tensors[-1].numel() != 1:          # (gamma: one scalar behind the network's gradients in the flat buffer)
+            return None
         st = opt.state
         for p in tensors:
             q = st.get(p)
@@ -415,6 +418,15 @@ class Trainer:
         if D.get("adam_side_sig") != sig:
             if torch.cuda.is_current_stream_capturing():
                 return None              # (the table is a host-to-device copy: built by an eager iteration, see _m_update's tail)
+            # adam_step_kernel takes the bias correction from the FIRST tensor's step counter and writes it back to all of them:
+            # only valid while the seven counters agree (they do when torch's own step created the state in one go; an
+            # optimizer.load_state_dict or a history that stepped the groups apart must keep torch's per-tensor step) -- read
+            # here, outside any capture, where a host synchronisation is affordable
+            steps = torch.stack([st[p]["step"].reshape(()) for p in tensors]).cpu()
+            if not bool((steps == steps[0]).all()):
+                D.pop("adam_side", None)
+                D["adam_side_sig"] = None
+                return None
             rows, off = [], 0
             for p in tensors:
                 rows.append([p.data_ptr(), st[p]["exp_avg"].data_ptr(), st[p]["exp_avg_sq"].data_ptr(), st[p]["step"].data_ptr(),
@@ -561,11 +573,12 @@ class Trainer:
         want_l2 = bool(loss_kwargs and loss_kwargs.get("compute_L2_error"))
         main_flat = None
         if shard is not None:
-            # the iteration's flat all-reduce buffer: [control-network gradient | objective, sum (w-c), sum (w-c)^2, n, L2 error]
+            # the iteration's flat all-reduce buffer: [control-network gradient | objective | one (n, mean, M2) slot per rank | L2 error]
             ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
             _lib.check(Lh.socmx_unet_backward_sizes(d, _lib.i3(sde.nabla_V.hdims), Kp * B, _lib.C.byref(ws), _lib.C.byref(ng)),
                        "socmx_unet_backward_sizes")
-            main_flat = torch.zeros(ng.value + 5, dtype=torch.float32, device=dev)
+            n_slots = 3 * shard.world_size
+            main_flat = torch.zeros(ng.value + 2 + n_slots, dtype=torch.float32, device=dev)
         # (G . d loss / d objective: the device scalar multiplies the gradient tiles as the backward kernel reads them)
         vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
                                                G.reshape(Kp * B, d), gout_scale=gout, return_flat=True,
@@ -584,18 +597,18 @@ class Trainer:
         if shard is not None:
             tail = main_flat[vflat.numel():]
             with _lib.on_device(dev):
-                _lib.check(Lh.socmx_shard_stats_f32(0, f(weight), B, f(D["norm1"]), f(obj), f(tail), None, _lib.stream_ptr(dev)),
-                           "socmx_shard_stats_f32")
+                _lib.check(Lh.socmx_shard_stats_f32(0, f(weight), B, shard.rank, shard.world_size, f(obj), f(tail), None,
+                                                    _lib.stream_ptr(dev)), "socmx_shard_stats_f32")
             if nsd is not None:
-                tail[4:5].copy_(nsd)
+                tail[1 + n_slots:2 + n_slots].copy_(nsd)
             shard.allreduce_flat_(main_flat)           # the iteration's ONE collective on this stream (captured in the graph)
             mean_std = torch.empty(2, dtype=torch.float32, device=dev)
             with _lib.on_device(dev):
-                _lib.check(Lh.socmx_shard_stats_f32(1, None, 0, f(D["norm1"]), None, f(tail), f(mean_std), _lib.stream_ptr(dev)),
-                           "socmx_shard_stats_f32")
+                _lib.check(Lh.socmx_shard_stats_f32(1, None, 0, shard.rank, shard.world_size, None, f(tail), f(mean_std),
+                                                    _lib.stream_ptr(dev)), "socmx_shard_stats_f32")
             obj, w_mean, w_std = tail[0:1], mean_std[0:1], mean_std[1:2]
             if nsd is not None:
-                nsd = tail[4:5]
+                nsd = tail[1 + n_slots:2 + n_slots]
         gn = gne = None
         adam = self._fused_adam_table(D, vparams, vflat)
         out = torch.empty(7, dtype=torch.float32, device=dev)
@@ -762,7 +775,8 @@ class Trainer:
             # (the manual body needs two eager iterations: the second one is the first to run the pair-grid network's
             #  update, which creates that group's Adam state -- it must exist before a capture)
             if not self.capture_graphs:
-                vals = body()           # (sharded default: the same body, never captured -- on the current stream)
+                vals = body()           # (transport that cannot be captured / "nocapture": the same body on the current stream)
+                mode = "body-eager" if manual else "autograd-body-eager"
             elif n < (max(2, self.graph_warmup) if manual else self.graph_warmup) or (manual and not self._m_pending):
                 self._graphs[("warm",) + key] = n + 1
                 side = private_stream(dev, "capture")        # (the stream the capture will run on: socmx/streams.py)
@@ -771,6 +785,7 @@ class Trainer:
                     vals = body()
                 torch.cuda.current_stream(dev).wait_stream(side)
                 vals.record_stream(torch.cuda.current_stream(dev))
+                mode = "graph-warmup"
             else:
                 g = torch.cuda.CUDAGraph()
                 # Every stream that joins this capture -- the capture stream itself, the solver's second stream -- is a stream of
@@ -779,10 +794,10 @@ class Trainer:
                 # -- which polls the events of earlier eager calls with hipEventQuery while this thread captures -- never meet the
                 # capture.  (Rounds 4-5 captured ProcessGroupNCCL calls, drew the capture stream from torch's pool and slept 0.35 s
                 # in front of the capture to let the watchdog drain; all three are gone.)
-                mode = "thread_local" if solver.shard is not None else "global"
+                cmode = "thread_local" if solver.shard is not None else "global"
                 err = None
                 try:
-                    with torch.cuda.graph(g, stream=private_stream(dev, "capture"), capture_error_mode=mode):
+                    with torch.cuda.graph(g, stream=private_stream(dev, "capture"), capture_error_mode=cmode):
                         static_vals = body()
                 except Exception as e:                       # noqa: BLE001 -- whatever the capture choked on, training goes on
                     err = e
@@ -795,19 +810,22 @@ class Trainer:
                 self._graphs_sig = self._optimizer_signature()
                 g.replay()                                   # capture does not execute: this replay IS the iteration
                 vals = static_vals.clone()
+                mode = "graph-capture"
         elif manual and not self._m_pending:
             # a flush (checkpoint, eager fallback) consumed the outstanding update the captured graph starts with: this one
             # iteration runs the same body eagerly (it skips the update), the next one replays again
             vals = body()
+            mode = "body-eager (after a flush)"
         else:
             entry[0].replay()
             vals = entry[1].clone()
+            mode = "graph-replay"
         if self.sync_timing:
             torch.cuda.synchronize(dev)
         time_per_iteration = time.time() - start
         self.itr += 1
         self.normalization_const = self._dev["norm"]         # (a live view of the device-side normaliser)
-        info = dict(loss=vals[0], time_per_iteration=time_per_iteration, weight_mean=vals[1], weight_std=vals[2],
+        info = dict(loss=vals[0], time_per_iteration=time_per_iteration, weight_mean=vals[1], weight_std=vals[2], mode=mode,
                     norm_before=vals[6], out=(None, vals[7] if vals.numel() > 7 else None, None, None, None, vals[1],
                                               vals[2], None))
         if self.grad_telemetry:
@@ -831,6 +849,7 @@ class Trainer:
             self._ema_grad_norm_sqd = self._dev["ema_gn"].clone()
         self.hip_graph = False
         self._graphs.clear()
+        self._eager_reason = "capture failed"
         return self._eager_step(**loss_kwargs)
 
     def _graph_eligible(self, loss_kwargs):
@@ -858,8 +877,14 @@ class Trainer:
                 D["ema_gn"].copy_(self._ema_grad_norm_sqd.detach().reshape(()))
 
     def step(self, **loss_kwargs):
+        """One iteration (main.py:280-359).  The returned dict's `mode` names the schedule THIS iteration took -- "graph-replay",
+        "graph-capture", "graph-warmup", "body-eager", "eager (<why>)" -- so that a run whose iterations silently left the
+        replayed graph (2.3x the time at configs[2]) shows it in its telemetry (main.py keeps it in training_info)."""
         if self._graph_eligible(loss_kwargs):
             return self._graph_step(loss_kwargs)
+        self._eager_why = (getattr(self, "_eager_reason", None) or ("hip_graph off" if not self.hip_graph else
+                           "control-objective burst" if loss_kwargs.get("compute_control_objective") else
+                           "verbose" if loss_kwargs.get("verbose") else "sharded run outside the autograd-free body"))
         if self.hip_graph:
             self._graph_state()
             self._flush_M()
@@ -883,18 +908,14 @@ class Trainer:
         # a sharded eager iteration keeps the pair-grid network's backward inside loss.backward(): every gradient exists
         # before the iteration's ONE collective
         solver.defer_M_backward = self.defer_M and shard is None   # only for this call: direct users of .loss() get the full graph
-        shift = None
-        if shard is not None:
-            nc = self.normalization_const
-            shift = nc.detach().to(dev, torch.float32).reshape(()) if torch.is_tensor(nc) else torch.tensor(float(nc), device=dev)
-        solver.defer_weight_stats = shift
+        solver.defer_weight_stats = shard is not None
         try:
             out = solver.loss(self.batch_size, algorithm=self.algorithm, use_warm_start=False,
                               use_stopping_time=bool(getattr(solver.neural_sde, "use_stopping_time", False)),
                               **loss_kwargs)
         finally:
             solver.defer_M_backward = False
-            solver.defer_weight_stats = None
+            solver.defer_weight_stats = False
         objective, weight_mean = out[0], out[5]
         if self.algorithm in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
             loss = objective / self.normalization_const                  # main.py:313-320
@@ -904,13 +925,13 @@ class Trainer:
             loss = objective
         loss.backward()                                                  # main.py:323
         if shard is not None:
-            # ONE flat all-reduce per iteration: every gradient + the loss value + the shifted weight sums + (when computed)
+            # ONE flat all-reduce per iteration: every gradient + the loss value + the ranks' (n, mean, M2) slots + (when computed)
             # this rank's share of the weighted L2 error, which solver.loss already divided by the GLOBAL (K+1) B
-            from .dist import mean_std_from_shifted_sums
+            from .dist import mean_std_from_slots
             extra = [loss.detach(), solver.__dict__.pop("_local_w_sums")] + ([out[1].detach()] if out[1] is not None else [])
             reduced = shard.allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]], extra=extra)
             loss_val = reduced[0].reshape(())
-            weight_mean, weight_std = mean_std_from_shifted_sums(reduced[1], shift)
+            weight_mean, weight_std = mean_std_from_slots(reduced[1])
             out = (out[0], reduced[2].reshape(()) if out[1] is not None else None) + tuple(out[2:5]) + (weight_mean, weight_std) \
                 + tuple(out[7:])
         else:
@@ -937,4 +958,4 @@ class Trainer:
         # iteration, which breaks a later hipGraph capture (see _body_dev)
         out = tuple(o.detach() if torch.is_tensor(o) else o for o in out)
         return dict(loss=loss_val, time_per_iteration=time_per_iteration, weight_mean=weight_mean.detach(),
-                    weight_std=out[6], out=out, **telemetry)
+                    weight_std=out[6], out=out, mode=f"eager ({getattr(self, '_eager_why', None) or 'hip_graph off'})", **telemetry)

@@ -136,7 +136,7 @@ def _train_worker(rank, world, port, name, ret):
 @pytest.mark.parametrize("name", ["train_ou_quadratic_easy_d2", "train_double_well_d10"])
 def test_sharded_trainer_steps_equal_the_reference_training_run(name, world):
     """world_size 2 and 3 (gloo): `Trainer.step` with a batch shard -- loss, backward, ONE flat all-reduce (gradients + loss
-    value + shifted weight sums), Adam with the reference's groups, EMA normaliser -- reproduces the reference's own training
+    value + the ranks' weight-statistics slots), Adam with the reference's groups, EMA normaliser -- reproduces the reference's own training
     run on the same noise, all ranks end with identical parameters, and exactly one collective is issued per iteration.
     The fixtures' batch is 16 rows: three ranks hold 6 / 5 / 5 of them (a split that does not divide)."""
     port = _free_port()
@@ -166,16 +166,20 @@ def test_sharded_trainer_steps_equal_the_reference_training_run(name, world):
         assert np.array_equal(r0["state"][k], r1["state"][k]), k      # replicas stay bit-identical
 
 
-def test_shifted_weight_sums_pool_exactly():
-    from socmx.dist import shifted_weight_sums, mean_std_from_shifted_sums
+def test_weight_stat_slots_pool_exactly():
+    """socmx/dist.py: each rank fills ITS (n, mean, M2) slot, the all-reduce(SUM) of slots that are zero elsewhere is exact, Chan's
+    rule pools them in fp64 -- one-process accuracy at any scale of the weights (1e-3 relative spread around 0.1, and weights of
+    size 1e-6: the cases where rounds 4-5's sums shifted by a far-off constant cancelled)."""
+    from socmx.dist import weight_stat_slots, mean_std_from_slots
     g = torch.Generator().manual_seed(1)
-    w = 0.1 + 0.01 * torch.rand(300, generator=g)
-    shift = torch.tensor(0.104)
-    parts = [w[:100], w[100:170], w[170:]]
-    total = sum(shifted_weight_sums(p, shift) for p in parts)
-    mean, std = mean_std_from_shifted_sums(total, shift)
-    np.testing.assert_allclose(mean.item(), w.double().mean().item(), rtol=1e-6)
-    np.testing.assert_allclose(std.item(), w.double().std().item(), rtol=1e-4)
+    for w in (0.1 + 1e-4 * torch.rand(300, generator=g), 1e-6 * torch.rand(300, generator=g), 30.0 + torch.randn(300, generator=g)):
+        parts = [w[:100], w[100:170], w[170:]]
+        total = sum(weight_stat_slots(p, r, 3) for r, p in enumerate(parts))
+        for r, p in enumerate(parts):                      # the sum IS the concatenation of the ranks' own slots
+            assert torch.equal(total[3 * r:3 * r + 3], weight_stat_slots(p, r, 3)[3 * r:3 * r + 3])
+        mean, std = mean_std_from_slots(total)
+        np.testing.assert_allclose(mean.item(), w.double().mean().item(), rtol=2e-7)
+        np.testing.assert_allclose(std.item(), w.double().std().item(), rtol=2e-6)
 
 
 def _agree_worker(rank, world, port, ret):

@@ -1,4 +1,7 @@
 #!/bin/bash
+# HISTORICAL (round 5): archived with the experiment it drove.  It expects the layout of that round -- this script, r1p_check.py
+# and r1p_mkplan.py under tools/, socmx_rollout1p.hip under soc-matching_amd/csrc/ -- and does not run from here as it stands:
+# to reproduce, copy socmx_rollout1p*.hip into soc-matching_amd/csrc/ and these scripts into tools/ first (README.md, "Reproducing").
 # Developer sweep of the packed-fma one-row kernel's source plans (csrc/socmx_rollout1p.hip: SOCMX_R1P_PLAN0 / 1): each plan is
 # compiled into ITS OWN library under tools/ubench/_bin/plans/ -- only socmx_rollout1p.o differs, the other objects are the shipped
 # build's; the shipped soc-matching_amd/socmx/libsocmx.so is never touched -- and loaded through SOCMX_LIB (socmx/_lib.py).
