@@ -318,24 +318,27 @@ struct TargetArgs {
 // last one adds the slots up in a fixed order (lane-strided partial sums, then the wave butterfly), adds the total to
 // objective[0] and re-arms the ticket.  Called by a WHOLE wave; `v` is read from lane 0.
 __device__ __forceinline__ void objective_commit(const TargetArgs& a, unsigned slot, unsigned nslots, float v) {
+  // No fences: a __threadfence() here is an L2 write-back of everything the XCD holds dirty (the G rows this kernel has just
+  // written), once per contributor -- 8 us at configs[2].  Device-scope read-modify-write atomics execute at the point all
+  // XCDs share, so the slot travels as an atomic exchange whose RETURN is waited for (complete = visible to everybody) before
+  // the ticket is drawn, and the last wave reads the slots the same way (an atomic add of zero).
   const int lane = threadIdx.x & 63;
   unsigned* const ticket = reinterpret_cast<unsigned*>(a.ws);
   float* const slots = a.ws + 2;
   unsigned last = 0u;
   if (lane == 0) {
-    slots[slot] = v;
-    __threadfence();
+    const float old = atomicExch(&slots[slot], v);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
     last = atomicAdd(ticket, 1u) == nslots - 1 ? 1u : 0u;
   }
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
-  __threadfence();
   float s = 0.f;
-  for (unsigned k = lane; k < nslots; k += 64) s += __builtin_nontemporal_load(&slots[k]);
+  for (unsigned k = lane; k < nslots; k += 64) s += atomicAdd(&slots[k], 0.f);
   s = wave_sum(s);
   if (lane == 0) {
     a.objective[0] += s;
-    *ticket = 0u;
+    atomicExch(ticket, 0u);
   }
 }
 

@@ -1465,6 +1465,232 @@ __global__ __launch_bounds__(NW * 64) void mnet_backward_kernel(const MArgs a) {
   m_stage<NW>(a.packedT, m.LT[1], lds, m.gz2, m.s2, scratch, b2);
 }
 
+// ---- RESIDENT form (hidden widths <= 128 and d*d <= 128: the reference's hdims_M = [128, 128] at d <= 11 -- BASELINE
+// configs[1], [2]) ---------------------------------------------------------------------------------------------------------
+// The tile kernels above launch ONE 16-pair tile per workgroup and stream the whole weight image (118 KB at d = 10) from L2
+// through a register ring for 32 rows of MFMA work: 150 MB of L2 traffic per launch at configs[2], and every stage starts with
+// an L2 round trip (0.27 / 0.36 of the fp32 MFMA peak stand-alone, 0.16-0.20 beside the rollout -- profiles/r5).  With at most
+// eight 16-wide output blocks per layer, wave w of eight OWNS output block w of every layer, and that block's fragments are
+// 4 x (fan-in / 16) <= 32 registers per layer: the whole image is REGISTER-RESIDENT across the workgroup (68 VGPRs per lane
+// forward, 100 backward), loaded once; a persistent workgroup then walks tiles b, b + grid, ... with nothing but LDS reads of
+// the activation tile (the MFMA B operand, shared by the eight waves) and MFMAs in its loop.  ReLU masks stay in the
+// registers of the wave that made them (the backward stage that needs a layer's mask produces the same units in the same
+// lanes).  Two barriers per tile.  Same slabs / outputs as the kernels above, so kernel B and the finish kernel are unchanged.
+struct MResFrag {
+  f32x4 k[8];
+};
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// fragments (nb = wave, kc = 0 .. KC-1) of one layer of a fragment-ordered image (zero beyond KC / for waves without a block)
+__device__ __forceinline__ void mres_load(MResFrag& f, const float* img, const LayerDesc& L, int wave, int lane) {
+  const int KC = L.in_pad >> 4, NB = L.out_pad >> 4;
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc)
+    f.k[kc] = (wave < NB && kc < KC) ? ldg4(img + L.w_off + ((size_t)(wave * KC + kc) * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// (av | at) += W_block . (X value rows | X tangent rows): xv = tile + row * S + 4 g (tangent rows 16 S further)
+__device__ __forceinline__ void mres_gemm(const MResFrag& f, int KC, const float* xv, int S, f32x4& av, f32x4& at) {
+  const float* xt = xv + 16 * S;
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc)
+    if (kc < KC) {
+      const f32x4 bv = lds4(xv + 16 * kc), bt = lds4(xt + 16 * kc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k[kc][i], bv[i], av, 0, 0, 0);
+        at = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k[kc][i], bt[i], at, 0, 0, 0);
+      }
+    }
+}
+
+// ReLU pair: value -> relu (NaN kept), tangent -> tangent where value > 0; returns the four mask bits
+__device__ __forceinline__ unsigned mres_relu(f32x4& v, f32x4& t) {
+  unsigned msk = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = v[i] > 0.f;
+    msk |= (on ? 1u : 0u) << i;
+    v[i] = relu_keep_nan(v[i]);
+    t[i] = on ? t[i] : 0.f;
+  }
+  return msk;
+}
+__device__ __forceinline__ void mres_mask(unsigned msk, f32x4& v, f32x4& t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = (msk >> i) & 1u;
+    v[i] = on ? v[i] : 0.f;
+    t[i] = on ? t[i] : 0.f;
+  }
+}
+
+// the (value | tangent) input tile of a 16-pair tile: value rows [t, s, z?, 0 ...], tangent rows d/ds = [0, 1, 0 ...]
+__device__ __forceinline__ void mres_write_x(const MArgs& a, float* X, int sx, int tile, float* slab) {
+  const int64_t p0 = (int64_t)tile * 16;
+  for (int e = threadIdx.x; e < 32 * 16; e += blockDim.x) {
+    const int r = e >> 4, c = e & 15;
+    float v = 0.f;
+    if (r < 16) {
+      const int64_t p = min(p0 + r, a.Np - 1);
+      v = c == 0 ? a.t[p] : (c == 1 ? a.s[p] : ((c == 2 && a.z) ? a.z[p] : 0.f));
+    } else {
+      v = c == 1 ? 1.f : 0.f;
+    }
+    X[r * sx + c] = v;
+    if (slab) slab[(r >> 4) * 256 + c * 16 + (r & 15)] = v;      // [h][unit][row16]
+  }
+}
+
+__host__ __device__ inline bool mres_ok(const MDesc& m) { return !m.wide && m.h0p <= 128 && m.h1p <= 128 && m.d2p <= 128; }
+__host__ __device__ inline int mres_fwd_lds_floats(const MDesc& m) { return 32 * (m.sx + m.s1 + m.s2); }
+__host__ __device__ inline int mres_bwd_lds_floats(const MDesc& m) { return 32 * (m.sx + m.s1 + m.s2 + 2 * m.so); }
+
+__global__ __launch_bounds__(512, 2) void mnet_forward_resident_kernel(const MArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MDesc& m = a.m;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = lane & 15, g = lane >> 4;
+  const int NB0 = m.h0p >> 4, NB1 = m.h1p >> 4, NB2 = m.d2p >> 4;
+  float* X = lds;
+  float* H1 = X + 32 * m.sx;
+  float* H2 = H1 + 32 * m.s1;
+  MResFrag w0, w1, w2;
+  mres_load(w0, a.packed, m.L[0], wave, lane);
+  mres_load(w1, a.packed, m.L[1], wave, lane);
+  mres_load(w2, a.packed, m.L[2], wave, lane);
+  const int n0 = 16 * wave + 4 * g;                         // this lane's four units of the wave's block
+  const f32x4 b0 = wave < NB0 ? ldg4(a.packed + m.L[0].b_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 b1 = wave < NB1 ? ldg4(a.packed + m.L[1].b_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 b2 = wave < NB2 ? ldg4(a.packed + m.L[2].b_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) mres_write_x(a, X, m.sx, tile, nullptr);
+  __syncthreads();
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    if (wave < NB0) {                                       // F1: H1 = relu-pair(L0 X + b)
+      f32x4 v = b0, t = zero;
+      mres_gemm(w0, 1, X + row * m.sx + 4 * g, m.sx, v, t);
+      mres_relu(v, t);
+      *reinterpret_cast<f32x4*>(H1 + row * m.s1 + n0) = v;
+      *reinterpret_cast<f32x4*>(H1 + (16 + row) * m.s1 + n0) = t;
+    }
+    __syncthreads();                                        // (A)
+    if (wave < NB1) {                                       // F2: H2 = relu-pair(L1 H1 + b)
+      f32x4 v = b1, t = zero;
+      mres_gemm(w1, NB0, H1 + row * m.s1 + 4 * g, m.s1, v, t);
+      mres_relu(v, t);
+      *reinterpret_cast<f32x4*>(H2 + row * m.s2 + n0) = v;
+      *reinterpret_cast<f32x4*>(H2 + (16 + row) * m.s2 + n0) = t;
+    }
+    // the next tile's inputs (X was last read in F1, in front of barrier A)
+    if (tile + (int)gridDim.x < a.ntiles) mres_write_x(a, X, m.sx, tile + gridDim.x, nullptr);
+    __syncthreads();                                        // (B)
+    if (wave < NB2) {                                       // F3: net | dnet = L2 (h2 | t2) + b, straight to HBM
+      f32x4 v = b2, t = zero;
+      mres_gemm(w2, NB1, H2 + row * m.s2 + 4 * g, m.s2, v, t);
+      MEpi e3{ME_OUT, lds, nullptr, -1, 0, 0, 0, nullptr, 0, a.net, a.dnet, m.d2, (int64_t)tile * 16, a.Np};
+      e3.fin(v, t, row, n0);
+    }
+    // (no barrier: F1 of the next tile writes H1, last read in front of B; F2 writes H2 behind the next A, which every wave
+    //  reaches only after its F3 reads)
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void mnet_backward_resident_kernel(const MArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MDesc& m = a.m;
+  const int lane = threadIdx.x & 63, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = lane & 15, g = lane >> 4;
+  const int NB0 = m.h0p >> 4, NB1 = m.h1p >> 4, NB2 = m.d2p >> 4;
+  float* X = lds;
+  float* H1 = X + 32 * m.sx;
+  float* GZ2 = H1 + 32 * m.s1;
+  float* Gb[2] = {GZ2 + 32 * m.s2, GZ2 + 32 * m.s2 + 32 * m.so};
+  const int64_t tile_rows = (int64_t)a.ntiles * 32;
+  MResFrag w0, w1, t2, t1;
+  mres_load(w0, a.packed, m.L[0], wave, lane);
+  mres_load(w1, a.packed, m.L[1], wave, lane);
+  mres_load(t2, a.packedT, m.LT[0], wave, lane);            // L2^T: d2p -> h1p
+  mres_load(t1, a.packedT, m.LT[1], wave, lane);            // L1^T: h1p -> h0p
+  const int n0 = 16 * wave + 4 * g;
+  const f32x4 b0 = wave < NB0 ? ldg4(a.packed + m.L[0].b_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 b1 = wave < NB1 ? ldg4(a.packed + m.L[1].b_off + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // upstream gradients of a tile: rows 0..15 d obj / d net, rows 16..31 d obj / d dnet (zero past Np and in the padding units)
+  auto load_g = [&](int tile, float* G) {
+    const int64_t p0 = (int64_t)tile * 16;
+    float* slG = a.ws + (size_t)tile_rows * m.pre[MT_GOUT] + (size_t)(2 * tile) * m.d2p * 16;
+    for (int e = tid; e < 32 * m.d2p; e += 512) {
+      const int r16 = e & 15, hc = e >> 4;
+      const int h = hc >= m.d2p ? 1 : 0, c = hc - h * m.d2p;
+      const float* src = h ? a.gdnet : a.gnet;
+      const float v = (p0 + r16 < a.Np && c < m.d2) ? src[(size_t)(p0 + r16) * m.d2 + c] : 0.f;
+      G[(h * 16 + r16) * m.so + c] = v;
+      slG[e] = v;
+    }
+  };
+  int tile = blockIdx.x, it = 0;
+  if (tile < a.ntiles) {
+    mres_write_x(a, X, m.sx, tile, a.ws + (size_t)tile_rows * m.pre[MT_X] + (size_t)(2 * tile) * 256);
+    load_g(tile, Gb[0]);
+  }
+  __syncthreads();
+  for (; tile < a.ntiles; tile += gridDim.x, ++it) {
+    float* G = Gb[it & 1];
+    unsigned m1 = 0, m2 = 0;
+    if (wave < NB0) {                                       // F1
+      f32x4 v = b0, t = zero;
+      mres_gemm(w0, 1, X + row * m.sx + 4 * g, m.sx, v, t);
+      m1 = mres_relu(v, t);
+      *reinterpret_cast<f32x4*>(H1 + row * m.s1 + n0) = v;
+      *reinterpret_cast<f32x4*>(H1 + (16 + row) * m.s1 + n0) = t;
+      float* sl = a.ws + (size_t)tile_rows * m.pre[MT_H1] + (size_t)(2 * tile) * m.h0p * 16;
+      export4_u(sl, row, n0, v);
+      export4_u(sl + (size_t)m.h0p * 16, row, n0, t);
+    }
+    __syncthreads();                                        // (A)
+    if (wave < NB1) {
+      {                                                     // F2: H2 leaves as a slab only (nothing downstream reads its tile)
+        f32x4 v = b1, t = zero;
+        mres_gemm(w1, NB0, H1 + row * m.s1 + 4 * g, m.s1, v, t);
+        m2 = mres_relu(v, t);
+        float* sl = a.ws + (size_t)tile_rows * m.pre[MT_H2] + (size_t)(2 * tile) * m.h1p * 16;
+        export4_u(sl, row, n0, v);
+        export4_u(sl + (size_t)m.h1p * 16, row, n0, t);
+      }
+      {                                                     // B1: (g_h2 | g_t2) = L2^T (g_net | g_dnet), masked by F2's sign
+        f32x4 v = zero, t = zero;
+        mres_gemm(t2, NB2, G + row * m.so + 4 * g, m.so, v, t);
+        mres_mask(m2, v, t);
+        *reinterpret_cast<f32x4*>(GZ2 + row * m.s2 + n0) = v;
+        *reinterpret_cast<f32x4*>(GZ2 + (16 + row) * m.s2 + n0) = t;
+        float* sl = a.ws + (size_t)tile_rows * m.pre[MT_GZ2] + (size_t)(2 * tile) * m.h1p * 16;
+        export4_u(sl, row, n0, v);
+        export4_u(sl + (size_t)m.h1p * 16, row, n0, t);
+      }
+    }
+    // the next tile's inputs: X was last read in F1 (in front of A), the other G buffer in B1 of the previous tile
+    const int nxt = tile + (int)gridDim.x;
+    if (nxt < a.ntiles) {
+      mres_write_x(a, X, m.sx, nxt, a.ws + (size_t)tile_rows * m.pre[MT_X] + (size_t)(2 * nxt) * 256);
+      load_g(nxt, Gb[(it + 1) & 1]);
+    }
+    __syncthreads();                                        // (B)
+    if (wave < NB0) {                                       // B2: (g_h1 | g_t1) = L1^T (gz2), masked by F1's sign: slab only
+      f32x4 v = zero, t = zero;
+      mres_gemm(t1, NB1, GZ2 + row * m.s2 + 4 * g, m.s2, v, t);
+      mres_mask(m1, v, t);
+      float* sl = a.ws + (size_t)tile_rows * m.pre[MT_GZ1] + (size_t)(2 * tile) * m.h0p * 16;
+      export4_u(sl, row, n0, v);
+      export4_u(sl + (size_t)m.h0p * 16, row, n0, t);
+    }
+  }
+}
+
 // ---- WIDE form (d*d outputs do not fit an LDS tile: BASELINE configs[4], d = 64) -----------------------------------------
 // Backward tile kernel: F1, F2 recomputed as above, then  (g_h2, g_t2) = L2^T (g_net, g_dnet)  with the reduction over the
 // d*d outputs SPLIT OVER THE (four) WAVES: wave w multiplies chunks [w KC / NW, (w+1) KC / NW) of all NOB = h1p / 16 output
@@ -2134,6 +2360,14 @@ extern "C" int socmx_mnet_forward_f32(const float* packed, int32_t d, const int3
     if (const int err = ensure_max_lds(mnet_forward_kernel<kK3WideWaves>)) return err;
     return launch(mnet_forward_kernel<kK3WideWaves>, dim3(a.ntiles), dim3(kK3WideWaves * 64), lds_bytes, stream, a);
   }
+  // (developer A/B switch, read once: SOCMX_K3_TILE=1 keeps the one-tile-per-workgroup kernels)
+  static const int tile_env = [] { const char* e = getenv("SOCMX_K3_TILE"); return e ? atoi(e) : 0; }();
+  if (mres_ok(a.m) && !tile_env) {
+    // persistent workgroups with register-resident weights: two per CU, tiles b, b + grid, ...
+    if (const int err = ensure_max_lds(mnet_forward_resident_kernel)) return err;
+    return launch(mnet_forward_resident_kernel, dim3(std::min(a.ntiles, 512)), dim3(512),
+                  (size_t)mres_fwd_lds_floats(a.m) * sizeof(float), stream, a);
+  }
   if (const int err = ensure_max_lds(mnet_forward_kernel<kK2Waves>)) return err;
   return launch(mnet_forward_kernel<kK2Waves>, dim3(a.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a);
 }
@@ -2227,8 +2461,15 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
                                      : launch(mnet_wgrad_wide_kernel<1, false>, dim3(wgrid), dim3(256), 0, stream, ga));
     if (err) return err;
   } else {
-    if (const int err = ensure_max_lds(mnet_backward_kernel<kK2Waves>)) return err;
-    if (const int err = launch(mnet_backward_kernel<kK2Waves>, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a)) return err;
+    static const int tile_env = [] { const char* e = getenv("SOCMX_K3_TILE"); return e ? atoi(e) : 0; }();
+    if (mres_ok(p.m) && !tile_env) {
+      if (const int err = ensure_max_lds(mnet_backward_resident_kernel)) return err;
+      if (const int err = launch(mnet_backward_resident_kernel, dim3(std::min(p.ntiles, 256)), dim3(512),
+                                 (size_t)mres_bwd_lds_floats(p.m) * sizeof(float), stream, a)) return err;
+    } else {
+      if (const int err = ensure_max_lds(mnet_backward_kernel<kK2Waves>)) return err;
+      if (const int err = launch(mnet_backward_kernel<kK2Waves>, dim3(p.ntiles), dim3(kK2Waves * 64), lds_bytes, stream, a)) return err;
+    }
   }
   // weight / bias gradient partials: kernel B over the 2 ntiles slab tiles (value, tangent alternating)
   WgradArgs wa{};
