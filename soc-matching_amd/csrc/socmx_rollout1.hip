@@ -36,6 +36,17 @@
 namespace socmx {
 
 constexpr int kR1Waves = 8;
+#ifndef SOCMX_R1_S2DIRECT
+#define SOCMX_R1_S2DIRECT 1
+#endif
+#ifndef SOCMX_R1_RES0_SLACK
+#define SOCMX_R1_RES0_SLACK 0
+#endif
+// stage 2 in the direct layout (round 6; developer A/B: -DSOCMX_R1_S2DIRECT=0).  configs[2]: 0.409 -> 0.386 ms per rollout call, A/B on one box
+constexpr bool R1_S2DIRECT = SOCMX_R1_S2DIRECT != 0;
+// res_0 [t, x] formed in wave 0's slack behind stage 4 instead of inside first_layer, on the serial section: measured, NO gain
+// (0.391 against 0.385 ms: the slack is not free -- a longer low-priority section makes wave 0 the last one at that barrier): off
+constexpr bool R1_RES0_SLACK = SOCMX_R1_RES0_SLACK != 0;
 constexpr int kR1Blocks = 20;   // main-program blocks per wave and step
 constexpr int kR1PD = 2;        // ring depth (blocks)
 
@@ -226,6 +237,17 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #pragma unroll
   for (int r = 0; r < NRES; ++r) {
     const int rb = r1_nth(CLS, DMX, 'R', r);            // (a constant once the loop is unrolled)
+    if (R1_S2DIRECT && rb == 4) {
+      // down_2's block in the DIRECT layout (round 6): lane (g, n), register j = W[unit 16 g + n][input 16 w + j] -- the row index
+      // picks the unit block, the broadcast position the input.  The operand is then the wave's r2 outputs as they are (y: position
+      // n of EVERY row = r2[16 w + n]) and lane (g, n) ends with the whole sum of unit 16 g + n: no cross-lane gather in front of
+      // the fmacs (it was a ds_bpermute round trip on the step's chain), no cross-row reduction behind them.  In the fragment
+      // image that element sits in fragment (nb = g, kc = w) at lane ((j >> 2), n), component j & 3: sixteen 4-byte reads, once.
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        wres[r][j] = Wp[u.L[2].w_off + (((g * (u.L[2].in_pad >> 4) + wave) * 64) + (j >> 2) * 16 + n) * 4 + (j & 3)];
+      continue;
+    }
     const f32x4* src = reinterpret_cast<const f32x4*>(Wp + r1_block_off<NET>(rb, wave)) + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -503,6 +525,17 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       pre_se = eps;
     }
   };
+  // res_0 [t_k, x_k] + b, the skip term of the evaluation UNDER WAY (added behind the network's last ReLU): eleven multiply-adds that
+  // sat in first_layer, on the serial section every other wave waits for; wave 0 now forms them in its slack behind stage 4
+  // (x is still x_k there, t_k was kept when first_layer ran)
+  float res_t = 0.f;
+  auto res0_update = [&]() {
+    if constexpr (R1_RES0_SLACK && H == 1 && CLS == 0) {
+      float r0 = b3 + res_t * w3[0], r1v = 0.f;
+      r1_state_one<DMAX>(r0, r1v, x, &w3[1]);
+      res0 = r0 + r1v;
+    }
+  };
   // y[unit] = relu(down_0 [t, x] + b) for the 256 units, lane-ordered into LDS (wave 0); res_0 [t, x] + b for the step's end
   auto first_layer = [&](float t) {
     if constexpr (H == 2) {
@@ -514,7 +547,8 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       }
       return;
     }
-    float acc[4], r0 = b3 + t * w3[0], r1v = 0.f;
+    float acc[4];
+    [[maybe_unused]] float r0 = b3 + t * w3[0], r1v = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = b0[m] + t * w0[m][0];
     if constexpr (DMAX <= 11) {
@@ -528,8 +562,12 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       r1_state_one<DMAX>(acc[3], e3, x, &w0[3][1]);
       acc[0] += e0; acc[1] += e1; acc[2] += e2; acc[3] += e3;
     }
-    r1_state_one<DMAX>(r0, r1v, x, &w3[1]);
-    res0 = r0 + r1v;
+    if constexpr (!R1_RES0_SLACK) {
+      r1_state_one<DMAX>(r0, r1v, x, &w3[1]);
+      res0 = r0 + r1v;
+    } else {
+      res_t = t;                               // (res_0 [t, x] + b is formed in the slack of the evaluation that uses it: res0_update)
+    }
     f32x4 y;
 #pragma unroll
     for (int m = 0; m < 4; ++m) y[m] = relu_keep_nan(acc[m]);
@@ -747,12 +785,20 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       // stage 2 without a barrier of its own: down_2 is linear in r2, so the wave multiplies ITS 16 outputs into all 64
       // units right away (block 4: unit blocks 0..3 x input chunk w) and stage 3 adds the eight waves' partial sums.
       // Row g of the operand register holds r2[16 w + 4 g + (p & 3)] at every position p: one cross-lane gather.
+      if constexpr (R1_S2DIRECT) {
+        float c0 = 0.f, c1 = 0.f;
+        pre(R1NX(5, 1));                        // (stage 3's first block, if it is an LDS block: read behind these fmacs)
+        r1_fmac8<0>(c0, c1, y, wres[r1_count(CLS, DMX, 'R', 4)]);
+        r1_fmac8<1>(c0, c1, y, wres[r1_count(CLS, DMX, 'R', 4)] + 8);
+        lds[LM::p2 + wave * 64 + lane] = c0 + c1;                           // lane (g, n): unit 16 g + n
+      } else {
       const float x4 = __shfl(y, (lane & 48) + 4 * g + (lane & 3));
       float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
       pre(R1NX(5, 1));                          // (stage 3's first block, if it is an LDS block: read behind these fmacs)
       r1_fmac16_4acc(c0, c1, c2, c3, x4, wres[r1_count(CLS, DMX, 'R', 4)]);
       const float tsum = r1_reduce4(c0, c1, c2, c3);                         // lane (g, n): unit 16 {0, 2, 1, 3}[g] + n
       lds[LM::p2 + wave * 64 + 16 * (((g & 1) << 1) | (g >> 1)) + n] = tsum;
+      }
     }
     R1_TICK(1)
     __syncthreads();
@@ -837,6 +883,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     // (closing the books in stage 3's slack instead was measured: 0.454 ms against 0.437 -- at the lowest priority the
     //  ~450-cycle chain of LDS reads and row sums outlasts that slack, and wave 0 becomes the wave stage 3 waits for)
     if constexpr (CLS == 0) {
+      res0_update();
       bookkeeping();
       prepare_step(cur_k);
     } else {
