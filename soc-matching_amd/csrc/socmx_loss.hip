@@ -843,6 +843,24 @@ __device__ __forceinline__ float async_load4(const void* sbase, uint32_t voff) {
 }
 
 constexpr int kStageWaves = 4;
+// LDS ring of the staged pair-matrix tiles and the barrier period: ONE barrier per kPeriod iterations, ring = 2 kPeriod stages.
+// Round 6 measured periods 2 / 4 / 6 (-DSOCMX_TARGET_PERIOD) and the three wave classes' issue priorities (-DSOCMX_TARGET_PRIO_*) at
+// the configs[4] slice: 5.98 / 5.98 / 7.25 ms, and every priority assignment within 1 % -- an iteration costs the SIMD ~4,600 cycles
+// for 4,096 of MFMA issue whoever waits for whom (profiles/r6/contraction_period.txt, contraction_prio.txt; tools/experiments/contraction)
+#ifndef SOCMX_TARGET_PERIOD
+#define SOCMX_TARGET_PERIOD 2
+#endif
+constexpr int kPeriod = SOCMX_TARGET_PERIOD, kRing = 2 * kPeriod;
+// issue priorities (s_setprio) of the three wave classes: staging waves / first multiplying wave of a SIMD / second one
+#ifndef SOCMX_TARGET_PRIO_STAGE
+#define SOCMX_TARGET_PRIO_STAGE 0
+#endif
+#ifndef SOCMX_TARGET_PRIO_MUL0
+#define SOCMX_TARGET_PRIO_MUL0 0
+#endif
+#ifndef SOCMX_TARGET_PRIO_MUL1
+#define SOCMX_TARGET_PRIO_MUL1 0
+#endif
 #ifdef SOCMX_CONTRACTION_PROF
 __device__ long long g_contraction_prof[kTargetWaves][4];
 #endif
@@ -851,7 +869,7 @@ template <bool NET, int KB>
 __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target_lds4_kernel(const TargetArgs a) {
   constexpr int CT = 2, ROWS = KB * 16;
   constexpr int NA = NET ? 3 : 2;            // requests per A prefetch: net piece, dnet piece [, delta]
-  __shared__ __attribute__((aligned(16))) float As[4][2][ROWS][kAStride];
+  __shared__ __attribute__((aligned(16))) float As[kRing][2][ROWS][kAStride];
   const int d = a.d, K = a.K, B = a.B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -860,9 +878,10 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
   const int dd = d * d;
   const int i = blockIdx.x;                  // one row per workgroup, longest rows first
   const int nit = (K - i + 1) * nlb;
-  const int nitp = (nit + 3) / 4 * 4;        // trips are unrolled by four (request slots and LDS stages: rings of four)
+  const int nitp = (nit + kRing - 1) / kRing * kRing;   // trips are unrolled by the ring length (request slots and LDS stages)
   const int lb_end = 16 * nlb;
   if (wave >= kTargetWaves) {
+    __builtin_amdgcn_s_setprio(SOCMX_TARGET_PRIO_STAGE);
     // ---- staging waves: thread = (row ak, 16-byte piece aq) of the 16-column tile, both tensors ----
     // (every instruction here costs about one MFMA time: scalar bookkeeping is kept to one cursor whose per-request state
     //  travels with the request slot, 32-bit offsets against per-row base pointers, one hazard nop per request group)
@@ -936,38 +955,36 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
       }
     };
 #define SOCMX_WAIT_A(N, P) asm volatile("s_waitcnt vmcnt(%3)" : "+v"((P).nt), "+v"((P).dn), "+v"((P).dl) : "n"(N) : "memory")
-    APend pend[4];
+    APend pend[kRing];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pend[u].dl = 0.f;
-    // ONE barrier per TWO iterations (period p = iterations 2p, 2p+1).  During period p the multiplying waves read the
-    // fragments of 2p+1 and 2p+2 (the fragments of 2p are in registers since the end of 2p-1), so those stages were written
-    // during period p-1, and this period writes the stages of 2p+3 and 2p+4 -- the ring of four holds exactly these (stage of
-    // 2p+4 = stage of 2p, whose reads were issued before this period's barrier).
-    // prologue: stages 0, 1, 2 staged synchronously, then A(3) .. A(6) in flight (slots 3, 0, 1, 2)
-    issueA(pend[0]);
-    issueA(pend[1]);
-    issueA(pend[2]);
-    SOCMX_WAIT_A(0, pend[0]);
-    SOCMX_WAIT_A(0, pend[1]);
-    SOCMX_WAIT_A(0, pend[2]);
-    stageA(pend[0], 0);
-    stageA(pend[1], 1);
-    stageA(pend[2], 2);
-    issueA(pend[3]);
-    issueA(pend[0]);
-    issueA(pend[1]);
-    issueA(pend[2]);
-    __syncthreads();                             // stages 0, 1, 2 visible
-    for (int it0 = 0; it0 < nitp; it0 += 4) {
+    for (int u = 0; u < kRing; ++u) pend[u].dl = 0.f;
+    // ONE barrier per kPeriod iterations (period p = iterations P p .. P p + P - 1).  During period p the multiplying waves read
+    // the fragments of P p + 1 .. P p + P (those of P p are in registers since the end of P p - 1), so those stages were written
+    // during period p - 1, and this period writes the stages of P p + P + 1 .. P p + 2 P -- the ring of 2 P holds exactly these
+    // (stage of P p + 2 P = stage of P p, whose reads were issued before this period's barrier).  Request slot of iteration t:
+    // t % (2 P); a slot's request is issued 2 P iterations ahead of its staging (2 P - 1 younger requests in flight at the wait).
+    // prologue: stages 0 .. P staged synchronously, then A(P + 1) .. A(3 P) in flight
 #pragma unroll
-      for (int u = 0; u < 4; u += 2) {           // it = it0 + u: an even iteration opens a period
+    for (int u = 0; u <= kPeriod; ++u) issueA(pend[u]);
+#pragma unroll
+    for (int u = 0; u <= kPeriod; ++u) SOCMX_WAIT_A(0, pend[u]);
+#pragma unroll
+    for (int u = 0; u <= kPeriod; ++u) stageA(pend[u], u);
+#pragma unroll
+    for (int u = kPeriod + 1; u <= 3 * kPeriod; ++u) issueA(pend[u % kRing]);
+    __syncthreads();                             // stages 0 .. P visible
+    for (int it0 = 0; it0 < nitp; it0 += kRing) {
+#pragma unroll
+      for (int u = 0; u < kRing; u += kPeriod) {   // it = it0 + u opens a period
         __syncthreads();
-        SOCMX_WAIT_A(3 * NA, pend[(u + 3) % 4]); // younger than A(it+3): A(it+4) A(it+5) A(it+6)
-        stageA(pend[(u + 3) % 4], (u + 3) % 4);  // iteration it+3
-        issueA(pend[(u + 3) % 4]);               // iteration it+7
-        SOCMX_WAIT_A(3 * NA, pend[u % 4]);       // younger than A(it+4): A(it+5) A(it+6) A(it+7)
-        stageA(pend[u % 4], u % 4);              // iteration it+4 -> the stage that held it
-        issueA(pend[u % 4]);                     // iteration it+8
+#pragma unroll
+        for (int v = 1; v <= kPeriod; ++v) {
+          constexpr int dummy = 0; (void)dummy;
+          const int sl = (u + kPeriod + v) % kRing;            // iteration it + P + v
+          SOCMX_WAIT_A((kRing - 1) * NA, pend[sl]);            // younger: the 2 P - 1 requests issued after it
+          stageA(pend[sl], sl);
+          issueA(pend[sl]);                                    // iteration it + 3 P + v
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-fetched requests of the last trips
@@ -975,6 +992,7 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
     return;
   }
   // ---- multiplying waves ----
+  if (wave < 4) __builtin_amdgcn_s_setprio(SOCMX_TARGET_PRIO_MUL0); else __builtin_amdgcn_s_setprio(SOCMX_TARGET_PRIO_MUL1);
   const int c16 = lane & 15, g4 = lane >> 4;
   int mcol[CT];
   uint32_t blane[CT], blane_last[CT];        // byte offset of this lane's piece relative to (operand row block + l-block)
@@ -1062,7 +1080,7 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
   BSlot bs[4];
 #pragma unroll
   for (int u = 0; u < 3; ++u) { requestB(bs[u]); advanceB(); }
-  __syncthreads();                               // stages 0, 1, 2 visible
+  __syncthreads();                               // stages 0 .. P visible
   readM(0);
   readD(0);
   // developer switch (tools/ubench/contraction_bench.hip builds this file with it): per-wave cycle counters of the three
@@ -1074,14 +1092,15 @@ __global__ __launch_bounds__(64 * (kTargetWaves + kStageWaves)) void socm_target
 #else
 #define TICK(k)
 #endif
-  for (int it0 = 0; it0 < nitp; it0 += 4) {
+  static_assert(kRing % 4 == 0, "the B request ring (four slots) and the stage ring advance together");
+  for (int it0 = 0; it0 < nitp; it0 += kRing) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if ((u & 1) == 0) __syncthreads();         // (it = it0 + u) one barrier per two iterations: see the staging waves
+    for (int u = 0; u < kRing; ++u) {
+      if (u % kPeriod == 0) __syncthreads();     // (it = it0 + u) one barrier per period: see the staging waves
       TICK(0)
-      SOCMX_WAIT_B(8, bs[u]);                    // younger than B(it): B(it+1) B(it+2)
+      SOCMX_WAIT_B(8, bs[u % 4]);                // younger than B(it): B(it+1) B(it+2)
       TICK(1)
-      iteration(bs[u], bs[(u + 3) % 4], (u + 1) % 4);
+      iteration(bs[u % 4], bs[(u + 3) % 4], (u + 1) % kRing);
       TICK(2)
     }
   }

@@ -21,9 +21,10 @@ int main(int argc, char** argv) {
   float *net = dev_rand(np * dd, 0.1f, 1), *dnet = dev_rand(np * dd, 0.1f, 2), *delta = dev_rand(np, 0.5f, 3);
   float *q = dev_rand((size_t)K * B * d, 1.f, 4), *v = dev_rand((size_t)K * B * d, 1.f, 5), *gT = dev_rand((size_t)B * d, 1.f, 6);
   float *nV = dev_rand((size_t)(K + 1) * B * d, 1.f, 7), *w = dev_rand(B, 0.2f, 8), *sig = dev_rand(dd, 0.1f, 9);
-  float *target, *G, *obj, *gM, *gdM, *ggp, *gam;
+  float *target, *G, *obj, *gM, *gdM, *ggp, *gam, *ows;
   hipMalloc(&target, (size_t)(K + 1) * B * d * 4); hipMalloc(&G, (size_t)(K + 1) * B * d * 4); hipMalloc(&obj, 4);
   hipMalloc(&gM, np * dd * 4); hipMalloc(&gdM, np * dd * 4);
+  { const size_t nws = (size_t)socmx_socm_objective_workspace_floats(K, B); hipMalloc(&ows, nws * 4); hipMemset(ows, 0, nws * 4); }
   const int nb = (d + 15) / 16;
   hipMalloc(&ggp, np * nb * nb * 4); hipMalloc(&gam, 4);
   const float g1 = 2.f; hipMemcpy(gam, &g1, 4, hipMemcpyHostToDevice);
@@ -34,7 +35,7 @@ int main(int argc, char** argv) {
     float ms = 0.f;
     for (int r = 0; r <= reps; ++r) {
       if (r == 1) hipEventRecord(e0, 0);
-      int st = pass == 0 ? socmx_socm_target_fwd_net_f32(&pb, K, B, net, dnet, delta, gam, q, v, gT, nV, w, 1e-3f, target, G, obj, 0)
+      int st = pass == 0 ? socmx_socm_target_fwd_net_f32(&pb, K, B, net, dnet, delta, gam, q, v, gT, nV, w, 1e-3f, target, G, obj, ows, 0)
                          : socmx_socm_target_bwd_net_f32(d, K, B, G, q, v, gT, nullptr, net, dnet, delta, gam, gM, gdM, ggp, 0);
       if (st) { printf("status %d\n", st); return 1; }
     }
