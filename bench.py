@@ -82,7 +82,7 @@ def build(device, setting=SETTING, d=D, num_steps=NUM_STEPS, gamma=GAMMA, batch=
     return cfg, ts, x0, sde, solver
 
 
-def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_dist, row0, defer_graph=False):
+def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_dist, row0, defer_graph=False, shard=None):
     """Rollout and full-iteration timings of another BASELINE configuration (driver-timed secondary entries: the
     headline `value` stays configs[2])."""
     from socmx import rollout
@@ -101,7 +101,7 @@ def secondary_config(device, label, setting, d, K, B, gamma, steps, warmup, use_
     roll_ms = e0.elapsed_time(e1) / steps
     if use_dist:
         from socmx import dist as sdist
-        solver.shard = sdist.Shard()
+        solver.shard = shard if shard is not None else sdist.Shard()     # (one Shard = one pair of RCCL communicators per process)
     world = dist.get_world_size() if use_dist else 1
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
     def time_iterations(graph):
@@ -219,14 +219,17 @@ def cpu_iteration_baseline(pb, vp, ts, d, K, B):
     faithful dense SOCM loss (the zero-filled (K+1, K+1, B, d, d) einsums of method.py:591-631 and functorch.jacrev for the
     s-derivative, method.py:510-515: ~10 GB at this size), backward, Adam step (main.py:280-352) -- at configs[2]'s own size
     when the host has the memory for it, else on a quarter of the rows (said in the sample text).  One timed iteration, no
-    warm-up (it is 10-30 s of CPU work); threads = min(host CPUs, 32): unlike the rollout this path is bandwidth-bound."""
+    warm-up (it is 10-30 s of CPU work); threads = min(host CPUs, 8): the calibrated setting (see below)."""
     from oracle import socm_oracle as O
     try:
         avail_gb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")) / 2 ** 20
     except Exception:
         avail_gb = 0.0
     rows = B if avail_gb >= 48 else B // 4
-    threads = max(1, min(os.cpu_count() or 1, 32))
+    # 8 threads: the thread count the oracle's iteration was calibrated at against the reference's own (authoring container,
+    # tests/golden/calibrate_cpu_iteration.py: oracle / reference = 1.14 at 8 threads and B = 128 -- inside SURVEY section 8d's
+    # +-15 %; 0.73 at 1 thread).  Rounds 4-5 timed this leg at 32 threads, where no ratio was ever measured.
+    threads = max(1, min(os.cpu_count() or 1, 8))
     torch.set_num_threads(threads)
     try:
         from socmx.nets import SigmoidMLP
@@ -250,8 +253,10 @@ def cpu_iteration_baseline(pb, vp, ts, d, K, B):
                 socm_sample=f"1 iteration (dense SOCM loss with jacrev + backward + Adam; oracle eager torch-CPU, {threads} threads) of "
                             f"double_well d=10 K=200 B={rows}" + ("" if rows == B else f" -- a QUARTER of configs[2]'s {B} rows: the "
                             f"host reports {avail_gb:.0f} GB available, the full size needs ~25 GB with its backward") +
-                            "; the oracle's iteration costs 0.7-1.1x the reference's own on the same CPU "
-                            "(tests/golden/calibrate_cpu_iteration.py, BASELINE.md section 4)")
+                            f"; calibrated in the authoring container at this thread count: the oracle's iteration costs 1.14x the "
+                            "reference's own at 8 threads and B = 128 (0.73x at 1 thread: tests/golden/calibrate_cpu_iteration.py, "
+                            "profiles/r6/calibrate_cpu_iteration.txt, BASELINE.md section 4); with a GPU / CPU gap of four orders of "
+                            "magnitude the ratio changes no conclusion")
 
 
 def launch_command(args, port, environ=None):
@@ -415,8 +420,9 @@ def main():
     value = world * B * K * args.steps / elapsed
 
     # ---- metric 2: full SOCM iterations ----------------------------------------------------------
+    shard = sdist.Shard() if use_dist else None      # (backend nccl: brings up the package's own RCCL communicators, socmx/rccl.py)
     if use_dist:
-        solver.shard = sdist.Shard()
+        solver.shard = shard
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
     it_steps, it_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
 
@@ -500,7 +506,7 @@ def main():
                       "OU_quadratic_easy", 2, 50, 128, 2.0, 4 * n2, 3, use_dist, rank * 128),
                      ("OU_linear d=64 num_steps=400 batch=512/GPU SOCM (one GPU's slice of BASELINE configs[4])",
                       "OU_linear", 64, 400, 512, 2.0, n2, 2, use_dist, rank * 512)):
-            entry, leg = secondary_config(device, *spec, defer_graph=defer_graph)
+            entry, leg = secondary_config(device, *spec, defer_graph=defer_graph, shard=shard)
             secondary.append(entry)
             if leg is not None:
                 graph_legs.append(leg)
@@ -540,6 +546,7 @@ def main():
             "timed_blocks": len(blocks), "block_ms_min_median_max": [1e3 * min(blocks), 1e3 * elapsed, 1e3 * max(blocks)],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+            "shard_transport": None if shard is None else shard.transport,
             "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in rank_devices}),
             "config": {"workload": "double_well d=10 num_steps=200 batch=128/GPU SOCM (BASELINE configs[2]; "
                                    "global batch 128*N)", "step": "one stochastic_trajectories call (full 8-tuple)",
