@@ -124,3 +124,20 @@ def test_variant_library_loads_in_concurrent_processes():
     for p in procs:
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0 and "ok" in out, err[-1500:]
+
+
+def test_rccl_binding_loads_torchs_library_and_exports_what_it_binds():
+    """socmx/rccl.py (the shard's own communicators) binds the librccl.so torch itself is linked against -- one RCCL per
+    process -- and every entry point it declares is there (no communicator is created without a GPU: symbols and version only)."""
+    import torch
+    from socmx import rccl
+    path = rccl.library_path()
+    assert os.path.exists(path) and os.path.dirname(path) == os.path.join(os.path.dirname(torch.__file__), "lib"), path
+    L = rccl.lib()
+    for name in ("ncclGetVersion", "ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommGetAsyncError",
+                 "ncclAllReduce", "ncclAllGather", "ncclGetErrorString"):
+        assert hasattr(L, name), name
+    v = rccl.version()
+    assert v >= 21800, v                       # NCCL_VERSION_CODE: 2.18 or newer (graph capture of collectives)
+    assert rccl._DTYPES[torch.float32] == 7 and rccl._OPS["sum"] == 0 and rccl._OPS["min"] == 3      # nccl.h enums
+    assert b"unhandled" in L.ncclGetErrorString(1).lower() or L.ncclGetErrorString(1)            # a string comes back
