@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 147 /* 0.1.9: the objective is summed without float atomics -- socmx_socm_target_fwd_f32 / _fwd_net_f32 / socmx_socm_residual_f32 take a caller-owned workspace (socmx_socm_objective_workspace_floats); socmx_shard_stats_f32 carries per-rank (n, mean, M2) slots instead of shifted sums; 0.1.8: + socmx_weights_stats_scalars_f32; 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
+#define SOCMX_VERSION 148 /* 0.2.0: + socmx_iteration_scalars_hist_f32, socmx_adam_step_scalars_hist_f32 (the iteration's scalars also land in row `itr` of a history array); 0.1.9: the objective is summed without float atomics -- socmx_socm_target_fwd_f32 / _fwd_net_f32 / socmx_socm_residual_f32 take a caller-owned workspace (socmx_socm_objective_workspace_floats); socmx_shard_stats_f32 carries per-rank (n, mean, M2) slots instead of shifted sums; 0.1.8: + socmx_weights_stats_scalars_f32; 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -459,6 +459,13 @@ int socmx_socm_stopping_target_bwd_f32(int32_t d, int32_t K, int32_t B, const fl
 int socmx_iteration_scalars_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
                                 const float* w_std, const float* obj, const float* gn, const float* gne,
                                 double c_norm, double c_grad, float* ab, float* out, socmx_stream_t stream);
+/* The same with a HISTORY: phase 1 also writes out[0..6] and extra[0] (0 if extra is NULL) into row itr of hist (hist_rows, 8) while
+ * itr < hist_rows -- the iteration's values stay where they were written (main.py keeps every iteration's loss, weight statistics
+ * and telemetry, main.py:398-413), so a replayed hipGraph's static `out` needs no device copy between two replays.  hist NULL: as above. */
+int socmx_iteration_scalars_hist_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
+                                     const float* w_std, const float* obj, const float* gn, const float* gne,
+                                     double c_norm, double c_grad, float* ab, float* out, float* hist, int32_t hist_rows,
+                                     const float* extra, socmx_stream_t stream);
 
 /*
  * Adam update of one parameter group from a FLAT gradient buffer, fused with the gradient telemetry of main.py:325-345:
@@ -493,6 +500,12 @@ int socmx_adam_step_scalars_f32(const socmx_adam_tensor* tensors, int32_t ntenso
                                 float* ema_grad, float* itr, double c_grad, float lr, float beta1, float beta2, float eps,
                                 float* scratch, float* sums_out, float* norm, float* ema_gn, const float* w_mean,
                                 const float* w_std, const float* obj, double c_norm, float* out, socmx_stream_t stream);
+/* ... and with the history of socmx_iteration_scalars_hist_f32 */
+int socmx_adam_step_scalars_hist_f32(const socmx_adam_tensor* tensors, int32_t ntensors, int64_t total, const float* grad,
+                                     float* ema_grad, float* itr, double c_grad, float lr, float beta1, float beta2, float eps,
+                                     float* scratch, float* sums_out, float* norm, float* ema_gn, const float* w_mean,
+                                     const float* w_std, const float* obj, double c_norm, float* out, float* hist,
+                                     int32_t hist_rows, const float* extra, socmx_stream_t stream);
 
 /*
  * Column sums of a tall row-major (R, C) matrix: out[c] = sum_r x[r][c].  Bias gradients of the nn.Linear layers

@@ -2087,6 +2087,11 @@ struct ScalarArgs {
   const float *w_mean, *w_std, *obj, *gn, *gne;
   float c_norm, one_minus_c_norm, warm_norm, c_grad, one_minus_c_grad, warm_grad;
   float *ab, *out;
+  // history (nullable): row itr of a (hist_rows, 8) device array also receives out[0..6] and extra[0] (column 7): the values of
+  // every iteration stay where they were written, so the host needs no copy of `out` between two replays of a captured iteration
+  float* hist;
+  int hist_rows;
+  const float* extra;
 };
 
 __device__ __forceinline__ float ema_update(float v, float ema, float c, float omc, float warm, float itr) {
@@ -2107,6 +2112,12 @@ __device__ __forceinline__ void iteration_scalars_phase1(const ScalarArgs& a, fl
   a.out[4] = ema_gn;
   a.out[5] = gne;
   a.out[6] = norm;                                         // the normaliser this iteration used
+  if (a.hist && itr < (float)a.hist_rows) {
+    float* h = a.hist + 8 * (int)itr;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) h[c] = a.out[c];
+    h[7] = a.extra ? a.extra[0] : 0.f;
+  }
   a.norm[0] = ema_update(a.w_mean[0], norm, a.c_norm, a.one_minus_c_norm, a.warm_norm, itr);   // main.py:354-359
   a.itr[0] = itr + 1.f;
 }
@@ -2251,6 +2262,17 @@ extern "C" int socmx_adam_step_scalars_f32(const socmx_adam_tensor* tensors, int
                                            float eps, float* scratch, float* sums_out, float* norm, float* ema_gn,
                                            const float* w_mean, const float* w_std, const float* obj, double c_norm, float* out,
                                            socmx_stream_t stream) {
+  return socmx_adam_step_scalars_hist_f32(tensors, ntensors, total, grad, ema_grad, itr, c_grad, lr, beta1, beta2, eps, scratch,
+                                          sums_out, norm, ema_gn, w_mean, w_std, obj, c_norm, out, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int socmx_adam_step_scalars_hist_f32(const socmx_adam_tensor* tensors, int32_t ntensors, int64_t total, const float* grad,
+                                                float* ema_grad, float* itr, double c_grad, float lr, float beta1, float beta2,
+                                                float eps, float* scratch, float* sums_out, float* norm, float* ema_gn,
+                                                const float* w_mean, const float* w_std, const float* obj, double c_norm,
+                                                float* out, float* hist, int32_t hist_rows, const float* extra,
+                                                socmx_stream_t stream) {
+  if (hist && hist_rows < 1) return SOCMX_E_DIM;
   if (!tensors || !grad || !scratch || !sums_out || !itr || !norm || !w_mean || !w_std || !obj || !out || (ema_grad && !ema_gn))
     return SOCMX_E_NULL;
   if (ntensors < 1 || ntensors > 64 || total < 1 || !(c_grad > 0.0) || !(c_norm > 0.0)) return SOCMX_E_DIM;
@@ -2263,6 +2285,7 @@ extern "C" int socmx_adam_step_scalars_f32(const socmx_adam_tensor* tensors, int
   ScalarArgs& q = a.post;
   q = ScalarArgs{};
   q.phase = 1; q.itr = itr; q.norm = norm; q.ema_gn = ema_gn; q.w_mean = w_mean; q.w_std = w_std; q.obj = obj; q.out = out;
+  q.hist = hist; q.hist_rows = hist_rows; q.extra = extra;
   q.c_norm = (float)c_norm; q.one_minus_c_norm = (float)(1.0 - c_norm); q.warm_norm = (float)(int)floor(1.0 / c_norm);
   q.c_grad = (float)c_grad; q.one_minus_c_grad = (float)(1.0 - c_grad); q.warm_grad = (float)(int)floor(1.0 / c_grad);
   const unsigned blocks = (unsigned)((total + kAdamPerBlock - 1) / kAdamPerBlock);
@@ -2272,12 +2295,22 @@ extern "C" int socmx_adam_step_scalars_f32(const socmx_adam_tensor* tensors, int
 extern "C" int socmx_iteration_scalars_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
                                            const float* w_std, const float* obj, const float* gn, const float* gne,
                                            double c_norm, double c_grad, float* ab, float* out, socmx_stream_t stream) {
+  return socmx_iteration_scalars_hist_f32(phase, itr, norm, ema_gn, w_mean, w_std, obj, gn, gne, c_norm, c_grad, ab, out, nullptr, 0,
+                                          nullptr, stream);
+}
+
+extern "C" int socmx_iteration_scalars_hist_f32(int32_t phase, float* itr, float* norm, float* ema_gn, const float* w_mean,
+                                                const float* w_std, const float* obj, const float* gn, const float* gne,
+                                                double c_norm, double c_grad, float* ab, float* out, float* hist,
+                                                int32_t hist_rows, const float* extra, socmx_stream_t stream) {
   if (!itr) return SOCMX_E_NULL;
+  if (hist && hist_rows < 1) return SOCMX_E_DIM;
   if (phase == 0 ? !ab : (!norm || !w_mean || !w_std || !obj || !out || (gn && !ema_gn))) return SOCMX_E_NULL;
   if (!(c_norm > 0.0) || !(c_grad > 0.0)) return SOCMX_E_DIM;
   ScalarArgs a;
   a.phase = phase; a.itr = itr; a.norm = norm; a.ema_gn = ema_gn; a.w_mean = w_mean; a.w_std = w_std; a.obj = obj;
   a.gn = gn; a.gne = gne; a.ab = ab; a.out = out;
+  a.hist = hist; a.hist_rows = hist_rows; a.extra = extra;
   a.c_norm = (float)c_norm; a.one_minus_c_norm = (float)(1.0 - c_norm); a.warm_norm = (float)(int)floor(1.0 / c_norm);
   a.c_grad = (float)c_grad; a.one_minus_c_grad = (float)(1.0 - c_grad); a.warm_grad = (float)(int)floor(1.0 / c_grad);
   return launch(iteration_scalars_kernel, dim3(1), dim3(64), 0, stream, a);

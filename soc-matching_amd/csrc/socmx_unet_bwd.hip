@@ -971,8 +971,19 @@ __global__ __launch_bounds__(256) void unet_unfold_kernel(const UnfoldArgs a) {
     const int kb = blockIdx.x % ((h0 + 63) / 64), mb = blockIdx.x / ((h0 + 63) / 64);
     const int k = kb * 64 + (threadIdx.x & 63), m = mb * 4 + (threadIdx.x >> 6);
     if (k < h0 && m < h0) {
+      // (all 2 d operands requested before the first multiply-add: a rolled loop ran d dependent round trips -- 10 us at d = 10)
       float acc = 0.f;
-      for (int n = 0; n < d; ++n) acc = fmaf(image_w(a.packed, a.u.L[8], n, m), G[(size_t)n * h0 + k], acc);
+      for (int n0 = 0; n0 < d; n0 += 8) {
+        float wv[8], gv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int n = min(n0 + j, d - 1);
+          wv[j] = image_w(a.packed, a.u.L[8], n, m);
+          gv[j] = G[(size_t)n * h0 + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf(n0 + j < d ? wv[j] : 0.f, gv[j], acc);
+      }
       a.grads[a.gw4 + (int64_t)m * h0 + k] = acc;
     }
     if (kb == 0 && (threadIdx.x & 63) == 0 && m < h0) {
@@ -986,8 +997,19 @@ __global__ __launch_bounds__(256) void unet_unfold_kernel(const UnfoldArgs a) {
   const int b = blockIdx.x - nb1, mblocks = (h0 + 15) / 16;
   const int n = b / mblocks, m = (b % mblocks) * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
   float acc = 0.f;
-  if (m < h0)
-    for (int k = part; k < h0; k += 16) acc = fmaf(G[(size_t)n * h0 + k], image_w(a.packed, a.u.L[4], m, k), acc);
+  if (m < h0) {
+    for (int k0 = part; k0 < h0; k0 += 16 * 8) {          // (eight terms' operands in flight at a time)
+      float gv[8], wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = min(k0 + 16 * j, h0 - 1);
+        gv[j] = G[(size_t)n * h0 + k];
+        wv[j] = image_w(a.packed, a.u.L[4], m, k);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf(k0 + 16 * j < h0 ? gv[j] : 0.f, wv[j], acc);
+    }
+  }
   red[part][threadIdx.x & 15] = acc;
   __syncthreads();
   if (part == 0 && m < h0) {

@@ -102,7 +102,8 @@ def run(cfg):
     trainer = Trainer(solver, optimizer, B, normalization_const=normalization_const, algorithm=algorithm,
                       gemm_select=bool(backend.get("gemm_select", False)),
                       tune_new_shapes=bool(backend.get("tune_new_shapes", False)),
-                      hip_graph=_graph_mode(backend.get("hip_graph", True)), log=log)
+                      hip_graph=_graph_mode(backend.get("hip_graph", True)), log=log,
+                      history_rows=int(cfg.method.num_iterations) + 1)
 
     solver.algorithm = algorithm
     info = solver.training_info = {k: [] for k in (

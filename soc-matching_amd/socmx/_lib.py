@@ -109,6 +109,10 @@ PROTOTYPES = {
     "socmx_socm_stopping_target_bwd_f32": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, C.c_float]
                                            + [_fp] * 14),
     "socmx_iteration_scalars_f32": (C.c_int, [C.c_int32] + [_fp] * 8 + [C.c_double, C.c_double, _fp, _fp, _fp]),
+    "socmx_iteration_scalars_hist_f32": (C.c_int, [C.c_int32] + [_fp] * 8 + [C.c_double, C.c_double, _fp, _fp, _fp, C.c_int32, _fp, _fp]),
+    "socmx_adam_step_scalars_hist_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_double, C.c_float, C.c_float,
+                                                   C.c_float, C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_double, _fp, _fp,
+                                                   C.c_int32, _fp, _fp]),
     "socmx_adam_step_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_double, C.c_float, C.c_float,
                                       C.c_float, C.c_float, _fp, _fp, _fp]),
     "socmx_adam_step_scalars_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, _fp, _fp, _fp, C.c_double, C.c_float, C.c_float,

@@ -47,7 +47,8 @@ def make_optimizer(solver, nabla_V_lr=1e-4, M_lr=1e-2, adam_eps=1e-4, algorithm=
 class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
                  ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=False, overlap_M_backward=True,
-                 grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2, fused_adam=True, log=None):
+                 grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2, fused_adam=True, log=None,
+                 history_rows=1 << 16):
         self.solver, self.optimizer = solver, optimizer
         self.batch_size = batch_size
         self.normalization_const = normalization_const
@@ -98,6 +99,12 @@ class Trainer:
                       "package's own RCCL communicators (backend nccl, SOCMX_RCCL unset) capture it")
         self.graph_warmup = int(graph_warmup)
         self.fused_adam = bool(fused_adam)    # hipGraph body: control-network Adam + telemetry as one launch (socmx_adam_step_f32)
+        # hipGraph mode: the scalars of iteration n (loss, weight statistics, telemetry, normaliser, L2 error) are ALSO written to row n
+        # of a device array by the kernel that forms them; `step` hands out views of that row instead of cloning the replayed graph's
+        # static output on the iteration's stream -- a copy and two launch gaps (~10 us) between Adam's end and the next rollout.
+        # Rows are written once and never reused (main.py keeps every iteration's values, main.py:398-413): beyond `history_rows`
+        # iterations the clone comes back.  main.py passes method.num_iterations.
+        self.history_rows = int(history_rows)
         self._graphs = {}
         self._dev = None
         self._m_pending = False          # hipGraph mode: the pair-grid network's update of the last iteration is outstanding
@@ -224,6 +231,7 @@ class Trainer:
             D = self._dev          # (1,) views of the 0-dim state tensors for the C ABI, and the (A, B) pair of the EMA
             D["itr1"], D["norm1"], D["ema_gn1"] = D["itr"].reshape(1), D["norm"].reshape(1), D["ema_gn"].reshape(1)
             D["ab"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            D["hist"] = (torch.zeros(self.history_rows, 8, dtype=torch.float32, device=dev) if self.history_rows > 0 else None)
             if getattr(self.solver, "philox_key", None) is None:
                 # a stream of its own: the host-side counter (rollout._philox_calls: evaluation bursts, eager rollouts)
                 # counts 0, 1, 2, ... under the same seed, the device key counts from 2^31 -- the 32-bit offset word of the
@@ -289,6 +297,8 @@ class Trainer:
                     1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(w_mean), f(w_std), f(obj),
                     f(gn) if gn is not None else None, f(gne) if gne is not None else None, self.coeff, 0.01, None, f(vals),
                     _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
+            # (this body -- the eight other losses, stopping-time SOCM -- keeps the cloned output: its loss value may be rescaled below)
+            D["hist_written"] = False
             if self.algorithm not in ("SOCM", "SOCM_const_M", "SOCM_exp", "SOCM_adjoint", "cross_entropy"):
                 vals[0:1].copy_(loss.detach().reshape(1))                # (another scaling of the objective: main.py:321-322)
             if out[1] is not None:
@@ -620,12 +630,15 @@ class Trainer:
             grp = self._groups_main[0]
             b1, b2 = grp["betas"]
             with _lib.on_device(dev):
-                _lib.check(Lh.socmx_adam_step_scalars_f32(
+                hist = D.get("hist")
+                _lib.check(Lh.socmx_adam_step_scalars_hist_f32(
                     table.data_ptr(), len(vparams), vflat.numel(), f(vflat),
                     f(D["ema_flat"]) if self.grad_telemetry else None, f(D["itr1"]), 0.01, float(grp["lr"]), float(b1),
                     float(b2), float(grp["eps"]), f(D["adam_scratch"]), f(sums), f(D["norm1"]),
                     f(D["ema_gn1"]) if self.grad_telemetry else None, f(w_mean), f(w_std), f(obj), self.coeff, f(out),
-                    _lib.stream_ptr(dev)), "socmx_adam_step_scalars_f32")
+                    f(hist), 0 if hist is None else hist.shape[0], f(nsd.contiguous()) if nsd is not None else None,
+                    _lib.stream_ptr(dev)), "socmx_adam_step_scalars_hist_f32")
+                D["hist_written"] = hist is not None
         else:
             for p, g in zip(vparams, vgrads):
                 p.grad = g
@@ -644,10 +657,13 @@ class Trainer:
                 p.grad = None
             # scalar bookkeeping: one one-thread kernel instead of ~35 elementwise launches (socmx_iteration_scalars_f32)
             with _lib.on_device(dev):
-                _lib.check(Lh.socmx_iteration_scalars_f32(
+                hist = D.get("hist")
+                _lib.check(Lh.socmx_iteration_scalars_hist_f32(
                     1, f(D["itr1"]), f(D["norm1"]), f(D["ema_gn1"]) if gn is not None else None, f(w_mean),
                     f(w_std), f(obj), f(gn) if gn is not None else None, f(gne) if gne is not None else None,
-                    self.coeff, 0.01, None, f(out), _lib.stream_ptr(dev)), "socmx_iteration_scalars_f32")
+                    self.coeff, 0.01, None, f(out), f(hist), 0 if hist is None else hist.shape[0],
+                    f(nsd.contiguous()) if nsd is not None else None, _lib.stream_ptr(dev)), "socmx_iteration_scalars_hist_f32")
+                D["hist_written"] = hist is not None
         self._m_pending = True
         if nsd is not None:
             out = torch.cat([out, nsd.reshape(1)])
@@ -806,10 +822,11 @@ class Trainer:
                     err = RuntimeError("another rank could not capture the iteration")
                 if err is not None:
                     return self._capture_failed(err, loss_kwargs)
-                self._graphs[key] = entry = (g, static_vals)
+                # (does this body leave its scalars in the history array?  decided while it was captured)
+                self._graphs[key] = entry = (g, static_vals, bool(self._dev.get("hist_written")))
                 self._graphs_sig = self._optimizer_signature()
                 g.replay()                                   # capture does not execute: this replay IS the iteration
-                vals = static_vals.clone()
+                vals = self._replayed_values(entry)
                 mode = "graph-capture"
         elif manual and not self._m_pending:
             # a flush (checkpoint, eager fallback) consumed the outstanding update the captured graph starts with: this one
@@ -818,7 +835,7 @@ class Trainer:
             mode = "body-eager (after a flush)"
         else:
             entry[0].replay()
-            vals = entry[1].clone()
+            vals = self._replayed_values(entry)
             mode = "graph-replay"
         if self.sync_timing:
             torch.cuda.synchronize(dev)
@@ -831,6 +848,16 @@ class Trainer:
         if self.grad_telemetry:
             info.update(grad_norm_sqd=vals[3], EMA_grad_norm_sqd=vals[4], sqd_norm_EMA_grad=vals[5])
         return info
+
+    def _replayed_values(self, entry):
+        """The scalars of the iteration just replayed: a VIEW of its row of the history array when the body writes one (no device
+        copy on the iteration's stream), else a clone of the graph's static output (the next replay overwrites it)."""
+        static_vals, in_hist = entry[1], entry[2]
+        hist = self._dev.get("hist")
+        if in_hist and hist is not None and self.itr < hist.shape[0]:
+            row = hist[self.itr]
+            return row if static_vals.numel() > 7 else row[:7]
+        return static_vals.clone()
 
     def _capture_failed(self, err, loss_kwargs):
         """A body that cannot be captured (an operation that synchronises, a library call without capture support on this
