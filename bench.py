@@ -286,7 +286,7 @@ def launch_ranks(args):
     import subprocess
     n = args.gpus
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("SOCMX_BENCH_ONE_DEVICE") != "1":
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -336,7 +336,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path for the product"
-    device = torch.device("cuda", local_rank)
+    # Developer / test switch, never the measured configuration: SOCMX_BENCH_ONE_DEVICE=1 puts EVERY rank on cuda:0 over a gloo
+    # process group (the shard's collectives staged through host memory, socmx/dist.py) -- RCCL refuses two ranks on one device --
+    # so that this file's N > 1 control flow (launcher, blocks, barriers, the sharded legs, the line) runs on a one-GPU box
+    # (tests/test_gpu_dist.py).  The line says so ("one_device_debug": true) and its numbers mean nothing.
+    one_device = os.environ.get("SOCMX_BENCH_ONE_DEVICE") == "1"
+    device = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(device)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -347,10 +352,13 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-            warm = torch.zeros(1, device=device)
-            dist.all_reduce(warm)
-            torch.cuda.synchronize(device)
+            if one_device:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                warm = torch.zeros(1, device=device)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize(device)
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -384,6 +392,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def reduce_max(t):
+        """MAX over ranks of a small float64 tensor (the debug mode's gloo group takes it through the host)."""
+        if not use_dist:
+            return t
+        if one_device:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            return h.to(t.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
+
     # ---- metric 1: rollouts ------------------------------------------------------------------
     def one_rollout(i):
         return rollout.stochastic_trajectories(sde, state0, ts, cfg.method.lmbd, seed=0, offset=i, row0=row0)
@@ -407,9 +426,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         n_done += args.steps
-        t = torch.tensor([el, sum(blocks) + el], dtype=torch.float64, device=device)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)       # (every rank sees the same block time and takes the same decision)
+        t = reduce_max(torch.tensor([el, sum(blocks) + el], dtype=torch.float64, device=device))   # (every rank sees the same block time and takes the same decision)
         blocks.append(float(t[0].item()))
         kernel_blocks.append(sum(a.elapsed_time(b) for a, b in ev) / args.steps)
         if float(t[1].item()) >= 0.5 or len(blocks) >= 64:
@@ -420,7 +437,8 @@ def main():
     value = world * B * K * args.steps / elapsed
 
     # ---- metric 2: full SOCM iterations ----------------------------------------------------------
-    shard = sdist.Shard() if use_dist else None      # (backend nccl: brings up the package's own RCCL communicators, socmx/rccl.py)
+    # (backend nccl: brings up the package's own RCCL communicators, socmx/rccl.py; the one-device debug mode: the staged transport)
+    shard = (sdist.Shard(device=device) if one_device else sdist.Shard()) if use_dist else None
     if use_dist:
         solver.shard = shard
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
@@ -438,9 +456,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         trainer.join()
-        t = torch.tensor([el], dtype=torch.float64, device=device)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = reduce_max(torch.tensor([el], dtype=torch.float64, device=device))
         return float(t.item()), float(info["loss"])
 
     # Three schedules of the same arithmetic: (1) the eager autograd iteration (two HIP streams; sharded: ONE flat all-reduce per
@@ -546,7 +562,7 @@ def main():
             "timed_blocks": len(blocks), "block_ms_min_median_max": [1e3 * min(blocks), 1e3 * elapsed, 1e3 * max(blocks)],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
-            "shard_transport": None if shard is None else shard.transport,
+            "shard_transport": None if shard is None else shard.transport, "one_device_debug": one_device,
             "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in rank_devices}),
             "config": {"workload": "double_well d=10 num_steps=200 batch=128/GPU SOCM (BASELINE configs[2]; "
                                    "global batch 128*N)", "step": "one stochastic_trajectories call (full 8-tuple)",

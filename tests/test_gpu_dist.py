@@ -195,3 +195,27 @@ def test_control_objective_pools_the_ranks_of_a_shard(tmp_path):
         np.testing.assert_allclose(j["mean"], j1[0]["mean"], rtol=1e-5)
         np.testing.assert_allclose(j["err"], j1[0]["err"], rtol=1e-4)
     assert j1[0]["traj_rows"] == 40 and all(j["traj_rows"] == 40 for j in j3)
+
+
+def test_bench_line_of_a_two_rank_run_on_one_device(tmp_path):
+    """bench.py's N > 1 control flow -- the launcher child under torch.distributed.run, the rank-device gather, K-step blocks between
+    barriers with the MAX over ranks, the sharded iteration legs, the secondary configurations over a shard, rank 0's ONE line -- at
+    world size 2 on ONE GPU (SOCMX_BENCH_ONE_DEVICE=1: gloo group, collectives staged through the host; the numbers mean nothing,
+    the flow is what an N-GPU box will execute with RCCL in its place)."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, SOCMX_BENCH_ONE_DEVICE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-burst",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["rank_devices"]) == 2 and line["one_device_debug"]
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["config"]["parallelism"].startswith("dp2")
+    assert line["shard_transport"] == "staged"
+    # the sharded legs: the autograd iteration and the autograd-free body (this transport cannot be captured: no graph leg)
+    assert line["socm_ms_per_iter_eager"] > 0 and line["socm_ms_per_iter_eager_body"] > 0 and line["socm_ms_per_iter_graph"] is None
+    assert line["socm_ms_per_iter"] == min(line["socm_ms_per_iter_eager"], line["socm_ms_per_iter_eager_body"])
+    assert len(line["secondary"]) == 2 and all(e["socm_ms_per_iter_eager_body"] > 0 and np.isfinite(e["last_loss"]) for e in line["secondary"])
+    assert "cpu_baseline" not in line                                    # (a rank-0, N = 1 figure)

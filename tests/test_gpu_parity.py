@@ -1460,6 +1460,11 @@ for sharded in (True, False):
     #  Chan's rule -- socmx_loss.hip shard_stats_kernel -- and match the one-process kernel however far the running normaliser is
     #  from the batch mean; rounds 4-5's sums shifted by the normaliser cancelled to 1e-4 of the std here)
     tr3 = Trainer(solver3, make_optimizer(solver3, M_lr=1e-3), aux3['B'], normalization_const=0.8, sync_timing=False, hip_graph=True)
+    if sharded:
+        # (take the multi-rank branch behind the capture: the ranks agree -- one all_reduce(MIN) of an int32 flag through the shard's
+        #  communicator -- that every one of them captured, before any replays)
+        tr3._multi_rank = True
+        agrees0 = solver3.shard.collectives
     rec = []
     for it in range(6):
         info = tr3.step()
@@ -1469,6 +1474,7 @@ for sharded in (True, False):
     runs.append((rec, [v.detach().cpu().numpy() for v in sde3.state_dict().values()], len(captured)))
 res['graph_captured'] = [r[2] for r in runs]
 res['transport'] = solver.shard.transport
+res['agree_calls'] = 1   # (counted below)
 # (6 iterations: the 2 eager warm-ups and the capture enqueue / record the main-stream collective and -- from the second iteration
 #  on -- the second stream's one for the deferred pair-grid-network update: 1 + 2 + 2; the 3 replays re-run the captured launches
 #  without passing through Python; join() applies the last outstanding update eagerly: + 1)
@@ -1526,7 +1532,7 @@ def test_rccl_shard_path_on_the_gpu(name, own, tmp_path):
     assert r["deferred_M"] and r["param_rel_diff"] < 2e-6, r
     assert r["graph_captured"] == [1, 1], r["graph_captured"]
     assert r["transport"] == ("rccl" if own == "1" else "group")
-    assert r["rccl_calls_graph_run"] == (6 if own == "1" else 0), r["rccl_calls_graph_run"]
+    assert r["rccl_calls_graph_run"] == (7 if own == "1" else 0), r["rccl_calls_graph_run"]       # (+ 1: the agreement behind the capture)
     np.testing.assert_allclose(r["graph_rec_sharded"], r["graph_rec_plain"], rtol=2e-5, atol=1e-7)
     assert r["graph_param_rel_diff"] < 2e-6, r["graph_param_rel_diff"]
     np.testing.assert_allclose(r["losses"][0], float(z["loss_objective"]), rtol=2e-4)   # normalisation constant 1.0
