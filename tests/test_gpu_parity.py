@@ -1474,7 +1474,6 @@ for sharded in (True, False):
     runs.append((rec, [v.detach().cpu().numpy() for v in sde3.state_dict().values()], len(captured)))
 res['graph_captured'] = [r[2] for r in runs]
 res['transport'] = solver.shard.transport
-res['agree_calls'] = 1   # (counted below)
 # (6 iterations: the 2 eager warm-ups and the capture enqueue / record the main-stream collective and -- from the second iteration
 #  on -- the second stream's one for the deferred pair-grid-network update: 1 + 2 + 2; the 3 replays re-run the captured launches
 #  without passing through Python; join() applies the last outstanding update eagerly: + 1)
