@@ -2387,7 +2387,9 @@ extern "C" int socmx_mnet_forward_f32(const float* packed, int32_t d, const int3
   if (mres_ok(a.m) && !tile_env) {
     // persistent workgroups with register-resident weights: two per CU, tiles b, b + grid, ...
     if (const int err = ensure_max_lds(mnet_forward_resident_kernel)) return err;
-    return launch(mnet_forward_resident_kernel, dim3(std::min(a.ntiles, 512)), dim3(512),
+    // (developer sweep, read once: SOCMX_K3_GRID = persistent workgroups of the forward kernel)
+    static const int grid_env = [] { const char* e = getenv("SOCMX_K3_GRID"); return e ? atoi(e) : 0; }();
+    return launch(mnet_forward_resident_kernel, dim3(std::min(a.ntiles, grid_env > 0 ? grid_env : 512)), dim3(512),
                   (size_t)mres_fwd_lds_floats(a.m) * sizeof(float), stream, a);
   }
   if (const int err = ensure_max_lds(mnet_forward_kernel<kK2Waves>)) return err;
@@ -2486,7 +2488,8 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
     static const int tile_env = [] { const char* e = getenv("SOCMX_K3_TILE"); return e ? atoi(e) : 0; }();
     if (mres_ok(p.m) && !tile_env) {
       if (const int err = ensure_max_lds(mnet_backward_resident_kernel)) return err;
-      if (const int err = launch(mnet_backward_resident_kernel, dim3(std::min(p.ntiles, 256)), dim3(512),
+      static const int bgrid_env = [] { const char* e = getenv("SOCMX_K3_BGRID"); return e ? atoi(e) : 0; }();
+      if (const int err = launch(mnet_backward_resident_kernel, dim3(std::min(p.ntiles, bgrid_env > 0 ? bgrid_env : 256)), dim3(512),
                                  (size_t)mres_bwd_lds_floats(p.m) * sizeof(float), stream, a)) return err;
     } else {
       if (const int err = ensure_max_lds(mnet_backward_kernel<kK2Waves>)) return err;
