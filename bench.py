@@ -650,6 +650,8 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
+        if shard is not None:
+            shard.close()            # (the shard's own RCCL communicators: destroyed before the process group that brought them up)
         dist.destroy_process_group()
 
 

@@ -2337,6 +2337,9 @@ extern "C" int socmx_unet_backward_scaled_f32(const float* packed, const float* 
 }
 
 // ---- K3: the pair-grid network ---------------------------------------------------------------------------------------
+// developer A/B switch, read once: SOCMX_K3_TILE=1 keeps the one-tile-per-workgroup kernels
+static int mnet_tile_env() { static const int v = [] { const char* e = getenv("SOCMX_K3_TILE"); return e ? atoi(e) : 0; }(); return v; }
+
 static const int kK3WideWaves = 4;   // the WIDE pair-net kernels: four waves per workgroup, two workgroups per CU
 
 static int mnet_plan(int32_t d, const int32_t hdims[2], MDesc& m) {
@@ -2382,9 +2385,7 @@ extern "C" int socmx_mnet_forward_f32(const float* packed, int32_t d, const int3
     if (const int err = ensure_max_lds(mnet_forward_kernel<kK3WideWaves>)) return err;
     return launch(mnet_forward_kernel<kK3WideWaves>, dim3(a.ntiles), dim3(kK3WideWaves * 64), lds_bytes, stream, a);
   }
-  // (developer A/B switch, read once: SOCMX_K3_TILE=1 keeps the one-tile-per-workgroup kernels)
-  static const int tile_env = [] { const char* e = getenv("SOCMX_K3_TILE"); return e ? atoi(e) : 0; }();
-  if (mres_ok(a.m) && !tile_env) {
+  if (mres_ok(a.m) && !mnet_tile_env()) {
     // persistent workgroups with register-resident weights: two per CU, tiles b, b + grid, ...
     if (const int err = ensure_max_lds(mnet_forward_resident_kernel)) return err;
     // (developer sweep, read once: SOCMX_K3_GRID = persistent workgroups of the forward kernel)
@@ -2485,7 +2486,7 @@ extern "C" int socmx_mnet_backward_f32(const float* packed, int32_t d, const int
                                      : launch(mnet_wgrad_wide_kernel<1, false>, dim3(wgrid), dim3(256), 0, stream, ga));
     if (err) return err;
   } else {
-    static const int tile_env = [] { const char* e = getenv("SOCMX_K3_TILE"); return e ? atoi(e) : 0; }();
+    const int tile_env = mnet_tile_env();
     if (mres_ok(p.m) && !tile_env) {
       if (const int err = ensure_max_lds(mnet_backward_resident_kernel)) return err;
       static const int bgrid_env = [] { const char* e = getenv("SOCMX_K3_BGRID"); return e ? atoi(e) : 0; }();

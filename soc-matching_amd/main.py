@@ -174,6 +174,12 @@ def run(cfg):
                 modes[m] = modes.get(m, 0) + 1
         log(f"time_per_iteration: median {1e3 * steady[len(steady) // 2]:.3f} ms over {len(steady)} steady-state iterations "
             f"(modes: {', '.join(f'{k} x{v}' for k, v in sorted(modes.items(), key=lambda kv: -kv[1]))})")
+    if shard is not None and world > 1:
+        trainer.join()
+        torch.cuda.synchronize()
+        import torch.distributed as dist
+        dist.barrier()
+        shard.close()                # (the shard's own RCCL communicators; the process group stays up for a multirun's next job)
     return solver
 
 
