@@ -2427,7 +2427,10 @@ static int launch_target_fwd(const socmx_problem* pb, int32_t K, int32_t B, cons
   }
   // 16-column batch tiles per wave (developer override SOCMX_TARGET_CT, read once)
   static const int ct_env = [] { const char* e = getenv("SOCMX_TARGET_CT"); return e ? atoi(e) : 0; }();
-  const int ct = (ct_env == 1 || ct_env == 2 || ct_env == 4) ? ct_env : (B > 32 ? 4 : (B > 16 ? 2 : 1));
+  // (four column tiles per wave amortise the pair-matrix requests best -- 50.9 / 65.1 / 82.7 us for 4 / 2 / 1 at configs[2] -- unless
+  //  that leaves most of the chip without a workgroup: configs[1] has 26 x 2 = 52 of them at four tiles, 17.1 us against 13.4 at two)
+  const int ct4 = (B > 32 && ((K + 2) / 2) * ((B + 63) / 64) < 128) ? 2 : 4;
+  const int ct = (ct_env == 1 || ct_env == 2 || ct_env == 4) ? ct_env : (B > 32 ? ct4 : (B > 16 ? 2 : 1));
   dim3 grid((K + 2) / 2, (B + 16 * ct - 1) / (16 * ct), (d + 15) / 16);
   const dim3 blk(64 * kTargetWaves);
 #define SOCMX_TARGET_LAUNCH(NETV, CTV, N1V) \
