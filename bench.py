@@ -577,18 +577,23 @@ def main():
                          "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU): 128 of 256 CUs work, and a "
                                  "v_fmac_f32_dpp (64 MACs) issues at 4.54 cycles per SIMD with two waves on it -- measured, "
-                                 "tools/ubench/valu_banks.hip, profiles/r5/valu_banks.txt -- i.e. 28.2 flop/clk/SIMD of the 64 the "
+                                 "tools/ubench/valu_banks.hip, profiles/r6/valu_banks.txt -- i.e. 28.2 flop/clk/SIMD of the 64 the "
                                  "peak is quoted at: frac <= 0.5 x 0.44 = 0.22 for executed flops in this form.  `achieved` counts the "
                                  "REFERENCE network's flops (BASELINE.md section 5); the kernel executes fewer: the skip res_1 r1 + b "
                                  "reaches the output's ReLU only through the linear up_0 (models.py:239-240), so the pack kernel folds "
                                  "up_0 res_1 into a d x 256 matrix and the 256 x 256 product (39 % of the MACs, 256 KB of the 677 KB "
-                                 "of weights) is never formed -- executed_flops_per_launch / executed_frac below.  With it every "
-                                 "weight is register- or LDS-resident (no L2 stream) and the step is 1,685 fmacs = 1.9k of its "
-                                 "~4.65k cycles; the rest is latency: four barriers with an LDS round trip each, the cross-row "
-                                 "reductions, the integrating wave's serial section (profiles/r5/r1_phases.txt).  Three packed-fma "
-                                 "rewrites (v_pk_fma_f32, 4.42 cycles per 128 MACs) were built and measured in round 5 and are not "
-                                 "faster: tools/experiments/r1p/README.md.  peak = 157.3 TF is the fp32 MFMA = packed-vector figure; "
-                                 "see roofline_full_chip for the MFMA kernel with the chip full (2,048 workgroups of two 16-row tiles)",
+                                 "of weights) is never formed -- executed_flops_per_launch / executed_frac below.  Every weight is "
+                                 "register- or LDS-resident (no L2 stream) and the step is 1,685 fmacs = 1.9k of its ~4.3k cycles; the "
+                                 "rest is latency: four barriers with an LDS round trip each, the cross-row reductions the 16-unit blocks "
+                                 "force, the two waves of a SIMD running nearly one after the other, the integrating wave's serial section "
+                                 "(profiles/r6/r1_phases.txt).  Round 6: stage 2 in a direct weight layout (no ds_bpermute gather, no "
+                                 "cross-row reduction on the chain): kernel 0.384 -> 0.362 ms.  Eight waves per workgroup are what it takes "
+                                 "to address the whole register file as fmac operands (256 architectural VGPRs per wave): one wave per SIMD "
+                                 "cannot hold the 437 KB of weights (DESIGN.md section 3.1).  Three packed-fma rewrites (round 5) and the "
+                                 "first layer's skip term in the slack (round 6) were built, measured and are not faster.  peak = 157.3 TF is "
+                                 "the fp32 MFMA = packed-vector figure; see roofline_full_chip for the MFMA kernel with the chip full (2,048 "
+                                 "workgroups of two 16-row tiles).  kernel_ms brackets the ~5 us weight re-pack in front of every rollout with "
+                                 "the launch (HIP events on the launch stream); the kernel alone: profiles/r6/kernel_stats.csv",
                          "executed_flops_per_launch": flops_exec,
                          "executed_frac": flops_exec / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
