@@ -52,6 +52,7 @@ class Shard:
                 transport = "staged"
         self.transport = transport
         self.transport_note = None
+        self._backend = backend
         if transport in ("rccl", "staged"):
             self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if transport == "rccl":
@@ -87,6 +88,8 @@ class Shard:
         if self.transport == "rccl" and t.is_cuda:
             return self._comms[slot].all_reduce_(t, op)
         rop = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op]
+        if self.transport == "group" and t.is_cuda and self._backend == "gloo":
+            self.transport, self.device = "staged", t.device      # (a gloo group handed a CUDA tensor: through the host from here on)
         if self.transport == "staged" and t.is_cuda:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("socmx.dist: the host-staged transport (gloo + CUDA tensors) cannot be captured into a hipGraph")
@@ -102,6 +105,8 @@ class Shard:
         self.collectives += 1
         if self.transport == "rccl" and t.is_cuda:
             return self._comms[slot].all_gather(t.contiguous())
+        if self.transport == "group" and t.is_cuda and self._backend == "gloo":
+            self.transport, self.device = "staged", t.device
         src = t.detach().to("cpu") if (self.transport == "staged" and t.is_cuda) else t
         gathered = [torch.empty_like(src) for _ in range(self.world_size)]
         dist.all_gather(gathered, src.contiguous(), group=self.group)
