@@ -113,6 +113,27 @@ def test_sharded_autograd_iteration_on_the_gpu(world, tmp_path):
             assert np.array_equal(zs[0][k], zr[k]), k
 
 
+def test_d64_slice_shape_sharded_over_two_ranks(tmp_path):
+    """The configs[4] kernels (d = 64: the wide pair-grid-network kernels, the LDS-staged contractions, the general 4-row rollout with a
+    dense sigma) under a shard: `cfg5_ou_linear_d64_B256_K3` (the reference's own run at B = 256) split 128 / 128 -- three iterations of
+    the sharded HIP body against the same iterations of one process, the first objective against the reference."""
+    name = "cfg5_ou_linear_d64_B256_K3"
+    j1, z1 = _launch(1, "train", name, tmp_path, name)
+    j2, z2 = _launch(2, "train", name, tmp_path, name)
+    assert [j["rows"] for j in j2] == [[128, 0], [128, 128]]
+    assert all(j["bodies"]["manual"] == 3 and j["bodies"]["eager"] == 0 for j in j2), [j["bodies"] for j in j2]
+    a, b = j1[0]["rec"], j2[0]["rec"]
+    for k in ("loss", "weight_mean", "weight_std", "norm"):
+        np.testing.assert_allclose(b[k], a[k], rtol=3e-4, err_msg=k)
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    np.testing.assert_allclose(b["loss"][0], float(z["loss_objective"]), rtol=5e-4)
+    num = sum(float(((z2[0][k] - z1[0][k]) ** 2).sum()) for k in z1[0].files)
+    den = sum(float((z1[0][k] ** 2).sum()) for k in z1[0].files)
+    assert (num / den) ** 0.5 < 5e-5, (num / den) ** 0.5
+    for k in z2[0].files:
+        assert np.array_equal(z2[0][k], z2[1][k]), k
+
+
 def test_headline_configuration_sharded_over_three_ranks(tmp_path):
     """configs[2] at its own size (double_well d=10, K=200, B=128, default widths: the one-row rollout kernel, 43 / 43 / 42 rows)
     through the sharded HIP body: three iterations on the reference's noise against the same iterations of ONE process, and the

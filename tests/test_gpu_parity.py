@@ -1866,3 +1866,33 @@ def test_philox_noise_does_not_depend_on_the_tile_shape(d):
     torch.cuda.synchronize()
     assert torch.equal(small[1], big[1][:, 512:768])
     assert float(small[1].abs().max()) > 0.5 and not torch.isnan(small[1]).any()
+
+
+@pytest.mark.parametrize("name", ["cfg3_full_double_well_d10_K200_B128", "cfg5_ou_linear_d64_B256_K3", "tiny_molecular_dynamics_d2_stopping",
+                                  "oul30_ou_linear_d30_K10_B16"])
+def test_objective_and_gradients_are_bit_reproducible(name):
+    """method.py:717-720 is one torch.sum: the reference's loss value is reproducible run to run, and so is this one -- the objective's
+    partial sums are added in a fixed order by the last contributor to finish (csrc/socmx_loss.hip: objective_commit), no float atomics.
+    Same inputs, other work on the chip in between (dirty caches, other kernels' leftovers in LDS): objective, weight statistics and
+    every gradient bit for bit; every code path of the objective (fused d <= 16 contraction, LDS-staged d = 64 contraction + MFMA
+    residual, masked stopping-time residual, the d = 30 general form)."""
+    from SOC_matching.method import SOC_Solver
+
+    def once():
+        sde, aux = build_sde(name, DEV)
+        solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
+        solver.noise_in = aux["noise"]
+        out = solver.loss(aux["B"], algorithm="SOCM", use_warm_start=False, use_stopping_time=aux["stopping"])
+        out[0].backward()
+        params = list(sde.nabla_V.parameters()) + list(sde.M.parameters())
+        torch.cuda.synchronize()
+        return [_np(out[0]), _np(out[5]), _np(out[6])] + [_np(p.grad) for p in params if p.grad is not None]
+
+    ref = once()
+    for rep in range(3):
+        a = torch.randn(2048, 2048, device=DEV)
+        (a @ a).sum().item()                                   # something else on the chip
+        got = once()
+        assert len(got) == len(ref)
+        for i, (x, y) in enumerate(zip(ref, got)):
+            assert np.array_equal(x, y, equal_nan=True), (name, rep, i, float(np.abs(x - y).max()))
