@@ -24,25 +24,31 @@ def _np(t):
 def main():
     rank, world, port, mode, name, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
-    dev = torch.device("cuda", 0)
+    # SOCMX_TEST_NCCL=1 (boxes with one GPU per rank): rank r on cuda:r over RCCL -- the shard's own communicators, the captured iteration
+    real = os.environ.get("SOCMX_TEST_NCCL") == "1"
+    dev = torch.device("cuda", rank if real else 0)
     torch.cuda.set_device(dev)
     sharded = world > 1
     if sharded:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if real:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     from test_host_cpu import build_sde
     from SOC_matching.method import SOC_Solver
     from socmx import rollout as R
     from socmx.dist import Shard
     from socmx.rollout import PhiloxKey
     from socmx.train import Trainer, make_optimizer
-    sde, aux = build_sde(name, "cuda:0")
+    sde, aux = build_sde(name, str(dev))
     z = aux["z"]
     solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
     B = 50 if mode == "philox" else aux["B"]
     Bl, row0 = B, 0
     if sharded:
-        solver.shard = Shard(device=dev)
-        assert solver.shard.transport == "staged" and not solver.shard.capturable
+        solver.shard = Shard() if real else Shard(device=dev)
+        assert solver.shard.transport == ("rccl" if real else "staged") and solver.shard.capturable == real, solver.shard.transport_note
         Bl, row0 = solver.shard.local_rows(B)
     res = dict(rank=rank, rows=[Bl, row0])
     arrays = {}
@@ -60,8 +66,10 @@ def main():
         lr_V, lr_M, eps, norm0 = [float(v) for v in z["meta_f"][5:9]] if len(z["meta_f"]) >= 9 else (1e-4, 1e-3, 1e-4, 1.0)
         opt = make_optimizer(solver, nabla_V_lr=lr_V, M_lr=lr_M, adam_eps=eps)
         logs = []
-        # (one process: the same body, not captured either -- every iteration hands over a fresh noise tensor)
+        # (one process: the same body, not captured either -- every iteration hands over a fresh noise tensor; over RCCL the iteration
+        #  IS captured: the noise of every iteration is copied into one static buffer, as the graph tests do)
         graph = False if mode == "train_eager" else (True if sharded else "nocapture")
+        static = torch.empty_like(aux["noise"][0][:, row0:row0 + Bl].contiguous()) if (real and aux["noise"].dim() == 4) else None
         tr = Trainer(solver, opt, B, normalization_const=norm0, sync_timing=False, hip_graph=graph, log=logs.append)
         count_bodies(tr)
         rec = dict(loss=[], weight_mean=[], weight_std=[], norm=[])
@@ -69,7 +77,11 @@ def main():
         noise = aux["noise"] if aux["noise"].dim() == 4 else aux["noise"].unsqueeze(0).expand(n_it, -1, -1, -1)
         c0 = solver.shard.collectives if sharded else 0
         for it in range(n_it):
-            solver.noise_in = noise[it][:, row0:row0 + Bl].contiguous()
+            if static is not None:
+                static.copy_(noise[it][:, row0:row0 + Bl])
+                solver.noise_in = static
+            else:
+                solver.noise_in = noise[it][:, row0:row0 + Bl].contiguous()
             o = tr.step()
             for k, v in (("loss", o["loss"]), ("weight_mean", o["weight_mean"]), ("weight_std", o["weight_std"]),
                          ("norm", tr.normalization_const)):
@@ -78,6 +90,7 @@ def main():
         tr.join()
         torch.cuda.synchronize()
         res["collectives_after_join"] = (solver.shard.collectives - c0) if sharded else 0
+        res["captured"] = len([k for k in tr._graphs if isinstance(k, tuple) and k and k[0] == "manual"])
         res.update(rec=rec, iters=n_it, bodies=bodies, capture_graphs=bool(tr.capture_graphs), hip_graph=bool(tr.hip_graph),
                    logs=logs, manual_ok=bool(tr._manual_ok({})))
         arrays.update({"V." + k: _np(v) for k, v in sde.nabla_V.state_dict().items()})

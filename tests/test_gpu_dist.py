@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _launch(world, mode, name, tmp_path, tag):
+def _launch(world, mode, name, tmp_path, tag, extra_env=None):
     """Start `world` ranks of gpu_dist_child.py and wait for all of them; returns ([json per rank], [npz per rank])."""
     out = str(tmp_path / f"{tag}_{mode}_{world}")
     for attempt in range(2):
@@ -30,6 +30,7 @@ def _launch(world, mode, name, tmp_path, tag):
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "2")
+        env.update(extra_env or {})
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "gpu_dist_child.py"), str(r), str(world), port, mode, name, out],
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
         outs = []
@@ -240,3 +241,28 @@ def test_bench_line_of_a_two_rank_run_on_one_device(tmp_path):
     assert line["socm_ms_per_iter"] == min(line["socm_ms_per_iter_eager"], line["socm_ms_per_iter_eager_body"])
     assert len(line["secondary"]) == 2 and all(e["socm_ms_per_iter_eager_body"] > 0 and np.isfinite(e["last_loss"]) for e in line["secondary"])
     assert "cpu_baseline" not in line                                    # (a rank-0, N = 1 figure)
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs one GPU per rank (the boxes this suite has run on so far have one)")
+@pytest.mark.parametrize("name", ["train_ou_quadratic_easy_d2", "train_double_well_d10"])
+def test_captured_sharded_iteration_over_rccl(name, tmp_path):
+    """What a multi-GPU box is for: two ranks on two devices over RCCL -- `Shard()` brings up the package's own communicators,
+    `Trainer(hip_graph=True)` captures the iteration with the `ncclAllReduce` launches inside after two eager warm-ups, the ranks
+    agree on the capture -- on the reference's own training run.  Skipped wherever there is one GPU."""
+    js, zs = _launch(2, "train", name, tmp_path, name, extra_env={"SOCMX_TEST_NCCL": "1"})
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n_it = js[0]["iters"]
+    for j in js:
+        assert j["manual_ok"] and j["hip_graph"] and j["capture_graphs"], j
+        assert j["captured"] == (1 if n_it > 2 else 0), j                       # two eager warm-ups, then the capture
+    np.testing.assert_allclose(js[0]["rec"]["loss"], z["train_loss"], rtol=1e-3)
+    np.testing.assert_allclose(js[0]["rec"]["norm"], z["train_norm_const"], rtol=1e-3)
+    assert js[1]["rec"] == js[0]["rec"]
+    assert _rel(zs[0], z, (("final_nablaV.", "V."), ("final_M.", "M."))) < 1e-2
+    for k in zs[0].files:
+        assert np.array_equal(zs[0][k], zs[1][k]), k
