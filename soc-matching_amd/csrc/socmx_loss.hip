@@ -2204,19 +2204,20 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
   // per-workgroup partial sums in scratch[4 + 2 b], combined in a FIXED order by the last workgroup to finish (no float
   // atomics: the telemetry is bit-reproducible like the rest of the library)
   if (tid == 0) {
-    a.scratch[4 + 2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    a.scratch[5 + 2 * blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    __threadfence();
+    // (the partial sums travel as device-scope atomic exchanges whose returns are waited for, the last workgroup reads them with
+    //  atomic add-zero: no __threadfence() -- a fence here writes back every parameter and moment this workgroup's XCD holds dirty)
+    const float o0 = atomicExch(&a.scratch[4 + 2 * blockIdx.x], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    const float o1 = atomicExch(&a.scratch[5 + 2 * blockIdx.x], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(o0), "v"(o1) : "memory");
     const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(a.scratch), 1u);
     last_flag = (ticket == gridDim.x - 1) ? 1u : 0u;
   }
   __syncthreads();
   if (last_flag) {                           // every workgroup has finished: publish the sums, re-arm, advance the step counters
-    __threadfence();
     float pg = 0.f, pe = 0.f;
     for (unsigned b = tid; b < gridDim.x; b += 256) {
-      pg += __builtin_nontemporal_load(&a.scratch[4 + 2 * b]);
-      pe += __builtin_nontemporal_load(&a.scratch[5 + 2 * b]);
+      pg += atomicAdd(&a.scratch[4 + 2 * b], 0.f);
+      pe += atomicAdd(&a.scratch[5 + 2 * b], 0.f);
     }
     pg = wave_sum(pg); pe = wave_sum(pe);
     __syncthreads();
@@ -2227,7 +2228,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
       const float se_all = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
       a.sums_out[0] = sg_all;
       a.sums_out[1] = se_all;
-      *reinterpret_cast<unsigned*>(a.scratch) = 0u;
+      atomicExch(reinterpret_cast<unsigned*>(a.scratch), 0u);
       // (every workgroup read the iteration counter before it took its ticket: advancing it here is ordered behind them)
       if (a.has_post) iteration_scalars_phase1(a.post, a.post.itr[0], a.ema != nullptr, sg_all, a.ema ? se_all : 0.f);
     }
