@@ -548,6 +548,7 @@ class Trainer:
             shares_chip=True)        # (the second stream's branch -- deferred contraction backward, pair-grid network -- runs beside it)
         packed_bwd = None
         scal3 = None
+        join_early = False
         if side is not None:
             gout_free = torch.cuda.Event()
             with torch.cuda.stream(side):
@@ -560,7 +561,15 @@ class Trainer:
             # anyway (on the second stream they were 20 us at the end of what has become the longer branch): 1 / running
             # normaliser = d loss / d objective (main.py:313-320) -- once the deferred backward has read the previous one -- and
             # the objective's cleared accumulator
-            main.wait_event(gout_free)
+            # Where the main stream joins the second one.  Small pair matrices (d <= 16: the branch is SHORTER than the rollout since the
+            # pair-grid network's kernels went resident): right here, in front of the weights -- the cross-queue hand-shake (~6 us as a
+            # separate wait in front of the contraction) then resolves while the rollout is still running.  Large ones (the d = 64 slice:
+            # the branch is three times the rollout): only the event, and the join behind the operands, which are formed meanwhile.
+            join_early = d <= 16
+            if join_early:
+                main.wait_stream(side)
+            else:
+                main.wait_event(gout_free)
             # (gamma is final once the deferred update ran; the three scalars ride in the weights' launch below)
             scal3 = (sde.gamma.detach().reshape(1), D["gam"], D["norm1"], D["gout"], D["obj"])
         # (the weights and the contraction's operands need the rollout only -- and, for the operand buffers the deferred backward
@@ -570,7 +579,8 @@ class Trainer:
         w_mean, w_std = L.mean_std_from_stats(stats)
         ops = L.socm_operands_hip(pb, ts, solver.lmbd, states, noises, controls, out=D)
         if side is not None:
-            main.wait_stream(side)
+            if not join_early:
+                main.wait_stream(side)
             net.record_stream(main)
             dnet.record_stream(main)
         gam = D["gam"]                                                     # (filled in m_branch)
