@@ -78,3 +78,6 @@ if [ -f soc-matching_amd/socmx/libsocmx_prof.so ]; then
   SOCMX_LIB=soc-matching_amd/socmx/libsocmx_prof.so python3 tools/r1_phases.py 64 OU_linear 10 100 > $R/r1_phases_oul10.txt 2>&1
 fi
 python3 tools/determinism_check.py cfg3_double_well_d10_K200 > $R/determinism_check.txt 2>&1
+DET_SHARD=1 python3 tools/determinism_check.py tiny_double_well_d10 2>&1 | grep -v -E "^RCCL|^HIP|^ROCm|^Hostname|^Librccl" >> $R/determinism_check.txt
+# round 6: the captured sharded iteration (own RCCL communicators) soaked at world size 1, eager process-group collectives in front of every capture
+python3 tools/soak_capture.py 120 2>&1 | grep -v -E "initialize_models|^RCCL|^HIP|^ROCm|^Hostname|^Librccl" > $R/soak_capture.txt
