@@ -114,6 +114,27 @@ def test_sharded_autograd_iteration_on_the_gpu(world, tmp_path):
             assert np.array_equal(zs[0][k], zr[k]), k
 
 
+@pytest.mark.parametrize("name,world", [("tiny_molecular_dynamics_d2_stopping", 2), ("md_default_d1_K150_B64_stopping", 3)])
+def test_stopping_time_training_sharded(name, world, tmp_path):
+    """Stopping-time SOCM (molecular_dynamics: per-sample M, the loss normaliser sum(stop_indicators) all-reduced BEFORE the backward,
+    method.py:713-715) through `Trainer.step` over a shard: three iterations at world size 2 / 3 (the README run at its default widths:
+    22 / 21 / 21 rows) against the same iterations of one process -- losses, weight statistics, normaliser, final parameters."""
+    j1, z1 = _launch(1, "train_eager", name, tmp_path, name)
+    jn, zn = _launch(world, "train_eager", name, tmp_path, name)
+    assert sum(j["rows"][0] for j in jn) == j1[0]["rows"][0]
+    for j in jn:
+        assert j["bodies"]["eager"] == 3 and j["collectives_in_steps"] == 2 * 3, j       # the normaliser + the flat gradient buffer
+    a, b = j1[0]["rec"], jn[0]["rec"]
+    for k in ("loss", "weight_mean", "weight_std", "norm"):
+        np.testing.assert_allclose(b[k], a[k], rtol=3e-4, err_msg=k)
+    num = sum(float(((zn[0][k] - z1[0][k]) ** 2).sum()) for k in z1[0].files)
+    den = sum(float((z1[0][k] ** 2).sum()) for k in z1[0].files)
+    assert (num / den) ** 0.5 < 5e-5, (num / den) ** 0.5
+    for zr in zn[1:]:
+        for k in zn[0].files:
+            assert np.array_equal(zn[0][k], zr[k]), k
+
+
 def test_d64_slice_shape_sharded_over_two_ranks(tmp_path):
     """The configs[4] kernels (d = 64: the wide pair-grid-network kernels, the LDS-staged contractions, the general 4-row rollout with a
     dense sigma) under a shard: `cfg5_ou_linear_d64_B256_K3` (the reference's own run at B = 256) split 128 / 128 -- three iterations of
