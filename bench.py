@@ -48,6 +48,9 @@ def rollout_workgroups(d, B):
     t16 = (B + 15) // 16
     return (B + 3) // 4 if (d <= 64 and (t16 <= 16 or (t16 <= 64 and d <= 31))) else t16
 PEAK_HBM_GBPS = 8000.0
+# multi-GPU runs: seconds metric 2 (sharded iterations, secondary configurations, hipGraph legs) may take before rank 0 prints the
+# line as far as it got (main())
+WATCHDOG_S = float(os.environ.get("SOCMX_BENCH_WATCHDOG_S", "600"))
 
 
 def unet_macs(d, h):
@@ -436,6 +439,116 @@ def main():
     elapsed, kernel_ms = blocks[mid], kernel_blocks[mid]
     value = world * B * K * args.steps / elapsed
 
+    if rank == 0:
+        flops = flops_per_traj_step(d, HDIMS) * B * K
+        # (what the one-row kernel executes: the 256 x 256 skip product replaced by the folded d x 256 one -- socmx.h)
+        flops_exec = flops - 2 * (HDIMS[0] * HDIMS[0] - d * HDIMS[0]) * B * K if rollout_workgroups(d, B) == B else flops
+        byts = bytes_per_traj_step(d) * B * K
+        achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/):
+        # WRITE_SIZE + 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-byte-per-lane reads), in bytes
+        traffic, traffic_src = None, None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
+            try:
+                pm = json.load(open(path))
+                # (a summary taken on another library version, or without the kernel this run launches, is refused: the
+                #  traffic of a kernel that no longer exists must not ride along silently)
+                if (pm.get("_meta") or {}).get("socmx_version") != _lib.lib().socmx_version():
+                    continue
+                for kname, v in pm.items():
+                    if kname == "_meta":
+                        continue
+                    if ROLLOUT_KERNEL_TAG in kname and "StaticNet<16" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                        traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
+                        traffic_src = (os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                       "passes of this command; FETCH_SIZE doubled per the gfx950 note)")
+            except Exception:
+                pass
+            if traffic is not None:
+                break
+        line = {
+            "metric": "trajectory-steps/sec", "value": value, "unit": "trajectory-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "timed_blocks": len(blocks), "block_ms_min_median_max": [1e3 * min(blocks), 1e3 * elapsed, 1e3 * max(blocks)],
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+            "shard_transport": None, "one_device_debug": one_device,
+            "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in rank_devices}),
+            "config": {"workload": "double_well d=10 num_steps=200 batch=128/GPU SOCM (BASELINE configs[2]; "
+                                   "global batch 128*N)", "step": "one stochastic_trajectories call (full 8-tuple)",
+                       "parallelism": f"dp{world} (batch-sharded, no data-path collective in the rollout)"},
+            # (metric 2's fields are filled in below as its legs finish: a multi-GPU run whose iteration legs do not come back
+            #  still delivers this line from the watchdog)
+            "socm_iters_per_sec": None, "socm_ms_per_iter": None, "socm_iters_timed": None, "socm_last_loss": None,
+            "socm_iteration_mode": None, "socm_ms_per_iter_eager": None, "socm_ms_per_iter_eager_body": None,
+            "socm_ms_per_iter_graph": None,
+            "roofline": {"bound": "mfma", "kernel": "socmx::rollout1_kernel<0,StaticNet<16,256,128,64,16>,11>",
+                         "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU): 128 of 256 CUs work, and a "
+                                 "v_fmac_f32_dpp (64 MACs) issues at 4.54 cycles per SIMD with two waves on it -- measured, "
+                                 "tools/ubench/valu_banks.hip, profiles/r6/valu_banks.txt -- i.e. 28.2 flop/clk/SIMD of the 64 the "
+                                 "peak is quoted at: frac <= 0.5 x 0.44 = 0.22 for executed flops in this form.  `achieved` counts the "
+                                 "REFERENCE network's flops (BASELINE.md section 5); the kernel executes fewer: the skip res_1 r1 + b "
+                                 "reaches the output's ReLU only through the linear up_0 (models.py:239-240), so the pack kernel folds "
+                                 "up_0 res_1 into a d x 256 matrix and the 256 x 256 product (39 % of the MACs, 256 KB of the 677 KB "
+                                 "of weights) is never formed -- executed_flops_per_launch / executed_frac below.  Every weight is "
+                                 "register- or LDS-resident (no L2 stream) and the step is 1,685 fmacs = 1.9k of its ~4.3k cycles; the "
+                                 "rest is latency: four barriers with an LDS round trip each, the cross-row reductions the 16-unit blocks "
+                                 "force, the two waves of a SIMD running nearly one after the other, the integrating wave's serial section "
+                                 "(profiles/r6/r1_phases.txt).  Round 6: stage 2 in a direct weight layout (no ds_bpermute gather, no "
+                                 "cross-row reduction on the chain): kernel 0.384 -> 0.362 ms.  Eight waves per workgroup are what it takes "
+                                 "to address the whole register file as fmac operands (256 architectural VGPRs per wave): one wave per SIMD "
+                                 "cannot hold the 437 KB of weights (DESIGN.md section 3.1).  Three packed-fma rewrites (round 5) and the "
+                                 "first layer's skip term in the slack (round 6) were built, measured and are not faster.  peak = 157.3 TF is "
+                                 "the fp32 MFMA = packed-vector figure; see roofline_full_chip for the MFMA kernel with the chip full (2,048 "
+                                 "workgroups of two 16-row tiles).  kernel_ms brackets the ~5 us weight re-pack in front of every rollout with "
+                                 "the launch (HIP events on the launch stream); the kernel alone: profiles/r6/kernel_stats.csv",
+                         "executed_flops_per_launch": flops_exec,
+                         "executed_frac": flops_exec / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
+                         "algorithmic_hbm_bytes_per_launch": byts,
+                         "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,
+                         "hbm_frac": byts / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         "active_workgroups": rollout_workgroups(d, B), "cus": 256},
+        }
+    else:
+        line = None
+    # Multi-GPU runs: everything behind this point has collectives in it (the shard's own RCCL communicators come up, sharded
+    # iterations, captured all-reduces) and has only ever met real peers on the driver's N-GPU node.  A watchdog covers ALL of it:
+    # if a leg does not come back, rank 0 prints the line as far as it got (metric 1 is complete, its fields never change below)
+    # and every rank exits on its own timer -- the scaling measurement survives a wedged collective.
+    import threading
+    finished = threading.Event()
+    stage = {"at": "metric 2: bringing up the shard"}
+
+    def bail():
+        if finished.is_set():
+            return
+        print(f"bench.py rank {rank}: watchdog after {WATCHDOG_S:.0f} s at [{stage['at']}]", file=sys.stderr, flush=True)
+        if line is not None:
+            line["watchdog"] = f"did not finish within {WATCHDOG_S:.0f} s at [{stage['at']}]: fields of unfinished legs are null"
+            try:
+                text = json.dumps(line)
+            except Exception as e:  # noqa: BLE001   (a half-updated line must not cost the measurement)
+                text = json.dumps({k: v for k, v in line.items() if isinstance(v, (int, float, str, bool, type(None)))}
+                                  | {"watchdog_error": repr(e)})
+            os.write(1, (text + "\n").encode())
+        # rank 0 delivered the line (exit 0 so that the launcher relays it as a result); every other rank reports the hang as a
+        # failure -- a wedged collective must not look like a clean run
+        # (the launcher tears every rank down as soon as one fails: rank 0 gets a head start to deliver)
+        if rank != 0:
+            time.sleep(5.0)
+        os._exit(0 if rank == 0 else 3)
+
+    timer = None
+    if world > 1 or args.defer_graph:
+        timer = threading.Timer(WATCHDOG_S, bail)
+        timer.daemon = True
+        timer.start()
+
     # ---- metric 2: full SOCM iterations ----------------------------------------------------------
     # (backend nccl: brings up the package's own RCCL communicators, socmx/rccl.py; the one-device debug mode: the staged transport)
     shard = (sdist.Shard(device=device) if one_device else sdist.Shard()) if use_dist else None
@@ -464,11 +577,13 @@ def main():
     # stream, the pair-grid network's small one on the second stream); (3) the whole iteration replayed as ONE captured hipGraph
     # -- main.py's default on one GPU and, with the all-reduces of the shard's own RCCL communicators inside and the ranks
     # agreeing on the capture first, over several
+    stage["at"] = "metric 2: eager autograd iterations"
     it_elapsed_eager, last_loss = time_iterations(False)
     it_elapsed = it_elapsed_eager
     it_mode = "eager (two HIP streams)" if not use_dist else "eager (one flat all-reduce per iteration)"
     it_elapsed_body = None
     if use_dist:
+        stage["at"] = "metric 2: autograd-free body, eager"
         it_elapsed_body, last_loss_b = time_iterations("nocapture")
         if it_elapsed_body < it_elapsed:
             it_elapsed, last_loss = it_elapsed_body, last_loss_b
@@ -487,6 +602,7 @@ def main():
     # ---- the MFMA form of the rollout with the chip full: one evaluation-burst launch (65,536 rows = 2,048 workgroups of two
     #      16-row tiles, csrc/socmx_rollout32.hip; what control_objective / normalization_constant issue, utils.py:131-231) ----
     burst = None
+    stage["at"] = "evaluation burst / secondary configurations"
     if rank == 0 and not args.no_burst:
         Bb = 65536
         big = x0.reshape(1, -1).expand(Bb, -1)
@@ -527,81 +643,14 @@ def main():
             if leg is not None:
                 graph_legs.append(leg)
 
-    if rank == 0:
-        flops = flops_per_traj_step(d, HDIMS) * B * K
-        # (what the one-row kernel executes: the 256 x 256 skip product replaced by the folded d x 256 one -- socmx.h)
-        flops_exec = flops - 2 * (HDIMS[0] * HDIMS[0] - d * HDIMS[0]) * B * K if rollout_workgroups(d, B) == B else flops
-        byts = bytes_per_traj_step(d) * B * K
-        achieved_tf = flops / (kernel_ms * 1e-3) / 1e12
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/):
-        # WRITE_SIZE + 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-byte-per-lane reads), in bytes
-        traffic, traffic_src = None, None
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
-            try:
-                pm = json.load(open(path))
-                # (a summary taken on another library version, or without the kernel this run launches, is refused: the
-                #  traffic of a kernel that no longer exists must not ride along silently)
-                if (pm.get("_meta") or {}).get("socmx_version") != _lib.lib().socmx_version():
-                    continue
-                for kname, v in pm.items():
-                    if kname == "_meta":
-                        continue
-                    if ROLLOUT_KERNEL_TAG in kname and "StaticNet<16" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                        traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
-                        traffic_src = (os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                       "passes of this command; FETCH_SIZE doubled per the gfx950 note)")
-            except Exception:
-                pass
-            if traffic is not None:
-                break
-        line = {
-            "metric": "trajectory-steps/sec", "value": value, "unit": "trajectory-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "timed_blocks": len(blocks), "block_ms_min_median_max": [1e3 * min(blocks), 1e3 * elapsed, 1e3 * max(blocks)],
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
-            "shard_transport": None if shard is None else shard.transport, "one_device_debug": one_device,
-            "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in rank_devices}),
-            "config": {"workload": "double_well d=10 num_steps=200 batch=128/GPU SOCM (BASELINE configs[2]; "
-                                   "global batch 128*N)", "step": "one stochastic_trajectories call (full 8-tuple)",
-                       "parallelism": f"dp{world} (batch-sharded, no data-path collective in the rollout)"},
+    if line is not None:
+        line.update({
+            "shard_transport": None if shard is None else shard.transport,
             "socm_iters_per_sec": it_steps / it_elapsed, "socm_ms_per_iter": 1e3 * it_elapsed / it_steps,
             "socm_iters_timed": it_steps, "socm_last_loss": last_loss, "socm_iteration_mode": it_mode,
             "socm_ms_per_iter_eager": 1e3 * it_elapsed_eager / it_steps,
             "socm_ms_per_iter_eager_body": None if it_elapsed_body is None else 1e3 * it_elapsed_body / it_steps,
-            "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps,
-            "roofline": {"bound": "mfma", "kernel": "socmx::rollout1_kernel<0,StaticNet<16,256,128,64,16>,11>",
-                         "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU): 128 of 256 CUs work, and a "
-                                 "v_fmac_f32_dpp (64 MACs) issues at 4.54 cycles per SIMD with two waves on it -- measured, "
-                                 "tools/ubench/valu_banks.hip, profiles/r6/valu_banks.txt -- i.e. 28.2 flop/clk/SIMD of the 64 the "
-                                 "peak is quoted at: frac <= 0.5 x 0.44 = 0.22 for executed flops in this form.  `achieved` counts the "
-                                 "REFERENCE network's flops (BASELINE.md section 5); the kernel executes fewer: the skip res_1 r1 + b "
-                                 "reaches the output's ReLU only through the linear up_0 (models.py:239-240), so the pack kernel folds "
-                                 "up_0 res_1 into a d x 256 matrix and the 256 x 256 product (39 % of the MACs, 256 KB of the 677 KB "
-                                 "of weights) is never formed -- executed_flops_per_launch / executed_frac below.  Every weight is "
-                                 "register- or LDS-resident (no L2 stream) and the step is 1,685 fmacs = 1.9k of its ~4.3k cycles; the "
-                                 "rest is latency: four barriers with an LDS round trip each, the cross-row reductions the 16-unit blocks "
-                                 "force, the two waves of a SIMD running nearly one after the other, the integrating wave's serial section "
-                                 "(profiles/r6/r1_phases.txt).  Round 6: stage 2 in a direct weight layout (no ds_bpermute gather, no "
-                                 "cross-row reduction on the chain): kernel 0.384 -> 0.362 ms.  Eight waves per workgroup are what it takes "
-                                 "to address the whole register file as fmac operands (256 architectural VGPRs per wave): one wave per SIMD "
-                                 "cannot hold the 437 KB of weights (DESIGN.md section 3.1).  Three packed-fma rewrites (round 5) and the "
-                                 "first layer's skip term in the slack (round 6) were built, measured and are not faster.  peak = 157.3 TF is "
-                                 "the fp32 MFMA = packed-vector figure; see roofline_full_chip for the MFMA kernel with the chip full (2,048 "
-                                 "workgroups of two 16-row tiles).  kernel_ms brackets the ~5 us weight re-pack in front of every rollout with "
-                                 "the launch (HIP events on the launch stream); the kernel alone: profiles/r6/kernel_stats.csv",
-                         "executed_flops_per_launch": flops_exec,
-                         "executed_frac": flops_exec / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops,
-                         "algorithmic_hbm_bytes_per_launch": byts,
-                         "achieved_hbm_GBps": byts / (kernel_ms * 1e-3) / 1e9,
-                         "hbm_frac": byts / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                         "active_workgroups": rollout_workgroups(d, B), "cus": 256},
-        }
+            "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps})
         if burst is not None:
             line["roofline_full_chip"] = burst
         if secondary:
@@ -609,32 +658,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 figure
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
-    else:
-        line = None
     # (world > 1: the hipGraph legs replay the iteration with the all-reduces of the shard's OWN RCCL communicators captured inside
     #  -- socmx/rccl.py: launches on the iteration's streams, nothing of torch's process group under capture -- which is what
     #  main.py does by default over several ranks; over torch's process group (SOCMX_RCCL=0) a multi-rank run never captures and
     #  these legs would only repeat the eager body)
     if defer_graph and not args.no_dist_graph and (world == 1 or solver.shard is None or solver.shard.capturable):
-        # Multi-GPU hipGraph legs (the iteration replayed with its RCCL all-reduces captured inside), LAST and under a watchdog:
-        # every eager number is already in the line; if a capture or a replay does not come back, every rank prints /
-        # exits on its own timer and the run still delivers its line.
-        import threading
-        finished = threading.Event()
-
-        def bail():
-            if finished.is_set():
-                return
-            if line is not None:
-                line["dist_graph"] = "hipGraph legs did not finish within 300 s: eager numbers reported"
-                print(json.dumps(line), flush=True)
-            # rank 0 delivered the line (exit 0 so that the launcher relays it as a result); every other rank reports the
-            # hang as a failure -- a wedged capture must not look like a clean run
-            os._exit(0 if rank == 0 else 3)
-
-        timer = threading.Timer(300.0, bail)
-        timer.daemon = True
-        timer.start()
+        # Multi-GPU hipGraph legs (the iteration replayed with its RCCL all-reduces captured inside), LAST: every eager number
+        # is already in the line should the watchdog have to deliver it
+        stage["at"] = "hipGraph legs (ncclAllReduce launches captured inside)"
         try:
             g_elapsed, g_loss = time_iterations(graph_mode)
             for leg in graph_legs:
@@ -649,7 +680,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             if line is not None:
                 line["dist_graph"] = f"hipGraph capture with RCCL failed: {type(e).__name__}: {str(e)[:200]}"
-        finished.set()
+    finished.set()
+    if timer is not None:
         timer.cancel()
     if line is not None:
         print(json.dumps(line), flush=True)

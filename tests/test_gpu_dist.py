@@ -264,6 +264,25 @@ def test_bench_line_of_a_two_rank_run_on_one_device(tmp_path):
     assert "cpu_baseline" not in line                                    # (a rank-0, N = 1 figure)
 
 
+def test_bench_watchdog_delivers_metric_1_when_the_sharded_legs_do_not_come_back(tmp_path):
+    """A multi-GPU bench run whose collectives wedge (first contact of the shard's own RCCL communicators with real peers happens on
+    the driver's N-GPU node) must still deliver the scaling measurement: with the watchdog at 1 s -- shorter than bringing the shard
+    up and running the first sharded iterations takes -- rank 0 prints the line as far as it got (metric 1 complete, the unfinished
+    legs null, the stage named) and the other rank exits non-zero."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, SOCMX_BENCH_ONE_DEVICE="1", SOCMX_BENCH_WATCHDOG_S="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-burst",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+    line = json.loads(lines[0])
+    assert "did not finish within 1 s at [" in line["watchdog"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["ms_per_step"] > 0 and line["roofline"]["kernel_ms"] > 0
+    assert line["socm_ms_per_iter_graph"] is None
+    assert res.returncode != 0                       # (the other rank reports the hang as a failure)
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()
