@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define SOCMX_VERSION 148 /* 0.2.0: + socmx_iteration_scalars_hist_f32, socmx_adam_step_scalars_hist_f32 (the iteration's scalars also land in row `itr` of a history array); 0.1.9: the objective is summed without float atomics -- socmx_socm_target_fwd_f32 / _fwd_net_f32 / socmx_socm_residual_f32 take a caller-owned workspace (socmx_socm_objective_workspace_floats); socmx_shard_stats_f32 carries per-rank (n, mean, M2) slots instead of shifted sums; 0.1.8: + socmx_weights_stats_scalars_f32; 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
+#define SOCMX_VERSION 149 /* 0.2.1: the one-row rollout can save the control network's activations and ReLU signs for the backward -- socmx_rollout_extra grew (act_workspace, act_records), + socmx_rollout_saves_activations, socmx_unet_backward_saved_f32; 0.2.0: + socmx_iteration_scalars_hist_f32, socmx_adam_step_scalars_hist_f32 (the iteration's scalars also land in row `itr` of a history array); 0.1.9: the objective is summed without float atomics -- socmx_socm_target_fwd_f32 / _fwd_net_f32 / socmx_socm_residual_f32 take a caller-owned workspace (socmx_socm_objective_workspace_floats); socmx_shard_stats_f32 carries per-rank (n, mean, M2) slots instead of shifted sums; 0.1.8: + socmx_weights_stats_scalars_f32; 0.1.7: the packed U-Net image carries the folded skip behind the nine layers -- F = up_0 res_1, f = up_0 b_res_1, cat = [F | up_0] (socmx_unet_packed_floats grew); the transposed image holds F^T in res_1^T's place (socmx_unet_packed_bwd_floats shrank); socmx_unet_backward_sizes: + the fold's scratch */
 
 #define SOCMX_E_NULL (-1)      /* required pointer is NULL            */
 #define SOCMX_E_DIM (-2)       /* dimension out of the supported range */
@@ -155,6 +155,14 @@ int socmx_unet_backward_f32(const float* packed, const float* packedT, int32_t d
 int socmx_unet_backward_scaled_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
                                    const float* x, const float* ts, int32_t rows_per_t, int64_t N, const float* gout,
                                    const float* gout_scale, float* workspace, float* grads, socmx_stream_t stream);
+/* The same from SAVED activations: `workspace` already holds the activation slabs and `records` the ReLU signs of the N rows, written by
+ * the rollout that produced x (socmx_rollout_ex_f32: act_workspace / act_records, same weights): kernel A runs its five backward
+ * stages only -- no forward re-computation (half of its multiply-adds), no activation exports.  N must be a multiple of 16 and
+ * (d, hdims) the library's constexpr-specialised default widths with d <= 15 (SOCMX_E_DIM otherwise: callers use the plain entry). */
+int socmx_unet_backward_saved_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
+                                  const float* x, const float* ts, int32_t rows_per_t, int64_t N, const float* gout,
+                                  const float* gout_scale, const uint32_t* records, float* workspace, float* grads,
+                                  socmx_stream_t stream);
 
 /*
  * The pair-grid network of the SOCM loss: SigmoidMLP.sigmoid_layers (models.py:245-257: Linear(2,h0) ReLU Linear(h0,h1) ReLU
@@ -247,12 +255,24 @@ int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, co
  *            launch leaves it 0.  Not to be combined with another launch reading the same key concurrently.
  */
 #define SOCMX_ROLLOUT_ADVANCES_KEY 2u
+/*   act_workspace / act_records (both or neither; need nabla_v): the launch SAVES what the control-network backward would otherwise
+ *            re-compute.  act_workspace is that backward's workspace (socmx_unet_backward_sizes floats for N = (K+1) B rows): the
+ *            activation slabs of every trajectory row -- R1, R2, R3, O2 and A1 = relu(up_1 O2 + b) of models.py:233-242, [16-row tile][unit][16]
+ *            -- are written where socmx_unet_backward_saved_f32 and the weight-gradient kernel read them; act_records is device
+ *            uint32[(K+1) B][32]: the ReLU signs of a row (layout: csrc/socmx_unet.h).  Honoured by the one-row kernel only (d <= 15,
+ *            B <= 256, default widths, no stopping time, (K+1) B a multiple of 16): socmx_rollout_saves_activations answers 1 / 0 for a
+ *            launch's arguments without launching, and a launch that cannot honour the request returns SOCMX_E_DIM.  The states, noises,
+ *            costs and nabla_v of the launch are bit-identical with and without the request.
+ */
 typedef struct socmx_rollout_extra {
   const uint64_t* key;
   float* nabla_v;
   uint32_t flags;
   uint32_t reserved;
+  float* act_workspace;
+  uint32_t* act_records;
 } socmx_rollout_extra;
+int socmx_rollout_saves_activations(const socmx_problem* problem, const int32_t hdims[3], int32_t B, int32_t K);
 int socmx_rollout_ex_f32(const socmx_problem* problem, const float* packed_unet, const int32_t hdims[3],
                          const float* x0, const float* ts, int32_t B, int32_t K, float lmbd,
                          uint64_t seed, uint64_t offset, int64_t row0, const float* noise_in,

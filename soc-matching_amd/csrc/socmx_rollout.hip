@@ -1447,7 +1447,8 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
                           const uint64_t* key_dev, float* nabla_v, uint32_t flags, int64_t row0, const float* noise_in, float* states,
                           float* noises, float* controls,
                           float* stop_indicators, float* fractional_timesteps, float* lpd, float* lps, float* ltw,
-                          long long* prof, socmx_stream_t stream) {
+                          long long* prof, socmx_stream_t stream, float* act_ws = nullptr, uint32_t* act_rec = nullptr,
+                          bool query_saves = false) {
   if (!pb || !packed_unet || !hdims || !x0 || !ts || !lpd || !lps || !ltw || !pb->sigma) return SOCMX_E_NULL;
   // the five trajectory buffers come together or not at all (costs-only launch: the evaluation bursts of
   // utils.py:131-231 read nothing but lpd / lps / ltw)
@@ -1480,6 +1481,7 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   a.states = states; a.noises = noises; a.controls = controls; a.stop_ind = stop_indicators;
   a.frac = fractional_timesteps; a.lpd = lpd; a.lps = lps; a.ltw = ltw;
   a.nabla_v = nabla_v;
+  a.act_ws = act_ws; a.act_rec = act_rec; a.act_tile_rows = (int)(((int64_t)K + 1) * B);
   a.prof = prof;
   static const int prof_wave = [] { const char* e = getenv("SOCMX_PROF_WAVE"); return (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 0; }();
   a.prof_wave = prof_wave;
@@ -1543,9 +1545,15 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   // (a dense sigma at d <= 15 -- the README's Linear OU, d = 10 -- takes the same kernel: sigma u = -(sigma sigma^T) nabla_V is the
   //  one extra product on its serial chain; not with a stopping time, which is built for sigma = I)
   const bool one_row_form = fast || (!force_slow && !a.sigma_identity && d <= 15 && !stopping);
-  if (is_default && one_row_form && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
-      (B <= 256 || (force_rows == 1 && B <= 1024)))
-    return rollout1_launch(a, stopping, stream);
+  const bool one_row = is_default && one_row_form && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
+                       (B <= 256 || (force_rows == 1 && B <= 1024));
+  // The activation export (act_workspace / act_records): the one-row kernel at d <= 15 without a stopping time, whole 16-row tiles of
+  // trajectory rows (the slabs of a ragged last tile would hold rows nobody wrote), offsets within 31 bits.  Anything else: refused,
+  // and socmx_rollout_saves_activations says so beforehand.
+  const bool saves = one_row && !stopping && (((int64_t)K + 1) * B) % 16 == 0 && ((int64_t)K + 1) * B * 1024 * 4 < ((int64_t)1 << 31);
+  if (query_saves) return saves ? 1 : 0;
+  if (act_ws && (!saves || !act_rec || !nabla_v)) return SOCMX_E_DIM;
+  if (one_row) return rollout1_launch(a, stopping, stream);
   // ... and 17 <= d <= 31 with sigma = I at the default widths (soc.yaml's default d = 20): the same kernel with two components
   // per lane and down_0 / res_0 as a stage of their own on all eight waves
   if (is_wide32 && !force_slow && a.sigma_identity && d >= 16 && d <= 31 && r1_prof_ok && rollout1_wide_available() &&
@@ -1613,7 +1621,20 @@ extern "C" int socmx_rollout_ex_f32(const socmx_problem* pb, const float* packed
   const uint64_t* key = extra ? extra->key : nullptr;
   float* nabla_v = extra ? extra->nabla_v : nullptr;
   return rollout_launch(pb, packed_unet, hdims, x0, ts, B, K, lmbd, seed, offset, key, nabla_v, extra ? extra->flags : 0u, row0, noise_in, states,
-                        noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream);
+                        noises, controls, stop_indicators, fractional_timesteps, lpd, lps, ltw, nullptr, stream,
+                        extra ? extra->act_workspace : nullptr, extra ? extra->act_records : nullptr);
+}
+
+// 1 when socmx_rollout_ex_f32 with these arguments (trajectory buffers, nabla_v) honours act_workspace / act_records, 0 when it would refuse
+// them, negative: invalid arguments.  Launches nothing.
+extern "C" int socmx_rollout_saves_activations(const socmx_problem* pb, const int32_t hdims[3], int32_t B, int32_t K) {
+  if (!pb || !hdims) return SOCMX_E_NULL;
+  static float dummy[4];
+  // (the selection is the launcher's own: every pointer it only checks for presence is `dummy`, nothing is dereferenced on the query path)
+  socmx_problem q = *pb;
+  if (!q.sigma) q.sigma = dummy;
+  return rollout_launch(&q, dummy, hdims, dummy, dummy, B, K, 1.f, 0, 0, nullptr, dummy, 0u, 0, nullptr, dummy, dummy, dummy, dummy, dummy, dummy,
+                        dummy, dummy, nullptr, nullptr, nullptr, nullptr, true);
 }
 
 extern "C" int socmx_philox_advance(uint64_t* key, uint64_t inc, socmx_stream_t stream) {

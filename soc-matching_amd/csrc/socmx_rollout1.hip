@@ -47,6 +47,9 @@ constexpr bool R1_S2DIRECT = SOCMX_R1_S2DIRECT != 0;
 // res_0 [t, x] formed in wave 0's slack behind stage 4 instead of inside first_layer, on the serial section: measured, NO gain
 // (0.391 against 0.385 ms: the slack is not free -- a longer low-priority section makes wave 0 the last one at that barrier): off
 constexpr bool R1_RES0_SLACK = SOCMX_R1_RES0_SLACK != 0;
+#ifndef SOCMX_R1_EX_PARTS
+#define SOCMX_R1_EX_PARTS 3     /* developer A/B: 1 = the activation stores, 2 = the sign records */
+#endif
 constexpr int kR1Blocks = 20;   // main-program blocks per wave and step
 constexpr int kR1PD = 2;        // ring depth (blocks)
 
@@ -198,7 +201,7 @@ static_assert((R1Lds::weights + r1_lds_blocks(103) * 1024 + 768) * 4 <= 160 * 10
 // DMAX: the state dimensions this instantiation takes (d <= DMAX): wave 0 holds 1 + DMAX input columns of down_0 / res_0
 // MODE: 0 elementwise drift (double_well), 1 the same with a stopping time (molecular_dynamics), 2 OU drift (A x; x'Px for
 // OU_quadratic); + 4: a dense sigma (u = -sigma^T nabla_V, sigma u = -(sigma sigma^T) nabla_V, sigma eps) -- MODE 4, 6
-template <int CLS, int MODE, class NET, int DMAX0>
+template <int CLS, int MODE, class NET, int DMAX0, bool EXPORT>
 __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const int wave, const int lane) {
   constexpr bool DENSE = (MODE & 4) != 0;
   constexpr int DMAX = DMAX0;                       // state dimensions this instantiation takes
@@ -209,6 +212,11 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   constexpr int H = NET::outp >> 4;
   static_assert(H == 1 || (H == 2 && DMAX0 == 31 && !DENSE), "17 <= d <= 31: sigma = I, one instantiation");
   typedef typename R1LdsOf<H>::type LM;
+  // EXPORT (socmx_rollout_ex_f32's act_workspace / act_records): every evaluation's activations leave as the slabs the control-network
+  // backward would otherwise re-compute, their ReLU signs as a 128-byte record per row (socmx_unet.h).  Stores only: a buffer store per
+  // tensor and wave (scalar base: tile and row of the evaluation; lane offset: the unit), one record store per wave.
+  constexpr bool EX = EXPORT;
+  static_assert(!EXPORT || (H == 1 && MODE != 1), "the activation export is built for d <= 15 without a stopping time");
   constexpr int MS = 16 * H;                        // row stride of the noise ring (and of A, P at d <= 15)
   constexpr int MSA = H == 2 ? 36 : 16;             // row stride of A, P in LDS
   constexpr int NBS = 8 / H;                        // steps per noise batch (noise_batch below); its ring holds three batches: slot = step % (3 NBS)
@@ -620,6 +628,53 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   // evaluation's stage 4, where wave 0 waits for the others anyway, from a few registers (the step's scalars sit in a
   // three-deep LDS ring: wave 3 writes those of step k + 2 in the same slack)
   int cur_k = 0;                       // the step network() runs for (the noise waves prepare steps cur_k + 1, cur_k + 2 inside)
+  // ---- the activation export (EX) ----
+  const __amdgpu_buffer_rsrc_t ex_rs = __builtin_amdgcn_make_buffer_rsrc(EX ? (void*)a.act_ws : (void*)lds, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ex_rr = __builtin_amdgcn_make_buffer_rsrc(EX ? (void*)a.act_rec : (void*)lds, 0, 0x7FFFFFFF, 0x00020000);
+  const int ex_pk = r1_perm(lane);
+  int ex_tile = 0, ex_r4 = 0, ex_row = 0;          // tile, 4 (row & 15), row of the evaluation under way (wave-uniform)
+  uint32_t ex_d0 = 0, ex_d1 = 0;
+  uint64_t ex_b64 = 0;
+  float bk_pre = 0.f;                               // wave 0: the output's pre-activation of the step whose books are open
+  float ex_o1 = 0.f;                                // waves 1 .. 7: this evaluation's A1 units, kept for ex_flush()
+  auto ex_begin = [&]() {
+    ex_row = cur_k * B + grow;
+    ex_tile = ex_row >> 4;
+    ex_r4 = (ex_row & 15) * 4;
+  };
+  // this lane's value of unit `unit` of slab tensor T (socmx_unet.h): [tile][unit][16 rows]
+  auto ex_store = [&](auto tc, int unit, float v) {
+    constexpr int T = decltype(tc)::value;
+    constexpr int W = tensor_width(u, T), P = tensor_prefix(u, T);
+    const int soff = (a.act_tile_rows * P + ex_tile * (W * 16)) * 4 + ex_r4;
+    if constexpr ((SOCMX_R1_EX_PARTS & 1) != 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ex_rs, unit * 64, soff, 0);
+  };
+  // a wave's own record: dwords 0, 1; dwords 2, 3 only where the wave itself formed them (waves 1 .. 3: their chunk of R1) -- slots 4 and 5
+  // get theirs from waves 0 and 1 (ex_aux), wave 0's dword 2 follows with its books
+  auto ex_record = [&]() {
+    if ((SOCMX_R1_EX_PARTS & 2) != 0 && lane == 0) {
+      const int soff = (ex_row * kActRecordDwords + wave * 4) * 4;
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      if (CLS == 1 && wave <= 3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ex_d0, ex_d1, (uint32_t)ex_b64, (uint32_t)(ex_b64 >> 32)}, ex_rr, 0, soff, 0);
+      else __builtin_amdgcn_raw_buffer_store_b64(u32x2{ex_d0, ex_d1}, ex_rr, 0, soff, 0);
+    }
+  };
+  auto ex_aux = [&](int slot, uint64_t b) {         // dwords 2, 3 of another wave's slot (64 signs in lane order)
+    if ((SOCMX_R1_EX_PARTS & 2) != 0 && lane == 0) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)b, (uint32_t)(b >> 32)}, ex_rr, 0, (ex_row * kActRecordDwords + slot * 4 + 2) * 4, 0);
+    }
+  };
+  auto ex_output_sign = [&](int row, float pre) {   // wave 0: the sign of the output's pre-activation -> dword 2 of its record
+    const uint32_t m = (uint32_t)__builtin_amdgcn_ballot_w64(pre > 0.f) & 0xFFFFu;
+    if ((SOCMX_R1_EX_PARTS & 2) != 0 && lane == 0) __builtin_amdgcn_raw_buffer_store_b32(m, ex_rr, 0, (row * kActRecordDwords + 2) * 4, 0);
+  };
+  using TR1 = std::integral_constant<int, T_R1>;
+  using TR2 = std::integral_constant<int, T_R2>;
+  using TR3 = std::integral_constant<int, T_R3>;
+  using TO2 = std::integral_constant<int, T_O2>;
+  using TO1 = std::integral_constant<int, T_O1>;
   int bk_k = -1;                       // the step whose bookkeeping is outstanding
   float bk_gv = 0.f, bk_step = 0.f, bk_eps = 0.f, bk_gvh = 0.f, bk_epsh = 0.f;
   float bk_sol = 0.f;                  // H = 2, OU_quadratic: step / lambda of the step whose -f x'Px term is outstanding
@@ -734,6 +789,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       (a.noises + kbd)[rowoff + 16] = bk_epsh;
       (a.states + kbd + step_floats)[rowoff + 16] = xh;
     }
+    if constexpr (EX) ex_output_sign(k * B + grow, bk_pre);
     kbd += step_floats;
     if (store0) {
       (a.frac + kb)[grow] = STOPPING ? bk_step : scal[0];
@@ -774,6 +830,19 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     // stage 1: r2 = relu(down_1 r1 + b)            wave w: units 16 w .. 16 w + 15
     const f32x4 xr1 = *reinterpret_cast<const f32x4*>(lds + LM::r1 + lane * 4);
     const float bias1 = BL[u.L[1].b_lds + 16 * wave + n];
+    if constexpr (EX) {
+      // R1 (every wave holds all of it): chunk c by the older wave of SIMD c -- waves 1, 2, 3 chunks 0, 1, 2 (their own slots' dwords 2, 3),
+      // wave 0 chunk 3 (slot 4's).  The older waves reach this stage's barrier hundreds of cycles before the younger ones.
+      ex_begin();
+      if constexpr (CLS == 0) {
+        ex_store(TR1{}, 64 * 3 + ex_pk, xr1[3]);
+        ex_aux(4, __builtin_amdgcn_ballot_w64(xr1[3] > 0.f));
+      } else if (wave <= 3) {
+        const float v = wave == 1 ? xr1[0] : wave == 2 ? xr1[1] : xr1[2];
+        ex_store(TR1{}, 64 * (wave - 1) + ex_pk, v);
+        ex_b64 = __builtin_amdgcn_ballot_w64(v > 0.f);
+      }
+    }
     float s0 = 0.f, s1 = 0.f;
     blk(R1B(0), R1NX(1, 1), s0, s1, xr1[0]);
     blk(R1B(1), R1NX(2, 1), s0, s1, xr1[1]);
@@ -785,6 +854,10 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       // stage 2 without a barrier of its own: down_2 is linear in r2, so the wave multiplies ITS 16 outputs into all 64
       // units right away (block 4: unit blocks 0..3 x input chunk w) and stage 3 adds the eight waves' partial sums.
       // Row g of the operand register holds r2[16 w + 4 g + (p & 3)] at every position p: one cross-lane gather.
+      if constexpr (EX) {
+        if constexpr (CLS == 0) { if (lane < 16) ex_store(TR2{}, 16 * wave + n, y); }     // (waves 1 .. 7: from LDS, in ex_flush)
+        ex_d0 = (uint32_t)__builtin_amdgcn_ballot_w64(y > 0.f) & 0xFFFFu;
+      }
       if constexpr (R1_S2DIRECT) {
         float c0 = 0.f, c1 = 0.f;
         pre(R1NX(5, 1));                        // (stage 3's first block, if it is an LDS block: read behind these fmacs)
@@ -820,6 +893,12 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     for (int w8 = 0; w8 < 4; ++w8) p2b[w8] = lds[LM::p2 + (4 + w8) * 64 + pk];
     blk(R1B(6), R1NX(7, 1), q0, q1, xr2.y);
     const float xr3 = relu_keep_nan((p2lo + ((p2b[0] + p2b[1]) + (p2b[2] + p2b[3]))) + bias2);
+    if constexpr (EX && CLS == 1) {
+      if (wave == 1) {                            // R3 is formed by every wave: an older one writes it (slot 5's dwords 2, 3)
+        ex_store(TR3{}, ex_pk, xr3);
+        ex_aux(5, __builtin_amdgcn_ballot_w64(xr3 > 0.f));
+      }
+    }
     blk(R1B(7), R1NX(16, 2), u0, u1, xr3);
     {
       const float t = r1_reduce4(u0 + u1, q0 + q1, 0.f, 0.f);     // rows 0: up_2's totals, rows 2: res_2's
@@ -827,6 +906,10 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       r1_halves(t, up, rs);
       const float y = relu_keep_nan(up + bu3) + (rs + br3);
       if (lane < 16) lds[LM::o2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
+      if constexpr (EX) {
+        if constexpr (CLS == 0) { if (lane < 16) ex_store(TO2{}, 16 * wave + n, y); }
+        ex_d0 |= ((uint32_t)__builtin_amdgcn_ballot_w64(up + bu3 > 0.f) & 0xFFFFu) << 16;
+      }
     }
     R1_TICK(5)
     __syncthreads();
@@ -863,6 +946,15 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       R1_TICK(7)
       o1 = relu_keep_nan(up + bu4);                       // lane (g, n): unit 32 w + 16 (g & 1) + n, both halves alike
     }
+    if constexpr (EX) {
+      ex_d1 = (uint32_t)__builtin_amdgcn_ballot_w64(o1 > 0.f);
+      if constexpr (CLS == 0) {                   // (wave 0 waits for the younger waves at the coming barrier: here; waves 1 .. 7: ex_flush)
+        if (lane < 32) ex_store(TO1{}, 32 * wave + lane, o1);
+        ex_record();
+      } else {
+        ex_o1 = o1;
+      }
+    }
     // stage 5, this wave's share: up_0 over the wave's own 32 outputs (no barrier in between), on top of the fold's share
     {
       const float x5 = r1_ror8_upper(o1);
@@ -896,12 +988,26 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     __syncthreads();
     R1_TICK(9)
   };
+  // Waves 1 .. 7 between the barrier that ends the network and the one behind wave 0's serial section (~700 idle cycles): their A1 units
+  // and records, and -- from LDS, where every wave's share still stands -- R2 and O2 (their halves by waves 1, 2 and 3, 5: lane x of half j
+  // holds unit 64 j + r1_perm(x)).  Wave 4 shares its SIMD with the integrating wave: its own two stores only, at the lowest priority.
+  auto ex_flush = [&]() {
+    if constexpr (EX && CLS == 1) {
+      __builtin_amdgcn_s_setprio(0);
+      if (lane < 32) ex_store(TO1{}, 32 * wave + lane, ex_o1);
+      ex_record();
+      if (wave == 1 || wave == 2) ex_store(TR2{}, 64 * (wave - 1) + ex_pk, lds[LM::r2 + lane * 2 + (wave - 1)]);
+      if (wave == 3 || wave == 5) ex_store(TO2{}, 64 * (wave == 3 ? 0 : 1) + ex_pk, lds[LM::o2 + lane * 2 + (wave == 3 ? 0 : 1)]);
+      __builtin_amdgcn_s_setprio(2);
+    }
+  };
   // nabla_V[i] in every row of wave 0 (the other waves: not used)
   auto network_output = [&]() -> float {
     const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8);
     const f32x4 pb = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8 + 4);
     const float s = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]));
     if constexpr (H == 2) return relu_keep_nan(s + b8) + lds[LM::res0 + n];
+    if constexpr (EX) bk_pre = s + b8;
     return relu_keep_nan(s + b8) + res0;
   };
   auto network_output_hi = [&]() -> float {                               // H = 2: unit 16 + n
@@ -920,12 +1026,18 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   if constexpr (CLS == 0) rollout_key_advance(a, key_offset);     // (every wave read the key in front of this barrier)
   __syncthreads();
   if constexpr (CLS == 0) prepare_step(0);
+  // EXPORT: every load of the prologue (the resident weights, the key) has landed before the first step -- said HERE, once, in a
+  // form the compiler's wait-count pass reads: without it the loop keeps conservative s_waitcnt vmcnt(0) in front of fmac blocks (a
+  // weight register might still be in flight on the first trip), and with stores inside the loop those waits become real every step:
+  // each one then waits for the export stores issued just before it (0.433 instead of 0.383 ms at configs[2])
+  if constexpr (EX) __builtin_amdgcn_s_waitcnt(0x0F70);          // s_waitcnt vmcnt(0)
   for (int k = 0; k < K; ++k) {
 #ifdef SOCMX_R1_PROF
     if (k == 0) prof_last = __builtin_readcyclecounter();
 #endif
     cur_k = k;
     network();
+    ex_flush();
     if constexpr (CLS == 0) {
       // every LDS operand of the chain is requested at once (left to the scheduler the three round trips ran one after the other)
       const f32x4 pa = *reinterpret_cast<const f32x4*>(lds + LM::p5 + n * 8);
@@ -949,7 +1061,9 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       }
       __builtin_amdgcn_sched_barrier(0);
       const float dt = scal[0], sq_ldt = scal[1];
-      const float gv = relu_keep_nan((((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + b8) + res0v;
+      const float gpre = (((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + b8;
+      const float gv = relu_keep_nan(gpre) + res0v;
+      if constexpr (EX) bk_pre = gpre;
       R1_TICK(12)
       // sigma u = -sigma sigma^T nabla_V: the one product that waits for the network (sigma = I: u = -nabla_V itself); the drift
       // and sigma eps were formed a stage ago (prepare_step)
@@ -998,10 +1112,12 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   cur_k = K;                              // (nothing left to prepare)
   if (a.nabla_v) {                        // nabla_V(T, X_K): r1 already holds down_0 [t_K, x_K]
     network();                            // (wave 0 closes the last step's books inside)
+    ex_flush();
     apply_quad_cost();
     if constexpr (CLS == 0) {
       const float gv = network_output();
       if (store) a.nabla_v[(size_t)K * B * d + rowoff] = gv;
+      if constexpr (EX) ex_output_sign(K * B + grow, bk_pre);
       if constexpr (H == 2) {
         const float gvh = network_output_hi();
         if (store_h) a.nabla_v[(size_t)K * B * d + rowoff + 16] = gvh;
@@ -1051,7 +1167,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
 #undef R1B
 }
 
-template <int MODE, class NET, int DMAX>
+template <int MODE, class NET, int DMAX, bool EXPORT = false>
 __global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutArgs a) {  // MODE: see r1_wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1060,8 +1176,8 @@ __global__ __launch_bounds__(kR1Waves * 64) void rollout1_kernel(const RolloutAr
   for (int e = tid; e < LM::bias; e += kR1Waves * 64) lds[e] = 0.f;
   unet_load_biases_at(a.packed, NET::desc(), lds + LM::bias, tid, kR1Waves * 64);
   __syncthreads();
-  if (wave == 0) r1_wave<0, MODE, NET, DMAX>(a, lds, 0, lane);
-  else r1_wave<1, MODE, NET, DMAX>(a, lds, wave, lane);
+  if (wave == 0) r1_wave<0, MODE, NET, DMAX, EXPORT>(a, lds, 0, lane);
+  else r1_wave<1, MODE, NET, DMAX, EXPORT>(a, lds, wave, lane);
 }
 
 bool rollout1_available() { return r1_supported<DefaultNet>(); }
@@ -1070,7 +1186,7 @@ bool rollout1_wide_available() { return r1_supported<Wide32Net>(); }
 int rollout1_wide_launch(const RolloutArgs& a, bool stopping, void* stream) {
   if constexpr (r1_supported<Wide32Net>()) {
     const bool ou = a.kind == SOCMX_OU_QUADRATIC || a.kind == SOCMX_OU_LINEAR;
-    if (!a.sigma_identity) return SOCMX_E_DIM;
+    if (!a.sigma_identity || a.act_ws) return SOCMX_E_DIM;
     void (*k)(const RolloutArgs) = stopping ? rollout1_kernel<1, Wide32Net, 31> : ou ? rollout1_kernel<2, Wide32Net, 31> : rollout1_kernel<0, Wide32Net, 31>;
     if (const int err = ensure_max_lds(k)) return err;
     return launch(k, dim3((unsigned)a.B), dim3(kR1Waves * 64), (size_t)kLdsBytesPerCU, stream, a);
@@ -1093,6 +1209,16 @@ int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream) {
     else if (a.d <= 11) k = R1PICK(11);
     else k = R1PICK(15);
 #undef R1PICK
+    if (a.act_ws) {                                        // the activation export: no stopping time, the terminal evaluation included
+      if (stopping || !a.act_rec || !a.nabla_v) return SOCMX_E_DIM;
+#define R1PICKX(DM)                                                                                                  \
+  (dense ? (ou ? rollout1_kernel<6, DefaultNet, DM, true> : rollout1_kernel<4, DefaultNet, DM, true>)                \
+         : (ou ? rollout1_kernel<2, DefaultNet, DM, true> : rollout1_kernel<0, DefaultNet, DM, true>))
+      if (a.d <= 3) k = R1PICKX(3);
+      else if (a.d <= 11) k = R1PICKX(11);
+      else k = R1PICKX(15);
+#undef R1PICKX
+    }
     if (const int err = ensure_max_lds(k)) return err;
     // (the CU's whole LDS: one workgroup per CU, nobody else's workgroups beside this latency-bound chain)
     return launch(k, dim3((unsigned)a.B), dim3(kR1Waves * 64), (size_t)kLdsBytesPerCU, stream, a);

@@ -25,6 +25,11 @@ struct RolloutArgs {
   const float *x0, *ts, *noise_in;
   float *states, *noises, *controls, *stop_ind, *frac, *lpd, *lps, *ltw;
   float* nabla_v;      // optional (K+1, B, d): the network output at every grid point incl. the terminal one (method.py:272-278)
+  // optional (socmx_rollout_ex_f32: act_workspace / act_records; the one-row kernel at d <= 15 only, (K+1) B a multiple of 16): the activation
+  // slabs T_X .. T_O1 of the control-network backward's workspace and the 128-byte sign record of every trajectory row (socmx_unet.h)
+  float* act_ws;
+  uint32_t* act_rec;
+  int act_tile_rows;   // 16 x the backward's 16-row tiles = (K+1) B
   int sigma_identity;  // problem->flags & SOCMX_SIGMA_IDENTITY
   int lds_mats;  // float offset (in LDS) of the sigma / A / P copies and the small per-step vectors
   long long* prof;  // diagnostics only (PROF variant): [blocks][64] accumulated s_memtime cycles per phase

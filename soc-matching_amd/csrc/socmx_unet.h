@@ -286,6 +286,43 @@ inline void fill_wave_work(UnetProgram& p, int NW) {
     for (int w = 0; w < NW; ++w) p.ww[si][w] = wave_work_of(p.st[si], NW, w);
 }
 
+// ---- tensors that travel from kernel A to kernel B, each [tile][width][16 rows] ---------------------------------------
+enum { T_X = 0, T_R1, T_R2, T_R3, T_O2, T_O1, T_G0, T_ZU0, T_GO1, T_ZU1, T_GO2, T_ZU2, T_ZD2, T_ZD1, T_ZD0, T_N };
+
+__host__ __device__ constexpr int tensor_width(const UnetDesc& u, int t) {
+  switch (t) {
+    case T_X: return u.in0p;
+    case T_R1: case T_O1: case T_GO1: case T_ZU1: case T_ZD0: return u.hp[0];
+    case T_R2: case T_O2: case T_GO2: case T_ZU2: case T_ZD1: return u.hp[1];
+    case T_R3: case T_ZD2: return u.hp[2];
+    default: return u.outp;   // T_G0, T_ZU0
+  }
+}
+__host__ __device__ constexpr int tensor_prefix(const UnetDesc& u, int t) {   // sum of the widths before tensor t
+  int s = 0;
+  for (int i = 0; i < t; ++i) s += tensor_width(u, i);
+  return s;
+}
+// ---- what the ONE-ROW rollout saves for the control-network backward (socmx_rollout_ex_f32: act_workspace / act_records) ----------
+// The rollout evaluates the network on every trajectory row anyway: with the activation slabs X.. O1 written by it (the layout above,
+// straight into the backward's workspace) and the ReLU signs of a row in a 128-byte RECORD, kernel A runs its five backward stages only.
+// Record of row r: eight waves x four dwords, rec[(r * 8 + w) * 4 + j]:
+//   j = 0: bits 0..15  sign of R2[16 w + n],  bits 16..31  sign of the up-path pre-activation of O2[16 w + n]   (n = bit & 15)
+//   j = 1: sign of A1[32 w + bit] = relu(up_1 O2 + b)
+//   j = 2, 3 (64 bits, LANE order: bit x <-> element r1_perm(x)): waves 1..4: R1[64 (w - 1) + r1_perm(x)];  wave 5: R3[r1_perm(x)]
+//   wave 0, j = 2: bits 0..15 sign of the output's pre-activation (up_0 A1 + F R1 + f + b)[bit]
+enum { MK_NONE = 0, MK_R1, MK_R2, MK_R3, MK_U2, MK_U1 };
+constexpr int kActRecordDwords = 32;
+// the nibble (units n0 .. n0 + 3, n0 a multiple of 4) of mask `mk` in the record of one row
+__host__ __device__ inline unsigned act_record_nibble(const uint32_t* rec, int mk, int n0) {
+  if (mk == MK_R2) return (rec[(n0 >> 4) * 4] >> (n0 & 12)) & 0xFu;
+  if (mk == MK_U2) return (rec[(n0 >> 4) * 4] >> (16 + (n0 & 12))) & 0xFu;
+  if (mk == MK_U1) return (rec[(n0 >> 5) * 4 + 1] >> (n0 & 31)) & 0xFu;
+  const int pos = 16 * ((n0 >> 2) & 3) + 4 * ((n0 >> 4) & 3);           // element 16 a + 4 b + i sits in lane 16 b + 4 a + i
+  const int w = mk == MK_R1 ? 1 + (n0 >> 6) : 5;
+  return (rec[w * 4 + 2 + (pos >> 5)] >> (pos & 31)) & 0xFu;
+}
+
 #if defined(__HIPCC__)
 
 __device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.f ? 0.f : x; }

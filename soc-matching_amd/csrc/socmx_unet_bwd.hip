@@ -59,23 +59,8 @@ __host__ __device__ constexpr BwdDesc make_bwd_desc(const UnetDesc& u) {
   return b;
 }
 
-// ---- tensors that travel from kernel A to kernel B, each [tile][width][16 rows] ---------------------------------------
-enum { T_X = 0, T_R1, T_R2, T_R3, T_O2, T_O1, T_G0, T_ZU0, T_GO1, T_ZU1, T_GO2, T_ZU2, T_ZD2, T_ZD1, T_ZD0, T_N };
-
-__host__ __device__ constexpr int tensor_width(const UnetDesc& u, int t) {
-  switch (t) {
-    case T_X: return u.in0p;
-    case T_R1: case T_O1: case T_GO1: case T_ZU1: case T_ZD0: return u.hp[0];
-    case T_R2: case T_O2: case T_GO2: case T_ZU2: case T_ZD1: return u.hp[1];
-    case T_R3: case T_ZD2: return u.hp[2];
-    default: return u.outp;   // T_G0, T_ZU0
-  }
-}
-__host__ __device__ constexpr int tensor_prefix(const UnetDesc& u, int t) {   // sum of the widths before tensor t
-  int s = 0;
-  for (int i = 0; i < t; ++i) s += tensor_width(u, i);
-  return s;
-}
+// (the slab tensors T_* that travel from kernel A to kernel B, their widths and prefixes: socmx_unet.h -- the one-row rollout exports the
+//  activation slabs itself when asked to, csrc/socmx_rollout1.hip)
 // (gradient tensor, activation tensor) of forward layer l: dW_l = grad^T . act
 __host__ __device__ constexpr int layer_grad_tensor(int l) {
   constexpr int g[9] = {T_ZD0, T_ZD1, T_ZD2, T_G0, T_ZU0 /* the fold: G' = ZU0^T R1, see unet_unfold_kernel */, T_GO2, T_ZU2, T_ZU1, T_ZU0};
@@ -156,6 +141,7 @@ struct K2Stage {
   int epi;
   int y2, sy2;           // second tile (EPI_DUAL: the masked copy; EPI_MASK0: ZU0) -- float offset / stride
   int mask;              // float offset of the nibble-mask byte array written (EPI_RES, EPI_MASK0) or read (EPI_DUAL)
+  int mkind;             // MK_* of the mask a backward stage reads (the SAVED form looks it up in the rows' records, socmx_unet.h)
   int aux, saux;         // EPI_ACTMASK: activation tile whose sign masks the result; EPI_MASK0: the G tile
   int ex1, ex2;          // exported tensor ids (T_*) of the primary / second result, -1 = none
   int w1, w2;            // their widths
@@ -165,7 +151,7 @@ struct K2Stage {
 __host__ __device__ constexpr K2Stage make_k2_stage(const UnetDesc& u, const BwdDesc& bd, const BwdLayout& b, int si) {
   const TileLayout& t = b.t;
   K2Stage s{};
-  s.y2 = -1; s.mask = -1; s.aux = -1; s.ex1 = -1; s.ex2 = -1;
+  s.y2 = -1; s.mask = -1; s.aux = -1; s.ex1 = -1; s.ex2 = -1; s.mkind = MK_NONE;
   auto fwd = [&](int l1, int x1, int s1, int has2, int l2, int x2, int s2, int y, int sy) {
     s.sd.L1 = u.L[l1]; s.sd.L2 = u.L[l2]; s.sd.x1 = x1; s.sd.s1 = s1; s.sd.x2 = x2; s.sd.s2 = s2; s.sd.y = y; s.sd.sy = sy;
     s.sd.has2 = has2; s.img1 = 0; s.img2 = 0;
@@ -182,15 +168,15 @@ __host__ __device__ constexpr K2Stage make_k2_stage(const UnetDesc& u, const Bwd
     case 4: fwd(7, t.o2, t.s2, 0, 7, t.o2, t.s2, t.o1, t.s1); s.epi = EPI_RELU; s.mask = b.mu1; s.ex1 = T_O1; break;   // (T_O1 carries A1)
     case 5: fwd(8, t.o1, t.s1, 1, 8, t.r1, t.s1, -1, 0); s.sd.L2 = u.fold; s.epi = EPI_MASK0; s.aux = t.gv; s.saux = t.sg;
             s.y2 = b.zu0; s.sy2 = t.sg; s.ex2 = T_ZU0; break;
-    case 6: bwd(KT_U0, b.zu0, t.sg, 0, KT_U0, b.zu0, t.sg, b.go1, t.s1); s.epi = EPI_DUAL; s.mask = b.mu1;
+    case 6: bwd(KT_U0, b.zu0, t.sg, 0, KT_U0, b.zu0, t.sg, b.go1, t.s1); s.epi = EPI_DUAL; s.mask = b.mu1; s.mkind = MK_U1;
             s.y2 = b.zu1; s.sy2 = t.s1; s.ex1 = -1 /* GO1 stays in LDS: nobody downstream reads its slab */; s.ex2 = T_ZU1; break;
-    case 7: bwd(KT_U1, b.zu1, t.s1, 0, KT_U1, b.zu1, t.s1, b.go2, t.s2); s.epi = EPI_DUAL; s.mask = b.mu2;
+    case 7: bwd(KT_U1, b.zu1, t.s1, 0, KT_U1, b.zu1, t.s1, b.go2, t.s2); s.epi = EPI_DUAL; s.mask = b.mu2; s.mkind = MK_U2;
             s.y2 = b.zu2; s.sy2 = t.s2; s.ex1 = T_GO2; s.ex2 = T_ZU2; break;
-    case 8: bwd(KT_U2, b.zu2, t.s2, 0, KT_U2, b.zu2, t.s2, b.zd2, t.s3); s.epi = EPI_ACTMASK; s.mask = b.mr3;
+    case 8: bwd(KT_U2, b.zu2, t.s2, 0, KT_U2, b.zu2, t.s2, b.zd2, t.s3); s.epi = EPI_ACTMASK; s.mask = b.mr3; s.mkind = MK_R3;
             s.ex1 = T_ZD2; break;
-    case 9: bwd(KT_D2, b.zd2, t.s3, 1, KT_R2, b.go2, t.s2, b.zd1, t.s2); s.epi = EPI_ACTMASK; s.mask = b.mr2;
+    case 9: bwd(KT_D2, b.zd2, t.s3, 1, KT_R2, b.go2, t.s2, b.zd1, t.s2); s.epi = EPI_ACTMASK; s.mask = b.mr2; s.mkind = MK_R2;
             s.ex1 = T_ZD1; break;
-    default: bwd(KT_D1, b.zd1, t.s2, 1, KT_R1 /* F^T */, b.zu0, t.sg, -1, 0); s.epi = EPI_ACTMASK; s.mask = b.mr1;
+    default: bwd(KT_D1, b.zd1, t.s2, 1, KT_R1 /* F^T */, b.zu0, t.sg, -1, 0); s.epi = EPI_ACTMASK; s.mask = b.mr1; s.mkind = MK_R1;
             s.ex1 = T_ZD0; break;
   }
   s.w1 = s.ex1 >= 0 ? tensor_width(u, s.ex1) : 0;
@@ -252,6 +238,7 @@ struct TileArgs {
   const float* gout;      // (N, d)  d objective / d nabla_V
   const float* gscale;    // (1,) device scalar that multiplies gout, or nullptr
   float* ws;              // workspace: T_N tensors, tensor t at ws + 16 * ntiles * prefix(t), each [tile][width][16]
+  const uint32_t* rec;    // SAVED form: the rows' sign records (socmx_unet.h), written by the rollout beside the activation slabs
   int64_t N;
   int rows_per_t;
   int ntiles;
@@ -297,12 +284,18 @@ struct EpiCtx {
   int64_t tile_rows;       // 16 * ntiles
   int tile;                // first 16-row tile of this workgroup (row r of the LDS tiles belongs to tile + r / 16)
   const float* fold_bias;  // f = up_0 b_res_1 (global memory, the forward image): added to stage 5's pre-activation
+  const uint32_t* rec_lds; // SAVED form: the tile's sixteen records in LDS
 };
 
-template <int EPI>
+template <int EPI, bool SAVED = false>
 struct Epi {
   const K2Stage& s;
   const EpiCtx& c;
+  // the nibble (units n0 .. n0 + 3 of row r) of the mask this backward stage reads
+  __device__ __forceinline__ unsigned nibble(int r, int n0) const {
+    if constexpr (SAVED) return act_record_nibble(c.rec_lds + r * kActRecordDwords, s.mkind, n0);
+    return reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
+  }
   __device__ __forceinline__ float* slab(int prefix, int width, int r) const {
     return c.ws ? c.ws + (size_t)c.tile_rows * prefix + (size_t)(c.tile + (r >> 4)) * width * 16 : nullptr;
   }
@@ -351,7 +344,7 @@ struct Epi {
       *reinterpret_cast<f32x4*>(c.lds + s.y2 + r * s.sy2 + n0) = z;
       put(s.p2, s.w2, r, n0, z, h, nblk);
     } else if constexpr (EPI == EPI_DUAL) {
-      const unsigned m = reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
+      const unsigned m = nibble(r, n0);
       f32x4 z;
 #pragma unroll
       for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
@@ -360,7 +353,7 @@ struct Epi {
       if (s.ex1 >= 0) put(s.p1, s.w1, r, n0, v, h, nblk);
       put(s.p2, s.w2, r, n0, z, h, nblk);
     } else {   // EPI_ACTMASK: the sign of the forward activation, saved as a nibble by that stage's EPI_RELU
-      const unsigned m = reinterpret_cast<const unsigned char*>(c.lds + s.mask)[r * (s.sd.L1.out_pad >> 2) + (n0 >> 2)];
+      const unsigned m = nibble(r, n0);
       f32x4 z;
 #pragma unroll
       for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
@@ -531,7 +524,7 @@ __device__ __forceinline__ void k2_stage(const float* __restrict__ W1, const flo
   }
 }
 
-template <int NW, class NET, int RT, int SI>
+template <int NW, class NET, int RT, int SI, bool SAVED = false>
 __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre& carry, const EpiCtx& ctx, int wave) {
   constexpr bool kStatic = !std::is_same<NET, void>::value;
   auto body = [&](const K2Stage& s, const WaveWorkS& w, const UnetDesc& u, const BwdLayout& lay) {
@@ -542,8 +535,8 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
     if (s.epi == EPI_RELU)       k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RELU>{s, ctx}, u);
     else if (s.epi == EPI_RES)   k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_RES>{s, ctx}, u);
     else if (s.epi == EPI_MASK0) k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_MASK0>{s, ctx}, u);
-    else if (s.epi == EPI_DUAL)  k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_DUAL>{s, ctx}, u);
-    else                         k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_ACTMASK>{s, ctx}, u);
+    else if (s.epi == EPI_DUAL)  k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_DUAL, SAVED>{s, ctx}, u);
+    else                         k2_stage<NW, RT, kStatic>(W1, W2, Wn, s.sd, w, lds, scratch, carry, Epi<EPI_ACTMASK, SAVED>{s, ctx}, u);
   };
   if constexpr (kStatic) {
     // every descriptor is a compile-time value: offsets fold into immediates, one NB variant and one epilogue survive
@@ -599,7 +592,10 @@ template <int NW> struct K2Const<NW, void> {
   __device__ static const BwdLayout& layout(const BwdLayout& x) { return x; }
 };
 
-template <int NW, class NET>
+// SAVED (socmx_unet_backward_saved_f32; constexpr instantiations, one tile per workgroup): the rollout that produced the rows wrote
+// the activation slabs and the rows' sign records -- no forward stages: ZU0 = G (.) [output pre-activation > 0] from the record, then
+// stages 6 .. 10 with their masks looked up in the sixteen records of the tile.
+template <int NW, class NET, bool SAVED = false>
 __global__ __launch_bounds__(NW * 64, 2) void unet_bwd_tile_kernel(const TileArgs a) {   // (two waves per SIMD is what the LDS admits: no AGPR copies to stay under 128 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool kStatic = !std::is_same<NET, void>::value;
@@ -631,44 +627,60 @@ __global__ __launch_bounds__(NW * 64, 2) void unet_bwd_tile_kernel(const TileArg
     float v = 0.f;
     if (c == 0) v = a.ts[grow / a.rows_per_t];
     else if (c <= d) v = a.x[grow * d + c - 1];
-    X0[r * t.s0 + c] = v;
+    if constexpr (!SAVED) X0[r * t.s0 + c] = v;     // (SAVED: no forward stage reads it, and ZU0 -- formed below -- lives in its place)
     slabX[e] = v;
   }
   const float gsc = a.gscale ? a.gscale[0] : 1.f;
+  float* slabZ = a.ws + (size_t)tile_rows * tensor_prefix(u, T_ZU0) + (size_t)tile * outp * 16;
+  uint32_t* recl = reinterpret_cast<uint32_t*>(lds + lay.mu2);      // SAVED: the tile's records (the mask arrays' place: 512 of >= 832 dwords)
   for (int e = tid; e < ROWS * outp; e += nthr) {
     const int r16 = e & 15, hc = e >> 4;
     const int h = hc >= outp ? 1 : 0, c = hc - h * outp, r = h * 16 + r16;
     const float v = (row0 + r < a.N && c < d) ? a.gout[(row0 + r) * d + c] * gsc : 0.f;
     G0[r * t.sg + c] = v;
     slabG[e] = v;
+    if constexpr (SAVED) {     // stage 5's result without its GEMMs: ZU0 = G (.) [up_0 A1 + F R1 + f + b > 0] (wave 0's record, dword 2)
+      const float z = ((a.rec[(size_t)(row0 + r) * kActRecordDwords + 2] >> c) & 1u) ? v : 0.f;
+      lds[lay.zu0 + r * t.sg + c] = z;
+      slabZ[e] = z;
+    }
   }
-  unet_load_biases(a.packed, u, t, lds, tid, nthr);
-  EpiCtx ctx{lds, a.ws, lds + t.bias, tile_rows, tile, a.packed + u.fold.b_off};
+  if constexpr (SAVED) {
+    static_assert(RT == 1, "SAVED: one 16-row tile per workgroup");
+    for (int e = tid; e < ROWS * kActRecordDwords; e += nthr) recl[e] = a.rec[(size_t)row0 * kActRecordDwords + e];
+  } else {
+    unet_load_biases(a.packed, u, t, lds, tid, nthr);
+  }
+  EpiCtx ctx{lds, a.ws, lds + t.bias, tile_rows, tile, a.packed + u.fold.b_off, recl};
   // first ring of stage 0 (GEMM 1 = down_0 of the forward image)
   Pre carry;
   {
+    // (SAVED: the first stage that runs is 6, GEMM 1 = up_0^T of the transposed image)
     LayerDesc L0; int img0 = 0;
-    if constexpr (kStatic) { constexpr UnetDesc uc = NET::desc(); L0 = uc.L[0]; } else { L0 = a.u.L[0]; }
+    if constexpr (SAVED) { constexpr BwdDesc bc = make_bwd_desc(NET::desc()); L0 = bc.L[KT_U0]; }
+    else if constexpr (kStatic) { constexpr UnetDesc uc = NET::desc(); L0 = uc.L[0]; } else { L0 = a.u.L[0]; }
     (void)img0;
     unsigned short pf[8] = {};
     first_fragment_numbers(L0, NW, wave, pf);
     WaveWorkS w{};
 #pragma unroll
     for (int f = 0; f < 8; ++f) w.pf[f] = pf[f];
-    carry = prefetch_fragments(a.packed, L0, w, lane);
+    carry = prefetch_fragments(SAVED ? a.packedT : a.packed, L0, w, lane);
   }
   __syncthreads();
-  k2_run_stage<NW, NET, RT, 0>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 1>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 2>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 3>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 4>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 5>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 6>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 7>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 8>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 9>(a, lds, carry, ctx, wave);
-  k2_run_stage<NW, NET, RT, 10>(a, lds, carry, ctx, wave);
+  if constexpr (!SAVED) {
+    k2_run_stage<NW, NET, RT, 0>(a, lds, carry, ctx, wave);
+    k2_run_stage<NW, NET, RT, 1>(a, lds, carry, ctx, wave);
+    k2_run_stage<NW, NET, RT, 2>(a, lds, carry, ctx, wave);
+    k2_run_stage<NW, NET, RT, 3>(a, lds, carry, ctx, wave);
+    k2_run_stage<NW, NET, RT, 4>(a, lds, carry, ctx, wave);
+    k2_run_stage<NW, NET, RT, 5>(a, lds, carry, ctx, wave);
+  }
+  k2_run_stage<NW, NET, RT, 6, SAVED>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 7, SAVED>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 8, SAVED>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 9, SAVED>(a, lds, carry, ctx, wave);
+  k2_run_stage<NW, NET, RT, 10, SAVED>(a, lds, carry, ctx, wave);
 }
 
 // ---- kernel B: weight / bias gradient partials -----------------------------------------------------------------------
@@ -2274,23 +2286,44 @@ extern "C" int socmx_unet_backward_f32(const float* packed, const float* packedT
   return socmx_unet_backward_scaled_f32(packed, packedT, d, hdims, x, ts, rows_per_t, N, gout, nullptr, workspace, grads, stream);
 }
 
+static int unet_backward_impl(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3], const float* x,
+                              const float* ts, int32_t rows_per_t, int64_t N, const float* gout, const float* gout_scale,
+                              const uint32_t* records, float* workspace, float* grads, socmx_stream_t stream);
+
 extern "C" int socmx_unet_backward_scaled_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
                                               const float* x, const float* ts, int32_t rows_per_t, int64_t N,
                                               const float* gout, const float* gout_scale, float* workspace, float* grads,
                                               socmx_stream_t stream) {
+  return unet_backward_impl(packed, packedT, d, hdims, x, ts, rows_per_t, N, gout, gout_scale, nullptr, workspace, grads, stream);
+}
+
+extern "C" int socmx_unet_backward_saved_f32(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3],
+                                             const float* x, const float* ts, int32_t rows_per_t, int64_t N,
+                                             const float* gout, const float* gout_scale, const uint32_t* records,
+                                             float* workspace, float* grads, socmx_stream_t stream) {
+  if (!records) return SOCMX_E_NULL;
+  return unet_backward_impl(packed, packedT, d, hdims, x, ts, rows_per_t, N, gout, gout_scale, records, workspace, grads, stream);
+}
+
+static int unet_backward_impl(const float* packed, const float* packedT, int32_t d, const int32_t hdims[3], const float* x,
+                              const float* ts, int32_t rows_per_t, int64_t N, const float* gout, const float* gout_scale,
+                              const uint32_t* records, float* workspace, float* grads, socmx_stream_t stream) {
   if (!packed || !packedT || !x || !ts || !gout || !workspace || !grads) return SOCMX_E_NULL;
   if (rows_per_t < 1) return SOCMX_E_DIM;
   K2Plan p;
   if (const int rc = k2_plan(d, hdims, N, p)) return rc;
+  // (the SAVED form: what the one-row rollout exports -- the 16-wide default-width network, whole tiles)
+  if (records && (p.variant != 1 || p.rt != 1 || N % 16 != 0)) return SOCMX_E_DIM;
   // ---- kernel A ----
   TileArgs ta;
   ta.u = p.u; ta.bd = p.bd; ta.lay = p.lay;
   for (int si = 0; si < kBwdStages; ++si) ta.prog.st[si] = k2_stage_desc(p.u, p.bd, p.lay, si);
   ta.packed = packed; ta.packedT = packedT; ta.x = x; ta.ts = ts; ta.gout = gout; ta.gscale = gout_scale; ta.ws = workspace;
-  ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles;
+  ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles; ta.rec = records;
   const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
   void (*kern)(const TileArgs) = unet_bwd_tile_kernel<kK2Waves, void>;
-  if (p.variant == 1) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>>;
+  if (p.variant == 1 && records) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>, true>;
+  else if (p.variant == 1) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>>;
   else if (p.variant == 2) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<32, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 32>>;
   else if (p.variant == 3) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<80, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 64>>;
   if (const int err = ensure_max_lds(kern)) return err;

@@ -103,7 +103,8 @@ def run(cfg):
                       gemm_select=bool(backend.get("gemm_select", False)),
                       tune_new_shapes=bool(backend.get("tune_new_shapes", False)),
                       hip_graph=_graph_mode(backend.get("hip_graph", True)), log=log,
-                      history_rows=int(cfg.method.num_iterations) + 1)
+                      history_rows=int(cfg.method.num_iterations) + 1,
+                      save_activations=bool(backend.get("save_activations", True)))
 
     solver.algorithm = algorithm
     info = solver.training_info = {k: [] for k in (

@@ -30,7 +30,8 @@ class Problem(C.Structure):
 
 
 class RolloutExtra(C.Structure):
-    _fields_ = [("key", _fp), ("nabla_v", _fp), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("key", _fp), ("nabla_v", _fp), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("act_workspace", _fp), ("act_records", _fp)]
 
 
 ROLLOUT_SHARES_CHIP = 1
@@ -68,6 +69,9 @@ PROTOTYPES = {
                                           _fp, _fp, _fp, _fp]),
     "socmx_unet_backward_scaled_f32": (C.c_int, [_fp, _fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, C.c_int32, C.c_int64,
                                                  _fp, _fp, _fp, _fp, _fp]),
+    "socmx_unet_backward_saved_f32": (C.c_int, [_fp, _fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, C.c_int32, C.c_int64,
+                                                _fp, _fp, _fp, _fp, _fp, _fp]),
+    "socmx_rollout_saves_activations": (C.c_int, [C.POINTER(Problem), C.POINTER(C.c_int32), C.c_int32, C.c_int32]),
     "socmx_mnet_packed_floats": (C.c_size_t, [C.c_int32, C.POINTER(C.c_int32)]),
     "socmx_mnet_pack_f32": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32] + [_fp] * 8),
     "socmx_mnet_forward_f32": (C.c_int, [_fp, C.c_int32, C.POINTER(C.c_int32), _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp]),

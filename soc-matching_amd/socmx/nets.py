@@ -248,11 +248,13 @@ def unet_backward_supported(net, n_rows):
 
 
 def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=None, out=None, packed_bwd=None,
-                      gout_scale=None):
+                      gout_scale=None, saved=None):
     """d objective / d parameters of `net` from gout = d objective / d net([ts[r // rows_per_t], x[r]]) for the N rows of
     x (N, d): socmx_unet_backward_f32 (forward recomputed in LDS, no library GEMM).  Returns the gradients in
     `net.parameters()` order (views of one flat buffer).  `gout_scale`: a (1,) fp32 device tensor that multiplies gout as
-    the kernel reads it (the iteration's d loss / d objective), instead of an elementwise launch in front of the call."""
+    the kernel reads it (the iteration's d loss / d objective), instead of an elementwise launch in front of the call.
+    `saved`: (workspace, records) that the rollout which produced `x` wrote with the SAME weights (rollout.hip_trajectories'
+    act_export): socmx_unet_backward_saved_f32 -- no forward re-computation."""
     L = net.hip_lib()
     dev = x.device
     N, d = x.shape
@@ -264,7 +266,12 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=No
     ws, ng = _lib.C.c_int64(0), _lib.C.c_int64(0)
     _lib.check(L.socmx_unet_backward_sizes(d, _lib.i3(net.hdims), N, _lib.C.byref(ws), _lib.C.byref(ng)),
                "socmx_unet_backward_sizes")
-    work = torch.empty(ws.value, dtype=torch.float32, device=dev)
+    if saved is not None:
+        work, records = saved
+        assert work.dtype == torch.float32 and work.numel() >= ws.value and work.device == dev and work.is_contiguous()
+        assert records.dtype == torch.int32 and records.numel() >= N * 32 and records.device == dev and records.is_contiguous()
+    else:
+        work = torch.empty(ws.value, dtype=torch.float32, device=dev)
     # (`out`: a caller-owned fp32 buffer of >= n_grad floats -- a sharded Trainer appends its scalars behind the gradient
     #  and all-reduces the whole buffer)
     flat = torch.empty(ng.value, dtype=torch.float32, device=dev) if out is None else out[:ng.value]
@@ -274,13 +281,16 @@ def unet_backward_hip(net, x, ts, rows_per_t, gout, return_flat=False, packed=No
         #  re-packing in front of the backward)
         if gout_scale is not None:
             assert gout_scale.dtype == torch.float32 and gout_scale.numel() == 1 and gout_scale.device == x.device
-        _lib.check(L.socmx_unet_backward_scaled_f32(_lib.ptr(packed if packed is not None else net.packed()),
-                                                    _lib.ptr(packed_bwd if packed_bwd is not None else net.packed_bwd()), d,
-                                                    _lib.i3(net.hdims),
-                                                    _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N, _lib.ptr(gout),
-                                                    _lib.ptr(gout_scale), _lib.ptr(work), _lib.ptr(flat),
-                                                    _lib.stream_ptr(dev)),
-                   "socmx_unet_backward_scaled_f32")
+        pk = _lib.ptr(packed if packed is not None else net.packed())
+        pkT = _lib.ptr(packed_bwd if packed_bwd is not None else net.packed_bwd())
+        if saved is not None:
+            _lib.check(L.socmx_unet_backward_saved_f32(pk, pkT, d, _lib.i3(net.hdims), _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N,
+                                                       _lib.ptr(gout), _lib.ptr(gout_scale), records.data_ptr(), _lib.ptr(work),
+                                                       _lib.ptr(flat), _lib.stream_ptr(dev)), "socmx_unet_backward_saved_f32")
+        else:
+            _lib.check(L.socmx_unet_backward_scaled_f32(pk, pkT, d, _lib.i3(net.hdims), _lib.ptr(x), _lib.ptr(ts), int(rows_per_t), N,
+                                                        _lib.ptr(gout), _lib.ptr(gout_scale), _lib.ptr(work), _lib.ptr(flat),
+                                                        _lib.stream_ptr(dev)), "socmx_unet_backward_scaled_f32")
     # flat is in SOCMX_L_* order (weight, bias per layer); parameters() follows the module construction order = the same
     grads, off = {}, 0
     for name in _lib.UNET_LAYERS:

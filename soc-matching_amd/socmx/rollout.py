@@ -59,11 +59,12 @@ def burst_eligible(sde, x0):
 
 
 def stochastic_trajectories(sde, x0, t, lmbd, detach=True, verbose=False, *, noise_in=None, seed=None,
-                            offset=None, row0=0, key=None, want_nabla_v=False, shares_chip=False):
+                            offset=None, row0=0, key=None, want_nabla_v=False, shares_chip=False, act_export=None):
     """`want_nabla_v` (HIP path only; ignored -- no ninth entry -- on the eager path): see hip_trajectories."""
     if _eligible_for_hip(sde, x0, detach):
         return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0, key=key,
-                                want_nabla_v=want_nabla_v, shares_chip=shares_chip)
+                                want_nabla_v=want_nabla_v, shares_chip=shares_chip, act_export=act_export)
+    assert act_export is None, "act_export: the fused HIP rollout only (ask saves_activations first)"
     if _eligible_for_hip_control(sde, x0, detach):
         return hip_trajectories(sde, x0, t, lmbd, noise_in=noise_in, seed=seed, offset=offset, row0=row0)
     return eager_trajectories(sde, x0, t, lmbd, detach=detach, verbose=verbose, noise_in=noise_in)
@@ -90,12 +91,23 @@ class PhiloxKey:
                        "socmx_philox_advance")
 
 
+def saves_activations(sde, x0, B, K, detach=True):
+    """True when a rollout of B rows and K steps of this SDE can save the control network's activations for the backward
+    (socmx_rollout_saves_activations: the one-row kernel, d <= 15, default widths, no stopping time, (K+1) B a multiple of 16)."""
+    if not _eligible_for_hip(sde, x0, detach):
+        return False
+    net = sde.nabla_V
+    return net.hip_lib().socmx_rollout_saves_activations(sde.problem.c_struct(), _lib.i3(net.hdims), int(B), int(K)) == 1
+
+
 def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None, row0=0, phase_cycles=None,
-                     costs_only=False, key=None, want_nabla_v=False, shares_chip=False):
+                     costs_only=False, key=None, want_nabla_v=False, shares_chip=False, act_export=None):
     """`phase_cycles`: optional int64 CUDA tensor ((B+15)//16, 64) -> run the instrumented kernel.
     `costs_only`: write lpd / lps / ltw only (the five trajectory entries of the returned tuple are None).
     `key`: a PhiloxKey -- seed/offset are read from device memory and advanced behind the launch.
-    `want_nabla_v`: also return nabla_V(t_k, X_k), k = 0..K, as a ninth entry (K+1, B, d)."""
+    `want_nabla_v`: also return nabla_V(t_k, X_k), k = 0..K, as a ninth entry (K+1, B, d).
+    `act_export`: (workspace fp32, records int32 ((K+1) B, 32)) -- the launch saves the control network's activations and ReLU signs for
+    socmx_unet_backward_saved_f32 (include/socmx.h; ask saves_activations() first: a launch that cannot raises)."""
     global _philox_calls
     L = _lib.lib()
     pb = sde.problem
@@ -173,13 +185,15 @@ def hip_trajectories(sde, x0, t, lmbd, *, noise_in=None, seed=None, offset=None,
             mid = (0, 0)
         if phase_cycles is not None:
             assert phase_cycles.dtype == torch.int64 and phase_cycles.is_cuda and phase_cycles.is_contiguous()
-            assert not want_nabla_v
+            assert not want_nabla_v and act_export is None
             status = L.socmx_rollout_phase_cycles_f32(*head, *mid, *tail, phase_cycles.data_ptr(), _lib.stream_ptr(dev))
-        elif key is not None or want_nabla_v or shares_chip:
+        elif key is not None or want_nabla_v or shares_chip or act_export is not None:
             # (shares_chip: the caller runs chip-filling kernels beside this launch -- SOCMX_ROLLOUT_SHARES_CHIP, include/socmx.h)
             extra = _lib.RolloutExtra(key=None if key is None else key.key.data_ptr(), nabla_v=_lib.ptr(nabla_v),
                                       flags=(_lib.ROLLOUT_SHARES_CHIP if shares_chip else 0) |
-                                            (_lib.ROLLOUT_ADVANCES_KEY if key is not None else 0), reserved=0)
+                                            (_lib.ROLLOUT_ADVANCES_KEY if key is not None else 0), reserved=0,
+                                      act_workspace=None if act_export is None else _lib.ptr(act_export[0]),
+                                      act_records=None if act_export is None else act_export[1].data_ptr())
             status = L.socmx_rollout_ex_f32(*head, *mid, *tail, extra, _lib.stream_ptr(dev))
         else:
             status = L.socmx_rollout_f32(*head, *mid, *tail, _lib.stream_ptr(dev))

@@ -48,8 +48,11 @@ class Trainer:
     def __init__(self, solver, optimizer, batch_size, normalization_const=1.0, algorithm="SOCM",
                  ema_weight_mean_coeff=0.002, sync_timing=True, gemm_select=False, overlap_M_backward=True,
                  grad_telemetry=True, tune_new_shapes=False, hip_graph=False, graph_warmup=2, fused_adam=True, log=None,
-                 history_rows=1 << 16):
+                 history_rows=1 << 16, save_activations=True):
         self.solver, self.optimizer = solver, optimizer
+        # the rollout saves the control network's activations / ReLU signs for the iteration's backward where its kernel can
+        # (socmx_rollout_ex_f32: act_workspace; the autograd-free SOCM body): False keeps the re-computing backward
+        self.save_activations = bool(save_activations)
         self.batch_size = batch_size
         self.normalization_const = normalization_const
         self.algorithm = algorithm
@@ -543,9 +546,27 @@ class Trainer:
         # The rollout is enqueued BEFORE the second stream's branch: its few workgroups claim whole CUs (exclusive LDS), and
         # behind a chip-filling kernel that keeps refilling every CU with small workgroups they wait for CUs to drain (the
         # d = 64 rollout took 13.0 instead of 7.3 ms behind the deferred contraction backward)
+        # The rollout SAVES the control network's activations and ReLU signs for this iteration's backward where it can (the one-row
+        # kernel: BASELINE configs[1], [2]): the backward's workspace and the rows' records are the Trainer's, at fixed addresses, written
+        # by the rollout and read behind the contraction -- kernel A then runs its five backward stages only (144 -> 86 us at configs[2]).
+        # backend.save_activations: False (Trainer(save_activations=False)) keeps the re-computing backward.
+        saved = None
+        if self.save_activations:
+            tag_s = (B, K, d, tuple(sde.nabla_V.hdims))
+            if D.get("saved_tag") != tag_s:
+                D["saved_tag"], D["saved"] = tag_s, None
+                if R.saves_activations(sde, state0, B, K):
+                    from . import _lib
+                    ws_n = _lib.C.c_int64(0)
+                    _lib.check(sde.nabla_V.hip_lib().socmx_unet_backward_sizes(d, _lib.i3(sde.nabla_V.hdims), Kp * B, _lib.C.byref(ws_n),
+                                                                               None), "socmx_unet_backward_sizes")
+                    D["saved"] = (torch.empty(ws_n.value, dtype=torch.float32, device=dev),
+                                  torch.zeros(Kp * B, 32, dtype=torch.int32, device=dev))
+            saved = D["saved"]
         (states, noises, stop, frac, lpd, lps, ltw, controls, nabla_v) = R.stochastic_trajectories(
             sde, state0, ts, solver.lmbd, noise_in=noise_in, key=solver.philox_key, want_nabla_v=True, row0=row0,
-            shares_chip=True)        # (the second stream's branch -- deferred contraction backward, pair-grid network -- runs beside it)
+            shares_chip=True,        # (the second stream's branch -- deferred contraction backward, pair-grid network -- runs beside it)
+            act_export=saved)
         packed_bwd = None
         scal3 = None
         join_early = False
@@ -603,7 +624,7 @@ class Trainer:
         vgrads, vflat = nets.unet_backward_hip(sde.nabla_V, states.reshape(Kp * B, d), ts, B,
                                                G.reshape(Kp * B, d), gout_scale=gout, return_flat=True,
                                                packed=sde.nabla_V._packed,     # (the image this iteration's rollout packed)
-                                               out=main_flat, packed_bwd=packed_bwd)
+                                               out=main_flat, packed_bwd=packed_bwd, saved=saved)
         vparams = list(sde.nabla_V.parameters())
         nsd = None
         if want_l2:

@@ -56,7 +56,7 @@ def test_binding_prototypes_have_the_declared_parameter_counts():
 def test_argument_validation_needs_no_gpu():
     from socmx import _lib
     L = _lib.lib()
-    assert L.socmx_version() == 148
+    assert L.socmx_version() == 149
     assert L.socmx_num_pairs(200) == 201 * 202 // 2
     assert L.socmx_unet_packed_floats(10, _lib.i3([256, 128, 64])) > 170562      # padded image >= parameter count
     assert L.socmx_unet_packed_floats(0, _lib.i3([256, 128, 64])) == 0

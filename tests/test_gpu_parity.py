@@ -26,7 +26,7 @@ def _np(t):
 def test_library_is_loaded_and_reports_gfx950():
     from socmx import _lib
     L = _lib.lib()
-    assert L.socmx_version() == 148
+    assert L.socmx_version() == 149
     buf = (b" " * 512)
     import ctypes
     b = ctypes.create_string_buffer(512)
