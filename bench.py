@@ -459,7 +459,10 @@ def main():
                 for kname, v in pm.items():
                     if kname == "_meta":
                         continue
-                    if ROLLOUT_KERNEL_TAG in kname and "StaticNet<16" in kname and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    # (metric 1's launch: the instantiation WITHOUT the activation export -- `..., 11, false>`; the exporting one, which a
+                    #  training iteration launches, writes 87 MB of slabs more)
+                    if (ROLLOUT_KERNEL_TAG in kname and "StaticNet<16" in kname and ", true>" not in kname and "FETCH_SIZE" in v
+                            and "WRITE_SIZE" in v):
                         traffic = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
                         traffic_src = (os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                        "passes of this command; FETCH_SIZE doubled per the gfx950 note)")
@@ -484,7 +487,7 @@ def main():
             "socm_iters_per_sec": None, "socm_ms_per_iter": None, "socm_iters_timed": None, "socm_last_loss": None,
             "socm_iteration_mode": None, "socm_ms_per_iter_eager": None, "socm_ms_per_iter_eager_body": None,
             "socm_ms_per_iter_graph": None,
-            "roofline": {"bound": "mfma", "kernel": "socmx::rollout1_kernel<0,StaticNet<16,256,128,64,16>,11>",
+            "roofline": {"bound": "mfma", "kernel": "socmx::rollout1_kernel<0,StaticNet<16,256,128,64,16>,11,false>",
                          "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "B=128 rows = 128 workgroups of one row (matrix-vector stages on the VALU): 128 of 256 CUs work, and a "
@@ -557,6 +560,8 @@ def main():
     opt = make_optimizer(solver, nabla_V_lr=cfg.optim.nabla_V_lr, M_lr=cfg.optim.M_lr, adam_eps=cfg.optim.adam_eps)
     it_steps, it_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
 
+    backward_form = {"saved": False}
+
     def time_iterations(graph):
         # (the shipped defaults of main.py / configs/soc.yaml: backend.gemm_select False)
         trainer = Trainer(solver, opt, batch_size=world * B, normalization_const=1.0, sync_timing=False, hip_graph=graph)
@@ -570,6 +575,8 @@ def main():
         el = time.perf_counter() - t0
         trainer.join()
         t = reduce_max(torch.tensor([el], dtype=torch.float64, device=device))
+        if (trainer._dev or {}).get("saved") is not None:
+            backward_form["saved"] = True       # (the rollout saved the control network's activations for the backward: socmx/train.py)
         return float(t.item()), float(info["loss"])
 
     # Three schedules of the same arithmetic: (1) the eager autograd iteration (two HIP streams; sharded: ONE flat all-reduce per
@@ -650,7 +657,9 @@ def main():
             "socm_iters_timed": it_steps, "socm_last_loss": last_loss, "socm_iteration_mode": it_mode,
             "socm_ms_per_iter_eager": 1e3 * it_elapsed_eager / it_steps,
             "socm_ms_per_iter_eager_body": None if it_elapsed_body is None else 1e3 * it_elapsed_body / it_steps,
-            "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps})
+            "socm_ms_per_iter_graph": None if it_elapsed_graph is None else 1e3 * it_elapsed_graph / it_steps,
+            "socm_control_backward": ("from the activations the rollout saved (socmx_unet_backward_saved_f32: no forward re-computation)"
+                                      if backward_form["saved"] else "re-computes the forward (socmx_unet_backward_scaled_f32)")})
         if burst is not None:
             line["roofline_full_chip"] = burst
         if secondary:

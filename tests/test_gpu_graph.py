@@ -71,7 +71,7 @@ def test_graph_replay_equals_the_eager_iteration(name, B):
         nw = 4e-6 if (k.startswith("M.") or "gamma" in k) else 2e-6
         assert np.linalg.norm(par_g[k] - par_e[k]) <= nw * max(np.linalg.norm(par_e[k]), 1e-12) + 1e-9, k
     rec_s, par_s, tr_s, _ = _run(name, True, 7, B)
-    if tr_s._graph_state().get("saved") is not None:                  # the rollout saved the activations (d <= 15, whole 16-row tiles)
+    if (tr_s._dev or {}).get("saved") is not None:                  # the rollout saved the activations (d <= 15, whole 16-row tiles)
         np.testing.assert_allclose(rec_s[:, :3], rec_e[:, :3], rtol=5e-5, atol=1e-7)       # loss, weight mean / std
         np.testing.assert_allclose(rec_s[:, 3:], rec_e[:, 3:], rtol=2e-3, atol=1e-7)       # gradient telemetry, normaliser
         for k in par_e:

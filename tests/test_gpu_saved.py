@@ -197,7 +197,7 @@ def test_training_is_the_same_with_and_without_saved_activations(name, B, graph)
                      hip_graph=graph, save_activations=save)
         losses = [float(tr.step()["loss"]) for _ in range(6)]
         tr.join()
-        assert (tr._graph_state().get("saved") is not None) == (save and graph)     # (the autograd-free body: what a captured iteration runs)
+        assert ((tr._dev or {}).get("saved") is not None) == (save and graph)     # (the autograd-free body: what a captured iteration runs)
         return losses, {k: v.detach().cpu().numpy().copy() for k, v in sde.nabla_V.state_dict().items()}, \
             {k: v.detach().cpu().numpy().copy() for k, v in sde.M.state_dict().items()}
 
@@ -222,7 +222,7 @@ def test_the_trainer_takes_the_saved_path_where_it_can():
         info = tr.step()
     tr.join()
     assert "graph" in info["mode"]
-    saved = tr._graph_state().get("saved")
+    saved = (tr._dev or {}).get("saved")
     assert saved is not None and saved[1].shape == ((aux["K"] + 1) * 32, 32)
     assert int((saved[1] != 0).sum()) > 0                        # the rollout wrote records
     # a batch whose rows do not fill 16-row tiles keeps the re-computing backward
@@ -232,4 +232,4 @@ def test_the_trainer_takes_the_saved_path_where_it_can():
     for _ in range(2):
         tr2.step()
     tr2.join()
-    assert tr2._graph_state().get("saved") is None
+    assert (tr2._dev or {}).get("saved") is None

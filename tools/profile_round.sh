@@ -81,3 +81,6 @@ python3 tools/determinism_check.py cfg3_double_well_d10_K200 > $R/determinism_ch
 DET_SHARD=1 python3 tools/determinism_check.py tiny_double_well_d10 2>&1 | grep -v -E "^RCCL|^HIP|^ROCm|^Hostname|^Librccl" >> $R/determinism_check.txt
 # round 6: the captured sharded iteration (own RCCL communicators) soaked at world size 1, eager process-group collectives in front of every capture
 python3 tools/soak_capture.py 120 2>&1 | grep -v -E "initialize_models|^RCCL|^HIP|^ROCm|^Hostname|^Librccl" > $R/soak_capture.txt
+# round 6: the SAVED control-network backward -- the rollout's activation slabs / sign records against kernel A's own, the gradients of the two
+# backward entries, the rollout with and without the export (stand-alone)
+(python3 tools/dbg_saved.py double_well 10 200 128; python3 tools/dbg_saved.py OU_quadratic_easy 2 50 128; python3 tools/dbg_saved.py OU_linear 10 100 64) 2>&1 | grep -v amdgpu.ids > $R/saved_backward.txt
