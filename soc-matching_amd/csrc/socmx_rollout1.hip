@@ -830,19 +830,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
     // stage 1: r2 = relu(down_1 r1 + b)            wave w: units 16 w .. 16 w + 15
     const f32x4 xr1 = *reinterpret_cast<const f32x4*>(lds + LM::r1 + lane * 4);
     const float bias1 = BL[u.L[1].b_lds + 16 * wave + n];
-    if constexpr (EX) {
-      // R1 (every wave holds all of it): chunk c by the older wave of SIMD c -- waves 1, 2, 3 chunks 0, 1, 2 (their own slots' dwords 2, 3),
-      // wave 0 chunk 3 (slot 4's).  The older waves reach this stage's barrier hundreds of cycles before the younger ones.
-      ex_begin();
-      if constexpr (CLS == 0) {
-        ex_store(TR1{}, 64 * 3 + ex_pk, xr1[3]);
-        ex_aux(4, __builtin_amdgcn_ballot_w64(xr1[3] > 0.f));
-      } else if (wave <= 3) {
-        const float v = wave == 1 ? xr1[0] : wave == 2 ? xr1[1] : xr1[2];
-        ex_store(TR1{}, 64 * (wave - 1) + ex_pk, v);
-        ex_b64 = __builtin_amdgcn_ballot_w64(v > 0.f);
-      }
-    }
+    if constexpr (EX) ex_begin();
     float s0 = 0.f, s1 = 0.f;
     blk(R1B(0), R1NX(1, 1), s0, s1, xr1[0]);
     blk(R1B(1), R1NX(2, 1), s0, s1, xr1[1]);
@@ -855,7 +843,6 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       // units right away (block 4: unit blocks 0..3 x input chunk w) and stage 3 adds the eight waves' partial sums.
       // Row g of the operand register holds r2[16 w + 4 g + (p & 3)] at every position p: one cross-lane gather.
       if constexpr (EX) {
-        if constexpr (CLS == 0) { if (lane < 16) ex_store(TR2{}, 16 * wave + n, y); }     // (waves 1 .. 7: from LDS, in ex_flush)
         ex_d0 = (uint32_t)__builtin_amdgcn_ballot_w64(y > 0.f) & 0xFFFFu;
       }
       if constexpr (R1_S2DIRECT) {
@@ -871,6 +858,19 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       r1_fmac16_4acc(c0, c1, c2, c3, x4, wres[r1_count(CLS, DMX, 'R', 4)]);
       const float tsum = r1_reduce4(c0, c1, c2, c3);                         // lane (g, n): unit 16 {0, 2, 1, 3}[g] + n
       lds[LM::p2 + wave * 64 + 16 * (((g & 1) << 1) | (g >> 1)) + n] = tsum;
+      }
+    }
+    if constexpr (EX) {
+      // R1 (every wave holds all of it): chunk c by the older wave of SIMD c -- waves 1, 2, 3 chunks 0, 1, 2 (their own slots' dwords 2, 3),
+      // wave 0 chunk 3 (slot 4's).  The older waves reach this stage's barrier hundreds of cycles before the younger ones:
+      // behind their last LDS write of the stage, in front of the barrier.
+      if constexpr (CLS == 0) {
+        ex_store(TR1{}, 64 * 3 + ex_pk, xr1[3]);
+        ex_aux(4, __builtin_amdgcn_ballot_w64(xr1[3] > 0.f));
+      } else if (wave <= 3) {
+        const float v = wave == 1 ? xr1[0] : wave == 2 ? xr1[1] : xr1[2];
+        ex_store(TR1{}, 64 * (wave - 1) + ex_pk, v);
+        ex_b64 = __builtin_amdgcn_ballot_w64(v > 0.f);
       }
     }
     R1_TICK(1)
@@ -907,7 +907,6 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
       const float y = relu_keep_nan(up + bu3) + (rs + br3);
       if (lane < 16) lds[LM::o2 + (16 * (n >> 2) + 4 * (wave & 3) + (n & 3)) * 2 + (wave >> 2)] = y;
       if constexpr (EX) {
-        if constexpr (CLS == 0) { if (lane < 16) ex_store(TO2{}, 16 * wave + n, y); }
         ex_d0 |= ((uint32_t)__builtin_amdgcn_ballot_w64(up + bu3 > 0.f) & 0xFFFFu) << 16;
       }
     }
