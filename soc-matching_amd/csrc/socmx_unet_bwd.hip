@@ -90,12 +90,30 @@ __host__ __device__ constexpr int k2_scratch_floats(const UnetDesc& u, int nwave
 
 // rt = 16-row tiles per workgroup (the tiles hold 16 rt rows): with rt = 2 every weight fragment that arrives from L2
 // feeds two MFMA column tiles -- half the weight traffic and half the barriers per row
-__host__ __device__ constexpr BwdLayout make_bwd_layout(const UnetDesc& u, int nwaves, int rt) {
+__host__ __device__ constexpr BwdLayout make_bwd_layout(const UnetDesc& u, int nwaves, int rt, bool saved = false) {
   BwdLayout b{};
   TileLayout& t = b.t;
   const int rows = 16 * rt;
   t.s0 = u.in0p + 4; t.s1 = u.hp[0] + 4; t.s2 = u.hp[1] + 4; t.s3 = u.hp[2] + 4; t.sg = u.outp + 4;
   int off = 0;
+  if (saved) {
+    // The SAVED form (no forward stages): only the tiles the backward chain READS -- ZU0, ZU1, GO2, ZU2, ZD2, ZD1, the G tile and the
+    // sixteen sign records; GO1 has no reader (its skip is folded: stage 10 multiplies F^T by ZU0) and is not stored.  51 KiB at the
+    // default widths: THREE workgroups per CU where the re-computing form's 77 KiB admit two.
+    b.zu0 = off; t.x0 = off; off += rows * t.sg;
+    t.gv = off; off += rows * t.sg;
+    b.go1 = -1; t.r1 = -1;
+    b.zu1 = off; t.o1 = off; off += rows * t.s1;
+    b.go2 = off; t.r2 = off; off += rows * t.s2;
+    b.zu2 = off; t.o2 = off; off += rows * t.s2;
+    b.zd2 = off; t.r3 = off; off += rows * t.s3;
+    b.zd1 = off; t.bias = off; off += rows * t.s2;
+    b.mu2 = off; b.mu1 = off; b.mr1 = off; b.mr2 = off; b.mr3 = off; off += rows * kActRecordDwords;
+    t.scratch = off;          // (no backward stage splits its reduction)
+    t.floats = off;
+    b.floats = off;
+    return b;
+  }
   t.x0 = off; off += rows * t.s0;
   t.r1 = off; off += rows * t.s1;
   t.r2 = off; off += rows * t.s2;
@@ -348,7 +366,7 @@ struct Epi {
       f32x4 z;
 #pragma unroll
       for (int i = 0; i < 4; ++i) z[i] = ((m >> i) & 1u) ? v[i] : 0.f;
-      *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;
+      if (s.sd.y >= 0) *reinterpret_cast<f32x4*>(c.lds + s.sd.y + r * s.sd.sy + n0) = v;      // (SAVED: GO1 has no reader and no tile)
       *reinterpret_cast<f32x4*>(c.lds + s.y2 + r * s.sy2 + n0) = z;
       if (s.ex1 >= 0) put(s.p1, s.w1, r, n0, v, h, nblk);
       put(s.p2, s.w2, r, n0, z, h, nblk);
@@ -542,7 +560,7 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
     // every descriptor is a compile-time value: offsets fold into immediates, one NB variant and one epilogue survive
     constexpr UnetDesc u = NET::desc();
     constexpr BwdDesc bd = make_bwd_desc(u);
-    constexpr BwdLayout lay = make_bwd_layout(u, NW, RT);
+    constexpr BwdLayout lay = make_bwd_layout(u, NW, RT, SAVED);
     constexpr K2Stage s = k2_stage_desc(u, bd, lay, SI);
     const WaveWork w0 = wave_work_of(s.sd, NW, wave);
     WaveWorkS w;
@@ -581,13 +599,13 @@ __device__ __forceinline__ void k2_run_stage(const TileArgs& a, float* lds, Pre&
 template <class NET> struct K2RowTiles { static constexpr int value = SOCMX_K2A_RT; };
 template <> struct K2RowTiles<void> { static constexpr int value = 1; };
 
-template <int NW, class NET> struct K2Const {
+template <int NW, class NET, bool SAVED = false> struct K2Const {
   static constexpr UnetDesc u = NET::desc();
-  static constexpr BwdLayout lay = make_bwd_layout(NET::desc(), NW, K2RowTiles<NET>::value);
+  static constexpr BwdLayout lay = make_bwd_layout(NET::desc(), NW, K2RowTiles<NET>::value, SAVED);
   __device__ static const UnetDesc& desc(const UnetDesc&) { return u; }
   __device__ static const BwdLayout& layout(const BwdLayout&) { return lay; }
 };
-template <int NW> struct K2Const<NW, void> {
+template <int NW> struct K2Const<NW, void, false> {
   __device__ static const UnetDesc& desc(const UnetDesc& x) { return x; }
   __device__ static const BwdLayout& layout(const BwdLayout& x) { return x; }
 };
@@ -596,7 +614,7 @@ template <int NW> struct K2Const<NW, void> {
 // the activation slabs and the rows' sign records -- no forward stages: ZU0 = G (.) [output pre-activation > 0] from the record, then
 // stages 6 .. 10 with their masks looked up in the sixteen records of the tile.
 template <int NW, class NET, bool SAVED = false>
-__global__ __launch_bounds__(NW * 64, 2) void unet_bwd_tile_kernel(const TileArgs a) {   // (two waves per SIMD is what the LDS admits: no AGPR copies to stay under 128 VGPRs)
+__global__ __launch_bounds__(NW * 64, SAVED ? 3 : 2) void unet_bwd_tile_kernel(const TileArgs a) {   // (two waves per SIMD is what the LDS admits: no AGPR copies to stay under 128 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool kStatic = !std::is_same<NET, void>::value;
   // constexpr instantiations: the descriptors are constants in the code object (a local copy whose address is handed on
@@ -604,8 +622,8 @@ __global__ __launch_bounds__(NW * 64, 2) void unet_bwd_tile_kernel(const TileArg
   UnetDesc u_arg;
   BwdLayout lay_arg;
   if constexpr (!kStatic) { u_arg = a.u; lay_arg = a.lay; }
-  const UnetDesc& u = K2Const<NW, NET>::desc(u_arg);
-  const BwdLayout& lay = K2Const<NW, NET>::layout(lay_arg);
+  const UnetDesc& u = K2Const<NW, NET, SAVED>::desc(u_arg);
+  const BwdLayout& lay = K2Const<NW, NET, SAVED>::layout(lay_arg);
   const TileLayout& t = lay.t;
   const int tid = threadIdx.x, nthr = NW * 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -2320,7 +2338,7 @@ static int unet_backward_impl(const float* packed, const float* packedT, int32_t
   for (int si = 0; si < kBwdStages; ++si) ta.prog.st[si] = k2_stage_desc(p.u, p.bd, p.lay, si);
   ta.packed = packed; ta.packedT = packedT; ta.x = x; ta.ts = ts; ta.gout = gout; ta.gscale = gout_scale; ta.ws = workspace;
   ta.N = N; ta.rows_per_t = rows_per_t; ta.ntiles = p.ntiles; ta.rec = records;
-  const size_t lds_bytes = (size_t)p.lay.floats * sizeof(float);
+  const size_t lds_bytes = (size_t)(records ? make_bwd_layout(p.u, SOCMX_K2A_WAVES, 1, true).floats : p.lay.floats) * sizeof(float);
   void (*kern)(const TileArgs) = unet_bwd_tile_kernel<kK2Waves, void>;
   if (p.variant == 1 && records) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>, true>;
   else if (p.variant == 1) kern = unet_bwd_tile_kernel<SOCMX_K2A_WAVES, StaticNet<16, SOCMX_H0P, SOCMX_H1P, SOCMX_H2P, 16>>;
