@@ -441,6 +441,7 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
   // (NS = 1: d <= 4; 3: d <= 12; 4: d <= 16; 0: several l-blocks of four MFMAs)
   constexpr int ns = NLB1 ? NS : 4;
   const float gam = NET ? a.gamma[0] : 0.f;
+  float ob_rows = 0.f;                           // (wave 0) the objective's share of this workgroup's rows
   for (int rep = 0; rep < 2; ++rep) {
     const int i = rep == 0 ? (int)blockIdx.x : K - (int)blockIdx.x;
     if (rep == 1 && i <= (int)blockIdx.x) break;
@@ -600,16 +601,20 @@ __global__ __launch_bounds__(64 * kTargetWaves) void socm_target_mfma_kernel(con
         if (lane == 0) objw[wave] = ob;
       }
     }
-    if (fuse) {                                           // one slot per (row, workgroup of the row): objective_commit
+    if (fuse) {                                           // this row's share of the objective, kept by wave 0 until both rows are done
       __syncthreads();
       if (wave == 0) {
         float ob = 0.f;
 #pragma unroll
         for (int c = 0; c < CT; ++c) ob += objw[c];
-        objective_commit(a, (unsigned)i * gridDim.y + blockIdx.y, (unsigned)(K + 1) * gridDim.y, ob * a.inv_norm);
+        ob_rows += ob * a.inv_norm;
       }
     }
   }
+  // ONE slot per workgroup (its two rows added in a fixed order): objective_commit is two dependent device-scope atomics with their
+  // returns waited for -- once per row it stood between the workgroup's two rows and again at its end (~3 us each at configs[2])
+  if (fuse && wave == 0)
+    objective_commit(a, blockIdx.x * gridDim.y + blockIdx.y, gridDim.x * gridDim.y, ob_rows);
 }
 
 // Wide form for 16 < d <= 64 and B >= 256 (the MFMA-bound regime, e.g. d = 64, K = 400, B = 512: 676 GFLOP), A operand
