@@ -44,7 +44,9 @@ def main():
     sde, aux = build_sde(name, str(dev))
     z = aux["z"]
     solver = SOC_Solver(sde, aux["x0"], None, T=aux["T"], num_steps=aux["K"], lmbd=aux["lmbd"], d=aux["d"], sigma=sde.sigma)
-    B = 50 if mode == "philox" else aux["B"]
+    # (SOCMX_TEST_PHILOX_B: another global batch for the Philox mode -- 64 over two ranks = whole 16-row tiles on every rank, where
+    #  the rollout SAVES the control network's activations for the sharded body's backward)
+    B = int(os.environ.get("SOCMX_TEST_PHILOX_B", "50")) if mode == "philox" else aux["B"]
     Bl, row0 = B, 0
     if sharded:
         solver.shard = Shard() if real else Shard(device=dev)
@@ -112,7 +114,8 @@ def main():
             rec.append([float(o["loss"]), float(o["weight_mean"]), float(o["weight_std"]), float(tr.normalization_const)])
         tr.join()
         torch.cuda.synchronize()
-        res.update(rec=rec, bodies=bodies, key=solver.philox_key.key.cpu().tolist())
+        res.update(rec=rec, bodies=bodies, key=solver.philox_key.key.cpu().tolist(),
+                   saved=bool((tr._dev or {}).get("saved") is not None))
         arrays.update({"V." + k: _np(v) for k, v in sde.nabla_V.state_dict().items()})
         arrays.update({"M." + k: _np(v) for k, v in sde.M.state_dict().items()})
         arrays["gamma"] = _np(sde.gamma)

@@ -201,6 +201,26 @@ def test_philox_rows_do_not_depend_on_the_sharding(name, world, tmp_path):
     assert (num / den) ** 0.5 < 5e-5, (num / den) ** 0.5
 
 
+def test_sharded_body_with_saved_activations(tmp_path):
+    """What every rank of an N-GPU run of the bench does (128 rows each: whole 16-row tiles): the rollout of the shard's rows saves the
+    control network's activations, the sharded body's backward runs from them (socmx_unet_backward_saved_f32) and writes into the flat
+    all-reduce buffer.  Global batch 64 over two ranks on one device against one process (which saves too) and against one process with the
+    re-computing backward: losses, statistics, parameters."""
+    name = "cfg3_double_well_d10_K200"
+    env = {"SOCMX_TEST_PHILOX_B": "64"}
+    j1, z1 = _launch(1, "philox", name, tmp_path, name + "_b64", extra_env=env)
+    jn, zn = _launch(2, "philox", name, tmp_path, name + "_b64", extra_env=env)
+    assert j1[0]["saved"] and all(j["saved"] for j in jn) and [j["rows"] for j in jn] == [[32, 0], [32, 32]]
+    for j, zr in zip(jn, zn):
+        Bl, row0 = j["rows"]
+        assert np.array_equal(zr["states"], z1[0]["states"][:, row0:row0 + Bl])
+        assert j["bodies"]["eager"] == 0 and j["bodies"]["manual"] == 4, j["bodies"]
+    np.testing.assert_allclose(jn[0]["rec"], j1[0]["rec"], rtol=2e-4)
+    num = sum(float(((zn[0][k] - z1[0][k]) ** 2).sum()) for k in z1[0].files if k[:2] in ("V.", "M."))
+    den = sum(float((z1[0][k] ** 2).sum()) for k in z1[0].files if k[:2] in ("V.", "M."))
+    assert (num / den) ** 0.5 < 5e-5, (num / den) ** 0.5
+
+
 @pytest.mark.parametrize("name,world", [("tiny_molecular_dynamics_d2_stopping", 2), ("md_default_d1_K150_B64_stopping", 3),
                                         ("tiny_double_well_d10", 3), ("tiny_ou_linear_d5_B20", 3)])
 def test_sharded_loss_call_on_the_gpu_matches_the_reference(name, world, tmp_path):
