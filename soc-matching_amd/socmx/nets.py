@@ -310,8 +310,9 @@ class UnetOnTrajectory(torch.autograd.Function):
     `nabla_v`) and the parameter gradients by socmx_unet_backward_f32.  No forward pass, no saved activations."""
 
     @staticmethod
-    def forward(ctx, values, states, ts, net, *params):
+    def forward(ctx, values, states, ts, net, saved, *params):
         ctx.net = net
+        ctx.saved = saved          # (workspace, records) the rollout wrote with these weights, or None: re-compute (unet_backward_hip)
         ctx.save_for_backward(states, ts)
         return values.view_as(values)
 
@@ -319,12 +320,13 @@ class UnetOnTrajectory(torch.autograd.Function):
     def backward(ctx, gout):
         states, ts = ctx.saved_tensors
         Kp, B, d = states.shape
-        grads = unet_backward_hip(ctx.net, states.reshape(Kp * B, d), ts, B, gout.reshape(Kp * B, d))
-        return (None, None, None, None) + tuple(grads)
+        saved, ctx.saved = ctx.saved, None          # (the backward consumes the workspace: a second backward re-computes)
+        grads = unet_backward_hip(ctx.net, states.reshape(Kp * B, d), ts, B, gout.reshape(Kp * B, d), saved=saved)
+        return (None, None, None, None, None) + tuple(grads)
 
 
-def unet_on_trajectory(net, values, states, ts):
-    return UnetOnTrajectory.apply(values, states, ts, net, *net.parameters())
+def unet_on_trajectory(net, values, states, ts, saved=None):
+    return UnetOnTrajectory.apply(values, states, ts, net, saved, *net.parameters())
 
 
 def unet_forward_hip(net, tx):

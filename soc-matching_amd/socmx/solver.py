@@ -210,9 +210,22 @@ class SOC_Solver(nn.Module):
         from . import nets as _nets
         fused_V = (detach and R._eligible_for_hip(sde, state0, detach) and getattr(self, "fused_nabla_V", True)
                    and _nets.unet_backward_supported(sde.nabla_V, Kp * B))
+        # ... and, where the one-row rollout kernel can (d <= 15, B <= 256, default widths, whole 16-row tiles), it SAVES the network's
+        # activations and ReLU signs for that backward (socmx_rollout_ex_f32: act_workspace / act_records): no forward re-computation in it.
+        # The autograd-free SOCM body of the Trainer does the same with buffers of its own (socmx/train.py); this is the autograd body --
+        # the eight other losses, the eager iteration.  solver.save_activations = False keeps the re-computing backward.
+        saved = None
+        if fused_V and getattr(self, "save_activations", True) and R.saves_activations(sde, state0, B, K, detach):
+            from . import _lib
+            ws_n = _lib.C.c_int64(0)
+            _lib.check(sde.nabla_V.hip_lib().socmx_unet_backward_sizes(self.dim, _lib.i3(sde.nabla_V.hdims), Kp * B, _lib.C.byref(ws_n), None),
+                       "socmx_unet_backward_sizes")
+            saved = (torch.empty(ws_n.value, dtype=torch.float32, device=state0.device),
+                     torch.empty(Kp * B, 32, dtype=torch.int32, device=state0.device))
         rolled = R.stochastic_trajectories(sde, state0, ts, self.lmbd, detach=detach, noise_in=noise_in, row0=row0,
                                            key=getattr(self, "philox_key", None), want_nabla_v=fused_V,
-                                           shares_chip=side is not None)     # (the pair-grid network runs beside it)
+                                           shares_chip=side is not None,     # (the pair-grid network runs beside it)
+                                           act_export=saved)
         (states, noises, stop_indicators, fractional_timesteps, lpd, lps, ltw, controls) = rolled[:8]
         if side is not None:
             with torch.cuda.stream(side):
@@ -246,7 +259,7 @@ class SOC_Solver(nn.Module):
 
         # nabla_V on all Kp*B trajectory rows (method.py:272-278): library GEMMs + autograd
         if fused_V:
-            nabla_V = _nets.unet_on_trajectory(sde.nabla_V, rolled[8], states, ts)
+            nabla_V = _nets.unet_on_trajectory(sde.nabla_V, rolled[8], states, ts, saved=saved)
         else:
             tx = torch.cat([ts.reshape(-1, 1, 1).expand(Kp, B, 1), states], dim=-1).reshape(-1, d + 1)
             nabla_V = sde.nabla_V(tx).reshape(Kp, B, d)

@@ -53,6 +53,7 @@ class Trainer:
         # the rollout saves the control network's activations / ReLU signs for the iteration's backward where its kernel can
         # (socmx_rollout_ex_f32: act_workspace; the autograd-free SOCM body): False keeps the re-computing backward
         self.save_activations = bool(save_activations)
+        solver.save_activations = self.save_activations     # (the autograd body's rollout: socmx/solver.py)
         self.batch_size = batch_size
         self.normalization_const = normalization_const
         self.algorithm = algorithm
