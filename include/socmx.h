@@ -260,7 +260,7 @@ int socmx_rollout_f32(const socmx_problem* problem, const float* packed_unet, co
  *            activation slabs of every trajectory row -- R1, R2, R3, O2 and A1 = relu(up_1 O2 + b) of models.py:233-242, [16-row tile][unit][16]
  *            -- are written where socmx_unet_backward_saved_f32 and the weight-gradient kernel read them; act_records is device
  *            uint32[(K+1) B][32]: the ReLU signs of a row (layout: csrc/socmx_unet.h).  Honoured by the one-row kernel only (d <= 15,
- *            B <= 256, default widths, no stopping time, (K+1) B a multiple of 16): socmx_rollout_saves_activations answers 1 / 0 for a
+ *            B <= 256, default widths, (K+1) B a multiple of 16; with or without a stopping time): socmx_rollout_saves_activations answers 1 / 0 for a
  *            launch's arguments without launching, and a launch that cannot honour the request returns SOCMX_E_DIM.  The states, noises,
  *            costs and nabla_v of the launch are bit-identical with and without the request.
  */

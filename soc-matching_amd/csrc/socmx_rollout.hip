@@ -1547,10 +1547,10 @@ static int rollout_launch(const socmx_problem* pb, const float* packed_unet, con
   const bool one_row_form = fast || (!force_slow && !a.sigma_identity && d <= 15 && !stopping);
   const bool one_row = is_default && one_row_form && r1_prof_ok && rollout1_available() && (force_rows == 0 || force_rows == 1) &&
                        (B <= 256 || (force_rows == 1 && B <= 1024));
-  // The activation export (act_workspace / act_records): the one-row kernel at d <= 15 without a stopping time, whole 16-row tiles of
+  // The activation export (act_workspace / act_records): the one-row kernel at d <= 15 (with or without a stopping time), whole 16-row tiles of
   // trajectory rows (the slabs of a ragged last tile would hold rows nobody wrote), offsets within 31 bits.  Anything else: refused,
   // and socmx_rollout_saves_activations says so beforehand.
-  const bool saves = one_row && !stopping && (((int64_t)K + 1) * B) % 16 == 0 && ((int64_t)K + 1) * B * 1024 * 4 < ((int64_t)1 << 31);
+  const bool saves = one_row && (((int64_t)K + 1) * B) % 16 == 0 && ((int64_t)K + 1) * B * 1024 * 4 < ((int64_t)1 << 31);
   if (query_saves) return saves ? 1 : 0;
   if (act_ws && (!saves || !act_rec || !nabla_v)) return SOCMX_E_DIM;
   if (one_row) return rollout1_launch(a, stopping, stream);

@@ -216,7 +216,7 @@ __device__ __forceinline__ void r1_wave(const RolloutArgs& a, float* lds, const 
   // backward would otherwise re-compute, their ReLU signs as a 128-byte record per row (socmx_unet.h).  Stores only: a buffer store per
   // tensor and wave (scalar base: tile and row of the evaluation; lane offset: the unit), one record store per wave.
   constexpr bool EX = EXPORT;
-  static_assert(!EXPORT || (H == 1 && MODE != 1), "the activation export is built for d <= 15 without a stopping time");
+  static_assert(!EXPORT || H == 1, "the activation export is built for d <= 15");
   constexpr int MS = 16 * H;                        // row stride of the noise ring (and of A, P at d <= 15)
   constexpr int MSA = H == 2 ? 36 : 16;             // row stride of A, P in LDS
   constexpr int NBS = 8 / H;                        // steps per noise batch (noise_batch below); its ring holds three batches: slot = step % (3 NBS)
@@ -1208,11 +1208,12 @@ int rollout1_launch(const RolloutArgs& a, bool stopping, void* stream) {
     else if (a.d <= 11) k = R1PICK(11);
     else k = R1PICK(15);
 #undef R1PICK
-    if (a.act_ws) {                                        // the activation export: no stopping time, the terminal evaluation included
-      if (stopping || !a.act_rec || !a.nabla_v) return SOCMX_E_DIM;
+    if (a.act_ws) {                                        // the activation export (the terminal evaluation included)
+      if (!a.act_rec || !a.nabla_v) return SOCMX_E_DIM;
 #define R1PICKX(DM)                                                                                                  \
-  (dense ? (ou ? rollout1_kernel<6, DefaultNet, DM, true> : rollout1_kernel<4, DefaultNet, DM, true>)                \
-         : (ou ? rollout1_kernel<2, DefaultNet, DM, true> : rollout1_kernel<0, DefaultNet, DM, true>))
+  (stopping ? rollout1_kernel<1, DefaultNet, DM, true>                                                               \
+            : dense ? (ou ? rollout1_kernel<6, DefaultNet, DM, true> : rollout1_kernel<4, DefaultNet, DM, true>)     \
+                    : (ou ? rollout1_kernel<2, DefaultNet, DM, true> : rollout1_kernel<0, DefaultNet, DM, true>))
       if (a.d <= 3) k = R1PICKX(3);
       else if (a.d <= 11) k = R1PICKX(11);
       else k = R1PICKX(15);

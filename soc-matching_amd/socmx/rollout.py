@@ -93,7 +93,7 @@ class PhiloxKey:
 
 def saves_activations(sde, x0, B, K, detach=True):
     """True when a rollout of B rows and K steps of this SDE can save the control network's activations for the backward
-    (socmx_rollout_saves_activations: the one-row kernel, d <= 15, default widths, no stopping time, (K+1) B a multiple of 16)."""
+    (socmx_rollout_saves_activations: the one-row kernel, d <= 15, default widths, (K+1) B a multiple of 16)."""
     if not _eligible_for_hip(sde, x0, detach):
         return False
     net = sde.nabla_V

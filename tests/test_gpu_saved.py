@@ -82,7 +82,7 @@ def _export_rollout(name):
 
 # the default-width fixtures the one-row kernel takes: MODE 0 / DMAX 11, MODE 2 / DMAX 3, a dense sigma (MODE 6 / DMAX 11), and a small batch
 CASES = ["cfg3_full_double_well_d10_K200_B128", "cfg1_full_ou_quadratic_easy_d2_K50_B128", "oul10_ou_linear_d10_K100_B64",
-         "cfg3_double_well_d10_K200"]
+         "cfg3_double_well_d10_K200", "md_default_d1_K150_B64_stopping"]       # (the last: with a stopping time, MODE 1)
 
 
 @pytest.mark.parametrize("name", CASES)
