@@ -90,6 +90,12 @@ __host__ __device__ constexpr int k2_scratch_floats(const UnetDesc& u, int nwave
 
 // rt = 16-row tiles per workgroup (the tiles hold 16 rt rows): with rt = 2 every weight fragment that arrives from L2
 // feeds two MFMA column tiles -- half the weight traffic and half the barriers per row
+#ifndef SOCMX_K2S_ALIAS
+#define SOCMX_K2S_ALIAS 1        /* SAVED form: ZD2 / ZD1 in ZU1's place (developer A/B: 0) */
+#endif
+#ifndef SOCMX_K2S_WGS
+#define SOCMX_K2S_WGS 4          /* SAVED form: workgroups per CU the launch bounds ask for */
+#endif
 __host__ __device__ constexpr BwdLayout make_bwd_layout(const UnetDesc& u, int nwaves, int rt, bool saved = false) {
   BwdLayout b{};
   TileLayout& t = b.t;
@@ -106,8 +112,14 @@ __host__ __device__ constexpr BwdLayout make_bwd_layout(const UnetDesc& u, int n
     b.zu1 = off; t.o1 = off; off += rows * t.s1;
     b.go2 = off; t.r2 = off; off += rows * t.s2;
     b.zu2 = off; t.o2 = off; off += rows * t.s2;
-    b.zd2 = off; t.r3 = off; off += rows * t.s3;
-    b.zd1 = off; t.bias = off; off += rows * t.s2;
+    if (SOCMX_K2S_ALIAS && rows * (t.s3 + t.s2) <= rows * t.s1) {
+      // ZU1 is read by stage 7 only: ZD2 (written by stage 8) and ZD1 (stage 9) live in its place -- 38 KiB at the default widths, FOUR workgroups per CU
+      b.zd2 = b.zu1; t.r3 = b.zd2;
+      b.zd1 = b.zu1 + rows * t.s3; t.bias = b.zd1;
+    } else {
+      b.zd2 = off; t.r3 = off; off += rows * t.s3;
+      b.zd1 = off; t.bias = off; off += rows * t.s2;
+    }
     b.mu2 = off; b.mu1 = off; b.mr1 = off; b.mr2 = off; b.mr3 = off; off += rows * kActRecordDwords;
     t.scratch = off;          // (no backward stage splits its reduction)
     t.floats = off;
@@ -614,7 +626,7 @@ template <int NW> struct K2Const<NW, void, false> {
 // the activation slabs and the rows' sign records -- no forward stages: ZU0 = G (.) [output pre-activation > 0] from the record, then
 // stages 6 .. 10 with their masks looked up in the sixteen records of the tile.
 template <int NW, class NET, bool SAVED = false>
-__global__ __launch_bounds__(NW * 64, SAVED ? 3 : 2) void unet_bwd_tile_kernel(const TileArgs a) {   // (two waves per SIMD is what the LDS admits: no AGPR copies to stay under 128 VGPRs)
+__global__ __launch_bounds__(NW * 64, SAVED ? SOCMX_K2S_WGS : 2) void unet_bwd_tile_kernel(const TileArgs a) {   // (two waves per SIMD is what the LDS admits: no AGPR copies to stay under 128 VGPRs)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool kStatic = !std::is_same<NET, void>::value;
   // constexpr instantiations: the descriptors are constants in the code object (a local copy whose address is handed on
